@@ -1,0 +1,111 @@
+"""ctypes binding of include/dto.h (the C-ABI boundary).  No compute happens in Python."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB, build_runtime
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+
+DTO_ABI_VERSION = 1
+DTO_OK = 0
+STATUS_NAMES = {0: "DTO_OK", 1: "DTO_ERR_INVALID", 2: "DTO_ERR_PLUGIN", 3: "DTO_ERR_DEVICE",
+                4: "DTO_ERR_UNSUPPORTED", 5: "DTO_ERR_NOT_CONVERGED"}
+
+(IDX_STATE, IDX_ACTION, IDX_STATE_ACTION, IDX_STATE_ACTION_NEXT, IDX_DYNAMICS_CONSTRAINT,
+ IDX_DYNAMICS_JACOBIAN, IDX_DYNAMICS_HESSIAN, IDX_STAGE_CONSTRAINT, IDX_STAGE_JACOBIAN,
+ IDX_STAGE_HESSIAN, IDX_OBJECTIVE_HESSIAN) = range(11)
+
+
+class ProblemSpec(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int),
+        ("model_library", C.c_char_p),
+        ("horizon", C.c_int),
+        ("stage_kind", c_int32_p),
+        ("variable_lower", c_double_p),
+        ("variable_upper", c_double_p),
+        ("parameters", c_double_p),
+        ("evaluate_hessian", C.c_int),
+    ]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "num_variables", "num_parameters", "num_constraint", "num_constraint_dynamics",
+        "num_constraint_stage", "num_constraint_general", "num_jacobian", "num_jacobian_dynamics",
+        "num_jacobian_stage", "num_jacobian_general", "nnz_hess_key", "nnz_hess_raw", "horizon",
+        "num_state_max", "num_action_max")]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("params", C.c_void_p),
+                ("ldp", C.c_int64), ("stream", C.c_void_p)]
+
+
+class DtoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libdto_hip.so (building it first if the sources changed). Fails loudly if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = build_runtime()
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP runtime library missing: {LIB}")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L.dto_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    sigs = {
+        "dto_problem_create": [C.POINTER(ProblemSpec), C.POINTER(vp)],
+        "dto_problem_destroy": [vp],
+        "dto_sizes": [vp, C.POINTER(Sizes)],
+        "dto_features_available": [vp, C.POINTER(C.c_int)],
+        "dto_jacobian_structure": [vp, c_int64_p, c_int64_p],
+        "dto_hessian_structure": [vp, c_int64_p, c_int64_p],
+        "dto_variable_bounds": [vp, c_double_p, c_double_p],
+        "dto_constraint_bounds": [vp, c_double_p, c_double_p],
+        "dto_stage_indices": [vp, C.c_int, C.c_int, c_int64_p, c_int64_p],
+        "dto_eval_f": [vp, c_double_p, c_double_p],
+        "dto_eval_grad_f": [vp, c_double_p, c_double_p],
+        "dto_eval_g": [vp, c_double_p, c_double_p],
+        "dto_eval_jac_g": [vp, c_double_p, c_double_p],
+        "dto_eval_h": [vp, c_double_p, C.c_double, c_double_p, c_double_p],
+        "dto_eval_f_batch": [vp, C.POINTER(Batch), vp],
+        "dto_eval_grad_f_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
+        "dto_eval_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
+        "dto_eval_jac_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
+        "dto_eval_h_batch": [vp, C.POINTER(Batch), C.c_double, vp, C.c_int64, vp, C.c_int64],
+        "dto_device_alloc": [C.POINTER(vp), C.c_int64],
+        "dto_device_free": [vp],
+        "dto_copy_to_device": [vp, vp, C.c_int64],
+        "dto_copy_to_host": [vp, vp, C.c_int64],
+        "dto_device_synchronize": [],
+        "dto_device_count": [C.POINTER(C.c_int)],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != DTO_OK:
+        raise DtoError(rc, lib().dto_last_error().decode(errors="replace"))
+
+
+def dptr(a):
+    """double* of a contiguous float64 numpy array."""
+    return a.ctypes.data_as(c_double_p)

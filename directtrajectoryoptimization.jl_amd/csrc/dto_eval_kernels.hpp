@@ -1,0 +1,415 @@
+// Hand-written gfx950 stage kernels for the five NLP callbacks, instance-major ("AoS") layout.
+//
+// These replace the serial stage loops of the reference:
+//   cost / gradient!          src/costs.jl:49-64
+//   constraints! / jacobian!  src/dynamics.jl:103-117, src/constraints.jl:80-94
+//   hessian!/hessian_lagrangian!  src/costs.jl:66-73, src/dynamics.jl:119-127, src/constraints.jl:96-104
+// and the unpack copies trajectory!/duals! (src/data.jl:258-278), which disappear: a lane reads its
+// knot straight out of the staged z.
+//
+// Mapping (MI355X-first, not a translation of the loop):
+//   * one 64-lane wavefront = 64 consecutive knots of ONE instance; lane = knot t.  The model's
+//     expression DAG (generated, straight-line, all VGPR) is evaluated per lane.
+//   * inputs: the wave's slice of z is contiguous ([x_t;u_t] are laid end to end), so it is staged
+//     into LDS with coalesced 8-byte-per-lane loads; each lane then picks (x_t,u_t,x_{t+1}) from LDS.
+//   * outputs: a knot's values (rows of c, nonzeros of J, key slots of H) are contiguous per stage
+//     and stages are contiguous per wave, so lanes deposit into an LDS image of the wave's output
+//     range and the wave streams that image to HBM fully coalesced (no scattered 8-byte stores).
+//   * the Hessian's `.+=` overlap (yy block of stage t-1 lands in the xx block of stage t,
+//     src/dynamics.jl:123) is resolved inside LDS in two phases instead of with f64 atomics; the wave
+//     owns 63 stages plus one halo lane that only contributes the overlap.
+//   * blocks are a single wave (64 threads): >= B*T/64 workgroups, LDS <= ~24 KiB per wave so 6+
+//     waves share a CU; nothing is reused across workgroups, so the block->XCD mapping is left to
+//     the round-robin dispatcher (tables are < 64 KiB and live in every XCD's L2).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "dto_model_plugin.h"
+
+namespace dto {
+
+constexpr int WAVE = 64;
+
+template <int N>
+struct arr {
+  double v[N > 0 ? N : 1];
+  __device__ __forceinline__ double& operator[](int i) { return v[i]; }
+  __device__ __forceinline__ const double& operator[](int i) const { return v[i]; }
+  __device__ __forceinline__ double* data() { return v; }
+  __device__ __forceinline__ const double* data() const { return v; }
+};
+
+// compile-time dispatch on the (wave-divergent but almost always uniform) stage kind
+template <class M, int K = 0, class F>
+__device__ __forceinline__ void dispatch_kind(int kind, F&& f) {
+  if constexpr (K < M::N_KIND) {
+    if (kind == K)
+      f(std::integral_constant<int, K>{});
+    else
+      dispatch_kind<M, K + 1>(kind, static_cast<F&&>(f));
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void lds_load(arr<N>& dst, const double* src) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = src[i];
+}
+
+template <int N>
+__device__ __forceinline__ void gmem_load(arr<N>& dst, const double* src) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = src[i];
+}
+
+// cooperative, coalesced copies between HBM and the wave's LDS image
+__device__ __forceinline__ void wave_load(double* lds, const double* g, int count) {
+  for (int i = threadIdx.x; i < count; i += WAVE) lds[i] = g[i];
+}
+__device__ __forceinline__ void wave_store(double* g, const double* lds, int count) {
+  for (int i = threadIdx.x; i < count; i += WAVE) g[i] = lds[i];
+}
+
+// LDS needed to stage z for 64(+1) knots
+template <class M>
+constexpr int z_stage_len() { return (WAVE + 1) * M::MAX_NXU + M::MAX_NX; }
+
+// ------------------------------------------------------------------------------------------------
+// objective: per-stage cost values -> scratch[B][T]   (summed in stage order by k_sum_rows)
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_obj(dto_eval_args a) {
+  __shared__ double s_z[z_stage_len<M>()];
+  const int wpi = (a.T + WAVE - 1) / WAVE;
+  const int64_t b = blockIdx.x / wpi;
+  const int t0 = (blockIdx.x % wpi) * WAVE;
+  const int tend = min(t0 + WAVE, a.T);
+  const int z0 = a.zoff[t0];
+  wave_load(s_z, a.z + b * a.ldz + z0, a.zoff[tend] - z0);
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t < a.T) {
+    double val = 0.0;
+    dispatch_kind<M>(a.kind[t], [&](auto kc) {
+      using KD = typename M::template Kind<decltype(kc)::value>;
+      using C = typename M::template Cost<KD::COST>;
+      arr<C::NX> x; arr<C::NU> u; arr<C::NW> w;
+      const double* zs = s_z + (a.zoff[t] - z0);
+      lds_load(x, zs); lds_load(u, zs + C::NX);
+      gmem_load(w, a.w + b * a.ldw + a.woff[t]);
+      double o[1];
+      C::eval(x.data(), u.data(), w.data(), o);
+      val = o[0];
+    });
+    a.scratch[b * (int64_t)a.T + t] = val;
+  }
+}
+
+// one wave per row: out[b] = sum_t rows[b][t], fixed order (lane-strided partials, then a tree)
+static __global__ __launch_bounds__(WAVE) void k_sum_rows(const double* rows, int64_t ld, int n, double* out) {
+  const int64_t b = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += WAVE) acc += rows[b * ld + i];
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, WAVE);
+  if (threadIdx.x == 0) out[b] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient: dense [x_t;u_t] gradient per stage, contiguous over the wave
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_grad(dto_eval_args a) {
+  __shared__ double s_z[z_stage_len<M>()];
+  __shared__ double s_o[WAVE * M::MAX_NXU];
+  const int wpi = (a.T + WAVE - 1) / WAVE;
+  const int64_t b = blockIdx.x / wpi;
+  const int t0 = (blockIdx.x % wpi) * WAVE;
+  const int tend = min(t0 + WAVE, a.T);
+  const int z0 = a.zoff[t0];
+  const int zlen = a.zoff[tend] - z0;
+  wave_load(s_z, a.z + b * a.ldz + z0, zlen);
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t < a.T) {
+    dispatch_kind<M>(a.kind[t], [&](auto kc) {
+      using KD = typename M::template Kind<decltype(kc)::value>;
+      using C = typename M::template Cost<KD::COST>;
+      arr<C::NX> x; arr<C::NU> u; arr<C::NW> w;
+      const int zo = a.zoff[t] - z0;
+      lds_load(x, s_z + zo); lds_load(u, s_z + zo + C::NX);
+      gmem_load(w, a.w + b * a.ldw + a.woff[t]);
+      arr<C::NX + C::NU> g;
+      C::grad(x.data(), u.data(), w.data(), g.data());
+#pragma unroll
+      for (int i = 0; i < C::NX + C::NU; ++i) s_o[zo + i] = g[i];
+    });
+  }
+  __syncthreads();
+  wave_store(a.out + b * a.ldout + z0, s_o, zlen);
+}
+
+// ------------------------------------------------------------------------------------------------
+// constraints: dynamics rows then stage rows
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_con(dto_eval_args a) {
+  __shared__ double s_z[z_stage_len<M>()];
+  __shared__ double s_d[WAVE * M::MAX_DYN_NC + 1];
+  __shared__ double s_c[WAVE * M::MAX_CON_NC + 1];
+  const int wpi = (a.T + WAVE - 1) / WAVE;
+  const int64_t b = blockIdx.x / wpi;
+  const int t0 = (blockIdx.x % wpi) * WAVE;
+  const int tend = min(t0 + WAVE, a.T);
+  const int z0 = a.zoff[t0];
+  const int zend = a.zoff[min(tend + 1, a.T)];
+  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  const int d0 = a.cdoff[t0], c0 = a.ccoff[t0];
+  if (t < a.T) {
+    dispatch_kind<M>(a.kind[t], [&](auto kc) {
+      using KD = typename M::template Kind<decltype(kc)::value>;
+      const double* zs = s_z + (a.zoff[t] - z0);
+      const double* wp = a.w + b * a.ldw + a.woff[t];
+      if constexpr (KD::DYN >= 0) {
+        using D = typename M::template Dyn<KD::DYN>;
+        arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NY> o;
+        lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+        gmem_load(w, wp);
+        D::eval(x.data(), u.data(), y.data(), w.data(), o.data());
+        const int off = a.cdoff[t] - d0;
+#pragma unroll
+        for (int i = 0; i < D::NY; ++i) s_d[off + i] = o[i];
+      }
+      if constexpr (KD::CON >= 0) {
+        using C = typename M::template Con<KD::CON>;
+        arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NC> o;
+        lds_load(x, zs); lds_load(u, zs + C::NX);
+        gmem_load(w, wp);
+        C::eval(x.data(), u.data(), w.data(), o.data());
+        const int off = a.ccoff[t] - c0;
+#pragma unroll
+        for (int i = 0; i < C::NC; ++i) s_c[off + i] = o[i];
+      }
+    });
+  }
+  __syncthreads();
+  double* ob = a.out + b * a.ldout;
+  wave_store(ob + d0, s_d, a.cdoff[tend] - d0);
+  wave_store(ob + c0, s_c, a.ccoff[tend] - c0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// constraint Jacobian nonzeros, reference COO order (dynamics block then stage block)
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_jac(dto_eval_args a) {
+  __shared__ double s_z[z_stage_len<M>()];
+  __shared__ double s_d[WAVE * M::MAX_DYN_NJ + 1];
+  __shared__ double s_c[WAVE * M::MAX_CON_NJ + 1];
+  const int wpi = (a.T + WAVE - 1) / WAVE;
+  const int64_t b = blockIdx.x / wpi;
+  const int t0 = (blockIdx.x % wpi) * WAVE;
+  const int tend = min(t0 + WAVE, a.T);
+  const int z0 = a.zoff[t0];
+  const int zend = a.zoff[min(tend + 1, a.T)];
+  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  const int d0 = a.jdoff[t0], c0 = a.jcoff[t0];
+  if (t < a.T) {
+    dispatch_kind<M>(a.kind[t], [&](auto kc) {
+      using KD = typename M::template Kind<decltype(kc)::value>;
+      const double* zs = s_z + (a.zoff[t] - z0);
+      const double* wp = a.w + b * a.ldw + a.woff[t];
+      if constexpr (KD::DYN >= 0) {
+        using D = typename M::template Dyn<KD::DYN>;
+        arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NJ> o;
+        lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+        gmem_load(w, wp);
+        D::jac(x.data(), u.data(), y.data(), w.data(), o.data());
+        const int off = a.jdoff[t] - d0;
+#pragma unroll
+        for (int i = 0; i < D::NJ; ++i) s_d[off + i] = o[i];
+      }
+      if constexpr (KD::CON >= 0) {
+        using C = typename M::template Con<KD::CON>;
+        arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NJ> o;
+        lds_load(x, zs); lds_load(u, zs + C::NX);
+        gmem_load(w, wp);
+        C::jac(x.data(), u.data(), w.data(), o.data());
+        const int off = a.jcoff[t] - c0;
+#pragma unroll
+        for (int i = 0; i < C::NJ; ++i) s_c[off + i] = o[i];
+      }
+    });
+  }
+  __syncthreads();
+  double* ob = a.out + b * a.ldout;
+  wave_store(ob + d0, s_d, a.jdoff[tend] - d0);
+  wave_store(ob + c0, s_c, a.jcoff[tend] - c0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hessian of the Lagrangian, reference key order (row-major sorted unique, both triangles)
+// ------------------------------------------------------------------------------------------------
+constexpr int HOWN = WAVE - 1;  // stages owned by one wave; lane 0 is the halo (stage t0-1)
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
+  __shared__ double s_z[z_stage_len<M>()];
+  __shared__ double s_o[HOWN * M::MAX_KEY + 1];
+  const int wpi = (a.T + HOWN - 1) / HOWN;
+  const int64_t b = blockIdx.x / wpi;
+  const int t0 = (blockIdx.x % wpi) * HOWN;      // first owned stage
+  const int tend = min(t0 + HOWN, a.T);          // one past the last owned stage
+  const int tlo = max(t0 - 1, 0);                // first staged stage (halo)
+  const int z0 = a.zoff[tlo];
+  const int zend = a.zoff[min(tend + 1, a.T)];
+  const int h0 = a.hoff[t0];
+  const int hlen = a.hoff[tend] - h0;
+  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
+  for (int i = threadIdx.x; i < hlen; i += WAVE) s_o[i] = 0.0;
+  __syncthreads();
+  const int s = t0 - 1 + (int)threadIdx.x;       // this lane's stage
+  const bool live = (s >= 0) && (s < tend);
+  const bool own = live && (s >= t0);
+  const double* mu = a.mu + b * a.ldmu;
+  const int kind = live ? a.kind[s] : -1;
+  // values of dyn(s) that land in the rows of stage s+1 are kept in registers across the barrier
+  arr<M::MAX_DYN_NH> hv;
+  int nh_dyn = 0;
+  if (live) {
+    dispatch_kind<M>(kind, [&](auto kc) {
+      using KD = typename M::template Kind<decltype(kc)::value>;
+      const double* zs = s_z + (a.zoff[s] - z0);
+      const double* wp = a.w + b * a.ldw + a.woff[s];
+      const int base = a.hoff[s] - h0;
+      const int* mrow = nullptr;
+      if constexpr (M::template Cost<KD::COST>::NH > 0) {
+        using C = typename M::template Cost<KD::COST>;
+        if (own) {
+          arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NH> o;
+          lds_load(x, zs); lds_load(u, zs + C::NX); gmem_load(w, wp);
+          C::hess(x.data(), u.data(), w.data(), o.data());
+          mrow = a.hmap_cost + decltype(kc)::value * a.hmap_stride;
+#pragma unroll
+          for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += a.sigma * o[i];
+        }
+      }
+      if constexpr (KD::DYN >= 0) {
+        using D = typename M::template Dyn<KD::DYN>;
+        if constexpr (D::NH > 0) {
+          arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NY> lam; arr<D::NH> o;
+          lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+          gmem_load(w, wp); gmem_load(lam, mu + a.cdoff[s]);
+          D::hess(x.data(), u.data(), y.data(), w.data(), lam.data(), o.data());
+          nh_dyn = D::NH;
+#pragma unroll
+          for (int i = 0; i < D::NH; ++i) hv[i] = o[i];
+          if (own) {
+            mrow = a.hmap_dyn_own + decltype(kc)::value * a.hmap_stride;
+#pragma unroll
+            for (int i = 0; i < D::NH; ++i) {
+              const int m = mrow[i];
+              if (m >= 0) s_o[base + m] += o[i];
+            }
+          }
+        }
+      }
+      if constexpr (KD::CON >= 0) {
+        using C = typename M::template Con<KD::CON>;
+        if constexpr (C::NH > 0) {
+          if (own) {
+            arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NC> lam; arr<C::NH> o;
+            lds_load(x, zs); lds_load(u, zs + C::NX); gmem_load(w, wp);
+            gmem_load(lam, mu + a.ccoff[s]);
+            C::hess(x.data(), u.data(), w.data(), lam.data(), o.data());
+            mrow = a.hmap_con + decltype(kc)::value * a.hmap_stride;
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += o[i];
+          }
+        }
+      }
+    });
+  }
+  __syncthreads();
+  // phase B: yy (and y-row) entries of dyn(s) go to the rows of stage s+1 (owned by lane+1)
+  if (live && nh_dyn > 0 && s + 1 < tend) {
+    const int base = a.hoff[s + 1] - h0;
+    const int* mrow = a.hmap_dyn_next + a.kind[s + 1] * a.hmap_stride;
+#pragma unroll
+    for (int i = 0; i < M::MAX_DYN_NH; ++i) {
+      if (i < nh_dyn) {
+        const int m = mrow[i];
+        if (m >= 0) s_o[base + m] += hv[i];
+      }
+    }
+  }
+  __syncthreads();
+  wave_store(a.out + b * a.ldout + h0, s_o, hlen);
+}
+
+// ------------------------------------------------------------------------------------------------
+// general constraint (src/general_constraint.jl:73-83): one lane per instance; rows/nonzeros are
+// appended after the stage blocks (src/data.jl:72-75)
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ void k_general_con(dto_eval_args a) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if constexpr (M::HAS_GENERAL) {
+    double o[M::General::NC > 0 ? M::General::NC : 1];
+    M::General::eval(a.z + b * a.ldz, a.w + b * a.ldw, o);
+    for (int i = 0; i < M::General::NC; ++i) a.out[b * a.ldout + a.general_row0 + i] = o[i];
+  }
+}
+
+template <class M>
+__global__ void k_general_jac(dto_eval_args a) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if constexpr (M::HAS_GENERAL) {
+    double o[M::General::NJ > 0 ? M::General::NJ : 1];
+    M::General::jac(a.z + b * a.ldz, a.w + b * a.ldw, o);
+    for (int i = 0; i < M::General::NJ; ++i) a.out[b * a.ldout + a.general_jac0 + i] = o[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher used by the generated plugin
+// ------------------------------------------------------------------------------------------------
+template <class M>
+int launch_eval(int op, const dto_eval_args* args, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const dto_eval_args& a = *args;
+  const int wpi = (a.T + WAVE - 1) / WAVE;
+  const unsigned grid = (unsigned)(a.B * wpi);
+  switch (op) {
+    case DTO_OP_OBJ:
+      hipLaunchKernelGGL(k_obj<M>, dim3(grid), dim3(WAVE), 0, stream, a);
+      hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)a.B), dim3(WAVE), 0, stream, (const double*)a.scratch, (int64_t)a.T, a.T, a.out);
+      break;
+    case DTO_OP_GRAD: hipLaunchKernelGGL(k_grad<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
+    case DTO_OP_CON: hipLaunchKernelGGL(k_con<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
+    case DTO_OP_JAC: hipLaunchKernelGGL(k_jac<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
+    case DTO_OP_HESS: {
+      const int wph = (a.T + HOWN - 1) / HOWN;
+      hipLaunchKernelGGL(k_hess<M>, dim3((unsigned)(a.B * wph)), dim3(WAVE), 0, stream, a);
+      break;
+    }
+    case DTO_OP_GENERAL_CON:
+      hipLaunchKernelGGL(k_general_con<M>, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, stream, a);
+      break;
+    case DTO_OP_GENERAL_JAC:
+      hipLaunchKernelGGL(k_general_jac<M>, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, stream, a);
+      break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace dto

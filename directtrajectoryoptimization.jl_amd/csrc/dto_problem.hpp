@@ -1,0 +1,43 @@
+// Problem handle behind the opaque `dto_problem*` of include/dto.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "dto_layout.hpp"
+#include "dto_model_plugin.h"
+
+namespace dto {
+
+int set_error(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+struct SolverState;  // dto_solver.cpp
+
+struct Problem {
+  void* dl = nullptr;
+  const dto_model_vtable* vt = nullptr;
+  Layout L;
+  // device tables
+  bool dev_ready = false;
+  int *d_kind = nullptr, *d_zoff = nullptr, *d_woff = nullptr, *d_cdoff = nullptr, *d_ccoff = nullptr;
+  int *d_jdoff = nullptr, *d_jcoff = nullptr, *d_hoff = nullptr;
+  int *d_hmap_cost = nullptr, *d_hmap_dyn_own = nullptr, *d_hmap_dyn_next = nullptr, *d_hmap_con = nullptr;
+  double* d_params = nullptr;
+  // single-instance staging for host-pointer callbacks
+  double *d_x1 = nullptr, *d_mu1 = nullptr, *d_out1 = nullptr;
+  double* d_scratch = nullptr;
+  size_t scratch_len = 0;
+  hipStream_t stream = nullptr;
+  SolverState* solver = nullptr;
+
+  int ensure_device();
+  int ensure_scratch(int64_t B);
+  void fill_args(dto_eval_args& a, int64_t B, const double* z, int64_t ldz, const double* w, int64_t ldw) const;
+  int launch(int op, const dto_eval_args& a, hipStream_t s);
+  void free_solver();
+  ~Problem();
+};
+
+}  // namespace dto

@@ -1,0 +1,326 @@
+"""Model plugin generation: traced stage objects -> HIP source -> gfx950 shared object.
+
+This is the build-time half of what `eval(Symbolics.build_function(...))` does in the
+reference constructors (src/dynamics.jl:26-27,34; src/costs.jl:22-26;
+src/constraints.jl:30-31,39; src/general_constraint.jl:26-27,35): turning the symbolic
+value / Jacobian-nonzero / Hessian-nonzero vectors into executable code.  Here the code is
+a set of `__device__` functions that the hand-written stage kernels in
+csrc/dto_eval_kernels.hpp (and the KKT kernels) inline; the result is compiled with
+`hipcc --offload-arch=gfx950` into one plugin .so per distinct problem structure and cached
+by content hash under _plugins/.
+
+Stage classes: objects are classified by identity, exactly as the reference shares one
+`Dynamics` object between stages (`[dt for t = 1:T-1]`, examples/acrobot/acrobot.jl:95).
+A stage *kind* is the tuple (dynamics class, previous dynamics class, cost class,
+constraint class) that meets at a knot; kernels dispatch on it at compile time.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+from typing import Dict, List, Sequence, Tuple
+
+from .model import Constraint, Cost, Dynamics, GeneralConstraint
+from .symbolic.codegen import emit_body
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+PLUGIN_DIR = os.path.join(_HERE, "_plugins")
+GENERATOR_VERSION = "3"
+
+
+class Structure:
+    """Classes, kinds and per-stage kind ids of one problem."""
+
+    def __init__(self, dynamics: Sequence[Dynamics], objective: Sequence[Cost],
+                 constraints: Sequence[Constraint], general: GeneralConstraint | None,
+                 evaluate_hessian: bool):
+        T = len(objective)
+        if len(dynamics) != T - 1 or len(constraints) != T:
+            raise ValueError("need T-1 dynamics, T costs and T constraints")
+        self.T = T
+        self.evaluate_hessian = bool(evaluate_hessian)
+        self.dyn: List[Dynamics] = []
+        self.cost: List[Cost] = []
+        self.con: List[Constraint] = []
+        self.general = general if (general is not None and general.num_constraint > 0) else None
+
+        def cls(lst, obj):
+            for i, o in enumerate(lst):
+                if o is obj:
+                    return i
+            lst.append(obj)
+            return len(lst) - 1
+
+        self.kinds: List[Tuple[int, int, int, int]] = []
+        self.stage_kind: List[int] = []
+        prev = -1
+        for t in range(T):
+            d = cls(self.dyn, dynamics[t]) if t < T - 1 else -1
+            c = cls(self.cost, objective[t])
+            k = constraints[t]
+            kc = cls(self.con, k) if k.num_constraint > 0 else -1
+            kind = (d, prev, c, kc)
+            if kind not in self.kinds:
+                self.kinds.append(kind)
+            self.stage_kind.append(self.kinds.index(kind))
+            prev = d
+        # consistency the reference leaves implicit (index vectors would mismatch otherwise)
+        for t in range(T):
+            d, p, c, kc = self.kinds[self.stage_kind[t]]
+            nx = self.dyn[d].num_state if d >= 0 else self.dyn[p].num_next_state
+            nu = self.dyn[d].num_action if d >= 0 else 0
+            if p >= 0 and self.dyn[p].num_next_state != nx:
+                raise ValueError(f"stage {t + 1}: next-state dim of previous dynamics != state dim")
+            if (self.cost[c].num_state, self.cost[c].num_action) != (nx, nu):
+                raise ValueError(f"stage {t + 1}: cost dims {self.cost[c].num_state, self.cost[c].num_action} != {(nx, nu)}")
+            if kc >= 0 and (self.con[kc].num_state, self.con[kc].num_action) != (nx, nu):
+                raise ValueError(f"stage {t + 1}: constraint dims != {(nx, nu)}")
+        if self.evaluate_hessian:
+            # all objects must agree on the flag
+            for o in list(self.dyn) + list(self.cost) + list(self.con):
+                if not o.evaluate_hessian and not getattr(o, "user_jacobian", False):
+                    raise ValueError("evaluate_hessian=True needs every object built with evaluate_hessian=True")
+
+    # number of Hessian key slots owned by the rows of a stage of kind k (exact, for LDS sizing)
+    def key_slots(self, kind: Tuple[int, int, int, int]) -> int:
+        d, p, c, kc = kind
+        slots = set()
+        if self.evaluate_hessian:
+            cc = self.cost[c]
+            for r, q in zip(*cc.sparsity):
+                slots.add((r - 1, q - 1))
+            if d >= 0:
+                dd = self.dyn[d]
+                npd = dd.num_state + dd.num_action
+                for r, q in zip(*dd.hessian_sparsity):
+                    if r - 1 < npd:
+                        slots.add((r - 1, q - 1))
+            if p >= 0:
+                pp = self.dyn[p]
+                npp = pp.num_state + pp.num_action
+                for r, q in zip(*pp.hessian_sparsity):
+                    if r - 1 >= npp:
+                        slots.add((r - 1 - npp, q - 1 - npp))
+            if kc >= 0:
+                kk = self.con[kc]
+                for r, q in zip(*kk.hessian_sparsity):
+                    slots.add((r - 1, q - 1))
+        return len(slots)
+
+
+def _int_array(name: str, vals: Sequence[int]) -> str:
+    body = ", ".join(str(int(v)) for v in vals) if len(vals) else "0"
+    return f"static const int {name}[] = {{{body}}};"
+
+
+def _fn(name: str, params: str, body: str) -> str:
+    return f"  static __device__ __forceinline__ void {name}({params}) {{\n{body}\n  }}\n"
+
+
+def generate_source(st: Structure, name: str) -> str:
+    h = st.evaluate_hessian
+    out: List[str] = []
+    out.append(f"// generated by directtrajectoryoptimization.jl_amd/plugin.py (v{GENERATOR_VERSION}) -- do not edit")
+    out.append('#include "dto_eval_kernels.hpp"')
+    out.append('#include "dto_kkt_kernels.hpp"')
+    out.append("namespace {")
+    mx = lambda xs: max([0] + [int(x) for x in xs])
+    max_nx = mx([d.num_state for d in st.dyn] + [d.num_next_state for d in st.dyn] + [c.num_state for c in st.cost])
+    max_nu = mx([c.num_action for c in st.cost])
+    max_nxu = mx([c.num_state + c.num_action for c in st.cost])
+    consts = dict(
+        N_KIND=len(st.kinds), N_DYN=len(st.dyn), N_COST=len(st.cost), N_CON=len(st.con),
+        MAX_NX=max(1, max_nx), MAX_NU=max_nu, MAX_NXU=max(1, max_nxu),
+        MAX_NY=max(1, mx(d.num_next_state for d in st.dyn)),
+        MAX_NW=mx([d.num_parameter for d in st.dyn] + [c.num_parameter for c in st.cost] + [c.num_parameter for c in st.con]),
+        MAX_DYN_NC=max(1, mx(d.num_next_state for d in st.dyn)),
+        MAX_DYN_NJ=max(1, mx(d.num_jacobian for d in st.dyn)),
+        MAX_DYN_NH=max(1, mx(d.num_hessian for d in st.dyn) if h else 0),
+        MAX_CON_NC=max(1, mx(c.num_constraint for c in st.con)),
+        MAX_CON_NJ=max(1, mx(c.num_jacobian for c in st.con)),
+        MAX_CON_NH=max(1, mx(c.num_hessian for c in st.con) if h else 0),
+        MAX_COST_NH=max(1, mx(c.num_hessian for c in st.cost) if h else 0),
+        MAX_KEY=max(1, mx(st.key_slots(k) for k in st.kinds)),
+        EVALUATE_HESSIAN=1 if h else 0,
+    )
+    out.append("struct Model {")
+    for k, v in consts.items():
+        out.append(f"  static constexpr int {k} = {v};")
+    out.append(f"  static constexpr bool HAS_GENERAL = {'true' if st.general is not None else 'false'};")
+    out.append("  template <int K> struct Kind;")
+    out.append("  template <int C> struct Dyn;")
+    out.append("  template <int C> struct Cost;")
+    out.append("  template <int C> struct Con;")
+    out.append("  struct General;")
+    out.append("};")
+    for i, (d, p, c, kc) in enumerate(st.kinds):
+        out.append(f"template <> struct Model::Kind<{i}> {{ static constexpr int DYN = {d}, PREV = {p}, COST = {c}, CON = {kc}; }};")
+
+    tables: List[str] = []
+    # ---- dynamics classes
+    for i, d in enumerate(st.dyn):
+        va = {"x": "x", "u": "u", "y": "y", "w": "w", "lam": "lam"}
+        nh = d.num_hessian if h else 0
+        out.append(f"template <> struct Model::Dyn<{i}> {{")
+        out.append(f"  static constexpr int NX = {d.num_state}, NU = {d.num_action}, NY = {d.num_next_state}, "
+                   f"NW = {d.num_parameter}, NJ = {d.num_jacobian}, NH = {nh};")
+        sig = "const double* x, const double* u, const double* y, const double* w, double* out"
+        out.append(_fn("eval", sig, emit_body(d.evaluate_expr, "out", va)))
+        out.append(_fn("jac", sig, emit_body(d.jacobian_expr, "out", va)))
+        if nh:
+            sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
+            out.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+        out.append("};")
+        tables.append(_int_array(f"dyn{i}_jr", d.jacobian_sparsity[0]))
+        tables.append(_int_array(f"dyn{i}_jc", d.jacobian_sparsity[1]))
+        tables.append(_int_array(f"dyn{i}_hr", d.hessian_sparsity[0] if h else []))
+        tables.append(_int_array(f"dyn{i}_hc", d.hessian_sparsity[1] if h else []))
+    # ---- cost classes
+    for i, c in enumerate(st.cost):
+        va = {"x": "x", "u": "u", "w": "w"}
+        nh = c.num_hessian if h else 0
+        out.append(f"template <> struct Model::Cost<{i}> {{")
+        out.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, NH = {nh};")
+        sig = "const double* x, const double* u, const double* w, double* out"
+        out.append(_fn("eval", sig, emit_body(c.evaluate_expr, "out", va)))
+        out.append(_fn("grad", sig, emit_body(c.gradient_expr, "out", va)))
+        if nh:
+            out.append(_fn("hess", sig, emit_body(c.hessian_expr, "out", va)))
+        out.append("};")
+        tables.append(_int_array(f"cost{i}_hr", c.sparsity[0] if h else []))
+        tables.append(_int_array(f"cost{i}_hc", c.sparsity[1] if h else []))
+    # ---- constraint classes
+    for i, c in enumerate(st.con):
+        va = {"x": "x", "u": "u", "w": "w", "lam": "lam"}
+        nh = c.num_hessian if h else 0
+        out.append(f"template <> struct Model::Con<{i}> {{")
+        out.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, "
+                   f"NC = {c.num_constraint}, NJ = {c.num_jacobian}, NH = {nh};")
+        sig = "const double* x, const double* u, const double* w, double* out"
+        out.append(_fn("eval", sig, emit_body(c.evaluate_expr, "out", va)))
+        out.append(_fn("jac", sig, emit_body(c.jacobian_expr, "out", va)))
+        if nh:
+            sigh = "const double* x, const double* u, const double* w, const double* lam, double* out"
+            out.append(_fn("hess", sigh, emit_body(c.hessian_expr, "out", va)))
+        ineq = sorted(c.indices_inequality)
+        flags = ["true" if (r + 1) in ineq else "false" for r in range(c.num_constraint)]
+        out.append(f"  static constexpr bool INEQ[{max(1, c.num_constraint)}] = {{{', '.join(flags) if flags else 'false'}}};")
+        out.append(f"  static constexpr int JR[{max(1, c.num_jacobian)}] = {{{', '.join(str(r - 1) for r in c.jacobian_sparsity[0]) or '0'}}};")
+        out.append(f"  static constexpr int JC[{max(1, c.num_jacobian)}] = {{{', '.join(str(r - 1) for r in c.jacobian_sparsity[1]) or '0'}}};")
+        hr = c.hessian_sparsity[0] if h else []
+        hc = c.hessian_sparsity[1] if h else []
+        out.append(f"  static constexpr int HR[{max(1, len(hr))}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
+        out.append(f"  static constexpr int HC[{max(1, len(hc))}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
+        out.append("};")
+        tables.append(_int_array(f"con{i}_jr", c.jacobian_sparsity[0]))
+        tables.append(_int_array(f"con{i}_jc", c.jacobian_sparsity[1]))
+        tables.append(_int_array(f"con{i}_hr", hr))
+        tables.append(_int_array(f"con{i}_hc", hc))
+        tables.append(_int_array(f"con{i}_iq", ineq))
+    # static pattern tables the KKT kernels unroll over (0-based)
+    for i, d in enumerate(st.dyn):
+        nh = d.num_hessian if h else 0
+        out.append(f"struct DynPat{i} {{")
+        out.append(f"  static constexpr int JR[{max(1, d.num_jacobian)}] = {{{', '.join(str(r - 1) for r in d.jacobian_sparsity[0]) or '0'}}};")
+        out.append(f"  static constexpr int JC[{max(1, d.num_jacobian)}] = {{{', '.join(str(r - 1) for r in d.jacobian_sparsity[1]) or '0'}}};")
+        hr = d.hessian_sparsity[0] if h else []
+        hc = d.hessian_sparsity[1] if h else []
+        out.append(f"  static constexpr int HR[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
+        out.append(f"  static constexpr int HC[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
+        out.append("};")
+    for i, c in enumerate(st.cost):
+        nh = c.num_hessian if h else 0
+        hr = c.sparsity[0] if h else []
+        hc = c.sparsity[1] if h else []
+        out.append(f"struct CostPat{i} {{")
+        out.append(f"  static constexpr int HR[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
+        out.append(f"  static constexpr int HC[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
+        out.append("};")
+    # ---- general constraint
+    g = st.general
+    if g is not None:
+        va = {"z": "z", "w": "w", "lam": "lam"}
+        out.append("struct Model::General {")
+        out.append(f"  static constexpr int NC = {g.num_constraint}, NJ = {g.num_jacobian};")
+        sig = "const double* z, const double* w, double* out"
+        out.append(_fn("eval", sig, emit_body(g.evaluate_expr, "out", va)))
+        out.append(_fn("jac", sig, emit_body(g.jacobian_expr, "out", va)))
+        out.append("};")
+        tables.append(_int_array("gen_jr", g.jacobian_sparsity[0]))
+        tables.append(_int_array("gen_jc", g.jacobian_sparsity[1]))
+        tables.append(_int_array("gen_hr", g.hessian_sparsity[0] if h else []))
+        tables.append(_int_array("gen_hc", g.hessian_sparsity[1] if h else []))
+        tables.append(_int_array("gen_iq", sorted(g.indices_inequality)))
+    else:
+        out.append("struct Model::General { static constexpr int NC = 0, NJ = 0; };")
+    out.extend(tables)
+    # ---- class tables
+    rows = []
+    for i, d in enumerate(st.dyn):
+        nh = d.num_hessian if h else 0
+        rows.append(f"  {{{d.num_next_state}, {d.num_state}, {d.num_action}, {d.num_parameter}, {d.num_jacobian}, {nh}, "
+                    f"dyn{i}_jr, dyn{i}_jc, dyn{i}_hr, dyn{i}_hc}}")
+    out.append("static const dto_dyn_class k_dyn[] = {\n" + (",\n".join(rows) if rows else "  {0}") + "\n};")
+    rows = []
+    for i, c in enumerate(st.cost):
+        nh = c.num_hessian if h else 0
+        rows.append(f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {nh}, cost{i}_hr, cost{i}_hc}}")
+    out.append("static const dto_cost_class k_cost[] = {\n" + ",\n".join(rows) + "\n};")
+    rows = []
+    for i, c in enumerate(st.con):
+        nh = c.num_hessian if h else 0
+        rows.append(f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_constraint}, {c.num_jacobian}, {nh}, "
+                    f"con{i}_jr, con{i}_jc, con{i}_hr, con{i}_hc, {len(c.indices_inequality)}, con{i}_iq}}")
+    out.append("static const dto_con_class k_con[] = {\n" + (",\n".join(rows) if rows else "  {0}") + "\n};")
+    rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
+    out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
+    if g is not None:
+        nh = g.num_hessian if h else 0
+        out.append(f"static const dto_general_class k_general = {{{g.num_variables}, {g.num_parameter}, {g.num_constraint}, "
+                   f"{g.num_jacobian}, {nh}, gen_jr, gen_jc, gen_hr, gen_hc, {len(g.indices_inequality)}, gen_iq}};")
+    out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::launch_eval<Model>(op, a, s); }")
+    out.append("static int launch_kkt(int op, const dto_kkt_args* a, void* s) { return dto::launch_kkt<Model>(op, a, s); }")
+    out.append("static const dto_model_vtable k_vtable = {")
+    out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
+    out.append(f"  k_dyn, k_cost, k_con, k_kinds, {'&k_general' if g is not None else 'nullptr'}, {1 if h else 0},")
+    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>")
+    out.append("};")
+    out.append("}  // namespace")
+    out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')
+    return "\n".join(out) + "\n"
+
+
+def _kernel_headers_digest() -> str:
+    hsh = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith((".hpp", ".h")):
+            with open(os.path.join(CSRC, fn), "rb") as f:
+                hsh.update(f.read())
+    return hsh.hexdigest()
+
+
+def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> str:
+    """Generate + compile (if not cached) and return the plugin path."""
+    src = generate_source(st, name)
+    digest = hashlib.sha256((src + _kernel_headers_digest() + GENERATOR_VERSION).encode()).hexdigest()[:16]
+    os.makedirs(PLUGIN_DIR, exist_ok=True)
+    base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")
+    so = base + ".so"
+    if os.path.exists(so):
+        return so
+    hip_src = base + ".hip"
+    with open(hip_src, "w") as f:
+        f.write(src)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = so + f".tmp{os.getpid()}"
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", CSRC,
+           "-Wno-unused-value", "-o", tmp, hip_src]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for plugin {name}:\n{res.stderr[-4000:]}")
+    os.replace(tmp, so)
+    return so

@@ -1,0 +1,245 @@
+"""The model equations behind the BASELINE configs, written as plain numpy closures.
+
+Each function restates one of the reference example scripts (constants matter for parity):
+
+* pendulum  examples/pendulum/pendulum.jl:22-39   (implicit midpoint, h = 0.05)
+* cartpole  examples/cartpole/cartpole.jl:19-56   (explicit RK3 written as y - rk3(x, u), h = 0.05)
+* acrobot   examples/acrobot/acrobot.jl:19-91     (implicit midpoint, h = 0.05)
+* car       examples/car/car.jl:19-26             (implicit midpoint, h = 0.1)
+
+plus the small models the reference's unit tests use (test/dynamics.jl:8-19,
+test/solve.jl:149-183).  The closures take numpy vectors of floats *or* of traced
+`Expr` nodes; they are traced once per `Dynamics/Cost/Constraint` object.
+`build_*` helpers assemble the full problem (objects + bounds + guesses) of a config.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .model import Bound, Constraint, Cost, Dynamics, linear_interpolation
+from .symbolic.expr import dot
+
+PI = math.pi
+
+
+# ----------------------------------------------------------------------------- pendulum
+def pendulum(x, u, w):
+    mass, length_com, gravity, damping = 1.0, 0.5, 9.81, 0.1
+    return np.array([
+        x[1],
+        u[0] / (mass * length_com * length_com)
+        - gravity * np.sin(x[0]) / length_com
+        - damping * x[1] / (mass * length_com * length_com),
+    ], dtype=object)
+
+
+def pendulum_midpoint(y, x, u, w, h=0.05):
+    return y - (x + h * pendulum(0.5 * (x + y), u, w))
+
+
+def pendulum_test(z, u, w):
+    """test/dynamics.jl:8-14 (lc = 1)."""
+    mass, lc, gravity, damping = 1.0, 1.0, 9.81, 0.1
+    return np.array([z[1], u[0] / (mass * lc * lc) - gravity * np.sin(z[0]) / lc - damping * z[1] / (mass * lc * lc)],
+                    dtype=object)
+
+
+def euler_implicit_test(y, x, u, w, h=0.1):
+    """test/dynamics.jl:16-19."""
+    return y - (x + h * pendulum_test(y, u, w))
+
+
+# ----------------------------------------------------------------------------- cartpole
+def cartpole(x, u, w):
+    mc, mp, l, g = 1.0, 0.2, 0.5, 9.81
+    qd = x[2:4]
+    s = np.sin(x[1])
+    c = np.cos(x[1])
+    H11, H12, H22 = mc + mp, mp * l * c, mp * l ** 2
+    det = H11 * H22 - H12 * H12
+    # C*qd + G - B*u  (C = [0 -mp*qd2*l*s; 0 0], G = [0, mp*g*l*s], B = [1, 0])
+    r1 = -mp * qd[1] * l * s * qd[1] - u[0]
+    r2 = mp * g * l * s
+    # qdd = -Hinv * r, Hinv = 1/det * [H22 -H12; -H12 H11]
+    qdd1 = -(1.0 / det) * (H22 * r1 - H12 * r2)
+    qdd2 = -(1.0 / det) * (-H12 * r1 + H11 * r2)
+    return np.array([qd[0], qd[1], qdd1, qdd2], dtype=object)
+
+
+def cartpole_rk3_explicit(x, u, w, h=0.05):
+    k1 = h * cartpole(x, u, w)
+    k2 = h * cartpole(x + 0.5 * k1, u, w)
+    k3 = h * cartpole(x - k1 + 2.0 * k2, u, w)
+    return x + (k1 + 4.0 * k2 + k3) / 6.0
+
+
+def cartpole_rk3_implicit(y, x, u, w):
+    return y - cartpole_rk3_explicit(x, u, w)
+
+
+# ----------------------------------------------------------------------------- acrobot
+def acrobot(x, u, w):
+    mass1, inertia1, length1, lengthcom1 = 1.0, 0.33, 1.0, 0.5
+    mass2, inertia2, length2, lengthcom2 = 1.0, 0.33, 1.0, 0.5
+    gravity, friction1, friction2 = 9.81, 0.1, 0.1
+    q1, q2, v1, v2 = x[0], x[1], x[2], x[3]
+    # Minv(q)
+    a = inertia1 + inertia2 + mass2 * length1 * length1 + 2.0 * mass2 * length1 * lengthcom2 * np.cos(q2)
+    b = inertia2 + mass2 * length1 * lengthcom2 * np.cos(q2)
+    c = inertia2
+    idet = 1.0 / (a * c - b * b)
+    # tau(q)
+    ta = (-1.0 * mass1 * gravity * lengthcom1 * np.sin(q1)
+          - mass2 * gravity * (length1 * np.sin(q1) + lengthcom2 * np.sin(q1 + q2)))
+    tb = -1.0 * mass2 * gravity * lengthcom2 * np.sin(q1 + q2)
+    # C(x)
+    Ca = -2.0 * mass2 * length1 * lengthcom2 * np.sin(q2) * v2
+    Cb = -1.0 * mass2 * length1 * lengthcom2 * np.sin(q2) * v2
+    Cc = mass2 * length1 * lengthcom2 * np.sin(q2) * v1
+    # rhs = -C v + tau + B u - friction .* v ,  B = [0; 1]
+    r1 = -1.0 * (Ca * v1 + Cb * v2) + ta - friction1 * v1
+    r2 = -1.0 * (Cc * v1) + tb + u[0] - friction2 * v2
+    qdd1 = idet * (c * r1 - b * r2)
+    qdd2 = idet * (-b * r1 + a * r2)
+    return np.array([v1, v2, qdd1, qdd2], dtype=object)
+
+
+def acrobot_midpoint(y, x, u, w, h=0.05):
+    return y - (x + h * acrobot(0.5 * (x + y), u, w))
+
+
+# ----------------------------------------------------------------------------- car
+def car(x, u, w):
+    return np.array([u[0] * np.cos(x[2]), u[0] * np.sin(x[2]), u[1]], dtype=object)
+
+
+def car_midpoint(y, x, u, w, h=0.1):
+    return y - (x + h * car(0.5 * (x + y), u, w))
+
+
+# ----------------------------------------------------------------------------- double integrator (test/solve.jl:149-183)
+def double_integrator(y, x, u, w):
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    B = np.array([0.0, 1.0])
+    return y - (A @ x + B * u[0])
+
+
+def double_integrator_grad(y, x, u, w):
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    B = np.array([[0.0], [1.0]])
+    return np.hstack([-A, -B, np.eye(2)])
+
+
+# ============================================================================= config builders
+def build_pendulum(T=50, evaluate_hessian=True):
+    """cfg1: examples/pendulum/pendulum.jl:41-77 with T = 50."""
+    n, m = 2, 1
+    x1 = np.array([0.0, 0.0])
+    xT = np.array([PI, 0.0])
+    dt = Dynamics(pendulum_midpoint, n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x[0:2], x[0:2]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x[0:2], x[0:2]), n, 0, evaluate_hessian=evaluate_hessian)
+    con1 = Constraint(lambda x, u, w: x - x1, n, m, evaluate_hessian=evaluate_hessian)
+    # quirk 9: the reference builds conT with num_action = 1 although u_T is empty;
+    # the closure never reads u, so num_action = 0 is equivalent and is what the layout needs.
+    conT = Constraint(lambda x, u, w: x - xT, n, 0, evaluate_hessian=evaluate_hessian)
+    return dict(
+        dynamics=[dt] * (T - 1),
+        objective=[ct] * (T - 1) + [cT],
+        constraints=[con1] + [Constraint() for _ in range(T - 2)] + [conT],
+        bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)],
+        x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
+    )
+
+
+def build_cartpole(T=200, evaluate_hessian=False):
+    """cfg2: examples/cartpole/cartpole.jl:58-106 with T = 200."""
+    n, m = 4, 1
+    x1 = np.zeros(4)
+    xT = np.array([0.0, PI, 0.0, 0.0])
+    Q, R, Qf = 1.0e-2, 1.0e-1, 1.0e2
+    dt = Dynamics(cartpole_rk3_implicit, n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.5 * Q * dot(x - xT, x - xT) + 0.5 * R * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: 0.5 * Qf * dot(x - xT, x - xT), n, 0, evaluate_hessian=evaluate_hessian)
+    u_bnd = 3.0
+    bnd = Bound(n, m, action_lower=[-u_bnd], action_upper=[u_bnd])
+    con1 = Constraint(lambda x, u, w: x - x1, n, m, evaluate_hessian=evaluate_hessian)
+    conT = Constraint(lambda x, u, w: x - xT, n, 0, evaluate_hessian=evaluate_hessian)
+
+    def guess(rng):
+        u_guess = [0.01 * np.ones(m) for _ in range(T - 1)]
+        xs = [x1.copy()]
+        for t in range(T - 1):
+            xs.append(np.asarray(cartpole_rk3_explicit(xs[-1], u_guess[t], np.zeros(0)), dtype=float))
+        return xs, u_guess
+
+    return dict(
+        dynamics=[dt] * (T - 1),
+        objective=[ct] * (T - 1) + [cT],
+        constraints=[con1] + [Constraint() for _ in range(T - 2)] + [conT],
+        bounds=[bnd] * (T - 1) + [Bound(n, 0)],
+        x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian, guess=guess,
+    )
+
+
+def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
+    """cfg3: examples/acrobot/acrobot.jl:93-118 with T = 1000 (endpoint equality constraints,
+    xT = [pi, 0, 0, 0]); endpoint="bounds" gives the variant of test/solve.jl:97-121
+    (xT = [0, pi, 0, 0], endpoints fixed through equal bounds, no stage constraints)."""
+    n, m = 4, 1
+    x1 = np.zeros(4)
+    dt = Dynamics(acrobot_midpoint, n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x[2:4], x[2:4]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x[2:4], x[2:4]), n, 0, evaluate_hessian=evaluate_hessian)
+    if endpoint == "constraints":
+        xT = np.array([PI, 0.0, 0.0, 0.0])
+        con1 = Constraint(lambda x, u, w: x - x1, n, m, evaluate_hessian=evaluate_hessian)
+        conT = Constraint(lambda x, u, w: x - xT, n, 0, evaluate_hessian=evaluate_hessian)
+        constraints = [con1] + [Constraint() for _ in range(T - 2)] + [conT]
+        bounds = [Bound(n, m)] * (T - 1) + [Bound(n, 0)]
+    else:
+        xT = np.array([0.0, PI, 0.0, 0.0])
+        constraints = [Constraint() for _ in range(T)]
+        bounds = ([Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2)
+                  + [Bound(n, 0, state_lower=xT, state_upper=xT)])
+    return dict(
+        dynamics=[dt] * (T - 1),
+        objective=[ct] * (T - 1) + [cT],
+        constraints=constraints, bounds=bounds,
+        x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
+    )
+
+
+def build_car(T=500, evaluate_hessian=False):
+    """cfg4 (one instance): examples/car/car.jl:28-67 with T = 500."""
+    n, m = 3, 2
+    x1 = np.zeros(3)
+    xT = np.array([1.0, 1.0, 0.0])
+    dt = Dynamics(car_midpoint, n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.0 * dot(x - xT, x - xT) + 1.0 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: 0.0 * dot(x - xT, x - xT), n, 0, evaluate_hessian=evaluate_hessian)
+    lo, hi = -0.5 * np.ones(m), 0.5 * np.ones(m)
+    bnd1 = Bound(n, m, state_lower=x1, state_upper=x1, action_lower=lo, action_upper=hi)
+    bndt = Bound(n, m, action_lower=lo, action_upper=hi)
+    bndT = Bound(n, 0, state_lower=xT, state_upper=xT)
+    p_obs = np.array([0.5, 0.5])
+    r_obs = 0.1
+
+    def obs(x, u, w):
+        e = x[0:2] - p_obs
+        return np.array([r_obs ** 2.0 - dot(e, e)], dtype=object)
+
+    cont = Constraint(obs, n, m, indices_inequality=[1], evaluate_hessian=evaluate_hessian)
+    conT = Constraint(obs, n, 0, indices_inequality=[1], evaluate_hessian=evaluate_hessian)
+    return dict(
+        dynamics=[dt] * (T - 1),
+        objective=[ct] * (T - 1) + [cT],
+        constraints=[cont] * (T - 1) + [conT],
+        bounds=[bnd1] + [bndt] * (T - 2) + [bndT],
+        x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        guess=lambda rng: (linear_interpolation(x1, xT, T), [0.001 * rng.standard_normal(m) for _ in range(T - 1)]),
+    )

@@ -1,0 +1,308 @@
+"""Solver / NLPData mirror over the C-ABI.
+
+* `NLPData`  -- the evaluator handed to Ipopt in the reference (src/data.jl:106-121,150-220) and its
+  MOI methods (src/moi.jl:1-125).  Here it is a thin object around a `dto_problem*`; every method is
+  one C-ABI call into libdto_hip.so, which runs the HIP kernels.  Nothing is evaluated in Python.
+* `Solver`   -- src/solver.jl:1-47: same constructor arguments and helper functions
+  (`initialize_states!` -> initialize_states, `initialize_controls!` -> initialize_controls,
+  `solve!` -> solve, get_trajectory).
+* `Options`  -- src/options.jl:6-36 (the tolerances that define convergence; print/file options are
+  accepted and ignored).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .model import Bound, Constraint, Cost, Dynamics, GeneralConstraint
+from .plugin import Structure, build_plugin
+
+
+@dataclass
+class Options:
+    """Base.@kwdef mutable struct Options (src/options.jl:6-36)."""
+    tol: float = 1e-6
+    s_max: float = 100.0
+    max_iter: int = 1000
+    max_cpu_time: float = 300.0
+    dual_inf_tol: float = 1.0
+    constr_viol_tol: float = 1.0e-3
+    compl_inf_tol: float = 1.0e-3
+    acceptable_tol: float = 1.0e-6
+    acceptable_iter: int = 15
+    acceptable_dual_inf_tol: float = 1.0e10
+    acceptable_constr_viol_tol: float = 1.0e-2
+    acceptable_compl_inf_tol: float = 1.0e-2
+    acceptable_obj_change_tol: float = 1.0e-5
+    diverging_iterates_tol: float = 1.0e8
+    mu_target: float = 1.0e-4
+    print_level: int = 5
+    output_file: str = "output.txt"
+    print_user_options: str = "no"
+    print_info_string: str = "no"
+    inf_pr_output: str = "original"
+    print_frequency_iter: int = 1
+    print_frequency_time: float = 0.0
+    skip_finalize_solution_call: str = "no"
+
+
+class Indices:
+    """TrajectoryOptimizationIndices (src/data.jl:44-59), 1-based vectors fetched lazily from the runtime."""
+
+    _FIELDS = dict(states=capi.IDX_STATE, actions=capi.IDX_ACTION, state_action=capi.IDX_STATE_ACTION,
+                   state_action_next_state=capi.IDX_STATE_ACTION_NEXT,
+                   dynamics_constraints=capi.IDX_DYNAMICS_CONSTRAINT, dynamics_jacobians=capi.IDX_DYNAMICS_JACOBIAN,
+                   dynamics_hessians=capi.IDX_DYNAMICS_HESSIAN, stage_constraints=capi.IDX_STAGE_CONSTRAINT,
+                   stage_jacobians=capi.IDX_STAGE_JACOBIAN, stage_hessians=capi.IDX_STAGE_HESSIAN,
+                   objective_hessians=capi.IDX_OBJECTIVE_HESSIAN)
+
+    def __init__(self, nlp: "NLPData"):
+        self._nlp = nlp
+        self._cache = {}
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name not in self._FIELDS:
+            raise AttributeError(name)
+        if name not in self._cache:
+            T = self._nlp.T
+            last = T - 1 if name in ("state_action_next_state", "dynamics_constraints", "dynamics_jacobians",
+                                     "dynamics_hessians") else T
+            if name == "actions":
+                last = T - 1
+            self._cache[name] = [self._nlp._stage_indices(self._FIELDS[name], t) for t in range(1, last + 1)]
+        return self._cache[name]
+
+
+class NLPData:
+    """The NLP evaluator (src/data.jl:106-121) backed by a device-resident problem."""
+
+    def __init__(self, dynamics: Sequence[Dynamics], objective: Sequence[Cost], constraints: Sequence[Constraint],
+                 bounds: Sequence[Bound], evaluate_hessian: bool = False,
+                 general_constraint: Optional[GeneralConstraint] = None, parameters=None, name: str = "model"):
+        self.structure = Structure(dynamics, objective, constraints, general_constraint, evaluate_hessian)
+        self.T = self.structure.T
+        self.hessian_lagrangian = bool(evaluate_hessian)
+        self.plugin_path = build_plugin(self.structure, name)
+        lib = capi.lib()
+        # variable bounds (primal_bounds, src/data.jl:123-133)
+        st = self.structure
+        nxs, nus = [], []
+        for t in range(self.T):
+            d, p, c, kc = st.kinds[st.stage_kind[t]]
+            nxs.append(st.cost[c].num_state)
+            nus.append(st.cost[c].num_action)
+        nz = sum(nxs) + sum(nus)
+        lo = np.full(nz, -np.inf)
+        hi = np.full(nz, np.inf)
+        off = 0
+        for t, bnd in enumerate(bounds):
+            nx, nu = nxs[t], nus[t]
+            if len(bnd.state_lower) > 0:
+                lo[off:off + nx] = bnd.state_lower
+            if len(bnd.state_upper) > 0:
+                hi[off:off + nx] = bnd.state_upper
+            if len(bnd.action_lower) > 0 and nu > 0:
+                lo[off + nx:off + nx + nu] = bnd.action_lower
+            if len(bnd.action_upper) > 0 and nu > 0:
+                hi[off + nx:off + nx + nu] = bnd.action_upper
+            off += nx + nu
+        par = None
+        if parameters is not None:
+            flat = [np.asarray(p, dtype=float).ravel() for p in parameters]
+            par = np.concatenate(flat) if flat else np.zeros(0)
+        kinds = np.asarray(st.stage_kind, dtype=np.int32)
+        spec = capi.ProblemSpec()
+        spec.abi_version = capi.DTO_ABI_VERSION
+        spec.model_library = self.plugin_path.encode()
+        spec.horizon = self.T
+        spec.stage_kind = kinds.ctypes.data_as(capi.c_int32_p)
+        spec.variable_lower = capi.dptr(lo)
+        spec.variable_upper = capi.dptr(hi)
+        spec.parameters = capi.dptr(par) if (par is not None and par.size) else None
+        spec.evaluate_hessian = 1 if evaluate_hessian else 0
+        h = C.c_void_p()
+        capi.check(lib.dto_problem_create(C.byref(spec), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        s = capi.Sizes()
+        capi.check(lib.dto_sizes(self._h, C.byref(s)))
+        self.sizes = s
+        self.num_variables = int(s.num_variables)
+        self.num_constraint = int(s.num_constraint)
+        self.num_jacobian = int(s.num_jacobian)
+        self.num_hessian_lagrangian = int(s.nnz_hess_raw)  # duplicate-counting, as src/data.jl:187
+        self.num_parameters = int(s.num_parameters)
+        self.state_dimensions = nxs
+        self.action_dimensions = nus
+        self.indices = Indices(self)
+        self._jac_structure = None
+        self._hess_structure = None
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dto_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure queries
+    def _stage_indices(self, which: int, t: int) -> List[int]:
+        n = C.c_int64()
+        capi.check(self._lib.dto_stage_indices(self._h, which, t, None, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=np.int64)
+        capi.check(self._lib.dto_stage_indices(self._h, which, t, out.ctypes.data_as(capi.c_int64_p), C.byref(n)))
+        return out[:n.value].tolist()
+
+    def features_available(self) -> List[str]:
+        bits = C.c_int()
+        capi.check(self._lib.dto_features_available(self._h, C.byref(bits)))
+        return ["Grad", "Jac"] + (["Hess"] if bits.value & 4 else [])
+
+    def jacobian_structure(self):
+        """MOI.jacobian_structure (src/moi.jl:124): list of 1-based (row, col)."""
+        if self._jac_structure is None:
+            r = np.zeros(max(1, self.num_jacobian), dtype=np.int64)
+            c = np.zeros(max(1, self.num_jacobian), dtype=np.int64)
+            capi.check(self._lib.dto_jacobian_structure(self._h, r.ctypes.data_as(capi.c_int64_p),
+                                                        c.ctypes.data_as(capi.c_int64_p)))
+            self._jac_structure = list(zip(r[:self.num_jacobian].tolist(), c[:self.num_jacobian].tolist()))
+        return self._jac_structure
+
+    def hessian_lagrangian_structure(self):
+        """MOI.hessian_lagrangian_structure (src/moi.jl:125)."""
+        if self._hess_structure is None:
+            n = int(self.sizes.nnz_hess_key)
+            r = np.zeros(max(1, n), dtype=np.int64)
+            c = np.zeros(max(1, n), dtype=np.int64)
+            capi.check(self._lib.dto_hessian_structure(self._h, r.ctypes.data_as(capi.c_int64_p),
+                                                       c.ctypes.data_as(capi.c_int64_p)))
+            self._hess_structure = list(zip(r[:n].tolist(), c[:n].tolist()))
+        return self._hess_structure
+
+    @property
+    def jacobian_sparsity(self):
+        return self.jacobian_structure()
+
+    @property
+    def hessian_lagrangian_sparsity(self):
+        return self.hessian_lagrangian_structure()
+
+    @property
+    def variable_bounds(self):
+        lo = np.zeros(self.num_variables)
+        hi = np.zeros(self.num_variables)
+        capi.check(self._lib.dto_variable_bounds(self._h, capi.dptr(lo), capi.dptr(hi)))
+        return [lo, hi]
+
+    @property
+    def constraint_bounds(self):
+        lo = np.zeros(max(1, self.num_constraint))
+        hi = np.zeros(max(1, self.num_constraint))
+        capi.check(self._lib.dto_constraint_bounds(self._h, capi.dptr(lo), capi.dptr(hi)))
+        return [lo[:self.num_constraint], hi[:self.num_constraint]]
+
+    # -- the five MOI evaluator methods (host vectors in, host vectors out; computed on the GPU)
+    @staticmethod
+    def _vec(x, n):
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        if a.size != n:
+            raise ValueError(f"expected a vector of length {n}, got {a.size}")
+        return a
+
+    def eval_objective(self, variables) -> float:
+        x = self._vec(variables, self.num_variables)
+        f = C.c_double()
+        capi.check(self._lib.dto_eval_f(self._h, capi.dptr(x), C.byref(f)))
+        return f.value
+
+    def eval_objective_gradient(self, gradient, variables) -> None:
+        x = self._vec(variables, self.num_variables)
+        assert gradient.dtype == np.float64 and gradient.flags.c_contiguous and gradient.size == self.num_variables
+        capi.check(self._lib.dto_eval_grad_f(self._h, capi.dptr(x), capi.dptr(gradient)))
+
+    def eval_constraint(self, violations, variables) -> None:
+        x = self._vec(variables, self.num_variables)
+        assert violations.dtype == np.float64 and violations.flags.c_contiguous and violations.size == self.num_constraint
+        capi.check(self._lib.dto_eval_g(self._h, capi.dptr(x), capi.dptr(violations)))
+
+    def eval_constraint_jacobian(self, jacobian, variables) -> None:
+        x = self._vec(variables, self.num_variables)
+        assert jacobian.dtype == np.float64 and jacobian.flags.c_contiguous and jacobian.size == self.num_jacobian
+        capi.check(self._lib.dto_eval_jac_g(self._h, capi.dptr(x), capi.dptr(jacobian)))
+
+    def eval_hessian_lagrangian(self, hessian, variables, scaling, duals) -> None:
+        x = self._vec(variables, self.num_variables)
+        mu = self._vec(duals, self.num_constraint)
+        assert hessian.dtype == np.float64 and hessian.flags.c_contiguous and hessian.size == int(self.sizes.nnz_hess_key)
+        capi.check(self._lib.dto_eval_h(self._h, capi.dptr(x), float(scaling), capi.dptr(mu), capi.dptr(hessian)))
+
+    # -- batched device-pointer forms (torch tensors or raw pointers)
+    def _batch(self, x_ptr: int, B: int, ldx: int, stream: int = 0, params_ptr: int = 0, ldp: int = 0):
+        b = capi.Batch()
+        b.B, b.x, b.ldx, b.params, b.ldp, b.stream = B, x_ptr, ldx, params_ptr or None, ldp, stream or None
+        return b
+
+    def eval_objective_batch(self, x_ptr, B, ldx, out_ptr, stream=0):
+        b = self._batch(x_ptr, B, ldx, stream)
+        capi.check(self._lib.dto_eval_f_batch(self._h, C.byref(b), out_ptr))
+
+    def eval_objective_gradient_batch(self, x_ptr, B, ldx, out_ptr, ldo, stream=0):
+        b = self._batch(x_ptr, B, ldx, stream)
+        capi.check(self._lib.dto_eval_grad_f_batch(self._h, C.byref(b), out_ptr, ldo))
+
+    def eval_constraint_batch(self, x_ptr, B, ldx, out_ptr, ldo, stream=0):
+        b = self._batch(x_ptr, B, ldx, stream)
+        capi.check(self._lib.dto_eval_g_batch(self._h, C.byref(b), out_ptr, ldo))
+
+    def eval_constraint_jacobian_batch(self, x_ptr, B, ldx, out_ptr, ldo, stream=0):
+        b = self._batch(x_ptr, B, ldx, stream)
+        capi.check(self._lib.dto_eval_jac_g_batch(self._h, C.byref(b), out_ptr, ldo))
+
+    def eval_hessian_lagrangian_batch(self, x_ptr, B, ldx, sigma, mu_ptr, ldmu, out_ptr, ldo, stream=0):
+        b = self._batch(x_ptr, B, ldx, stream)
+        capi.check(self._lib.dto_eval_h_batch(self._h, C.byref(b), float(sigma), mu_ptr, ldmu, out_ptr, ldo))
+
+
+class Solver:
+    """Solver(dynamics, objective, constraints, bounds; evaluate_hessian=false,
+    general_constraint=GeneralConstraint(), options=Options(), parameters=...) -- src/solver.jl:6-21."""
+
+    def __init__(self, dynamics, objective, constraints, bounds, evaluate_hessian: bool = False,
+                 general_constraint: Optional[GeneralConstraint] = None, options: Optional[Options] = None,
+                 parameters=None, name: str = "model"):
+        self.options = options or Options()
+        self.nlp = NLPData(dynamics, objective, constraints, bounds, evaluate_hessian=evaluate_hessian,
+                           general_constraint=general_constraint, parameters=parameters, name=name)
+        self._z0 = np.zeros(self.nlp.num_variables)
+        self._solution = None
+
+    @property
+    def num_variables(self):
+        return self.nlp.num_variables
+
+
+def initialize_states(solver: Solver, states) -> None:
+    """initialize_states!(solver, states) -- src/solver.jl:23-30."""
+    idx = solver.nlp.indices.states
+    for t, xt in enumerate(states):
+        xt = np.asarray(xt, dtype=float)
+        for i in range(len(xt)):
+            solver._z0[idx[t][i] - 1] = xt[i]
+
+
+def initialize_controls(solver: Solver, actions) -> None:
+    """initialize_controls!(solver, actions) -- src/solver.jl:32-39."""
+    idx = solver.nlp.indices.actions
+    for t, ut in enumerate(actions):
+        ut = np.asarray(ut, dtype=float)
+        for j in range(len(ut)):
+            solver._z0[idx[t][j] - 1] = ut[j]

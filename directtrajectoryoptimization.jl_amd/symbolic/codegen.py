@@ -1,0 +1,129 @@
+"""Straight-line C/HIP emission for lists of Expr outputs.
+
+Takes the place of `Symbolics.build_function(...)[2]` + `eval` (src/dynamics.jl:26-27,34;
+src/costs.jl:22-26; src/constraints.jl:30-31,39) -- but the target is a `__device__`
+function body that the hand-written stage kernels in csrc/ inline, not a Julia closure.
+
+The emitted body is pure straight-line code over `double` temporaries: every DAG node is
+computed once (the DAG is interned, so this is global CSE across *all* outputs of the
+function -- the reference's generated closures recompute shared sub-expressions per entry),
+sin/cos of one argument are paired into a single `sincos`, integer powers are expanded into
+multiplications.  No indexing is dynamic, so after inlining everything lives in VGPRs.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+from . import expr as E
+from .expr import Expr
+
+
+def _lit(v: float) -> str:
+    if v != v:
+        return "(0.0/0.0)"
+    if v in (float("inf"), float("-inf")):
+        return "(1.0/0.0)" if v > 0 else "(-1.0/0.0)"
+    s = repr(float(v))
+    if "." not in s and "e" not in s and "n" not in s:
+        s += ".0"
+    return s if v >= 0 else f"({s})"
+
+
+def _powi(a: str, k: int) -> str:
+    if k == 1:
+        return a
+    if k % 2 == 0:
+        h = _powi(a, k // 2)
+        return f"({h}*{h})"
+    return f"({_powi(a, k - 1)}*{a})"
+
+
+_CFN = {"sin": "sin", "cos": "cos", "tan": "tan", "exp": "exp", "log": "log", "sqrt": "sqrt",
+        "tanh": "tanh", "atan": "atan", "asin": "asin", "acos": "acos", "sinh": "sinh",
+        "cosh": "cosh", "abs": "fabs"}
+
+
+def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str],
+              tmp_prefix: str = "t", indent: str = "    ", scale: str | None = None) -> str:
+    """C statements assigning `out_name[k] = outputs[k]` for all k.
+
+    var_arrays maps a VAR family name ('x', 'u', 'y', 'w', 'lam', 'z') to the C array it is read from.
+    """
+    order = E.topo_order(outputs)
+    name: Dict[int, str] = {}
+    lines: List[str] = []
+    # which arguments have both sin and cos taken
+    sin_of: Dict[int, Expr] = {}
+    cos_of: Dict[int, Expr] = {}
+    for n in order:
+        if n.op == E.FUNC and n.fn == "sin":
+            sin_of[n.args[0].id] = n
+        elif n.op == E.FUNC and n.fn == "cos":
+            cos_of[n.args[0].id] = n
+    paired = {aid for aid in sin_of if aid in cos_of}
+    done_pairs = set()
+
+    def ref(a: Expr) -> str:
+        return name[a.id]
+
+    for n in order:
+        op = n.op
+        if op == E.CONST:
+            name[n.id] = _lit(n.value)
+            continue
+        if op == E.VAR:
+            name[n.id] = f"{var_arrays[n.name]}[{n.index}]"
+            continue
+        if op == E.NEG:
+            name[n.id] = f"(-{ref(n.args[0])})"
+            continue
+        t = f"{tmp_prefix}{n.id}"
+        if op == E.ADD:
+            rhs = f"{ref(n.args[0])} + {ref(n.args[1])}"
+        elif op == E.SUB:
+            rhs = f"{ref(n.args[0])} - {ref(n.args[1])}"
+        elif op == E.MUL:
+            rhs = f"{ref(n.args[0])} * {ref(n.args[1])}"
+        elif op == E.DIV:
+            rhs = f"{ref(n.args[0])} / {ref(n.args[1])}"
+        elif op == E.POWI:
+            rhs = _powi(ref(n.args[0]), n.value)
+        elif op == E.POW:
+            rhs = f"pow({ref(n.args[0])}, {ref(n.args[1])})"
+        else:
+            aid = n.args[0].id
+            if n.fn in ("sin", "cos") and aid in paired:
+                if aid not in done_pairs:
+                    done_pairs.add(aid)
+                    s, c = f"{tmp_prefix}{sin_of[aid].id}", f"{tmp_prefix}{cos_of[aid].id}"
+                    lines.append(f"{indent}double {s}, {c}; sincos({ref(n.args[0])}, &{s}, &{c});")
+                name[n.id] = t
+                continue
+            rhs = f"{_CFN[n.fn]}({ref(n.args[0])})"
+        lines.append(f"{indent}const double {t} = {rhs};")
+        name[n.id] = t
+    for k, o in enumerate(outputs):
+        v = name[o.id]
+        if scale is not None:
+            v = f"{scale} * ({v})"
+        lines.append(f"{indent}{out_name}[{k}] = {v};")
+    return "\n".join(lines)
+
+
+def op_count(outputs: Sequence[Expr]) -> Dict[str, int]:
+    """Arithmetic census of the emitted body (for DESIGN.md roofline arithmetic)."""
+    c = {"addsub": 0, "mul": 0, "div": 0, "trans": 0, "nodes": 0}
+    for n in E.topo_order(outputs):
+        if n.op in (E.ADD, E.SUB):
+            c["addsub"] += 1
+        elif n.op == E.MUL:
+            c["mul"] += 1
+        elif n.op == E.POWI:
+            c["mul"] += max(1, n.value.bit_length())
+        elif n.op == E.DIV:
+            c["div"] += 1
+        elif n.op in (E.FUNC, E.POW):
+            c["trans"] += 1
+        if n.op not in (E.CONST, E.VAR):
+            c["nodes"] += 1
+    return c

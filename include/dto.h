@@ -1,0 +1,151 @@
+/*
+ * dto.h -- C ABI of the MI355X-native sparse NLP callback + KKT engine.
+ *
+ * Drop-in boundary for DirectTrajectoryOptimization.jl's collocation hot path.  The reference
+ * has no FFI of its own: its boundary is the MathOptInterface evaluator protocol implemented on
+ * `NLPData` (reference src/data.jl:106, src/moi.jl:1-125) and consumed by Ipopt.jl.  Every entry
+ * point below names the reference method it replaces; a Julia `ccall` shim that implements the
+ * MOI methods on top of these calls is shown in INTEGRATION.md.
+ *
+ * Conventions (same as the reference unless stated):
+ *   - all numerics are double, all structure indices are int64 and 1-BASED (Julia convention),
+ *   - variables      z = [x_1; u_1; ...; x_{T-1}; u_{T-1}; x_T]          (src/dynamics.jl:188-195)
+ *   - constraints    [dynamics t=1..T-1; stage t=1..T; general]           (src/data.jl:64-75)
+ *   - Jacobian       COO list, dynamics ++ stage ++ general, local CSC order (src/data.jl:170-175)
+ *   - Hessian        sort(unique(raw)) key, row-major, BOTH triangles       (src/data.jl:184)
+ *   - output buffers are caller-owned and fully overwritten (src/moi.jl:16,33,53,73),
+ *   - every function returns an int status (DTO_OK = 0); nothing throws across the ABI,
+ *   - a handle is not thread-safe (the reference evaluator is not re-entrant either).
+ *
+ * Pointers are HOST pointers for the dto_eval_* family (the MOI-callback replacement: one
+ * instance, copied over PCIe) and DEVICE pointers for the *_batch / kkt / solve families
+ * (B instances resident in HBM, instance-major: instance b starts at ptr + b*ld).
+ */
+#ifndef DTO_H
+#define DTO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTO_ABI_VERSION 1
+
+enum dto_status {
+  DTO_OK = 0,
+  DTO_ERR_INVALID = 1,      /* bad argument / inconsistent spec */
+  DTO_ERR_PLUGIN = 2,       /* model plugin missing or wrong ABI */
+  DTO_ERR_DEVICE = 3,       /* HIP error (no GPU, OOM, launch failure) */
+  DTO_ERR_UNSUPPORTED = 4,  /* feature outside the built path */
+  DTO_ERR_NOT_CONVERGED = 5
+};
+
+/* feature bits, MOI.features_available (src/moi.jl:122) */
+#define DTO_FEATURE_GRAD 1
+#define DTO_FEATURE_JAC 2
+#define DTO_FEATURE_HESS 4
+
+typedef struct dto_problem dto_problem; /* opaque; plays the role of NLPData (src/data.jl:106-121) */
+
+/*
+ * Problem description: what `Solver(dynamics, objective, constraints, bounds; ...)` receives
+ * (src/solver.jl:6-21) after the per-stage objects have been compiled into a model plugin.
+ * `stage_kind[t]` selects, for stage t (0-based here), one entry of the plugin's kind table
+ * = (dynamics class, previous dynamics class, cost class, constraint class).
+ */
+typedef struct dto_problem_spec {
+  int abi_version;            /* DTO_ABI_VERSION */
+  const char* model_library;  /* path of the generated plugin .so (gfx950 code object inside) */
+  int horizon;                /* T */
+  const int32_t* stage_kind;  /* [T] */
+  const double* variable_lower; /* [num_variables] or NULL = -Inf  (src/data.jl:123-133) */
+  const double* variable_upper; /* [num_variables] or NULL = +Inf */
+  const double* parameters;     /* [num_parameters] flattened w_1..w_T (src/data.jl:218) or NULL */
+  int evaluate_hessian;         /* Solver(...; evaluate_hessian) (src/solver.jl:7) */
+} dto_problem_spec;
+
+int dto_problem_create(const dto_problem_spec* spec, dto_problem** out);
+int dto_problem_destroy(dto_problem* p);
+const char* dto_last_error(void);
+
+/* totals of NLPData (src/data.jl:155-167,187): nnz_hess_key = length(hessian_lagrangian_structure),
+ * nnz_hess_raw = nlp.num_hessian_lagrangian (duplicate-counting). */
+typedef struct dto_sizes_t {
+  int64_t num_variables, num_parameters;
+  int64_t num_constraint, num_constraint_dynamics, num_constraint_stage, num_constraint_general;
+  int64_t num_jacobian, num_jacobian_dynamics, num_jacobian_stage, num_jacobian_general;
+  int64_t nnz_hess_key, nnz_hess_raw;
+  int64_t horizon, num_state_max, num_action_max;
+} dto_sizes_t;
+int dto_sizes(const dto_problem* p, dto_sizes_t* out);
+
+/* MOI.features_available (src/moi.jl:122) */
+int dto_features_available(const dto_problem* p, int* feature_bits);
+/* MOI.jacobian_structure (src/moi.jl:124): rows/cols [num_jacobian], 1-based */
+int dto_jacobian_structure(const dto_problem* p, int64_t* rows, int64_t* cols);
+/* MOI.hessian_lagrangian_structure (src/moi.jl:125): rows/cols [nnz_hess_key], 1-based */
+int dto_hessian_structure(const dto_problem* p, int64_t* rows, int64_t* cols);
+/* nlp.variable_bounds / nlp.constraint_bounds (src/data.jl:123-148) */
+int dto_variable_bounds(const dto_problem* p, double* lower, double* upper);
+int dto_constraint_bounds(const dto_problem* p, double* lower, double* upper);
+
+/* TrajectoryOptimizationIndices (src/data.jl:44-104): 1-based index vector of stage t (1-based t).
+ * Returns the length in *n; `out` may be NULL to query the length. */
+enum dto_index_kind {
+  DTO_IDX_STATE = 0,                 /* indices.states[t]               src/dynamics.jl:188-191 */
+  DTO_IDX_ACTION = 1,                /* indices.actions[t]              src/dynamics.jl:193-195 */
+  DTO_IDX_STATE_ACTION = 2,          /* indices.state_action[t]         src/dynamics.jl:197-200 */
+  DTO_IDX_STATE_ACTION_NEXT = 3,     /* indices.state_action_next_state src/dynamics.jl:202-204 */
+  DTO_IDX_DYNAMICS_CONSTRAINT = 4,   /* indices.dynamics_constraints[t] src/dynamics.jl:162-165 */
+  DTO_IDX_DYNAMICS_JACOBIAN = 5,     /* indices.dynamics_jacobians[t]   src/dynamics.jl:167-170 */
+  DTO_IDX_DYNAMICS_HESSIAN = 6,      /* indices.dynamics_hessians[t]    src/dynamics.jl:172-186 */
+  DTO_IDX_STAGE_CONSTRAINT = 7,      /* indices.stage_constraints[t]    src/constraints.jl:141-153 */
+  DTO_IDX_STAGE_JACOBIAN = 8,        /* indices.stage_jacobians[t]      src/constraints.jl:155-166 */
+  DTO_IDX_STAGE_HESSIAN = 9,         /* indices.stage_hessians[t]       src/constraints.jl:168-183 */
+  DTO_IDX_OBJECTIVE_HESSIAN = 10     /* indices.objective_hessians[t]   src/costs.jl:88-104 */
+};
+int dto_stage_indices(const dto_problem* p, int which, int t, int64_t* out, int64_t* n);
+
+/* ---- the five MOI evaluator methods, one instance, HOST pointers --------------------------- */
+/* MOI.eval_objective (src/moi.jl:1-13) */
+int dto_eval_f(dto_problem* p, const double* x, double* f);
+/* MOI.eval_objective_gradient (src/moi.jl:15-30): g[num_variables] */
+int dto_eval_grad_f(dto_problem* p, const double* x, double* g);
+/* MOI.eval_constraint (src/moi.jl:32-50): c[num_constraint] */
+int dto_eval_g(dto_problem* p, const double* x, double* c);
+/* MOI.eval_constraint_jacobian (src/moi.jl:52-70): J[num_jacobian], order of dto_jacobian_structure */
+int dto_eval_jac_g(dto_problem* p, const double* x, double* J);
+/* MOI.eval_hessian_lagrangian (src/moi.jl:72-120): H[nnz_hess_key], order of dto_hessian_structure */
+int dto_eval_h(dto_problem* p, const double* x, double sigma, const double* mu, double* H);
+
+/* ---- batched forms: B independent instances, DEVICE pointers, asynchronous on `stream` -------
+ * x: [B][ldx] (ldx >= num_variables); outputs instance-major with the given leading dimension.
+ * params: NULL = the spec's parameters shared by all instances, else [B][ldp].
+ * These run the same kernels as above without the PCIe copies. `stream` is a hipStream_t. */
+typedef struct dto_batch {
+  int64_t B;
+  const double* x;      int64_t ldx;
+  const double* params; int64_t ldp;
+  void* stream;
+} dto_batch;
+int dto_eval_f_batch(dto_problem* p, const dto_batch* b, double* f /* [B] */);
+int dto_eval_grad_f_batch(dto_problem* p, const dto_batch* b, double* g, int64_t ldg);
+int dto_eval_g_batch(dto_problem* p, const dto_batch* b, double* c, int64_t ldc);
+int dto_eval_jac_g_batch(dto_problem* p, const dto_batch* b, double* J, int64_t ldj);
+/* sigma: host scalar applied to every instance; mu: [B][ldmu] */
+int dto_eval_h_batch(dto_problem* p, const dto_batch* b, double sigma, const double* mu, int64_t ldmu,
+                     double* H, int64_t ldh);
+
+/* device memory helpers so a host language without a HIP binding can stay on this ABI */
+int dto_device_alloc(void** ptr, int64_t bytes);
+int dto_device_free(void* ptr);
+int dto_copy_to_device(void* dst, const void* src, int64_t bytes);
+int dto_copy_to_host(void* dst, const void* src, int64_t bytes);
+int dto_device_synchronize(void);
+int dto_device_count(int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTO_H */
