@@ -1,0 +1,32 @@
+"""Build every model plugin the tests, smoke() and bench.py use, so they travel prebuilt to the GPU box."""
+from __future__ import annotations
+
+from . import problems as P
+from .plugin import Structure, build_plugin
+
+
+def all_structures():
+    out = []
+    for name, builder, kw in [
+        ("pendulum", P.build_pendulum, dict(T=6, evaluate_hessian=True)),
+        ("pendulum", P.build_pendulum, dict(T=2, evaluate_hessian=True)),
+        ("cartpole", P.build_cartpole, dict(T=5, evaluate_hessian=True)),
+        ("acrobot", P.build_acrobot, dict(T=5, evaluate_hessian=True)),
+        ("acrobot_bounds", P.build_acrobot, dict(T=4, evaluate_hessian=True, endpoint="bounds")),
+        ("car", P.build_car, dict(T=6, evaluate_hessian=True)),
+        ("car", P.build_car, dict(T=6, evaluate_hessian=False)),
+        ("ref_objective", P.build_ref_objective, {}),
+        ("ref_dynamics", P.build_ref_dynamics, {}),
+        ("ref_constraints", P.build_ref_constraints, {}),
+        ("ref_hesslag", P.build_ref_hesslag, {}),
+    ]:
+        p = builder(**kw)
+        out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], None, p["evaluate_hessian"])))
+    return out
+
+
+def build_all(verbose: bool = False):
+    paths = []
+    for name, st in all_structures():
+        paths.append(build_plugin(st, name, verbose=verbose))
+    return paths

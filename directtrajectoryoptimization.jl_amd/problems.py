@@ -243,3 +243,52 @@ def build_car(T=500, evaluate_hessian=False):
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [0.001 * rng.standard_normal(m) for _ in range(T - 1)]),
     )
+
+
+# ============================================================================= reference unit-test problems
+def build_ref_objective():
+    """test/objective.jl:1-20 (T = 3, n = 2, m = 1)."""
+    T, n, m = 3, 2, 1
+    ct = Cost(lambda x, u, w: dot(x, x) + 0.1 * dot(u, u), n, m)
+    cT = Cost(lambda x, u, w: 10.0 * dot(x, x), n, 0)
+    dyn = Dynamics(double_integrator, n, n, m)
+    return dict(dynamics=[dyn] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
+                bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], T=T, n=n, m=m, evaluate_hessian=False)
+
+
+def build_ref_dynamics():
+    """test/dynamics.jl:1-36 (pendulum, implicit Euler, T = 3)."""
+    T, n, m = 3, 2, 1
+    dt = Dynamics(euler_implicit_test, n, n, m)
+    ct = Cost(lambda x, u, w: dot(x, x), n, m)
+    cT = Cost(lambda x, u, w: dot(x, x), n, 0)
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
+                bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], T=T, n=n, m=m, evaluate_hessian=False)
+
+
+def build_ref_constraints():
+    """test/constraints.jl:1-28 (T = 5; ct = [-1 - x; x - 1] all rows inequality, cT = x)."""
+    T, n, m = 5, 2, 1
+    cont = Constraint(lambda x, u, w: np.concatenate([-np.ones(n) - x, x - np.ones(n)]), n, m,
+                      indices_inequality=list(range(1, 2 * n + 1)))
+    conT = Constraint(lambda x, u, w: x, n, 0)
+    dyn = Dynamics(double_integrator, n, n, m)
+    ct = Cost(lambda x, u, w: dot(x, x), n, m)
+    cT = Cost(lambda x, u, w: dot(x, x), n, 0)
+    return dict(dynamics=[dyn] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[cont] * (T - 1) + [conT],
+                bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], T=T, n=n, m=m, evaluate_hessian=False)
+
+
+def build_ref_hesslag():
+    """test/hessian_lagrangian.jl:97-128 (acrobot midpoint, T = 3, nonlinear stage constraints, exact Hessians)."""
+    T, n, m = 3, 4, 1
+    dt = Dynamics(acrobot_midpoint, n, n, m, evaluate_hessian=True)
+    objt = Cost(lambda x, u, w: 0.1 * dot(x[2:4], x[2:4]) + 0.1 * dot(u, u), n, m, evaluate_hessian=True)
+    objT = Cost(lambda x, u, w: 0.1 * dot(x[2:4], x[2:4]), n, 0, evaluate_hessian=True)
+    ctf = lambda x, u, w: np.concatenate([-5.0 * np.ones(m) - np.cos(u) * np.sum(x ** 2),
+                                          np.cos(x) * np.tan(u) - 5.0 * np.ones(n)])
+    cTf = lambda x, u, w: np.sin(x ** 3.0)
+    cont = Constraint(ctf, n, m, indices_inequality=list(range(1, m + n + 1)), evaluate_hessian=True)
+    conT = Constraint(cTf, n, 0, evaluate_hessian=True)
+    return dict(dynamics=[dt] * 2, objective=[objt, objt, objT], constraints=[cont, cont, conT],
+                bounds=[Bound(n, m)] * 2 + [Bound(n, 0)], T=T, n=n, m=m, evaluate_hessian=True)

@@ -395,31 +395,3 @@ def topo_order(roots: Iterable[Expr]) -> List[Expr]:
                     seen.add(node.id)
                     out.append(node)
     return out
-
-
-def evaluate(roots: Sequence[Expr], env: Dict[Tuple[str, int], float]) -> List[float]:
-    """Numeric evaluation with python floats (used by host-side tests only)."""
-    val: Dict[int, float] = {}
-    for n in topo_order(roots):
-        if n.op == CONST:
-            v = n.value
-        elif n.op == VAR:
-            v = env[(n.name, n.index)]
-        elif n.op == ADD:
-            v = val[n.args[0].id] + val[n.args[1].id]
-        elif n.op == SUB:
-            v = val[n.args[0].id] - val[n.args[1].id]
-        elif n.op == MUL:
-            v = val[n.args[0].id] * val[n.args[1].id]
-        elif n.op == DIV:
-            v = val[n.args[0].id] / val[n.args[1].id]
-        elif n.op == NEG:
-            v = -val[n.args[0].id]
-        elif n.op == POWI:
-            v = val[n.args[0].id] ** n.value
-        elif n.op == POW:
-            v = val[n.args[0].id] ** val[n.args[1].id]
-        else:
-            v = _FOLD[n.fn](val[n.args[0].id])
-        val[n.id] = v
-    return [val[r.id] for r in roots]
