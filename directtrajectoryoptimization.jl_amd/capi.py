@@ -46,6 +46,18 @@ class Batch(C.Structure):
                 ("ldp", C.c_int64), ("stream", C.c_void_p)]
 
 
+class COptions(C.Structure):
+    _fields_ = [("tol", C.c_double), ("s_max", C.c_double), ("max_iter", C.c_int), ("dual_inf_tol", C.c_double),
+                ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double), ("mu_init", C.c_double),
+                ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int)]
+
+
+# enum dto_scal (csrc/dto_kkt_kernels.hpp)
+SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
+           "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
+           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma"]
+
+
 class DtoError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
@@ -86,6 +98,16 @@ def lib() -> C.CDLL:
         "dto_eval_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
         "dto_eval_jac_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
         "dto_eval_h_batch": [vp, C.POINTER(Batch), C.c_double, vp, C.c_int64, vp, C.c_int64],
+        "dto_options_default": [C.POINTER(COptions)],
+        "dto_kkt_step_batch": [vp, C.POINTER(Batch), vp, C.c_int64, C.c_double, C.c_double, vp, C.c_int64, vp, C.c_int64,
+                               C.POINTER(C.c_int)],
+        "dto_solve_batch": [vp, C.POINTER(COptions), C.POINTER(Batch), vp, C.c_int64, vp, C.c_int64, c_int32_p, c_int32_p],
+        "dto_solver_begin": [vp, C.POINTER(COptions), C.POINTER(Batch)],
+        "dto_solver_iterate": [vp, C.c_int, vp],
+        "dto_solver_stats": [vp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p],
+        "dto_solver_end": [vp, vp, C.c_int64, vp, C.c_int64, vp],
+        "dto_solver_scalar": [vp, C.c_int, c_double_p],
+        "dto_solve": [vp, C.POINTER(COptions), c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p],
         "dto_device_alloc": [C.POINTER(vp), C.c_int64],
         "dto_device_free": [vp],
         "dto_copy_to_device": [vp, vp, C.c_int64],

@@ -1,14 +1,1192 @@
-// KKT assembly + block-tridiagonal LDL^T kernels (filled in by the KKT milestone).
+// KKT assembly, block-tridiagonal LDL^T factor/solve and the interior-point outer iteration,
+// hand-written for gfx950.  Everything here is work the reference leaves to Ipopt (external):
+// KKT assembly + symmetric indefinite factorisation + step acceptance.  The only in-tree trace of
+// the linear system is the scratch at reference examples/pendulum/pendulum.jl:138-198:
+//     K = [ H + delta_w I   C' ;  C   -delta_c I ],   rhs = [ grad L ; c ]
+// which is exactly the system solved here (stage-interleaved so that it is block tridiagonal,
+// SURVEY.md Appendix F).
+//
+// Data layout ("SoA tiles"): B problem instances are grouped in tiles of 64; every per-instance
+// vector v[N] is stored as v[tile][i][lane] so that lane = instance and each row i is one fully
+// coalesced 512-byte line.  A wavefront therefore owns one time step t of 64 instances
+// (k_stage_eval, k_linesearch) or the whole horizon chain of 64 instances (k_kkt): all lanes of a
+// wave see the same stage kind, so the compile-time kind dispatch is wave-uniform and the generated
+// expression code and the dense block algebra run entirely in VGPRs with literal indices.
+//
+// Stage blocks (kind K: NP = nx+nu primal, Q stage-constraint rows, NY = n_{t+1} dynamics rows):
+//     v_t = (p_t, nu_t, lam_t),  S_t = [ W+Sigma+dw I + [P_t]_xx   G'        F'      ]
+//                                      [ G                     -Dc        0       ]
+//                                      [ F                      0       -dc I     ]
+//     coupling to x_{t+1}:  O_t = [ V ; 0 ; E ]   (only the x columns of the next block are touched)
+// forward sweep:  S_t = L D L',  X = L^-1 O_t,  w = L^-1 y_t,
+//                 P_{t+1} = YY_t - X' D^-1 X,  y_{t+1}[x] -= X' D^-1 w
+// backward sweep: v_t = L^-T D^-1 (w - X x_{t+1}).
+// Inertia: the negative pivots of all stage factorisations are counted (Sylvester's law: the count is
+// the number of negative eigenvalues of K).  K is accepted when the count equals the number of
+// constraint rows and no pivot is tiny; otherwise delta_w is raised (Ipopt's schedule) and the sweep
+// is repeated inside the kernel.  This is Ipopt's inertia criterion (reduced Hessian positive
+// definite), not the stricter quasi-definiteness of W + delta_w I.
 #pragma once
+
 #include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "dto_eval_kernels.hpp"
 #include "dto_model_plugin.h"
 
-struct dto_kkt_args { int op; };
-struct dto_kkt_info { int supported; };
+// ---- ops --------------------------------------------------------------------------------------
+enum dto_kkt_op {
+  DTO_KKT_PACK = 0,        // instance-major z (and lam) -> SoA tiles
+  DTO_KKT_UNPACK = 1,      // SoA tiles -> instance-major
+  DTO_KKT_INIT = 2,        // bound push, slack and multiplier initialisation, scalar state
+  DTO_KKT_EVAL = 3,        // per-stage derivative blocks + residual partials
+  DTO_KKT_CONV = 4,        // reduce partials, convergence test, barrier update
+  DTO_KKT_FACTOR_SOLVE = 5,  // block-tridiagonal LDL^T + solve + step bounds + merit derivative
+  DTO_KKT_LINESEARCH = 6,  // merit partials of the trial step sizes
+  DTO_KKT_LS_REDUCE = 7,   // pick the step size
+  DTO_KKT_UPDATE = 8,      // take the step
+  DTO_KKT_OP_COUNT
+};
+
+// per-instance scalar slots (SoA rows of `scal`)
+enum dto_scal {
+  SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed
+  SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
+  SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
+  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA,
+  SC_COUNT
+};
+
+constexpr int DTO_NPART = 9;    // per-stage residual partials written by k_stage_eval
+constexpr int DTO_LS_TRIALS = 8;
+constexpr int DTO_FILTER_CAP = 24;  // filter entries kept per instance (ring)
+
+struct dto_kkt_info {
+  int supported;
+  int n_kind;
+  int rec_size[16];   // doubles per stage record, by kind
+  int fac_size[16];   // doubles per stage factor record, by kind
+  int n_ineq[16];     // inequality rows (slacks) by kind
+  int npart, nscal, ls_trials, filter_cap;
+};
+
+struct dto_solver_opts {
+  double tol, s_max, dual_inf_tol, constr_viol_tol, compl_inf_tol;
+  int max_iter;
+  double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
+  double delta_c, delta_w_init, delta_w_min, delta_w_max, kappa_w_minus, kappa_w_plus, kappa_w_plus_first;
+  double delta_w_exact_cap;  // largest delta_w tried with the exact Hessian before the Gauss-Newton fallback
+  double eta_armijo, rho_penalty, piv_tol;
+  int max_refactor;
+  int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (test entry dto_kkt_step)
+  double fixed_delta_w;
+};
+
+struct dto_kkt_args {
+  int T;
+  int64_t B;
+  int G;  // tiles of 64 instances
+  int64_t Nz, Nc, Ni;
+  int64_t n_mult, n_bnd;  // multiplier / bound-multiplier counts for Ipopt's error scaling
+  const int* kind; const int* zoff; const int* woff; const int* cdoff; const int* ccoff;
+  const int* ioff;    // [T+1] slack offsets
+  const int64_t* recoff;  // [T+1] record offsets (doubles per lane)
+  const int64_t* facoff;  // [T+1]
+  int64_t rec_total, fac_total;
+  const double* lo; const double* hi;  // [Nz] shared variable bounds
+  const double* params;                // shared parameters
+  // SoA state, doubles
+  double* z; double* lam; double* zl; double* zu; double* s; double* zs;
+  double* dz; double* dlam; double* ds;
+  double* rec; double* fac; double* part; double* lspart; double* scal;
+  double* filt;  // [G][2*DTO_FILTER_CAP][64] filter entries (theta, phi)
+  // instance-major mirrors for pack/unpack
+  const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
+  dto_solver_opts opt;
+};
 
 namespace dto {
+
+// index helpers -----------------------------------------------------------------------------------
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+
+__device__ __forceinline__ double* soa(double* base, int64_t tile, int64_t n, int64_t i) {
+  return base + ((tile * n + i) << 6) + threadIdx.x;
+}
+__device__ __forceinline__ const double* soa(const double* base, int64_t tile, int64_t n, int64_t i) {
+  return base + ((tile * n + i) << 6) + threadIdx.x;
+}
+
+template <class M, int K>
+struct KindDims {
+  using KD = typename M::template Kind<K>;
+  using C = typename M::template Cost<KD::COST>;
+  static constexpr int NX = C::NX, NU = C::NU, NP = NX + NU;
+  static constexpr int Q = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NC; else return 0; }();
+  static constexpr int QI = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NI; else return 0; }();
+  static constexpr int NY = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NY; else return 0; }();
+  static constexpr int BD = NP + Q + NY;
+  // record layout
+  static constexpr int R_W = 0;                          // sigma * objective Hessian (packed lower)
+  static constexpr int R_WD = R_W + NP * (NP + 1) / 2;   // curvature of lam'd + nu'c, pp block (packed lower)
+  static constexpr int R_V = R_WD + NP * (NP + 1) / 2;
+  static constexpr int R_YY = R_V + NP * NY;
+  static constexpr int R_F = R_YY + NY * (NY + 1) / 2;
+  static constexpr int R_E = R_F + NY * NP;
+  static constexpr int R_G = R_E + NY * NY;
+  static constexpr int R_RP = R_G + Q * NP;
+  static constexpr int R_D = R_RP + NP;
+  static constexpr int R_C = R_D + NY;
+  static constexpr int REC = R_C + Q;
+  // factor layout
+  static constexpr int F_L = 0;                       // strict lower, row-major packed: (i,j) at i(i-1)/2 + j
+  static constexpr int F_DI = F_L + BD * (BD - 1) / 2;  // 1/d_i
+  static constexpr int F_X = F_DI + BD;               // BD x NY
+  static constexpr int F_W = F_X + BD * NY;           // BD
+  static constexpr int FAC = F_W + BD;
+  __host__ __device__ static constexpr bool ineq(int j) {
+    if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::ineq(j); else return false;
+  }
+  __host__ __device__ static constexpr int slack(int j) {
+    if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::slack(j); else return -1;
+  }
+};
+
+template <class M, int K = 0>
+void fill_info(dto_kkt_info* o) {
+  if constexpr (K < M::N_KIND) {
+    using D = KindDims<M, K>;
+    o->rec_size[K] = D::REC;
+    o->fac_size[K] = D::FAC;
+    o->n_ineq[K] = D::QI;
+    fill_info<M, K + 1>(o);
+  }
+}
+
 template <class M>
-int launch_kkt(int, const dto_kkt_args*, void*) { return -1; }
+int kkt_info(dto_kkt_info* out) {
+  out->supported = (M::EVALUATE_HESSIAN != 0 && M::N_KIND <= 16 && !M::HAS_GENERAL) ? 1 : 0;
+  out->n_kind = M::N_KIND;
+  for (int i = 0; i < 16; ++i) out->rec_size[i] = out->fac_size[i] = out->n_ineq[i] = 0;
+  fill_info<M>(out);
+  out->npart = DTO_NPART;
+  out->nscal = SC_COUNT;
+  out->ls_trials = DTO_LS_TRIALS;
+  out->filter_cap = DTO_FILTER_CAP;
+  return 0;
+}
+
+// wave-uniform kind dispatch (all lanes of a tile are at the same stage)
+template <class M, int K = 0, class F>
+__device__ __forceinline__ void dispatch_uniform(int kind, F&& f) {
+  if constexpr (K < M::N_KIND) {
+    if (kind == K) f(std::integral_constant<int, K>{});
+    else dispatch_uniform<M, K + 1>(kind, static_cast<F&&>(f));
+  }
+}
+
+__device__ __forceinline__ bool finite_lo(double v) { return v > -1e300; }
+__device__ __forceinline__ bool finite_hi(double v) { return v < 1e300; }
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack between the C-ABI's instance-major buffers and SoA tiles
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, double* dst) {
+  // grid: (ceil(n/4), G); block 256 = 4 rows x 64 lanes
+  const int64_t tile = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t inst = tile * 64 + lane;
+  if (i >= n) return;
+  double v = 0.0;
+  if (inst < a.B) v = a.aos_in[inst * a.ld_aos + i];
+  dst[((tile * n + i) << 6) + lane] = v;
+}
+
+static __global__ __launch_bounds__(256) void k_unpack(dto_kkt_args a, int64_t n, const double* src) {
+  const int64_t tile = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t inst = tile * 64 + lane;
+  if (i >= n || inst >= a.B) return;
+  a.aos_out[inst * a.ld_aos + i] = src[((tile * n + i) << 6) + lane];
+}
+
+// ------------------------------------------------------------------------------------------------
+// initialisation (Ipopt-style): push the guess into the bounds, slacks from the inequality values,
+// multipliers on the central path of mu_init
+// ------------------------------------------------------------------------------------------------
 template <class M>
-int kkt_info(dto_kkt_info* out) { out->supported = 0; return 0; }
+__global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const dto_solver_opts& o = a.opt;
+  const double mu0 = o.mu_init;
+  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    using KD = typename D::KD;
+    const int z0 = a.zoff[t];
+    arr<D::NP> p;
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      double v = *soa(a.z, g, a.Nz, z0 + i);
+      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      double zl = 0.0, zu = 0.0;
+      if (!o.newton_only) {
+        if (lo == hi) {
+          v = lo;
+        } else {
+          const bool fl = finite_lo(lo), fh = finite_hi(hi);
+          if (fl && fh) {
+            const double pl = fmin(o.bound_push * fmax(1.0, fabs(lo)), o.bound_frac * (hi - lo));
+            const double pu = fmin(o.bound_push * fmax(1.0, fabs(hi)), o.bound_frac * (hi - lo));
+            v = fmin(fmax(v, lo + pl), hi - pu);
+          } else if (fl) {
+            v = fmax(v, lo + o.bound_push * fmax(1.0, fabs(lo)));
+          } else if (fh) {
+            v = fmin(v, hi - o.bound_push * fmax(1.0, fabs(hi)));
+          }
+          if (fl) zl = mu0 / (v - lo);
+          if (fh) zu = mu0 / (hi - v);
+        }
+      }
+      p[i] = v;
+      *soa(a.z, g, a.Nz, z0 + i) = v;
+      *soa(a.zl, g, a.Nz, z0 + i) = zl;
+      *soa(a.zu, g, a.Nz, z0 + i) = zu;
+    }
+    // multipliers: lam = 0; inequality rows: slack from c(z), nu = zs = mu0 / s
+    // (newton_only keeps the caller's multipliers: dto_kkt_step evaluates at a given (z, lam))
+    if constexpr (KD::DYN >= 0) {
+      if (!o.newton_only) {
+#pragma unroll
+        for (int i = 0; i < D::NY; ++i) *soa(a.lam, g, a.Nc, a.cdoff[t] + i) = 0.0;
+      }
+    }
+    if constexpr (KD::CON >= 0) {
+      if (!o.newton_only) {
+      using C = typename M::template Con<KD::CON>;
+      arr<C::NW> w; arr<C::NC> c;
+      gmem_load(w, a.params + a.woff[t]);
+      C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
+#pragma unroll
+      for (int j = 0; j < C::NC; ++j) {
+        double nu = 0.0;
+        if (!o.newton_only && D::ineq(j)) {
+          const double sv = fmax(-c[j], o.bound_push * fmax(1.0, fabs(c[j])));
+          nu = mu0 / sv;
+          *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) = sv;
+          *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = nu;
+        }
+        *soa(a.lam, g, a.Nc, a.ccoff[t] + j) = nu;
+      }
+      }
+    }
+  });
+  if (t == 0) {
+    *soa(a.scal, g, SC_COUNT, SC_STATUS) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_ITER) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_MU) = o.newton_only ? 0.0 : o.mu_init;
+    *soa(a.scal, g, SC_COUNT, SC_PENALTY) = 1.0;
+    *soa(a.scal, g, SC_COUNT, SC_DELTA_W) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_DELTA_LAST) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_LS_FAIL) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_NFACT) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_ALPHA) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_THETA_MAX) = -1.0;  // set from theta_0 at the first convergence check
+    *soa(a.scal, g, SC_COUNT, SC_THETA_MIN) = -1.0;
+    *soa(a.scal, g, SC_COUNT, SC_FILTER_N) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_LS_KIND) = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-stage derivative blocks.  grid = G*T waves; wave = (tile, stage); lane = instance.
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const dto_solver_opts& o = a.opt;
+  if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;  // finished instance: its record stays frozen
+  const double mu = *soa(a.scal, g, SC_COUNT, SC_MU);
+  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    using KD = typename D::KD;
+    using CO = typename M::template Cost<KD::COST>;
+    const int z0 = a.zoff[t];
+    double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+    auto put = [&](int e, double v) { rec[(int64_t)e << 6] = v; };
+
+    arr<D::NP> p;
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) p[i] = *soa(a.z, g, a.Nz, z0 + i);
+    arr<CO::NW> wc;
+    gmem_load(wc, a.params + a.woff[t]);
+
+    arr<D::NP*(D::NP + 1) / 2> W, WD;
+#pragma unroll
+    for (int i = 0; i < D::NP * (D::NP + 1) / 2; ++i) W[i] = WD[i] = 0.0;
+    arr<D::NP> rp;
+    double cost_val;
+    {
+      double o1[1];
+      CO::eval(p.data(), p.data() + CO::NX, wc.data(), o1);
+      cost_val = o1[0];
+      CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
+      if constexpr (CO::NH > 0) {
+        arr<CO::NH> hv;
+        CO::hess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
+        CO::scatter_hess(hv.data(), W.data());
+      }
+    }
+    double th1 = 0.0, thinf = 0.0, sumlam = 0.0;
+
+    if constexpr (KD::DYN >= 0) {
+      using DY = typename M::template Dyn<KD::DYN>;
+      arr<DY::NY> y, lam, d;
+      arr<DY::NW> w;
+      gmem_load(w, a.params + a.woff[t]);
+#pragma unroll
+      for (int i = 0; i < DY::NY; ++i) {
+        y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
+        lam[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
+      }
+      DY::eval(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data());
+      arr<DY::NJ> jv;
+      DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jv.data());
+      arr<DY::NY * D::NP> F;
+      arr<DY::NY * DY::NY> E;
+#pragma unroll
+      for (int i = 0; i < DY::NY * D::NP; ++i) F[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < DY::NY * DY::NY; ++i) E[i] = 0.0;
+      DY::scatter_jac(jv.data(), F.data(), E.data());
+      DY::jtlam(jv.data(), lam.data(), rp.data());
+      arr<D::NP * DY::NY> V;
+      arr<DY::NY*(DY::NY + 1) / 2> YY;
+#pragma unroll
+      for (int i = 0; i < D::NP * DY::NY; ++i) V[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < DY::NY * (DY::NY + 1) / 2; ++i) YY[i] = 0.0;
+      if constexpr (DY::NH > 0) {
+        arr<DY::NH> hv;
+        DY::hess(p.data(), p.data() + DY::NX, y.data(), w.data(), lam.data(), hv.data());
+        DY::scatter_hess(hv.data(), WD.data(), V.data(), YY.data());
+      }
+#pragma unroll
+      for (int i = 0; i < D::NP * DY::NY; ++i) put(D::R_V + i, V[i]);
+#pragma unroll
+      for (int i = 0; i < DY::NY * (DY::NY + 1) / 2; ++i) put(D::R_YY + i, YY[i]);
+#pragma unroll
+      for (int i = 0; i < DY::NY * D::NP; ++i) put(D::R_F + i, F[i]);
+#pragma unroll
+      for (int i = 0; i < DY::NY * DY::NY; ++i) put(D::R_E + i, E[i]);
+#pragma unroll
+      for (int i = 0; i < DY::NY; ++i) {
+        put(D::R_D + i, d[i]);
+        th1 += fabs(d[i]);
+        thinf = fmax(thinf, fabs(d[i]));
+        sumlam += fabs(lam[i]);
+      }
+    }
+    double dinf = 0.0, compl0 = 0.0, complmu = 0.0, sumz = 0.0, logbar = 0.0;
+    if constexpr (KD::CON >= 0) {
+      using C = typename M::template Con<KD::CON>;
+      arr<C::NW> w; arr<C::NC> c, nu; arr<C::NJ> jv;
+      gmem_load(w, a.params + a.woff[t]);
+#pragma unroll
+      for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+      C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
+      C::jac(p.data(), p.data() + C::NX, w.data(), jv.data());
+      arr<C::NC * D::NP> G;
+#pragma unroll
+      for (int i = 0; i < C::NC * D::NP; ++i) G[i] = 0.0;
+      C::scatter_jac(jv.data(), G.data());
+      C::jtlam(jv.data(), nu.data(), rp.data());
+      if constexpr (C::NH > 0) {
+        arr<C::NH> hv;
+        C::hess(p.data(), p.data() + C::NX, w.data(), nu.data(), hv.data());
+        C::scatter_hess(hv.data(), WD.data());
+      }
+#pragma unroll
+      for (int i = 0; i < C::NC * D::NP; ++i) put(D::R_G + i, G[i]);
+#pragma unroll
+      for (int j = 0; j < C::NC; ++j) {
+        double r = c[j];
+        if (!o.newton_only && D::ineq(j)) {
+          const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
+          const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+          r = c[j] + sv;
+          dinf = fmax(dinf, fabs(nu[j] - zv));
+          compl0 = fmax(compl0, sv * zv);
+          complmu = fmax(complmu, fabs(sv * zv - mu));
+          sumz += fabs(zv);
+          logbar += log(sv);
+        }
+        put(D::R_C + j, r);
+        th1 += fabs(r);
+        thinf = fmax(thinf, fabs(r));
+        sumlam += fabs(nu[j]);
+      }
+    }
+    // E_{t-1}' lam_{t-1}: re-evaluate the previous stage's Jacobian (cheaper than a carry pass)
+    if constexpr (KD::PREV >= 0) {
+      using DP = typename M::template Dyn<KD::PREV>;
+      arr<DP::NX + DP::NU> pp; arr<DP::NY> lamp; arr<DP::NW> w; arr<DP::NJ> jv;
+      gmem_load(w, a.params + a.woff[t - 1]);
+#pragma unroll
+      for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = *soa(a.z, g, a.Nz, a.zoff[t - 1] + i);
+#pragma unroll
+      for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, a.cdoff[t - 1] + i);
+      DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
+      DP::etlam(jv.data(), lamp.data(), rp.data());
+    }
+#pragma unroll
+    for (int i = 0; i < D::NP * (D::NP + 1) / 2; ++i) {
+      put(D::R_W + i, W[i]);
+      put(D::R_WD + i, WD[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      put(D::R_RP + i, rp[i]);
+      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      if (o.newton_only) {
+        dinf = fmax(dinf, fabs(rp[i]));
+      } else if (lo != hi) {
+        const double zl = *soa(a.zl, g, a.Nz, z0 + i), zu = *soa(a.zu, g, a.Nz, z0 + i);
+        dinf = fmax(dinf, fabs(rp[i] - zl + zu));
+        if (finite_lo(lo)) {
+          compl0 = fmax(compl0, (p[i] - lo) * zl);
+          complmu = fmax(complmu, fabs((p[i] - lo) * zl - mu));
+          sumz += fabs(zl);
+          logbar += log(p[i] - lo);
+        }
+        if (finite_hi(hi)) {
+          compl0 = fmax(compl0, (hi - p[i]) * zu);
+          complmu = fmax(complmu, fabs((hi - p[i]) * zu - mu));
+          sumz += fabs(zu);
+          logbar += log(hi - p[i]);
+        }
+      }
+    }
+    double* part = a.part + (((g * a.T + t) * DTO_NPART) << 6) + threadIdx.x;
+    part[0 << 6] = cost_val;
+    part[1 << 6] = th1;
+    part[2 << 6] = thinf;
+    part[3 << 6] = dinf;
+    part[4 << 6] = compl0;
+    part[5 << 6] = complmu;
+    part[6 << 6] = sumlam;
+    part[7 << 6] = sumz;
+    part[8 << 6] = logbar;
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce the stage partials in stage order (deterministic), test convergence, update mu.
+// grid = G waves.
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_mult, int64_t n_bnd) {
+  const int64_t g = blockIdx.x;
+  const dto_solver_opts& o = a.opt;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  double f = 0, th1 = 0, thinf = 0, dinf = 0, c0 = 0, cmu = 0, slam = 0, sz = 0, lb = 0;
+  for (int t = 0; t < a.T; ++t) {
+    const double* part = a.part + (((g * a.T + t) * DTO_NPART) << 6) + threadIdx.x;
+    f += part[0 << 6];
+    th1 += part[1 << 6];
+    thinf = fmax(thinf, part[2 << 6]);
+    dinf = fmax(dinf, part[3 << 6]);
+    c0 = fmax(c0, part[4 << 6]);
+    cmu = fmax(cmu, part[5 << 6]);
+    slam += part[6 << 6];
+    sz += part[7 << 6];
+    lb += part[8 << 6];
+  }
+  double mu = sc[SC_MU << 6];
+  const double sd = fmax(o.s_max, (slam + sz) / (double)(n_mult + n_bnd > 0 ? n_mult + n_bnd : 1)) / o.s_max;
+  const double scn = fmax(o.s_max, sz / (double)(n_bnd > 0 ? n_bnd : 1)) / o.s_max;
+  const double e0 = fmax(fmax(dinf / sd, thinf), c0 / scn);
+  const double emu = fmax(fmax(dinf / sd, thinf), cmu / scn);
+  sc[SC_F << 6] = f;
+  sc[SC_THETA1 << 6] = th1;
+  sc[SC_THETA_INF << 6] = thinf;
+  sc[SC_DINF << 6] = dinf;
+  sc[SC_COMPL << 6] = c0;
+  sc[SC_E0 << 6] = e0;
+  sc[SC_LOGBAR << 6] = lb;
+  const double iter = sc[SC_ITER << 6];
+  const bool nonfinite = !(f == f) || !(th1 == th1) || !(dinf == dinf) || fabs(f) > 1e300 || th1 > 1e300;
+  if (nonfinite) {
+    sc[SC_STATUS << 6] = 3.0;
+  } else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) {
+    sc[SC_STATUS << 6] = 1.0;
+  } else if (iter >= (double)o.max_iter) {
+    sc[SC_STATUS << 6] = 2.0;
+  } else if (n_bnd > 0 && emu <= o.kappa_eps * mu) {
+    mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    sc[SC_MU << 6] = mu;
+    sc[SC_FILTER_N << 6] = 0.0;  // new barrier problem: the filter is reset (Ipopt, step A-3)
+  }
+  if (sc[SC_THETA_MAX << 6] < 0.0) {
+    sc[SC_THETA_MAX << 6] = 1e4 * fmax(1.0, th1);
+    sc[SC_THETA_MIN << 6] = 1e-4 * fmax(1.0, th1);
+  }
+  // merit value of the current iterate with the (possibly updated) barrier parameter
+  sc[SC_MERIT0 << 6] = f - mu * lb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense block helpers (all indices are literals after unrolling)
+// ------------------------------------------------------------------------------------------------
+template <int BD>
+__device__ __forceinline__ void ldl_inplace(double* S, double* dinv, double piv_tol, bool& ok, int& nneg) {
+  // right-looking LDL^T on the packed lower triangle, static order, no pivoting; L overwrites the strict
+  // lower part.  Negative pivots are counted (Sylvester: their total over the whole block-tridiagonal
+  // factorisation is the number of negative eigenvalues of K); a pivot that is tiny relative to its
+  // column marks the factorisation as unusable so that the caller raises delta_w.
+#pragma unroll
+  for (int j = 0; j < BD; ++j) {
+    double dj = S[tri(j, j)];
+    double cmax = 0.0;
+#pragma unroll
+    for (int i = j + 1; i < BD; ++i) cmax = fmax(cmax, fabs(S[tri(i, j)]));
+    if (!(fabs(dj) > piv_tol * fmax(1.0, cmax))) {
+      ok = false;
+      dj = (dj < 0.0 ? -1.0 : 1.0) * fmax(fabs(dj), piv_tol);
+    }
+    if (dj < 0.0) ++nneg;
+    const double inv = 1.0 / dj;
+    dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < BD; ++i) {
+      const double lij = S[tri(i, j)] * inv;
+#pragma unroll
+      for (int k = j + 1; k <= i; ++k) S[tri(i, k)] -= lij * S[tri(k, j)];
+    }
+#pragma unroll
+    for (int i = j + 1; i < BD; ++i) S[tri(i, j)] *= inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-tridiagonal factor + solve over the whole horizon of one tile.  grid = G waves.
+// ------------------------------------------------------------------------------------------------
+template <class M>
+struct Carry {
+  double P[M::MAX_NX * (M::MAX_NX + 1) / 2];  // cost-to-arrive Schur complement on x_t (packed lower)
+  double py[M::MAX_NX];                        // rhs carry
+};
+
+template <class M, int K>
+__device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
+                                              double gam, Carry<M>& cy, bool& ok, int& nneg) {
+  using D = KindDims<M, K>;
+  constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
+  const dto_solver_opts& o = a.opt;
+  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+  double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
+  auto R = [&](int e) { return rec[(int64_t)e << 6]; };
+  const int z0 = a.zoff[t];
+
+  double S[BD * (BD + 1) / 2];
+  double y[BD];
+  // --- primal block
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) S[tri(i, j)] = R(D::R_W + tri(i, j)) + gam * R(D::R_WD + tri(i, j));
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) S[tri(i, j)] += cy.P[tri(i, j)];
+  }
+  bool fixed[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double rp = R(D::R_RP + i);
+    double sig = dw;
+    fixed[i] = false;
+    if (!o.newton_only) {
+      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      if (lo == hi) {
+        fixed[i] = true;
+      } else {
+        const double p = *soa(a.z, g, a.Nz, z0 + i);
+        if (finite_lo(lo)) {
+          const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+          sig += zl / (p - lo);
+          rp -= mu / (p - lo);
+        }
+        if (finite_hi(hi)) {
+          const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+          sig += zu / (hi - p);
+          rp += mu / (hi - p);
+        }
+      }
+    }
+    S[tri(i, i)] += sig;
+    y[i] = -rp - (i < NX ? cy.py[i] : 0.0);
+  }
+  // --- stage-constraint rows
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) S[tri(NP + j, i)] = R(D::R_G + j * NP + i);
+#pragma unroll
+    for (int k = 0; k < j; ++k) S[tri(NP + j, NP + k)] = 0.0;
+    double dc = o.delta_c;
+    double r = R(D::R_C + j);
+    if (!o.newton_only && D::ineq(j)) {
+      const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
+      const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+      const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+      dc += sv / zv;
+      r -= (sv / zv) * (nu - mu / sv);
+    }
+    S[tri(NP + j, NP + j)] = -dc;
+    y[NP + j] = -r;
+  }
+  // --- dynamics rows
+#pragma unroll
+  for (int k = 0; k < NY; ++k) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) S[tri(NP + Q + k, i)] = R(D::R_F + k * NP + i);
+#pragma unroll
+    for (int j = 0; j < Q + k; ++j) S[tri(NP + Q + k, NP + j)] = 0.0;
+    S[tri(NP + Q + k, NP + Q + k)] = -o.delta_c;
+    y[NP + Q + k] = -R(D::R_D + k);
+  }
+  // --- coupling O = [V; 0; E]
+  double X[BD * (NY > 0 ? NY : 1)];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+#pragma unroll
+    for (int c = 0; c < NY; ++c) X[i * NY + c] = gam * R(D::R_V + i * NY + c);
+  }
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+#pragma unroll
+    for (int c = 0; c < NY; ++c) X[(NP + j) * NY + c] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < NY; ++k) {
+#pragma unroll
+    for (int c = 0; c < NY; ++c) X[(NP + Q + k) * NY + c] = R(D::R_E + k * NY + c);
+  }
+  // --- fixed variables: identity rows/columns
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (fixed[i]) {
+#pragma unroll
+      for (int r2 = 0; r2 < BD; ++r2) {
+        if (r2 > i) S[tri(r2, i)] = 0.0;
+        if (r2 < i) S[tri(i, r2)] = 0.0;
+      }
+      S[tri(i, i)] = 1.0;
+      y[i] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NY; ++c) X[i * NY + c] = 0.0;
+    }
+  }
+  // --- factor
+  double dinv[BD];
+  ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
+  // --- X = L^-1 O, w = L^-1 y
+#pragma unroll
+  for (int i = 1; i < BD; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) {
+      const double l = S[tri(i, k)];
+#pragma unroll
+      for (int c = 0; c < NY; ++c) X[i * NY + c] -= l * X[k * NY + c];
+      y[i] -= l * y[k];
+    }
+  }
+  // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w
+#pragma unroll
+  for (int c = 0; c < NY; ++c) {
+#pragma unroll
+    for (int e = 0; e <= c; ++e) {
+      double acc = gam * R(D::R_YY + tri(c, e));
+#pragma unroll
+      for (int i = 0; i < BD; ++i) acc -= X[i * NY + c] * X[i * NY + e] * dinv[i];
+      cy.P[tri(c, e)] = acc;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < BD; ++i) acc += X[i * NY + c] * dinv[i] * y[i];
+    cy.py[c] = acc;
+  }
+  // --- store factors
+#pragma unroll
+  for (int i = 1; i < BD; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) fac[(int64_t)(D::F_L + i * (i - 1) / 2 + k) << 6] = S[tri(i, k)];
+  }
+#pragma unroll
+  for (int i = 0; i < BD; ++i) {
+    fac[(int64_t)(D::F_DI + i) << 6] = dinv[i];
+    fac[(int64_t)(D::F_W + i) << 6] = y[i];
+#pragma unroll
+    for (int c = 0; c < NY; ++c) fac[(int64_t)(D::F_X + i * NY + c) << 6] = X[i * NY + c];
+  }
+}
+
+struct StepAcc {
+  double apmax, admax, gphid, rlam;
+};
+
+template <class M, int K>
+__device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
+                                               double* xn, StepAcc& acc) {
+  using D = KindDims<M, K>;
+  constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
+  const dto_solver_opts& o = a.opt;
+  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+  const double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
+  auto R = [&](int e) { return rec[(int64_t)e << 6]; };
+  auto Fv = [&](int e) { return fac[(int64_t)e << 6]; };
+  double v[BD];
+#pragma unroll
+  for (int i = 0; i < BD; ++i) {
+    double r = Fv(D::F_W + i);
+#pragma unroll
+    for (int c = 0; c < NY; ++c) r -= Fv(D::F_X + i * NY + c) * xn[c];
+    v[i] = r * Fv(D::F_DI + i);
+  }
+#pragma unroll
+  for (int i = BD - 1; i >= 1; --i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) v[k] -= Fv(D::F_L + i * (i - 1) / 2 + k) * v[i];
+  }
+  const int z0 = a.zoff[t];
+  // primal step, fraction to the boundary, barrier directional derivative
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double dp = v[i];
+    *soa(a.dz, g, a.Nz, z0 + i) = dp;
+    acc.gphid += R(D::R_RP + i) * dp;
+    if (!o.newton_only) {
+      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      if (lo != hi) {
+        const double p = *soa(a.z, g, a.Nz, z0 + i);
+        if (finite_lo(lo)) {
+          const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+          const double gap = p - lo;
+          const double dzl = mu / gap - zl - (zl / gap) * dp;
+          if (dp < 0.0) acc.apmax = fmin(acc.apmax, -tau * gap / dp);
+          if (dzl < 0.0) acc.admax = fmin(acc.admax, -tau * zl / dzl);
+          acc.gphid -= mu / gap * dp;
+        }
+        if (finite_hi(hi)) {
+          const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+          const double gap = hi - p;
+          const double dzu = mu / gap - zu + (zu / gap) * dp;
+          if (dp > 0.0) acc.apmax = fmin(acc.apmax, tau * gap / dp);
+          if (dzu < 0.0) acc.admax = fmin(acc.admax, -tau * zu / dzu);
+          acc.gphid += mu / gap * dp;
+        }
+      }
+    }
+  }
+  // constraint multipliers; grad f' dp = rp' dp + sum lam_j (r_j - dc dlam_j [+ ds_j])
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const double dnu = v[NP + j];
+    const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+    const double r = R(D::R_C + j);
+    *soa(a.dlam, g, a.Nc, a.ccoff[t] + j) = dnu;
+    double dsv = 0.0;
+    if (!o.newton_only && D::ineq(j)) {
+      const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
+      const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+      dsv = -(sv / zv) * (nu - mu / sv + dnu);
+      const double dzs = mu / sv - zv - (zv / sv) * dsv;
+      *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j)) = dsv;
+      if (dsv < 0.0) acc.apmax = fmin(acc.apmax, -tau * sv / dsv);
+      if (dzs < 0.0) acc.admax = fmin(acc.admax, -tau * zv / dzs);
+      acc.gphid -= mu / sv * dsv;
+    }
+    acc.gphid += nu * (r - o.delta_c * dnu + dsv);
+    acc.rlam += r * (nu + dnu);
+  }
+#pragma unroll
+  for (int k = 0; k < NY; ++k) {
+    const double dl = v[NP + Q + k];
+    const double lam = *soa(a.lam, g, a.Nc, a.cdoff[t] + k);
+    const double r = R(D::R_D + k);
+    *soa(a.dlam, g, a.Nc, a.cdoff[t] + k) = dl;
+    acc.gphid += lam * (r - o.delta_c * dl);
+    acc.rlam += r * (lam + dl);
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xn[i] = v[i];
+}
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  const dto_solver_opts& o = a.opt;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  const bool running = sc[SC_STATUS << 6] == 0.0;
+  if (__all(!running)) return;
+  const double mu = sc[SC_MU << 6];
+  const double dlast = sc[SC_DELTA_LAST << 6];
+  double dw;
+  if (o.newton_only) {
+    dw = o.fixed_delta_w;
+  } else {
+    dw = 0.0;  // Ipopt's Algorithm IC: always try the unmodified matrix first
+    if (sc[SC_LS_FAIL << 6] != 0.0) dw = fmax(10.0 * dlast, o.delta_w_init);
+  }
+  int nfact = 0;
+  bool ok = true;
+  double gam = 1.0;  // 1: exact Hessian of the Lagrangian, 0: Gauss-Newton (constraint curvature dropped)
+  for (int attempt = 0; attempt <= o.max_refactor; ++attempt) {
+    Carry<M> cy;
+#pragma unroll
+    for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = 0.0;
+    ok = true;
+    int nneg = 0;
+    for (int t = 0; t < a.T; ++t) {
+      dispatch_uniform<M>(a.kind[t], [&](auto kc) { stage_forward<M, decltype(kc)::value>(a, g, t, mu, dw, gam, cy, ok, nneg); });
+    }
+    // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
+    if (nneg != (int)a.Nc) ok = false;
+    ++nfact;
+    const bool need = running && !ok && !o.newton_only;
+    if (!__any(need)) break;
+    if (need) {
+      if (gam != 0.0) {
+        // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
+        // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
+        // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
+        const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
+        if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+        else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
+        if (skip_ladder || dw > o.delta_w_exact_cap) {
+          gam = 0.0;
+          dw = o.delta_w_init;
+        }
+      } else {
+        dw *= o.kappa_w_plus;
+        if (dw > o.delta_w_max) dw = o.delta_w_max;
+      }
+    }
+  }
+  // backward sweep
+  const double tau = fmax(o.tau_min, 1.0 - mu);
+  StepAcc acc{1.0, 1.0, 0.0, 0.0};
+  double xn[M::MAX_NX];
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX; ++i) xn[i] = 0.0;
+  for (int t = a.T - 1; t >= 0; --t) {
+    dispatch_uniform<M>(a.kind[t], [&](auto kc) { stage_backward<M, decltype(kc)::value>(a, g, t, mu, tau, xn, acc); });
+  }
+  if (!running) return;
+  // directional derivative of the barrier objective along the step (filter line search, switching condition)
+  sc[SC_DMERIT << 6] = acc.gphid;
+  sc[SC_ALPHA_PMAX << 6] = acc.apmax;
+  sc[SC_ALPHA_DMAX << 6] = acc.admax;
+  sc[SC_DELTA_W << 6] = dw;
+  sc[SC_GAMMA << 6] = gam;
+  if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
+  if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
+  sc[SC_NFACT << 6] += (double)nfact;
+  if (!ok && !o.newton_only) sc[SC_LS_FAIL << 6] = 1.0;  // regularisation cap reached: force growth next time
+}
+
+// ------------------------------------------------------------------------------------------------
+// line search: merit partials of DTO_LS_TRIALS step sizes alpha_k = alpha_pmax * 2^-k per stage
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const dto_solver_opts& o = a.opt;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const double mu = sc[SC_MU << 6];
+  const double amax = sc[SC_ALPHA_PMAX << 6];
+  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    using KD = typename D::KD;
+    using CO = typename M::template Cost<KD::COST>;
+    const int z0 = a.zoff[t];
+    arr<D::NP> p, dp;
+    arr<D::NY> y, dy;
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      p[i] = *soa(a.z, g, a.Nz, z0 + i);
+      dp[i] = *soa(a.dz, g, a.Nz, z0 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < D::NY; ++i) {
+      y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
+      dy[i] = *soa(a.dz, g, a.Nz, a.zoff[t + 1] + i);
+    }
+    arr<CO::NW> w;
+    gmem_load(w, a.params + a.woff[t]);
+    double* out = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
+    double alpha = amax;
+#pragma unroll 1
+    for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+      arr<D::NP> pk;
+      double phi, th = 0.0;
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) pk[i] = p[i] + alpha * dp[i];
+      {
+        double o1[1];
+        CO::eval(pk.data(), pk.data() + CO::NX, w.data(), o1);
+        phi = o1[0];
+      }
+      if (!o.newton_only) {
+#pragma unroll
+        for (int i = 0; i < D::NP; ++i) {
+          const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+          if (lo != hi) {
+            if (finite_lo(lo)) phi -= mu * log(pk[i] - lo);
+            if (finite_hi(hi)) phi -= mu * log(hi - pk[i]);
+          }
+        }
+      }
+      if constexpr (KD::DYN >= 0) {
+        using DY = typename M::template Dyn<KD::DYN>;
+        arr<DY::NY> yk, d;
+#pragma unroll
+        for (int i = 0; i < DY::NY; ++i) yk[i] = y[i] + alpha * dy[i];
+        DY::eval(pk.data(), pk.data() + DY::NX, yk.data(), w.data(), d.data());
+#pragma unroll
+        for (int i = 0; i < DY::NY; ++i) th += fabs(d[i]);
+      }
+      if constexpr (KD::CON >= 0) {
+        using C = typename M::template Con<KD::CON>;
+        arr<C::NC> c;
+        C::eval(pk.data(), pk.data() + C::NX, w.data(), c.data());
+#pragma unroll
+        for (int j = 0; j < C::NC; ++j) {
+          double r = c[j];
+          if (!o.newton_only && D::ineq(j)) {
+            const double sk = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) + alpha * *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j));
+            r += sk;
+            phi -= mu * log(sk);
+          }
+          th += fabs(r);
+        }
+      }
+      out[(int64_t)(2 * k) << 6] = phi;
+      out[(int64_t)(2 * k + 1) << 6] = th;
+      alpha *= 0.5;
+    }
+  });
+}
+
+static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
+  // Filter line search of Ipopt (Waechter & Biegler 2006, Algorithm A, steps A-5..A-8) over the
+  // precomputed trial step sizes alpha_k = alpha_max 2^-k; no restoration phase: if every trial is
+  // rejected the most feasible trial is taken and more regularisation is requested.
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
+#pragma unroll
+  for (int k = 0; k < DTO_LS_TRIALS; ++k) phi[k] = th[k] = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    const double* in = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+      phi[k] += in[(int64_t)(2 * k) << 6];
+      th[k] += in[(int64_t)(2 * k + 1) << 6];
+    }
+  }
+  constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8, DELTA = 1.0;
+  const double th0 = sc[SC_THETA1 << 6];
+  const double phi0 = sc[SC_MERIT0 << 6];
+  const double dphi = sc[SC_DMERIT << 6];
+  const double thmax = sc[SC_THETA_MAX << 6], thmin = sc[SC_THETA_MIN << 6];
+  double* fl = a.filt + ((g * (2 * DTO_FILTER_CAP)) << 6) + threadIdx.x;
+  const int nf_total = (int)sc[SC_FILTER_N << 6];
+  const int nf = nf_total < DTO_FILTER_CAP ? nf_total : DTO_FILTER_CAP;
+  double alpha = sc[SC_ALPHA_PMAX << 6];
+  double chosen = -1.0;
+  bool ftype = false;
+  int best = 0;
+#pragma unroll 1
+  for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+    const double tk = th[k], pk = phi[k];
+    if (th[k] < th[best] || !(th[best] == th[best])) best = k;
+    bool ok = (tk == tk) && (pk == pk) && tk <= thmax;
+    const bool sw = dphi < 0.0 && alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
+    bool armijo = false;
+    if (ok) {
+      if (sw && th0 <= thmin) {
+        armijo = pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0);
+        ok = armijo;
+      } else {
+        ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
+      }
+    }
+    if (ok) {
+      for (int i = 0; i < nf; ++i) {
+        const double tf = fl[(int64_t)(2 * i) << 6], pf = fl[(int64_t)(2 * i + 1) << 6];
+        if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
+      }
+    }
+    if (ok) {
+      chosen = alpha;
+      ftype = sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0));
+      break;
+    }
+    alpha *= 0.5;
+  }
+  bool augment = false;
+  if (chosen < 0.0) {
+    // no acceptable trial: take the most feasible one if it improves feasibility, else the shortest step
+    double ab = sc[SC_ALPHA_PMAX << 6];
+    for (int k = 0; k < best; ++k) ab *= 0.5;
+    if (th[best] == th[best] && th[best] < th0) chosen = ab;
+    else chosen = alpha * 2.0;  // alpha_max 2^-(TRIALS-1)
+    sc[SC_LS_FAIL << 6] = 1.0;
+    augment = true;
+  } else {
+    sc[SC_LS_FAIL << 6] = 0.0;
+    augment = !ftype;
+  }
+  if (augment) {
+    const int slot = nf_total % DTO_FILTER_CAP;
+    fl[(int64_t)(2 * slot) << 6] = (1.0 - G_TH) * th0;
+    fl[(int64_t)(2 * slot + 1) << 6] = phi0 - G_PHI * th0;
+    sc[SC_FILTER_N << 6] = (double)(nf_total + 1);
+  }
+  sc[SC_LS_KIND << 6] = chosen < 0.0 ? -1.0 : (ftype ? 1.0 : 2.0);
+  sc[SC_ALPHA << 6] = chosen;
+}
+
+// ------------------------------------------------------------------------------------------------
+// take the step.  grid = G*T waves.
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const dto_solver_opts& o = a.opt;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  const bool running = sc[SC_STATUS << 6] == 0.0;
+  if (!running) return;
+  const double mu = sc[SC_MU << 6];
+  const double al = sc[SC_ALPHA << 6];
+  const double ad = sc[SC_ALPHA_DMAX << 6];
+  constexpr double KSIG = 1e10;
+  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    if (!running) return;
+    const int z0 = a.zoff[t];
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      const double p = *soa(a.z, g, a.Nz, z0 + i);
+      const double dp = *soa(a.dz, g, a.Nz, z0 + i);
+      const double pn = p + al * dp;
+      if (!o.newton_only) {
+        const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+        if (lo != hi) {
+          if (finite_lo(lo)) {
+            const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+            const double gap = p - lo;
+            const double dzl = mu / gap - zl - (zl / gap) * dp;
+            double zn = zl + ad * dzl;
+            const double gn = pn - lo;
+            zn = fmin(fmax(zn, mu / (KSIG * gn)), KSIG * mu / gn);
+            *soa(a.zl, g, a.Nz, z0 + i) = zn;
+          }
+          if (finite_hi(hi)) {
+            const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+            const double gap = hi - p;
+            const double dzu = mu / gap - zu + (zu / gap) * dp;
+            double zn = zu + ad * dzu;
+            const double gn = hi - pn;
+            zn = fmin(fmax(zn, mu / (KSIG * gn)), KSIG * mu / gn);
+            *soa(a.zu, g, a.Nz, z0 + i) = zn;
+          }
+        }
+      }
+      *soa(a.z, g, a.Nz, z0 + i) = pn;
+    }
+#pragma unroll
+    for (int j = 0; j < D::Q; ++j) {
+      const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+      const double dnu = *soa(a.dlam, g, a.Nc, a.ccoff[t] + j);
+      if (!o.newton_only && D::ineq(j)) {
+        const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
+        const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+        const double dsv = *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j));
+        const double dzs = mu / sv - zv - (zv / sv) * dsv;
+        const double sn = sv + al * dsv;
+        double zn = zv + ad * dzs;
+        zn = fmin(fmax(zn, mu / (KSIG * sn)), KSIG * mu / sn);
+        *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) = sn;
+        *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = zn;
+      }
+      *soa(a.lam, g, a.Nc, a.ccoff[t] + j) = nu + al * dnu;
+    }
+#pragma unroll
+    for (int k = 0; k < D::NY; ++k) {
+      const double lam = *soa(a.lam, g, a.Nc, a.cdoff[t] + k);
+      *soa(a.lam, g, a.Nc, a.cdoff[t] + k) = lam + al * *soa(a.dlam, g, a.Nc, a.cdoff[t] + k);
+    }
+  });
+  if (t == 0 && running) sc[SC_ITER << 6] += 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+template <class M>
+int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  const dto_kkt_args& a = *args;
+  const unsigned gt = (unsigned)((int64_t)a.G * a.T);
+  if constexpr (M::EVALUATE_HESSIAN == 0 || M::HAS_GENERAL) {
+    return (int)hipErrorNotSupported;
+  } else {
+    switch (op) {
+      case DTO_KKT_PACK:
+      case DTO_KKT_UNPACK: {
+        int64_t n = 0;
+        double* buf = nullptr;
+        switch (a.aos_which) {
+          case 0: n = a.Nz; buf = a.z; break;
+          case 1: n = a.Nc; buf = a.lam; break;
+          case 2: n = a.Nz; buf = a.dz; break;
+          case 3: n = a.Nc; buf = a.dlam; break;
+          default: return -1;
+        }
+        if (n == 0) break;
+        dim3 grid((unsigned)((n + 3) / 4), (unsigned)a.G);
+        if (op == DTO_KKT_PACK) hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, n, buf);
+        else hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, a, n, (const double*)buf);
+        break;
+      }
+      case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_CONV: hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd); break;
+      case DTO_KKT_FACTOR_SOLVE: hipLaunchKernelGGL(k_kkt<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_LS_REDUCE: hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
+}
+
 }  // namespace dto

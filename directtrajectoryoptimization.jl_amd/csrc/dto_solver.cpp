@@ -1,6 +1,387 @@
-// KKT / interior-point driver (filled in by the KKT milestone).
+// Host driver of the batched interior-point / KKT path (the part of the reference that lives inside
+// Ipopt: src/solver.jl:45-47 `solve!` -> MOI.optimize!).  All numerics run in the plugin's kernels
+// (dto_kkt_kernels.hpp); this file only owns device state and the launch sequence of one iteration:
+//     EVAL -> CONV -> FACTOR_SOLVE -> LINESEARCH -> LS_REDUCE -> UPDATE
+// No host round trip happens inside an iteration; the host polls completion every `check_every`
+// iterations.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dto.h"
+#include "dto_kkt_kernels.hpp"
 #include "dto_problem.hpp"
+
+#define HIP_TRY(expr)                                       \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) return dto::hip_fail(e_, #expr);  \
+  } while (0)
+
 namespace dto {
-struct SolverState {};
-void Problem::free_solver() { delete solver; solver = nullptr; }
+
+struct SolverState {
+  int64_t B = 0;
+  int G = 0;
+  int64_t Ni = 0, rec_total = 0, fac_total = 0, n_bnd = 0;
+  std::vector<int> ioff;
+  std::vector<int64_t> recoff, facoff;
+  int* d_ioff = nullptr;
+  int64_t *d_recoff = nullptr, *d_facoff = nullptr;
+  double *d_lo = nullptr, *d_hi = nullptr;
+  // SoA state
+  double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
+  double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
+  double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
+  dto_kkt_info info{};
+  dto_solver_opts opt{};
+  dto_options user{};
+  bool begun = false;
+  std::vector<double> h_scal;  // host copy of the scalar block
+
+  void release() {
+    for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
+                    (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
+                    (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt})
+      if (p) (void)hipFree(p);
+    d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
+    z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
+    B = 0; G = 0;
+  }
+};
+
+void Problem::free_solver() {
+  if (solver) {
+    solver->release();
+    delete solver;
+    solver = nullptr;
+  }
+}
+
+static void default_opts(dto_solver_opts& o, const dto_options& u) {
+  o.tol = u.tol; o.s_max = u.s_max; o.dual_inf_tol = u.dual_inf_tol; o.constr_viol_tol = u.constr_viol_tol;
+  o.compl_inf_tol = u.compl_inf_tol; o.max_iter = u.max_iter;
+  o.mu_init = u.mu_init; o.kappa_eps = 10.0; o.kappa_mu = 0.2; o.theta_mu = 1.5; o.tau_min = 0.99;
+  o.bound_push = 1e-2; o.bound_frac = 1e-2;
+  o.delta_c = u.delta_c; o.delta_w_init = u.delta_w_init; o.delta_w_min = 1e-20; o.delta_w_max = 1e20;
+  o.kappa_w_minus = 1.0 / 3.0; o.kappa_w_plus = 8.0; o.kappa_w_plus_first = 100.0;
+  o.delta_w_exact_cap = 1.0;
+  o.eta_armijo = 1e-4; o.rho_penalty = 0.1; o.piv_tol = 1e-9;
+  o.max_refactor = 12;
+  o.newton_only = 0; o.fixed_delta_w = 0.0;
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t count) {
+  HIP_TRY(hipMalloc((void**)p, std::max<size_t>(1, count) * sizeof(T)));
+  HIP_TRY(hipMemset(*p, 0, std::max<size_t>(1, count) * sizeof(T)));
+  return DTO_OK;
+}
+
+static int ensure_state(Problem* p, int64_t B) {
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  if (!p->vt->kkt_info || !p->vt->launch_kkt) return set_error(DTO_ERR_UNSUPPORTED, "plugin has no KKT kernels");
+  if (!p->solver) p->solver = new SolverState();
+  SolverState& S = *p->solver;
+  if (S.B == B && S.z) return DTO_OK;
+  S.release();
+  const Layout& L = p->L;
+  p->vt->kkt_info(&S.info);
+  if (!S.info.supported)
+    return set_error(DTO_ERR_UNSUPPORTED,
+                     "the KKT/solver path needs evaluate_hessian=true objects and no GeneralConstraint (DESIGN.md)");
+  for (int t = 1; t < L.T; ++t)
+    if (L.nx[t] != L.nx[0]) return set_error(DTO_ERR_UNSUPPORTED, "the solver path needs a uniform state dimension");
+  S.B = B;
+  S.G = (int)((B + 63) / 64);
+  S.ioff.assign(L.T + 1, 0); S.recoff.assign(L.T + 1, 0); S.facoff.assign(L.T + 1, 0);
+  for (int t = 0; t < L.T; ++t) {
+    const int k = L.kind[t];
+    S.ioff[t + 1] = S.ioff[t] + S.info.n_ineq[k];
+    S.recoff[t + 1] = S.recoff[t] + S.info.rec_size[k];
+    S.facoff[t + 1] = S.facoff[t] + S.info.fac_size[k];
+  }
+  S.Ni = S.ioff[L.T]; S.rec_total = S.recoff[L.T]; S.fac_total = S.facoff[L.T];
+  S.n_bnd = S.Ni;
+  for (int64_t i = 0; i < L.Nz; ++i) {
+    if (L.var_lo[i] == L.var_hi[i]) continue;
+    if (std::isfinite(L.var_lo[i])) ++S.n_bnd;
+    if (std::isfinite(L.var_hi[i])) ++S.n_bnd;
+  }
+  const size_t lanes = (size_t)S.G * 64;
+  HIP_TRY(hipMalloc((void**)&S.d_ioff, (L.T + 1) * sizeof(int)));
+  HIP_TRY(hipMemcpy(S.d_ioff, S.ioff.data(), (L.T + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&S.d_recoff, (L.T + 1) * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(S.d_recoff, S.recoff.data(), (L.T + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&S.d_facoff, (L.T + 1) * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(S.d_facoff, S.facoff.data(), (L.T + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&S.d_lo, std::max<size_t>(1, L.Nz) * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&S.d_hi, std::max<size_t>(1, L.Nz) * sizeof(double)));
+  HIP_TRY(hipMemcpy(S.d_lo, L.var_lo.data(), L.Nz * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.d_hi, L.var_hi.data(), L.Nz * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(&S.z, lanes * L.Nz))) return rc;
+  if ((rc = dev_alloc(&S.lam, lanes * L.Nc))) return rc;
+  if ((rc = dev_alloc(&S.zl, lanes * L.Nz))) return rc;
+  if ((rc = dev_alloc(&S.zu, lanes * L.Nz))) return rc;
+  if ((rc = dev_alloc(&S.s, lanes * S.Ni))) return rc;
+  if ((rc = dev_alloc(&S.zs, lanes * S.Ni))) return rc;
+  if ((rc = dev_alloc(&S.dz, lanes * L.Nz))) return rc;
+  if ((rc = dev_alloc(&S.dlam, lanes * L.Nc))) return rc;
+  if ((rc = dev_alloc(&S.ds, lanes * S.Ni))) return rc;
+  if ((rc = dev_alloc(&S.rec, lanes * S.rec_total))) return rc;
+  if ((rc = dev_alloc(&S.fac, lanes * S.fac_total))) return rc;
+  if ((rc = dev_alloc(&S.part, lanes * (size_t)L.T * S.info.npart))) return rc;
+  if ((rc = dev_alloc(&S.lspart, lanes * (size_t)L.T * 2 * S.info.ls_trials))) return rc;
+  if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
+  if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
+  S.h_scal.assign(lanes * S.info.nscal, 0.0);
+  return DTO_OK;
+}
+
+static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
+  SolverState& S = *p->solver;
+  const Layout& L = p->L;
+  std::memset(&a, 0, sizeof(a));
+  a.T = L.T; a.B = S.B; a.G = S.G;
+  a.Nz = L.Nz; a.Nc = L.Nc; a.Ni = S.Ni;
+  a.n_mult = L.Nc; a.n_bnd = S.n_bnd;
+  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.ccoff = p->d_ccoff;
+  a.ioff = S.d_ioff; a.recoff = S.d_recoff; a.facoff = S.d_facoff;
+  a.rec_total = S.rec_total; a.fac_total = S.fac_total;
+  a.lo = S.d_lo; a.hi = S.d_hi; a.params = p->d_params;
+  a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
+  a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
+  a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
+  a.opt = S.opt;
+}
+
+static int kkt_launch(Problem* p, int op, const dto_kkt_args& a, hipStream_t st) {
+  const int rc = p->vt->launch_kkt(op, &a, (void*)st);
+  if (rc != 0) return hip_fail((hipError_t)rc, "KKT kernel launch");
+  return DTO_OK;
+}
+
+static int pack(Problem* p, dto_kkt_args a, int which, const double* src, int64_t ld, hipStream_t st) {
+  a.aos_in = src; a.ld_aos = ld; a.aos_which = which;
+  return kkt_launch(p, DTO_KKT_PACK, a, st);
+}
+static int unpack(Problem* p, dto_kkt_args a, int which, double* dst, int64_t ld, hipStream_t st) {
+  a.aos_out = dst; a.ld_aos = ld; a.aos_which = which;
+  return kkt_launch(p, DTO_KKT_UNPACK, a, st);
+}
+
+static int fetch_scalars(Problem* p, hipStream_t st) {
+  SolverState& S = *p->solver;
+  HIP_TRY(hipMemcpyAsync(S.h_scal.data(), S.scal, S.h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return DTO_OK;
+}
+
+static inline double hscal(const SolverState& S, int64_t inst, int slot) {
+  return S.h_scal[((inst >> 6) * S.info.nscal + slot) * 64 + (inst & 63)];
+}
+
 }  // namespace dto
+
+using dto::Problem;
+using dto::set_error;
+using dto::SolverState;
+
+extern "C" {
+
+int dto_options_default(dto_options* o) {
+  if (!o) return set_error(DTO_ERR_INVALID, "null argument");
+  o->tol = 1e-6; o->s_max = 100.0; o->max_iter = 1000;
+  o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-3; o->compl_inf_tol = 1e-3;
+  o->mu_init = 0.1; o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->check_every = 10;
+  return DTO_OK;
+}
+
+int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int64_t ldmu, double delta_w,
+                       double delta_c, double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !b || !b->x || !mu || !dx || !dmu) return set_error(DTO_ERR_INVALID, "null argument");
+  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported on the KKT path yet");
+  if (b->ldx < p->L.Nz || ldmu < p->L.Nc || lddx < p->L.Nz || lddmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  int rc = dto::ensure_state(p, b->B);
+  if (rc) return rc;
+  SolverState& S = *p->solver;
+  dto_options u;
+  dto_options_default(&u);
+  u.delta_c = delta_c;
+  dto::default_opts(S.opt, u);
+  S.opt.newton_only = 1;
+  S.opt.fixed_delta_w = delta_w;
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  if ((rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
+  if ((rc = dto::pack(p, a, 1, mu, ldmu, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
+  // CONV may flag "converged"/"failed" for this artificial point; the step is wanted regardless
+  for (int g = 0; g < S.G; ++g)
+    HIP_TRY(hipMemsetAsync(S.scal + ((size_t)g * S.info.nscal + SC_STATUS) * 64, 0, 64 * sizeof(double), st));
+  if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+  if ((rc = dto::unpack(p, a, 2, dx, lddx, st))) return rc;
+  if ((rc = dto::unpack(p, a, 3, dmu, lddmu, st))) return rc;
+  if (inertia_ok) {
+    if ((rc = dto::fetch_scalars(p, st))) return rc;
+    *inertia_ok = 1;
+    for (int64_t i = 0; i < S.B; ++i)
+      if (dto::hscal(S, i, SC_LS_FAIL) != 0.0) *inertia_ok = 0;
+  }
+  S.begun = false;
+  return DTO_OK;
+}
+
+int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !b || !b->x) return set_error(DTO_ERR_INVALID, "null argument");
+  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported on the KKT path yet");
+  if (b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
+  int rc = dto::ensure_state(p, b->B);
+  if (rc) return rc;
+  SolverState& S = *p->solver;
+  dto_options u;
+  if (opt) u = *opt; else dto_options_default(&u);
+  S.user = u;
+  dto::default_opts(S.opt, u);
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  const size_t lanes = (size_t)S.G * 64;
+  HIP_TRY(hipMemsetAsync(S.lam, 0, std::max<size_t>(1, lanes * p->L.Nc) * sizeof(double), st));
+  if ((rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
+  S.begun = true;
+  return DTO_OK;
+}
+
+int dto_solver_iterate(dto_problem* h, int n, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin has not been called");
+  hipStream_t st = (hipStream_t)stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  int rc;
+  for (int it = 0; it < n; ++it) {
+    if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
+    if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
+    if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+    if ((rc = dto::kkt_launch(p, DTO_KKT_LINESEARCH, a, st))) return rc;
+    if ((rc = dto::kkt_launch(p, DTO_KKT_LS_REDUCE, a, st))) return rc;
+    if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE, a, st))) return rc;
+  }
+  return DTO_OK;
+}
+
+int dto_solver_stats(dto_problem* h, int32_t* status, int32_t* iterations, double* objective, double* constr_viol,
+                     double* dual_inf, double* mu, double* delta_w, double* alpha) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
+  SolverState& S = *p->solver;
+  HIP_TRY(hipDeviceSynchronize());
+  int rc = dto::fetch_scalars(p, p->stream);
+  if (rc) return rc;
+  for (int64_t i = 0; i < S.B; ++i) {
+    if (status) status[i] = (int32_t)dto::hscal(S, i, SC_STATUS);
+    if (iterations) iterations[i] = (int32_t)dto::hscal(S, i, SC_ITER);
+    if (objective) objective[i] = dto::hscal(S, i, SC_F);
+    if (constr_viol) constr_viol[i] = dto::hscal(S, i, SC_THETA_INF);
+    if (dual_inf) dual_inf[i] = dto::hscal(S, i, SC_DINF);
+    if (mu) mu[i] = dto::hscal(S, i, SC_MU);
+    if (delta_w) delta_w[i] = dto::hscal(S, i, SC_DELTA_W);
+    if (alpha) alpha[i] = dto::hscal(S, i, SC_ALPHA);
+  }
+  return DTO_OK;
+}
+
+int dto_solver_scalar(dto_problem* h, int slot, double* out) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->z || !out) return set_error(DTO_ERR_INVALID, "no solver state");
+  SolverState& S = *p->solver;
+  if (slot < 0 || slot >= S.info.nscal) return set_error(DTO_ERR_INVALID, "slot out of range");
+  HIP_TRY(hipDeviceSynchronize());
+  int rc = dto::fetch_scalars(p, p->stream);
+  if (rc) return rc;
+  for (int64_t i = 0; i < S.B; ++i) out[i] = dto::hscal(S, i, slot);
+  return DTO_OK;
+}
+
+int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
+  hipStream_t st = (hipStream_t)stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  int rc;
+  if (x_out) {
+    if (ldxo < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldxo < num_variables");
+    if ((rc = dto::unpack(p, a, 0, x_out, ldxo, st))) return rc;
+  }
+  if (mu_out) {
+    if (ldmuo < p->L.Nc) return set_error(DTO_ERR_INVALID, "ldmuo < num_constraint");
+    if ((rc = dto::unpack(p, a, 1, mu_out, ldmuo, st))) return rc;
+  }
+  return DTO_OK;
+}
+
+int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                    double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  int rc = dto_solver_begin(h, opt, b);
+  if (rc) return rc;
+  SolverState& S = *p->solver;
+  hipStream_t st = (hipStream_t)b->stream;
+  const int chunk = std::max(1, S.user.check_every);
+  int done_iters = 0;
+  // max_iter + 1 evaluations: the last one only classifies the final iterate
+  while (done_iters <= S.user.max_iter) {
+    const int n = std::min(chunk, S.user.max_iter + 1 - done_iters);
+    if ((rc = dto_solver_iterate(h, n, (void*)st))) return rc;
+    done_iters += n;
+    if ((rc = dto::fetch_scalars(p, st))) return rc;
+    bool any = false;
+    for (int64_t i = 0; i < S.B && !any; ++i) any = dto::hscal(S, i, SC_STATUS) == 0.0;
+    if (!any) break;
+  }
+  if ((rc = dto_solver_end(h, x_out, ldxo, mu_out, ldmuo, (void*)st))) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < S.B; ++i) {
+    if (status) status[i] = (int32_t)dto::hscal(S, i, SC_STATUS);
+    if (iterations) iterations[i] = (int32_t)dto::hscal(S, i, SC_ITER);
+  }
+  return DTO_OK;
+}
+
+int dto_solve(dto_problem* h, const dto_options* opt, const double* x0, double* x, double* mu, int32_t* status,
+              int32_t* iterations) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !x0 || !x) return set_error(DTO_ERR_INVALID, "null argument");
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  const dto::Layout& L = p->L;
+  double* d_x = nullptr;
+  double* d_mu = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_x, std::max<size_t>(1, L.Nz) * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&d_mu, std::max<size_t>(1, L.Nc) * sizeof(double)));
+  HIP_TRY(hipMemcpy(d_x, x0, L.Nz * sizeof(double), hipMemcpyHostToDevice));
+  dto_batch b;
+  b.B = 1; b.x = d_x; b.ldx = L.Nz; b.params = nullptr; b.ldp = 0; b.stream = (void*)p->stream;
+  rc = dto_solve_batch(h, opt, &b, d_x, L.Nz, d_mu, L.Nc, status, iterations);
+  if (rc == DTO_OK) {
+    HIP_TRY(hipMemcpy(x, d_x, L.Nz * sizeof(double), hipMemcpyDeviceToHost));
+    if (mu) HIP_TRY(hipMemcpy(mu, d_mu, L.Nc * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_x);
+  (void)hipFree(d_mu);
+  return rc;
+}
+
+}  // extern "C"

@@ -27,7 +27,7 @@ from .symbolic.codegen import emit_body
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PLUGIN_DIR = os.path.join(_HERE, "_plugins")
-GENERATOR_VERSION = "3"
+GENERATOR_VERSION = "5"
 
 
 class Structure:
@@ -119,6 +119,70 @@ def _fn(name: str, params: str, body: str) -> str:
     return f"  static __device__ __forceinline__ void {name}({params}) {{\n{body}\n  }}\n"
 
 
+def _tri(i: int, j: int) -> int:
+    """index of (i, j), i >= j, in a packed lower triangle"""
+    return i * (i + 1) // 2 + j
+
+
+def _scatter_dyn(d: Dynamics, h: bool) -> str:
+    """Straight-line scatter of a dynamics class's local nonzeros into the dense stage blocks the KKT
+    kernels use (all indices are literals, so everything stays in registers):
+      jac  -> F = d(d_t)/d[x_t;u_t] (NY x NP, row-major), E = d(d_t)/d x_{t+1} (NY x NY)
+      hess -> W (pp block, packed lower), V (NP x NY cross block), YY (packed lower)
+      jtlam: rp += F' lam ; etlam: rx += E' lam
+    """
+    npd, ny = d.num_state + d.num_action, d.num_next_state
+    out = []
+    body = []
+    for k, (r, c) in enumerate(zip(*d.jacobian_sparsity)):
+        r, c = r - 1, c - 1
+        body.append(f"    F[{r * npd + c}] = jv[{k}];" if c < npd else f"    E[{r * ny + (c - npd)}] = jv[{k}];")
+    out.append(_fn("scatter_jac", "const double* jv, double* F, double* E", "\n".join(body) or "    (void)jv;"))
+    body = [f"    rp[{c - 1}] += jv[{k}] * lam[{r - 1}];" for k, (r, c) in enumerate(zip(*d.jacobian_sparsity)) if c - 1 < npd]
+    out.append(_fn("jtlam", "const double* jv, const double* lam, double* rp", "\n".join(body) or "    (void)jv;"))
+    body = [f"    rx[{c - 1 - npd}] += jv[{k}] * lam[{r - 1}];" for k, (r, c) in enumerate(zip(*d.jacobian_sparsity)) if c - 1 >= npd]
+    out.append(_fn("etlam", "const double* jv, const double* lam, double* rx", "\n".join(body) or "    (void)jv;"))
+    body = []
+    if h:
+        for k, (r, c) in enumerate(zip(*d.hessian_sparsity)):
+            r, c = r - 1, c - 1
+            if r < c:
+                continue
+            if r < npd:
+                body.append(f"    W[{_tri(r, c)}] += hv[{k}];")
+            elif c < npd:
+                body.append(f"    V[{c * ny + (r - npd)}] += hv[{k}];")
+            else:
+                body.append(f"    YY[{_tri(r - npd, c - npd)}] += hv[{k}];")
+    out.append(_fn("scatter_hess", "const double* hv, double* W, double* V, double* YY", "\n".join(body) or "    (void)hv;"))
+    return "".join(out)
+
+
+def _scatter_cost(c: Cost, h: bool) -> str:
+    body = []
+    if h:
+        for k, (r, q) in enumerate(zip(*c.sparsity)):
+            if r >= q:
+                body.append(f"    W[{_tri(r - 1, q - 1)}] += hv[{k}];")
+    return _fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;")
+
+
+def _scatter_con(c: Constraint, h: bool) -> str:
+    npd = c.num_state + c.num_action
+    out = []
+    body = [f"    G[{(r - 1) * npd + (q - 1)}] = jv[{k}];" for k, (r, q) in enumerate(zip(*c.jacobian_sparsity))]
+    out.append(_fn("scatter_jac", "const double* jv, double* G", "\n".join(body) or "    (void)jv;"))
+    body = [f"    rp[{q - 1}] += jv[{k}] * lam[{r - 1}];" for k, (r, q) in enumerate(zip(*c.jacobian_sparsity))]
+    out.append(_fn("jtlam", "const double* jv, const double* lam, double* rp", "\n".join(body) or "    (void)jv;"))
+    body = []
+    if h:
+        for k, (r, q) in enumerate(zip(*c.hessian_sparsity)):
+            if r >= q:
+                body.append(f"    W[{_tri(r - 1, q - 1)}] += hv[{k}];")
+    out.append(_fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;"))
+    return "".join(out)
+
+
 def generate_source(st: Structure, name: str) -> str:
     h = st.evaluate_hessian
     out: List[str] = []
@@ -172,6 +236,7 @@ def generate_source(st: Structure, name: str) -> str:
         if nh:
             sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
             out.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+        out.append(_scatter_dyn(d, h))
         out.append("};")
         tables.append(_int_array(f"dyn{i}_jr", d.jacobian_sparsity[0]))
         tables.append(_int_array(f"dyn{i}_jc", d.jacobian_sparsity[1]))
@@ -188,6 +253,7 @@ def generate_source(st: Structure, name: str) -> str:
         out.append(_fn("grad", sig, emit_body(c.gradient_expr, "out", va)))
         if nh:
             out.append(_fn("hess", sig, emit_body(c.hessian_expr, "out", va)))
+        out.append(_scatter_cost(c, h))
         out.append("};")
         tables.append(_int_array(f"cost{i}_hr", c.sparsity[0] if h else []))
         tables.append(_int_array(f"cost{i}_hc", c.sparsity[1] if h else []))
@@ -206,38 +272,20 @@ def generate_source(st: Structure, name: str) -> str:
             out.append(_fn("hess", sigh, emit_body(c.hessian_expr, "out", va)))
         ineq = sorted(c.indices_inequality)
         flags = ["true" if (r + 1) in ineq else "false" for r in range(c.num_constraint)]
-        out.append(f"  static constexpr bool INEQ[{max(1, c.num_constraint)}] = {{{', '.join(flags) if flags else 'false'}}};")
-        out.append(f"  static constexpr int JR[{max(1, c.num_jacobian)}] = {{{', '.join(str(r - 1) for r in c.jacobian_sparsity[0]) or '0'}}};")
-        out.append(f"  static constexpr int JC[{max(1, c.num_jacobian)}] = {{{', '.join(str(r - 1) for r in c.jacobian_sparsity[1]) or '0'}}};")
+        cond = " || ".join(f"j == {r - 1}" for r in ineq) or "false"
+        out.append(f"  static constexpr __host__ __device__ bool ineq(int j) {{ return {cond}; }}")
+        slk = " : ".join(f"j == {r - 1} ? {k}" for k, r in enumerate(ineq))
+        out.append(f"  static constexpr __host__ __device__ int slack(int j) {{ return {slk + ' : -1' if ineq else '-1'}; }}")
         hr = c.hessian_sparsity[0] if h else []
         hc = c.hessian_sparsity[1] if h else []
-        out.append(f"  static constexpr int HR[{max(1, len(hr))}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
-        out.append(f"  static constexpr int HC[{max(1, len(hc))}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
+        out.append(f"  static constexpr int NI = {len(ineq)};")
+        out.append(_scatter_con(c, h))
         out.append("};")
         tables.append(_int_array(f"con{i}_jr", c.jacobian_sparsity[0]))
         tables.append(_int_array(f"con{i}_jc", c.jacobian_sparsity[1]))
         tables.append(_int_array(f"con{i}_hr", hr))
         tables.append(_int_array(f"con{i}_hc", hc))
         tables.append(_int_array(f"con{i}_iq", ineq))
-    # static pattern tables the KKT kernels unroll over (0-based)
-    for i, d in enumerate(st.dyn):
-        nh = d.num_hessian if h else 0
-        out.append(f"struct DynPat{i} {{")
-        out.append(f"  static constexpr int JR[{max(1, d.num_jacobian)}] = {{{', '.join(str(r - 1) for r in d.jacobian_sparsity[0]) or '0'}}};")
-        out.append(f"  static constexpr int JC[{max(1, d.num_jacobian)}] = {{{', '.join(str(r - 1) for r in d.jacobian_sparsity[1]) or '0'}}};")
-        hr = d.hessian_sparsity[0] if h else []
-        hc = d.hessian_sparsity[1] if h else []
-        out.append(f"  static constexpr int HR[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
-        out.append(f"  static constexpr int HC[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
-        out.append("};")
-    for i, c in enumerate(st.cost):
-        nh = c.num_hessian if h else 0
-        hr = c.sparsity[0] if h else []
-        hc = c.sparsity[1] if h else []
-        out.append(f"struct CostPat{i} {{")
-        out.append(f"  static constexpr int HR[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hr) or '0'}}};")
-        out.append(f"  static constexpr int HC[{max(1, nh)}] = {{{', '.join(str(r - 1) for r in hc) or '0'}}};")
-        out.append("};")
     # ---- general constraint
     g = st.general
     if g is not None:

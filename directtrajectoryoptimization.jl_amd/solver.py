@@ -272,6 +272,15 @@ class NLPData:
         capi.check(self._lib.dto_eval_h_batch(self._h, C.byref(b), float(sigma), mu_ptr, ldmu, out_ptr, ldo))
 
 
+def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
+    c = capi.COptions()
+    capi.check(capi.lib().dto_options_default(C.byref(c)))
+    c.tol, c.s_max, c.max_iter = o.tol, o.s_max, int(o.max_iter)
+    c.dual_inf_tol, c.constr_viol_tol, c.compl_inf_tol = o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol
+    c.check_every = check_every
+    return c
+
+
 class Solver:
     """Solver(dynamics, objective, constraints, bounds; evaluate_hessian=false,
     general_constraint=GeneralConstraint(), options=Options(), parameters=...) -- src/solver.jl:6-21."""
@@ -288,6 +297,78 @@ class Solver:
     @property
     def num_variables(self):
         return self.nlp.num_variables
+
+    # ---- batched device entry points (torch tensors / raw device pointers)
+    def kkt_step_batch(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, dx_ptr, lddx, dmu_ptr, lddmu, stream=0):
+        """One regularised Newton-KKT step (include/dto.h: dto_kkt_step_batch). Returns inertia_ok."""
+        b = self.nlp._batch(x_ptr, B, ldx, stream)
+        ok = C.c_int(1)
+        capi.check(self.nlp._lib.dto_kkt_step_batch(self.nlp._h, C.byref(b), mu_ptr, ldmu, float(delta_w), float(delta_c),
+                                                    dx_ptr, lddx, dmu_ptr, lddmu, C.byref(ok)))
+        return bool(ok.value)
+
+    def solve_batch(self, x0_ptr, B, ldx, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0, check_every=10):
+        """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays."""
+        b = self.nlp._batch(x0_ptr, B, ldx, stream)
+        co = _c_options(self.options, check_every)
+        status = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        capi.check(self.nlp._lib.dto_solve_batch(self.nlp._h, C.byref(co), C.byref(b), x_out_ptr, ldxo,
+                                                 mu_out_ptr or None, ldmuo, status.ctypes.data_as(capi.c_int32_p),
+                                                 iters.ctypes.data_as(capi.c_int32_p)))
+        return status, iters
+
+    def begin_batch(self, x0_ptr, B, ldx, stream=0):
+        b = self.nlp._batch(x0_ptr, B, ldx, stream)
+        co = _c_options(self.options)
+        capi.check(self.nlp._lib.dto_solver_begin(self.nlp._h, C.byref(co), C.byref(b)))
+        self._B = B
+
+    def iterate_batch(self, n, stream=0):
+        capi.check(self.nlp._lib.dto_solver_iterate(self.nlp._h, int(n), stream or None))
+
+    def stats_batch(self):
+        B = self._B
+        st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        arrs = [np.zeros(B) for _ in range(6)]
+        capi.check(self.nlp._lib.dto_solver_stats(self.nlp._h, st.ctypes.data_as(capi.c_int32_p), it.ctypes.data_as(capi.c_int32_p),
+                                                  *[capi.dptr(a) for a in arrs]))
+        names = ["objective", "constr_viol", "dual_inf", "mu", "delta_w", "alpha"]
+        return dict(status=st, iterations=it, **dict(zip(names, arrs)))
+
+    def scalar_batch(self, name: str):
+        out = np.zeros(self._B)
+        capi.check(self.nlp._lib.dto_solver_scalar(self.nlp._h, capi.SCALARS.index(name), capi.dptr(out)))
+        return out
+
+    def end_batch(self, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0):
+        capi.check(self.nlp._lib.dto_solver_end(self.nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo, stream or None))
+
+
+def solve(solver: Solver):
+    """solve!(solver) -- src/solver.jl:45-47: run the GPU interior-point solve from the initial guess."""
+    n = solver.nlp
+    x = np.zeros(n.num_variables)
+    mu = np.zeros(max(1, n.num_constraint))
+    status, iters = C.c_int32(0), C.c_int32(0)
+    co = _c_options(solver.options)
+    capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver._z0)), capi.dptr(x), capi.dptr(mu),
+                                C.byref(status), C.byref(iters)))
+    solver._solution = x
+    solver._duals = mu[:n.num_constraint]
+    solver.status, solver.iterations = int(status.value), int(iters.value)
+    return solver.status
+
+
+def get_trajectory(solver: Solver):
+    """get_trajectory(solver) -- src/solver.jl:41-43: (states[1..T], actions[1..T-1]) of the accepted final iterate."""
+    if solver._solution is None:
+        raise RuntimeError("solve(solver) has not been called")
+    z = solver._solution
+    idx = solver.nlp.indices
+    xs = [z[np.array(i) - 1] for i in idx.states]
+    us = [z[np.array(i) - 1] for i in idx.actions]
+    return xs, us
 
 
 def initialize_states(solver: Solver, states) -> None:

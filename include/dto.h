@@ -137,6 +137,58 @@ int dto_eval_jac_g_batch(dto_problem* p, const dto_batch* b, double* J, int64_t 
 int dto_eval_h_batch(dto_problem* p, const dto_batch* b, double sigma, const double* mu, int64_t ldmu,
                      double* H, int64_t ldh);
 
+/* ---- KKT step and solver: the work the reference delegates to Ipopt (src/solver.jl:45-47,
+ *      src/data.jl:229-255) -------------------------------------------------------------------- */
+
+/* Solver options: the subset of reference `Options` (src/options.jl:6-36) that defines convergence,
+ * plus the interior-point constants Ipopt documents as defaults.  Print/file options of the
+ * reference are out of scope. */
+typedef struct dto_options {
+  double tol;               /* 1e-6  src/options.jl:7  */
+  double s_max;             /* 100   src/options.jl:8  */
+  int max_iter;             /* 1000  src/options.jl:9  */
+  double dual_inf_tol;      /* 1.0   src/options.jl:12 */
+  double constr_viol_tol;   /* 1e-3  src/options.jl:13 */
+  double compl_inf_tol;     /* 1e-3  src/options.jl:14 */
+  double mu_init;           /* 0.1   (Ipopt default)   */
+  double delta_c;           /* 1e-8  dual regularisation, examples/pendulum/pendulum.jl:195 uses 1e-5 */
+  double delta_w_init;      /* 1e-4  first primal regularisation tried when the inertia is wrong */
+  int check_every;          /* host polls the batch for completion every this many iterations */
+} dto_options;
+int dto_options_default(dto_options* o);
+
+/* One regularised Newton-KKT step at given (x, mu), all constraints treated as equalities and bounds
+ * ignored -- exactly the system of examples/pendulum/pendulum.jl:138-198:
+ *     [ H + delta_w I   J' ] [dx ]     [ grad f + J' mu ]
+ *     [ J         -delta_c I ] [dmu] = - [ c              ]
+ * assembled stage-interleaved and solved by the block-tridiagonal LDL^T.  DEVICE pointers,
+ * instance-major; dx: [B][lddx], dmu: [B][lddmu].  *inertia_ok (host, may be NULL) is set to 0 if any
+ * instance had a pivot of the wrong sign (the matrix is not quasi-definite for this delta_w). */
+int dto_kkt_step_batch(dto_problem* p, const dto_batch* b, const double* mu, int64_t ldmu, double delta_w,
+                       double delta_c, double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok);
+
+/* Batched interior-point solve, one independent NLP per instance, same structure, different guesses.
+ * x0: DEVICE [B][ldx] initial guesses (what initialize_states!/initialize_controls! set,
+ * src/solver.jl:23-39); x_out/mu_out: DEVICE [B][ld*] final accepted iterates (get_trajectory,
+ * src/solver.jl:41-43, returns the last *evaluated* point in the reference -- here it is the accepted one);
+ * status/iterations: HOST [B] (0 running/cut off, 1 converged, 2 max_iter, 3 failed). */
+int dto_solve_batch(dto_problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                    double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations);
+
+/* The same solve split in three so a caller (bench.py) can time exactly K iterations. */
+int dto_solver_begin(dto_problem* p, const dto_options* opt, const dto_batch* b);
+int dto_solver_iterate(dto_problem* p, int n_iterations, void* stream);
+/* per-instance scalars, HOST [B] each, any may be NULL */
+int dto_solver_stats(dto_problem* p, int32_t* status, int32_t* iterations, double* objective, double* constr_viol,
+                     double* dual_inf, double* mu, double* delta_w, double* alpha);
+/* diagnostic: one per-instance scalar slot of the device state (enum dto_scal in csrc/dto_kkt_kernels.hpp), HOST [B] */
+int dto_solver_scalar(dto_problem* p, int slot, double* out);
+int dto_solver_end(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream);
+
+/* single instance, HOST pointers: solve!(solver) (src/solver.jl:45-47) */
+int dto_solve(dto_problem* p, const dto_options* opt, const double* x0, double* x, double* mu, int32_t* status,
+              int32_t* iterations);
+
 /* device memory helpers so a host language without a HIP binding can stay on this ABI */
 int dto_device_alloc(void** ptr, int64_t bytes);
 int dto_device_free(void* ptr);

@@ -1,0 +1,124 @@
+"""End-to-end solves on the GPU (the reference's test/solve.jl, plus the BASELINE configs at reduced and
+full horizon).  The reference asserts only the endpoints (test/solve.jl:136-137,223-224,294-295); here
+the returned point is additionally checked against the ORACLE evaluator: primal feasibility, stationarity
+of the Lagrangian with the returned multipliers, complementarity/bounds.  Iterates cannot be compared
+with Ipopt's (not runnable here; reference guesses are unseeded) -- "parity unpinned", see DESIGN.md.
+"""
+import numpy as np
+import pytest
+
+from conftest import product_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_for(model, T):
+    from oracle import dto_oracle as O, sympy_models as S
+    p = S.build(model, T, evaluate_hessian=True)
+    return O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True)
+
+
+def kkt_report(onlp, z, lam):
+    """Unscaled KKT residuals of (z, lam) computed with the oracle; bound multipliers are eliminated by
+    projecting the stationarity residual onto the active bound directions."""
+    g = onlp.eval_objective_gradient(z)
+    c = onlp.eval_constraint(z)
+    J = np.zeros((onlp.num_constraint, onlp.num_variables))
+    for (r, cc), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
+        J[r - 1, cc - 1] = v
+    r = g + J.T @ lam
+    lo, hi = onlp.variable_bounds
+    tol = 1e-4   # an interior-point iterate sits ~mu/z_L inside an active bound
+    at_lo = np.isfinite(lo) & (z - lo <= tol * np.maximum(1, np.abs(lo)))
+    at_hi = np.isfinite(hi) & (hi - z <= tol * np.maximum(1, np.abs(hi)))
+    stat = r.copy()
+    stat[at_lo] = np.minimum(stat[at_lo], 0.0)   # z_L >= 0 absorbs positive residual
+    stat[at_hi] = np.maximum(stat[at_hi], 0.0)
+    stat[lo == hi] = 0.0
+    clo, chi = onlp.constraint_bounds
+    viol = np.where(np.isneginf(clo), np.maximum(c, 0.0), np.abs(c))
+    ineq = np.isneginf(clo)
+    compl = np.abs(lam[ineq] * c[ineq]) if np.any(ineq) else np.zeros(1)
+    return dict(stationarity=np.max(np.abs(stat)), violation=np.max(viol), compl=np.max(compl),
+                bound_viol=max(np.max(lo - z), np.max(z - hi), 0.0), sign_ok=bool(np.all(lam[ineq] >= -1e-8)))
+
+
+def run_solve(model, T, seeds, max_iter=1000):
+    import torch
+    import dto_amd
+    s, p = product_solver(model, T)
+    s.options.max_iter = max_iter
+    n = s.nlp
+    B, nz, nc = len(seeds), n.num_variables, n.num_constraint
+    Z = np.zeros((B, nz))
+    for b, seed in enumerate(seeds):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        xs, us = p["guess"](rng)
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, us)
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    return s, p, zo.cpu().numpy(), lo.cpu().numpy(), status, iters
+
+
+@pytest.mark.parametrize("model,T,nseeds", [("pendulum", 50, 6), ("acrobot", 101, 4), ("cartpole", 101, 2)])
+def test_equality_constrained_swingups(model, T, nseeds):
+    s, p, Z, L, status, iters = run_solve(model, T, list(range(nseeds)))
+    onlp = oracle_for(model, T)
+    idx = s.nlp.indices
+    assert np.all(status == 1), (status, iters)
+    for b in range(len(Z)):
+        x1 = Z[b][np.array(idx.states[0]) - 1]
+        xT = Z[b][np.array(idx.states[-1]) - 1]
+        assert np.linalg.norm(x1 - p["x1"]) < 1e-3 and np.linalg.norm(xT - p["xT"]) < 1e-3   # test/solve.jl:136-137
+        rep = kkt_report(onlp, Z[b], L[b])
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["bound_viol"] <= 1e-12, rep
+
+
+def test_reference_solve_test_acrobot_with_fixed_endpoints():
+    """test/solve.jl:1-138: acrobot T = 101, h = 0.05, endpoints fixed through equal bounds, no stage constraints."""
+    s, p, Z, L, status, iters = run_solve("acrobot_bounds", 101, [0, 1, 2])
+    idx = s.nlp.indices
+    assert np.all(status == 1), (status, iters)
+    onlp = oracle_for("acrobot_bounds", 101)
+    for b in range(len(Z)):
+        assert np.linalg.norm(Z[b][np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3
+        assert np.linalg.norm(Z[b][np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3
+        rep = kkt_report(onlp, Z[b], L[b])
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5, rep
+
+
+def test_car_with_obstacle_bounds_and_fixed_endpoints():
+    """examples/car/car.jl at T = 51: control bounds, obstacle inequality at every knot, endpoints fixed by bounds."""
+    s, p, Z, L, status, iters = run_solve("car", 51, [0, 1, 2, 3])
+    idx = s.nlp.indices
+    assert np.all(status == 1), (status, iters)
+    onlp = oracle_for("car", 51)
+    for b in range(len(Z)):
+        assert np.linalg.norm(Z[b][np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3
+        assert np.linalg.norm(Z[b][np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3
+        rep = kkt_report(onlp, Z[b], L[b])
+        assert rep["violation"] <= 1e-5 and rep["bound_viol"] <= 1e-12 and rep["sign_ok"], rep
+        assert rep["stationarity"] <= 1e-3 and rep["compl"] <= 1e-3, rep      # barrier accuracy: compl_inf_tol = 1e-3
+        # the path really avoids the obstacle
+        xs = np.array([Z[b][np.array(i) - 1] for i in idx.states])
+        assert np.min(np.hypot(xs[:, 0] - 0.5, xs[:, 1] - 0.5)) >= 0.1 - 1e-6
+
+
+def test_single_instance_host_solve_matches_batched():
+    """solve!(solver) through host pointers gives the same iterate as the same instance inside a batch."""
+    import dto_amd
+    s, p, Z, L, status, iters = run_solve("pendulum", 50, [0, 1, 2])
+    rng = np.random.Generator(np.random.PCG64(1))
+    xs, us = p["guess"](rng)
+    dto_amd.initialize_states(s, xs)
+    dto_amd.initialize_controls(s, us)
+    assert dto_amd.solve(s) == 1
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert len(x_sol) == 50 and len(u_sol) == 49
+    z = np.concatenate([np.concatenate([x_sol[t], u_sol[t]]) for t in range(49)] + [x_sol[49]])
+    assert np.array_equal(z, Z[1]) and s.iterations == iters[1]
