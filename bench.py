@@ -1,0 +1,203 @@
+"""Headline benchmark: SQP iterations/sec + Jacobian nnz/sec, acrobot T=1000, 1 -> 8 GPU (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one interior-point/SQP iteration of the whole batch resident on this rank's GPU:
+derivative blocks (value, gradient, Jacobian, Hessian of the Lagrangian) -> KKT assembly ->
+block-tridiagonal LDL^T factor + solve (with inertia correction) -> filter line search -> update.
+Workload: config 3 of BASELINE.json, acrobot swing-up, implicit midpoint h = 0.05, T = 1000, endpoint
+equality constraints, exact Hessians; `--batch` independent instances per GPU (MPC rollouts / random seeds),
+guess = linear interpolation + u ~ N(0,1) from a seeded stream (rank-dependent).  Instances are sharded
+across ranks with no data-path collective (weak scaling); converged trajectories are all-gathered over
+RCCL after the timed region.  Inputs are resident in HBM when the timed region starts.
+
+value = (solver iterations actually executed by all instances of all ranks in the timed region) / time.
+Extra keys: jacobian_nnz_per_sec (batched MOI Jacobian callback), roofline (dominant kernel of the step,
+HIP events on the launch stream), cpu_baseline (oracle C port on the host, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def make_guesses(s, p, B, seed):
+    """linear_interpolation + u ~ N(0,1) (examples/acrobot/acrobot.jl:126-127), vectorised."""
+    n = s.nlp
+    T, nx, nu = p["T"], p["n"], p["m"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Z = np.zeros((B, n.num_variables))
+    xs = np.stack([(p["xT"] - p["x1"]) / (T - 1) * t + p["x1"] for t in range(T)])  # src/utils.jl:1-10
+    U = rng.standard_normal((B, T - 1, nu))
+    for t in range(T):
+        o = t * (nx + nu)
+        Z[:, o:o + nx] = xs[t]
+        if t < T - 1:
+            Z[:, o + nx:o + nx + nu] = U[:, t]
+    return Z
+
+
+def event_time_ms(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import dto_amd
+    from dto_amd import problems as P
+    from dto_amd.parallel import gather_trajectories
+
+    T, B = a.horizon, a.batch
+    p = P.build_acrobot(T=T, evaluate_hessian=True)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
+    n = s.nlp
+    nz, nc, nj, nh = n.num_variables, n.num_constraint, n.num_jacobian, int(n.sizes.nnz_hess_key)
+    Z = make_guesses(s, p, B, seed=1000 + rank)
+    z0 = torch.tensor(Z, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    # ---- solver: W warmup iterations, then exactly K timed iterations
+    s.begin_batch(z0.data_ptr(), B, nz, stream=st)
+    s.iterate_batch(a.warmup, stream=st)
+    torch.cuda.synchronize()
+    it0 = s.scalar_batch("iter").copy()
+    nf0 = s.scalar_batch("nfact").copy()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.iterate_batch(a.steps, stream=st)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    it1 = s.scalar_batch("iter")
+    nf1 = s.scalar_batch("nfact")
+    iters_done = float(np.sum(it1 - it0))
+    facts_done = float(np.sum(nf1 - nf0))
+    tt = torch.tensor([dt, iters_done, facts_done], device=dev, dtype=torch.float64)
+    if dist is not None:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        iters_done, facts_done = float(tt[1]), float(tt[2])
+
+    # ---- per-kernel time of one iteration (HIP events on the launch stream), dominant kernel roofline
+    ops = ["eval", "conv", "factor_solve", "linesearch", "ls_reduce", "update"]
+    op_ms = {}
+    reps = 3
+    acc = {o: 0.0 for o in ops}
+    for _ in range(reps):
+        for o in ops:
+            acc[o] += event_time_ms(lambda: s.launch_op(o, stream=st), 1)
+    op_ms = {o: acc[o] / reps for o in ops}
+    fp = s.footprint()
+    nfact_per_iter = facts_done / max(iters_done, 1.0)
+    nnz_K = nj + (nh + nz) // 2 + nc                     # structural lower-triangular KKT entries
+    alg_bytes = {
+        # fused KKT value scatter = 8 (Nz + Nw + Nc + 1) + 8 nnz_K
+        "eval": 8 * (nz + nc + 1) + 8 * nnz_K,
+        # factor + solve: read K once, write the factors once, read them once, read rhs, write the step
+        "factor_solve": 8 * (nnz_K + 2 * fp["factor_doubles"] + 2 * (nz + nc)),
+        "linesearch": 8 * (2 * nz + 1) + 8 * 16,
+        "update": 8 * 3 * (nz + nc),
+        "conv": 8 * 9 * T, "ls_reduce": 8 * 16 * T,
+    }
+    dom = max(op_ms, key=op_ms.get)
+    achieved = B * alg_bytes[dom] / (op_ms[dom] * 1e-3) / 1e9
+    roofline = dict(kernel={"eval": "k_stage_eval", "factor_solve": "k_kkt", "linesearch": "k_linesearch",
+                            "update": "k_update", "conv": "k_conv", "ls_reduce": "k_ls_reduce"}[dom],
+                    bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    avg_launch_ms=round(op_ms[dom], 4), algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
+                    step_kernel_ms={k: round(v, 4) for k, v in op_ms.items()})
+
+    # ---- Jacobian assembly (the MOI callback, instance-major, reference COO order)
+    jout = torch.empty((B, nj), device=dev, dtype=torch.float64)
+    jfn = lambda: n.eval_constraint_jacobian_batch(z0.data_ptr(), B, nz, jout.data_ptr(), nj, st)
+    for _ in range(3):
+        jfn()
+    jac_ms = event_time_ms(jfn, 20)
+    jac_bytes = B * (8 * nz + 8 * nj)
+    jac = dict(kernel="k_jac", nnz_per_sec=B * nj / (jac_ms * 1e-3), avg_launch_ms=round(jac_ms, 4),
+               achieved_GBps=round(jac_bytes / (jac_ms * 1e-3) / 1e9, 1),
+               frac_of_hbm_peak=round(jac_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    jt = torch.tensor([jac["nnz_per_sec"]], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(jt, op=dist.ReduceOp.SUM)
+
+    # ---- converged trajectories: finish the solves of this shard and all-gather them (RCCL over xGMI)
+    zout = torch.empty((B, nz), device=dev, dtype=torch.float64)
+    s.end_batch(zout.data_ptr(), nz, stream=st)
+    status = torch.tensor(s.scalar_batch("status"), device=dev, dtype=torch.float64)
+    gathered = gather_trajectories(zout, status, dist)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            from oracle.cpu_port import cpu_baseline
+            cpu = cpu_baseline(T=T, seed=1000, seconds=12.0)
+        except Exception as e:  # the baseline is a reported extra, never part of the measured path
+            cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
+
+    if rank == 0:
+        out = dict(
+            metric="SQP iterations/sec + Jacobian nnz/sec, acrobot T=1000, 1->8 GPU",
+            value=iters_done / dt, unit="SQP iterations/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+            ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="f64", data="synthetic",
+            config=dict(workload=f"acrobot swing-up, implicit midpoint h=0.05, T={T}, exact Hessians, "
+                                 f"{B} independent instances per GPU (BASELINE.json configs[2])",
+                        horizon=T, instances_per_gpu=B, instances_total=B * world, num_variables=nz, num_constraint=nc,
+                        jacobian_nnz=nj, hessian_key=nh, parallelism=f"instance sharding x{world}, all-gather of trajectories"),
+            jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
+            factorizations_per_iteration=round(nfact_per_iter, 3),
+            gathered_trajectories=int(gathered.shape[0]),
+            roofline=roofline, cpu_baseline=cpu,
+        )
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

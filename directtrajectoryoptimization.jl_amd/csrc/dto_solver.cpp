@@ -302,6 +302,24 @@ int dto_solver_stats(dto_problem* h, int32_t* status, int32_t* iterations, doubl
   return DTO_OK;
 }
 
+int dto_solver_launch_op(dto_problem* h, int op, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin has not been called");
+  if (op < DTO_KKT_EVAL || op > DTO_KKT_UPDATE) return set_error(DTO_ERR_INVALID, "op out of range");
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  return dto::kkt_launch(p, op, a, (hipStream_t)stream);
+}
+
+int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
+  if (rec) *rec = p->solver->rec_total;
+  if (fac) *fac = p->solver->fac_total;
+  if (ni) *ni = p->solver->Ni;
+  return DTO_OK;
+}
+
 int dto_solver_scalar(dto_problem* h, int slot, double* out) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !p->solver->z || !out) return set_error(DTO_ERR_INVALID, "no solver state");

@@ -336,6 +336,16 @@ class Solver:
         names = ["objective", "constr_viol", "dual_inf", "mu", "delta_w", "alpha"]
         return dict(status=st, iterations=it, **dict(zip(names, arrs)))
 
+    KKT_OPS = dict(eval=3, conv=4, factor_solve=5, linesearch=6, ls_reduce=7, update=8)
+
+    def launch_op(self, name: str, stream=0):
+        capi.check(self.nlp._lib.dto_solver_launch_op(self.nlp._h, self.KKT_OPS[name], stream or None))
+
+    def footprint(self):
+        r, f, n = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(self.nlp._lib.dto_solver_footprint(self.nlp._h, C.byref(r), C.byref(f), C.byref(n)))
+        return dict(record_doubles=r.value, factor_doubles=f.value, num_slacks=n.value)
+
     def scalar_batch(self, name: str):
         out = np.zeros(self._B)
         capi.check(self.nlp._lib.dto_solver_scalar(self.nlp._h, capi.SCALARS.index(name), capi.dptr(out)))

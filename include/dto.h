@@ -181,6 +181,11 @@ int dto_solver_iterate(dto_problem* p, int n_iterations, void* stream);
 /* per-instance scalars, HOST [B] each, any may be NULL */
 int dto_solver_stats(dto_problem* p, int32_t* status, int32_t* iterations, double* objective, double* constr_viol,
                      double* dual_inf, double* mu, double* delta_w, double* alpha);
+/* diagnostic: launch ONE kernel of the iteration (enum dto_kkt_op in csrc/dto_kkt_kernels.hpp: 3 EVAL, 4 CONV,
+ * 5 FACTOR_SOLVE, 6 LINESEARCH, 7 LS_REDUCE, 8 UPDATE) so a caller can time it with events on `stream` */
+int dto_solver_launch_op(dto_problem* p, int op, void* stream);
+/* per-instance footprint of the solver state in doubles: stage records, factors (for roofline arithmetic) */
+int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* factor_doubles, int64_t* num_slacks);
 /* diagnostic: one per-instance scalar slot of the device state (enum dto_scal in csrc/dto_kkt_kernels.hpp), HOST [B] */
 int dto_solver_scalar(dto_problem* p, int slot, double* out);
 int dto_solver_end(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream);

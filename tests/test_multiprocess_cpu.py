@@ -1,0 +1,68 @@
+"""Multi-process path on CPU (gloo, world_size 2): instance sharding and the all-gather of trajectories."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+import dto_amd
+from dto_amd.parallel import shard_range
+
+
+def test_shard_ranges_partition_the_batch():
+    for B in (1, 7, 512, 513):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_range(B, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == B
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    import dto_amd
+    from dto_amd.parallel import gather_trajectories, shard_range
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B, nz = 7, 5                                  # uneven shards: 3 and 4 instances
+    lo, hi = shard_range(B, rank, world)
+    z = torch.tensor([[100.0 * b + i for i in range(nz)] for b in range(lo, hi)], dtype=torch.float64)
+    status = torch.tensor([float(b % 3) for b in range(lo, hi)], dtype=torch.float64)
+    out = gather_trajectories(z, status, dist)
+    exp = np.array([[100.0 * b + i for i in range(nz)] + [float(b % 3)] for b in range(B)])
+    assert out.shape == (B, nz + 1), out.shape
+    assert np.array_equal(out.numpy(), exp)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_all_gather_of_trajectories_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2
+
+
+def test_single_process_gather_is_identity():
+    import torch
+    from dto_amd.parallel import gather_trajectories
+    z = torch.arange(12, dtype=torch.float64).reshape(3, 4)
+    st = torch.tensor([1.0, 0.0, 2.0], dtype=torch.float64)
+    out = gather_trajectories(z, st, None)
+    assert out.shape == (3, 5) and torch.equal(out[:, :4], z) and torch.equal(out[:, 4], st)

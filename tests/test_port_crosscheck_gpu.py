@@ -1,0 +1,72 @@
+"""GPU solver vs the independent serial C port of the same algorithm (oracle/cpu_port): iterate-level agreement.
+
+Both implement the iteration documented in DESIGN.md (same constants).  They are written independently
+(HIP templates over generated device code vs plain C over sympy-generated code), so agreement of the
+iteration history pins the GPU path far more tightly than the end-point checks of test_solve_gpu.py.
+Tolerance: objective / violation histories agree to 1e-6 relative while both are in the same branch of the
+line search; the final points agree to 1e-7 (Newton's quadratic tail erases rounding differences).
+"""
+import numpy as np
+import pytest
+
+from conftest import product_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_history(model, T, z0, iters):
+    import torch
+    s, p = product_solver(model, T)
+    nz = s.nlp.num_variables
+    d = torch.tensor(z0[None, :], device="cuda")
+    s.begin_batch(d.data_ptr(), 1, nz)
+    hist = []
+    for _ in range(iters):
+        s.iterate_batch(1)
+        st = s.stats_batch()
+        hist.append((int(st["iterations"][0]), st["objective"][0], st["constr_viol"][0], st["alpha"][0], st["delta_w"][0],
+                     int(st["status"][0])))
+        if st["status"][0] != 0:
+            break
+    out = torch.zeros((1, nz), device="cuda", dtype=torch.float64)
+    lam = torch.zeros((1, s.nlp.num_constraint), device="cuda", dtype=torch.float64)
+    s.end_batch(out.data_ptr(), nz, lam.data_ptr(), s.nlp.num_constraint)
+    torch.cuda.synchronize()
+    return hist, out.cpu().numpy()[0], lam.cpu().numpy()[0]
+
+
+def port_history(model, T, x1, xT, z0, iters):
+    from oracle.cpu_port import PortSolver
+    s = PortSolver(model, T, x1, xT)
+    s.begin(z0)
+    hist = []
+    for _ in range(iters):
+        ran = s.iterate()
+        st = s.stats()
+        hist.append((s.iterations, st["objective"], st["constr_viol"], st["alpha"], st["delta_w"], s.status))
+        if not ran:
+            break
+    return hist, s.z, s.lam
+
+
+@pytest.mark.parametrize("model,T,seed", [("pendulum", 50, 0), ("pendulum", 50, 3), ("acrobot", 101, 7), ("acrobot", 101, 1)])
+def test_iteration_history_matches_cpu_port(model, T, seed):
+    import dto_amd
+    s, p = product_solver(model, T)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xs, us = p["guess"](rng)
+    dto_amd.initialize_states(s, xs)
+    dto_amd.initialize_controls(s, us)
+    z0 = s._z0.copy()
+    gh, gz, gl = gpu_history(model, T, z0, 400)
+    ph, pz, pl = port_history(model, T, p["x1"], p["xT"], z0, 400)
+    assert gh[-1][5] == 1 and ph[-1][5] == 1
+    # same number of iterations, same step sizes and regularisation decisions, same objective history
+    assert gh[-1][0] == ph[-1][0], (gh[-1], ph[-1])
+    for a, b in zip(gh, ph):
+        assert a[0] == b[0]
+        assert abs(a[1] - b[1]) <= 1e-6 * max(1.0, abs(b[1])), (a, b)
+        assert a[3] == b[3] and abs(a[4] - b[4]) <= 1e-12 * max(1.0, b[4]), (a, b)
+    assert np.max(np.abs(gz - pz)) <= 1e-7 * max(1.0, np.max(np.abs(pz)))
+    # multipliers: GPU order is the reference order (dynamics rows, then stage rows = first pin, last pin)
+    assert np.max(np.abs(gl - pl)) <= 1e-6 * max(1.0, np.max(np.abs(pl)))
