@@ -55,7 +55,7 @@ class COptions(C.Structure):
 # enum dto_scal (csrc/dto_kkt_kernels.hpp)
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
-           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma"]
+           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt"]
 
 
 class DtoError(RuntimeError):
@@ -109,6 +109,8 @@ def lib() -> C.CDLL:
         "dto_solver_scalar": [vp, C.c_int, c_double_p],
         "dto_solver_launch_op": [vp, C.c_int, vp],
         "dto_solver_footprint": [vp, c_int64_p, c_int64_p, c_int64_p],
+        "dto_solver_set_partitions": [vp, C.c_int],
+        "dto_solver_partitions": [vp, C.POINTER(C.c_int)],
         "dto_solve": [vp, C.POINTER(COptions), c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p],
         "dto_device_alloc": [C.POINTER(vp), C.c_int64],
         "dto_device_free": [vp],

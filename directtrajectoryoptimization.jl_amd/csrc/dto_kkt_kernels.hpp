@@ -41,10 +41,11 @@ enum dto_kkt_op {
   DTO_KKT_INIT = 2,        // bound push, slack and multiplier initialisation, scalar state
   DTO_KKT_EVAL = 3,        // per-stage derivative blocks + residual partials
   DTO_KKT_CONV = 4,        // reduce partials, convergence test, barrier update
-  DTO_KKT_FACTOR_SOLVE = 5,  // block-tridiagonal LDL^T + solve + step bounds + merit derivative
+  DTO_KKT_FACTOR_SOLVE = 5,  // all rounds of (chunk forward sweeps, separator system) + back substitution + post
   DTO_KKT_LINESEARCH = 6,  // merit partials of the trial step sizes
   DTO_KKT_LS_REDUCE = 7,   // pick the step size
   DTO_KKT_UPDATE = 8,      // take the step
+  DTO_KKT_FWD = 9, DTO_KKT_SEP = 10, DTO_KKT_BWD = 11, DTO_KKT_POST = 12,  // the four kernels behind FACTOR_SOLVE
   DTO_KKT_OP_COUNT
 };
 
@@ -53,7 +54,7 @@ enum dto_scal {
   SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed
   SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
-  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA,
+  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT,
   SC_COUNT
 };
 
@@ -68,6 +69,7 @@ struct dto_kkt_info {
   int fac_size[16];   // doubles per stage factor record, by kind
   int n_ineq[16];     // inequality rows (slacks) by kind
   int npart, nscal, ls_trials, filter_cap;
+  int chunk_sum_size, sep_fac_size, nx;  // per (tile, chunk) doubles of the partitioned factorisation
 };
 
 struct dto_solver_opts {
@@ -100,6 +102,9 @@ struct dto_kkt_args {
   double* dz; double* dlam; double* ds;
   double* rec; double* fac; double* part; double* lspart; double* scal;
   double* filt;  // [G][2*DTO_FILTER_CAP][64] filter entries (theta, phi)
+  int P;               // chunks of the time-partitioned factorisation
+  const int* cstart;   // [P+1] first stage of every chunk
+  double* csum; double* sfac; double* xsep; double* cacc;  // chunk summaries, separator factors/solutions, step partials
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -143,13 +148,28 @@ struct KindDims {
   static constexpr int F_DI = F_L + BD * (BD - 1) / 2;  // 1/d_i
   static constexpr int F_X = F_DI + BD;               // BD x NY
   static constexpr int F_W = F_X + BD * NY;           // BD
-  static constexpr int FAC = F_W + BD;
+  static constexpr int F_Z = F_W + BD;                // BD x NX spike (chunks p >= 1)
+  static constexpr int FAC = F_Z + BD * NX;
   __host__ __device__ static constexpr bool ineq(int j) {
     if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::ineq(j); else return false;
   }
   __host__ __device__ static constexpr int slack(int j) {
     if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::slack(j); else return -1;
   }
+};
+
+// chunk summary layout (doubles per (tile, chunk)), n = M::MAX_NX
+template <class M>
+struct ChunkSum {
+  static constexpr int N = M::MAX_NX, NT = N * (N + 1) / 2;
+  static constexpr int P = 0, PY = P + NT, RLL = PY + N, RL = RLL + NT, CX = RL + N, OK = CX + N * N, NNEG = OK + 1;
+  static constexpr int SIZE = NNEG + 1;
+};
+// separator factor layout
+template <class M>
+struct SepFac {
+  static constexpr int N = M::MAX_NX;
+  static constexpr int L = 0, DI = L + N * (N - 1) / 2, W = DI + N, MM = W + N, SIZE = MM + N * N;
 };
 
 template <class M, int K = 0>
@@ -173,6 +193,9 @@ int kkt_info(dto_kkt_info* out) {
   out->nscal = SC_COUNT;
   out->ls_trials = DTO_LS_TRIALS;
   out->filter_cap = DTO_FILTER_CAP;
+  out->chunk_sum_size = ChunkSum<M>::SIZE;
+  out->sep_fac_size = SepFac<M>::SIZE;
+  out->nx = M::MAX_NX;
   return 0;
 }
 
@@ -538,6 +561,17 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   }
   // merit value of the current iterate with the (possibly updated) barrier parameter
   sc[SC_MERIT0 << 6] = f - mu * lb;
+  // factorisation request of this iteration (consumed by k_kkt_fwd / k_kkt_sep)
+  sc[SC_NEED << 6] = (o.newton_only || sc[SC_STATUS << 6] == 0.0) ? 1.0 : 0.0;
+  sc[SC_ATTEMPT << 6] = 0.0;
+  sc[SC_TRY_GAM << 6] = 1.0;  // exact Hessian of the Lagrangian first
+  if (o.newton_only) {
+    sc[SC_TRY_DW << 6] = o.fixed_delta_w;
+  } else {
+    const double dlast = sc[SC_DELTA_LAST << 6];
+    // Ipopt's Algorithm IC: always try the unmodified matrix first (unless the last line search failed)
+    sc[SC_TRY_DW << 6] = (sc[SC_LS_FAIL << 6] != 0.0) ? fmax(10.0 * dlast, o.delta_w_init) : 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,17 +608,42 @@ __device__ __forceinline__ void ldl_inplace(double* S, double* dinv, double piv_
 }
 
 // ------------------------------------------------------------------------------------------------
-// block-tridiagonal factor + solve over the whole horizon of one tile.  grid = G waves.
+// block-tridiagonal LDL^T, parallel in time.
+//
+// The horizon is cut into P chunks [a_p, a_{p+1}).  The state x_{a_p} at the head of every chunk
+// p >= 1 is a *separator*: with the separators fixed the chunks decouple, so
+//   k_kkt_fwd  (G*P waves): every chunk eliminates its interior by the forward sweep below while
+//              carrying the coupling of its interior to the left separator ("spike" Z = L^-1 C) and
+//              accumulates its Schur-complement contributions R_LL, R_LR, r_L (left separator) and
+//              P, py (right separator);
+//   k_kkt_sep  (G waves):   the reduced block-tridiagonal system over the P-1 separators (n x n
+//              blocks) is factorised and solved, the inertia of the whole KKT matrix is summed
+//              (Sylvester) and the per-instance retry state machine (delta_w ladder / Gauss-Newton
+//              fallback) advances; the two kernels are launched a fixed number of rounds and exit at
+//              once when no instance of the tile needs another factorisation;
+//   k_kkt_bwd  (G*P waves): back substitution inside every chunk given x_L and x_R, step-length
+//              bounds and merit derivative partials;
+//   k_kkt_post (G waves):   deterministic reduction of the chunk partials.
+// P = 1 is the plain sequential sweep.  Work grows by ~1.6x (the spike) while the number of
+// wavefronts grows P-fold, which is what fills the 1024 SIMDs at moderate batch sizes.
 // ------------------------------------------------------------------------------------------------
 template <class M>
 struct Carry {
-  double P[M::MAX_NX * (M::MAX_NX + 1) / 2];  // cost-to-arrive Schur complement on x_t (packed lower)
+  double P[M::MAX_NX * (M::MAX_NX + 1) / 2];  // Schur complement on x_{t+1} (packed lower)
   double py[M::MAX_NX];                        // rhs carry
 };
 
-template <class M, int K>
+template <class M>
+struct Spike {
+  double Cx[M::MAX_NX * M::MAX_NX];              // K[x_t rows, x_L cols] of the stage about to be eliminated
+  double RLL[M::MAX_NX * (M::MAX_NX + 1) / 2];   // separator diagonal block contribution
+  double rL[M::MAX_NX];                          // separator rhs contribution
+};
+
+template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
-                                              double gam, Carry<M>& cy, bool& ok, int& nneg) {
+                                              double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
+                                              bool& ok, int& nneg) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
@@ -694,10 +753,55 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       for (int c = 0; c < NY; ++c) X[i * NY + c] = 0.0;
     }
   }
+  // --- spike: coupling of this stage to the chunk's left separator x_L
+  double Z[SPK ? BD * NX : 1];
+  double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
+  if constexpr (SPK) {
+#pragma unroll
+    for (int i = 0; i < (NY > 0 ? NY : 1) * NX; ++i) cx_direct[i] = 0.0;
+    if (first) {
+      // the head stage's own x IS the separator: export its diagonal block / rhs, turn its
+      // couplings into the spike, and pin it inside the chunk
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) sp.RLL[tri(i, j)] = S[tri(i, j)];
+        sp.rL[i] = y[i];
+      }
+#pragma unroll
+      for (int i = 0; i < BD; ++i) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Z[i * NX + c] = (i < NX) ? 0.0 : S[tri(i, c)];
+      }
+#pragma unroll
+      for (int aa = 0; aa < NY; ++aa) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) cx_direct[aa * NX + c] = X[c * NY + aa];  // V_x': x_L <-> x_{t+1}
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int r2 = 0; r2 < BD; ++r2) {
+          if (r2 > i) S[tri(r2, i)] = 0.0;
+          if (r2 < i) S[tri(i, r2)] = 0.0;
+        }
+        S[tri(i, i)] = 1.0;
+        y[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NY; ++c) X[i * NY + c] = 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BD; ++i) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Z[i * NX + c] = (i < NX && !fixed[i < NP ? i : 0]) ? sp.Cx[i * NX + c] : 0.0;
+      }
+    }
+  }
   // --- factor
   double dinv[BD];
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
-  // --- X = L^-1 O, w = L^-1 y
+  // --- X = L^-1 O, w = L^-1 y, Z = L^-1 C
 #pragma unroll
   for (int i = 1; i < BD; ++i) {
 #pragma unroll
@@ -706,6 +810,10 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
 #pragma unroll
       for (int c = 0; c < NY; ++c) X[i * NY + c] -= l * X[k * NY + c];
       y[i] -= l * y[k];
+      if constexpr (SPK) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Z[i * NX + c] -= l * Z[k * NX + c];
+      }
     }
   }
   // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w
@@ -723,28 +831,289 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
     for (int i = 0; i < BD; ++i) acc += X[i * NY + c] * dinv[i] * y[i];
     cy.py[c] = acc;
   }
-  // --- store factors
+  if constexpr (SPK) {
+    // separator contributions and the coupling handed to the next stage's x rows
 #pragma unroll
-  for (int i = 1; i < BD; ++i) {
+    for (int c = 0; c < NX; ++c) {
 #pragma unroll
-    for (int k = 0; k < i; ++k) fac[(int64_t)(D::F_L + i * (i - 1) / 2 + k) << 6] = S[tri(i, k)];
+      for (int e = 0; e <= c; ++e) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < BD; ++i) acc += Z[i * NX + c] * Z[i * NX + e] * dinv[i];
+        sp.RLL[tri(c, e)] -= acc;
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < BD; ++i) acc += Z[i * NX + c] * dinv[i] * y[i];
+      sp.rL[c] -= acc;
+    }
+#pragma unroll
+    for (int aa = 0; aa < NY; ++aa) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        double acc = cx_direct[aa * NX + c];
+#pragma unroll
+        for (int i = 0; i < BD; ++i) acc -= X[i * NY + aa] * dinv[i] * Z[i * NX + c];
+        sp.Cx[aa * NX + c] = acc;
+      }
+    }
+  }
+  // --- store factors (only for instances that asked for this factorisation)
+  if (need) {
+#pragma unroll
+    for (int i = 1; i < BD; ++i) {
+#pragma unroll
+      for (int k = 0; k < i; ++k) fac[(int64_t)(D::F_L + i * (i - 1) / 2 + k) << 6] = S[tri(i, k)];
+    }
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      fac[(int64_t)(D::F_DI + i) << 6] = dinv[i];
+      fac[(int64_t)(D::F_W + i) << 6] = y[i];
+#pragma unroll
+      for (int c = 0; c < NY; ++c) fac[(int64_t)(D::F_X + i * NY + c) << 6] = X[i * NY + c];
+      if constexpr (SPK) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) fac[(int64_t)(D::F_Z + i * NX + c) << 6] = Z[i * NX + c];
+      }
+    }
+  }
+}
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.P;
+  const int p = blockIdx.x % a.P;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
+  if (!__any(need)) return;
+  const double mu = sc[SC_MU << 6];
+  const double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
+  const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
+  Carry<M> cy;
+  Spike<M> sp;
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = sp.RLL[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = sp.rL[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
+  bool ok = true;
+  int nneg = 0;
+  if (p == 0) {
+    for (int t = t0; t < t1; ++t)
+      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+      });
+  } else {
+    for (int t = t0; t < t1; ++t)
+      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
+        if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
+          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
+      });
+  }
+  if (!need) return;
+  using CS = ChunkSum<M>;
+  double* cs = a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < CS::NT; ++i) {
+    cs[(int64_t)(CS::P + i) << 6] = cy.P[i];
+    cs[(int64_t)(CS::RLL + i) << 6] = sp.RLL[i];
   }
 #pragma unroll
-  for (int i = 0; i < BD; ++i) {
-    fac[(int64_t)(D::F_DI + i) << 6] = dinv[i];
-    fac[(int64_t)(D::F_W + i) << 6] = y[i];
-#pragma unroll
-    for (int c = 0; c < NY; ++c) fac[(int64_t)(D::F_X + i * NY + c) << 6] = X[i * NY + c];
+  for (int i = 0; i < CS::N; ++i) {
+    cs[(int64_t)(CS::PY + i) << 6] = cy.py[i];
+    cs[(int64_t)(CS::RL + i) << 6] = sp.rL[i];
   }
+#pragma unroll
+  for (int i = 0; i < CS::N * CS::N; ++i) cs[(int64_t)(CS::CX + i) << 6] = sp.Cx[i];
+  cs[(int64_t)CS::OK << 6] = ok ? 1.0 : 0.0;
+  cs[(int64_t)CS::NNEG << 6] = (double)nneg;
+}
+
+// reduced system over the separators + inertia + retry state machine.  grid = G waves.
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  const dto_solver_opts& o = a.opt;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
+  if (!__any(need)) return;
+  using CS = ChunkSum<M>;
+  using SF = SepFac<M>;
+  constexpr int N = CS::N, NT = CS::NT;
+  auto csp = [&](int p) { return a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x; };
+  auto sfp = [&](int p) { return a.sfac + (((g * a.P + p) * SF::SIZE) << 6) + threadIdx.x; };
+  bool ok = true;
+  int nneg = 0;
+  for (int p = 0; p < a.P; ++p) {
+    const double* cs = csp(p);
+    if (cs[(int64_t)CS::OK << 6] == 0.0) ok = false;
+    nneg += (int)cs[(int64_t)CS::NNEG << 6];
+  }
+  // forward elimination over separators p = 1 .. P-1
+  double Lp[N * (N + 1) / 2], dip[N], wp[N];  // factor of the previous separator block
+  for (int p = 1; p < a.P; ++p) {
+    const double* cl = csp(p - 1);
+    const double* cr = csp(p);
+    double Dg[NT], r[N], Bt[N * N];  // Bt[c][aa] = K[s_p(aa), s_{p-1}(c)] = CX of chunk p-1, transposed access below
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Dg[i] = cl[(int64_t)(CS::P + i) << 6] + cr[(int64_t)(CS::RLL + i) << 6];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = cr[(int64_t)(CS::RL + i) << 6] - cl[(int64_t)(CS::PY + i) << 6];
+    const int z0 = a.zoff[a.cstart[p]];
+    bool fx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) fx[i] = !o.newton_only && (a.lo[z0 + i] == a.hi[z0 + i]);
+    if (p > 1) {
+      // coupling with the previous separator: rows = this separator (x_R of chunk p-1), cols = previous (x_L)
+      const double* cx = csp(p - 1) + ((int64_t)CS::CX << 6);
+      double Mm[N * N];  // Mm = L_{p-1}^-1 B', B'[c][aa] = cx[aa][c]
+      const int zp = a.zoff[a.cstart[p - 1]];
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const bool fc = !o.newton_only && (a.lo[zp + c] == a.hi[zp + c]);
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) Mm[c * N + aa] = (fc || fx[aa]) ? 0.0 : cx[(int64_t)(aa * N + c) << 6];
+      }
+#pragma unroll
+      for (int i = 1; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          const double l = Lp[tri(i, k)];
+#pragma unroll
+          for (int aa = 0; aa < N; ++aa) Mm[i * N + aa] -= l * Mm[k * N + aa];
+        }
+      }
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+        for (int bb = 0; bb <= aa; ++bb) {
+          double acc = 0.0;
+#pragma unroll
+          for (int i = 0; i < N; ++i) acc += Mm[i * N + aa] * Mm[i * N + bb] * dip[i];
+          Dg[tri(aa, bb)] -= acc;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += Mm[i * N + aa] * dip[i] * wp[i];
+        r[aa] -= acc;
+      }
+      if (need) {
+        double* sf = sfp(p - 1);
+#pragma unroll
+        for (int i = 0; i < N * N; ++i) sf[(int64_t)(SF::MM + i) << 6] = Mm[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (fx[i]) {
+#pragma unroll
+        for (int r2 = 0; r2 < N; ++r2) {
+          if (r2 > i) Dg[tri(r2, i)] = 0.0;
+          if (r2 < i) Dg[tri(i, r2)] = 0.0;
+        }
+        Dg[tri(i, i)] = 1.0;
+        r[i] = 0.0;
+      }
+    }
+    ldl_inplace<N>(Dg, dip, o.piv_tol, ok, nneg);
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+#pragma unroll
+      for (int k = 0; k < i; ++k) r[i] -= Dg[tri(i, k)] * r[k];
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Lp[i] = Dg[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) wp[i] = r[i];
+    if (need) {
+      double* sf = sfp(p);
+#pragma unroll
+      for (int i = 1; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) sf[(int64_t)(SF::L + i * (i - 1) / 2 + k) << 6] = Dg[tri(i, k)];
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        sf[(int64_t)(SF::DI + i) << 6] = dip[i];
+        sf[(int64_t)(SF::W + i) << 6] = r[i];
+      }
+    }
+  }
+  // backward substitution over the separators
+  double sn[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) sn[i] = 0.0;
+  for (int p = a.P - 1; p >= 1; --p) {
+    const double* sf = sfp(p);
+    double v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double rr = sf[(int64_t)(SF::W + i) << 6];
+      if (p < a.P - 1) {
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) rr -= sf[(int64_t)(SF::MM + i * N + aa) << 6] * sn[aa];
+      }
+      v[i] = rr * sf[(int64_t)(SF::DI + i) << 6];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 1; --i) {
+#pragma unroll
+      for (int k = 0; k < i; ++k) v[k] -= sf[(int64_t)(SF::L + i * (i - 1) / 2 + k) << 6] * v[i];
+    }
+    if (need) {
+      double* xs = a.xsep + (((g * a.P + p) * N) << 6) + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < N; ++i) xs[(int64_t)i << 6] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) sn[i] = v[i];
+  }
+  if (!need) return;
+  // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
+  if (nneg != (int)a.Nc) ok = false;
+  sc[SC_NFACT << 6] += 1.0;
+  double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
+  const double dlast = sc[SC_DELTA_LAST << 6];
+  const int attempt = (int)sc[SC_ATTEMPT << 6];
+  const bool done = ok || o.newton_only || attempt >= o.max_refactor;
+  if (done) {
+    sc[SC_NEED << 6] = 0.0;
+    sc[SC_DELTA_W << 6] = dw;
+    sc[SC_GAMMA << 6] = gam;
+    if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
+    if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
+    sc[SC_LS_FAIL << 6] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
+    return;
+  }
+  if (gam != 0.0) {
+    // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
+    // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
+    // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
+    const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
+    if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+    else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
+    if (skip_ladder || dw > o.delta_w_exact_cap) {
+      gam = 0.0;
+      dw = o.delta_w_init;
+    }
+  } else {
+    dw *= o.kappa_w_plus;
+    if (dw > o.delta_w_max) dw = o.delta_w_max;
+  }
+  sc[SC_TRY_DW << 6] = dw;
+  sc[SC_TRY_GAM << 6] = gam;
+  sc[SC_ATTEMPT << 6] = (double)(attempt + 1);
 }
 
 struct StepAcc {
   double apmax, admax, gphid, rlam;
 };
 
-template <class M, int K>
+template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
-                                               double* xn, StepAcc& acc) {
+                                               bool first, const double* xL, double* xn, StepAcc& acc) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
@@ -758,12 +1127,22 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
     double r = Fv(D::F_W + i);
 #pragma unroll
     for (int c = 0; c < NY; ++c) r -= Fv(D::F_X + i * NY + c) * xn[c];
+    if constexpr (SPK) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) r -= Fv(D::F_Z + i * NX + c) * xL[c];
+    }
     v[i] = r * Fv(D::F_DI + i);
   }
 #pragma unroll
   for (int i = BD - 1; i >= 1; --i) {
 #pragma unroll
     for (int k = 0; k < i; ++k) v[k] -= Fv(D::F_L + i * (i - 1) / 2 + k) * v[i];
+  }
+  if constexpr (SPK) {
+    if (first) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) v[i] = xL[i];  // the head stage's x is the separator itself
+    }
   }
   const int z0 = a.zoff[t];
   // primal step, fraction to the boundary, barrier directional derivative
@@ -830,78 +1209,58 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
 }
 
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_kkt(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+__global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.P;
+  const int p = blockIdx.x % a.P;
   const dto_solver_opts& o = a.opt;
-  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   const bool running = sc[SC_STATUS << 6] == 0.0;
   if (__all(!running)) return;
+  constexpr int N = M::MAX_NX;
   const double mu = sc[SC_MU << 6];
-  const double dlast = sc[SC_DELTA_LAST << 6];
-  double dw;
-  if (o.newton_only) {
-    dw = o.fixed_delta_w;
-  } else {
-    dw = 0.0;  // Ipopt's Algorithm IC: always try the unmodified matrix first
-    if (sc[SC_LS_FAIL << 6] != 0.0) dw = fmax(10.0 * dlast, o.delta_w_init);
-  }
-  int nfact = 0;
-  bool ok = true;
-  double gam = 1.0;  // 1: exact Hessian of the Lagrangian, 0: Gauss-Newton (constraint curvature dropped)
-  for (int attempt = 0; attempt <= o.max_refactor; ++attempt) {
-    Carry<M> cy;
-#pragma unroll
-    for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = 0.0;
-    ok = true;
-    int nneg = 0;
-    for (int t = 0; t < a.T; ++t) {
-      dispatch_uniform<M>(a.kind[t], [&](auto kc) { stage_forward<M, decltype(kc)::value>(a, g, t, mu, dw, gam, cy, ok, nneg); });
-    }
-    // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
-    if (nneg != (int)a.Nc) ok = false;
-    ++nfact;
-    const bool need = running && !ok && !o.newton_only;
-    if (!__any(need)) break;
-    if (need) {
-      if (gam != 0.0) {
-        // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
-        // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
-        // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
-        const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
-        if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
-        else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
-        if (skip_ladder || dw > o.delta_w_exact_cap) {
-          gam = 0.0;
-          dw = o.delta_w_init;
-        }
-      } else {
-        dw *= o.kappa_w_plus;
-        if (dw > o.delta_w_max) dw = o.delta_w_max;
-      }
-    }
-  }
-  // backward sweep
   const double tau = fmax(o.tau_min, 1.0 - mu);
-  StepAcc acc{1.0, 1.0, 0.0, 0.0};
-  double xn[M::MAX_NX];
+  const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
+  double xL[N], xn[N];
 #pragma unroll
-  for (int i = 0; i < M::MAX_NX; ++i) xn[i] = 0.0;
-  for (int t = a.T - 1; t >= 0; --t) {
-    dispatch_uniform<M>(a.kind[t], [&](auto kc) { stage_backward<M, decltype(kc)::value>(a, g, t, mu, tau, xn, acc); });
+  for (int i = 0; i < N; ++i) {
+    xL[i] = (p > 0) ? a.xsep[(((g * a.P + p) * N + i) << 6) + threadIdx.x] : 0.0;
+    xn[i] = (p < a.P - 1) ? a.xsep[(((g * a.P + p + 1) * N + i) << 6) + threadIdx.x] : 0.0;
   }
-  if (!running) return;
+  StepAcc acc{1.0, 1.0, 0.0, 0.0};
+  if (p == 0) {
+    for (int t = t1 - 1; t >= t0; --t)
+      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, false, xL, xn, acc);
+      });
+  } else {
+    for (int t = t1 - 1; t >= t0; --t)
+      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
+          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, t == t0, xL, xn, acc);
+      });
+  }
+  double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
+  ca[0 << 6] = acc.apmax;
+  ca[1 << 6] = acc.admax;
+  ca[2 << 6] = acc.gphid;
+  ca[3 << 6] = acc.rlam;
+}
+
+static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  double apmax = 1.0, admax = 1.0, gphid = 0.0;
+  for (int p = 0; p < a.P; ++p) {
+    const double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
+    apmax = fmin(apmax, ca[0 << 6]);
+    admax = fmin(admax, ca[1 << 6]);
+    gphid += ca[2 << 6];
+  }
   // directional derivative of the barrier objective along the step (filter line search, switching condition)
-  sc[SC_DMERIT << 6] = acc.gphid;
-  sc[SC_ALPHA_PMAX << 6] = acc.apmax;
-  sc[SC_ALPHA_DMAX << 6] = acc.admax;
-  sc[SC_DELTA_W << 6] = dw;
-  sc[SC_GAMMA << 6] = gam;
-  if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
-  if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
-  sc[SC_NFACT << 6] += (double)nfact;
-  if (!ok && !o.newton_only) sc[SC_LS_FAIL << 6] = 1.0;  // regularisation cap reached: force growth next time
+  sc[SC_DMERIT << 6] = gphid;
+  sc[SC_ALPHA_PMAX << 6] = apmax;
+  sc[SC_ALPHA_DMAX << 6] = admax;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1179,7 +1538,21 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_CONV: hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd); break;
-      case DTO_KKT_FACTOR_SOLVE: hipLaunchKernelGGL(k_kkt<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_FACTOR_SOLVE: {
+        const unsigned gp = (unsigned)((int64_t)a.G * a.P);
+        const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
+        for (int r = 0; r < rounds; ++r) {
+          hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        }
+        hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        break;
+      }
+      case DTO_KKT_FWD: hipLaunchKernelGGL(k_kkt_fwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_SEP: hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_BWD: hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LS_REDUCE: hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;

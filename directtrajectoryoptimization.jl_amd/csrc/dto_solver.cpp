@@ -36,6 +36,11 @@ struct SolverState {
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
+  double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr;
+  int P = 1;            // chunks of the time-partitioned factorisation
+  int forced_P = 0;     // 0 = choose from the batch size
+  std::vector<int> cstart;
+  int* d_cstart = nullptr;
   dto_kkt_info info{};
   dto_solver_opts opt{};
   dto_options user{};
@@ -45,10 +50,12 @@ struct SolverState {
   void release() {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
-                    (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt})
+                    (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
+                    (void*)cacc, (void*)d_cstart})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
+    csum = sfac = xsep = cacc = nullptr; d_cstart = nullptr;
     B = 0; G = 0;
   }
 };
@@ -70,7 +77,7 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.kappa_w_minus = 1.0 / 3.0; o.kappa_w_plus = 8.0; o.kappa_w_plus_first = 100.0;
   o.delta_w_exact_cap = 1.0;
   o.eta_armijo = 1e-4; o.rho_penalty = 0.1; o.piv_tol = 1e-9;
-  o.max_refactor = 12;
+  o.max_refactor = 9;
   o.newton_only = 0; o.fixed_delta_w = 0.0;
 }
 
@@ -87,9 +94,16 @@ static int ensure_state(Problem* p, int64_t B) {
   if (!p->vt->kkt_info || !p->vt->launch_kkt) return set_error(DTO_ERR_UNSUPPORTED, "plugin has no KKT kernels");
   if (!p->solver) p->solver = new SolverState();
   SolverState& S = *p->solver;
-  if (S.B == B && S.z) return DTO_OK;
-  S.release();
   const Layout& L = p->L;
+  const int G_new = (int)((B + 63) / 64);
+  // chunks: enough wavefronts to put one on every SIMD (256 CUs x 4), at least 8 stages per chunk
+  int P_new = S.forced_P > 0 ? S.forced_P : (1024 + G_new - 1) / G_new;
+  P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / 8))));
+  if (S.B == B && S.z && S.P == P_new) return DTO_OK;
+  const int keep_forced = S.forced_P;
+  S.release();
+  S.forced_P = keep_forced;
+  S.P = P_new;
   p->vt->kkt_info(&S.info);
   if (!S.info.supported)
     return set_error(DTO_ERR_UNSUPPORTED,
@@ -138,6 +152,14 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.lspart, lanes * (size_t)L.T * 2 * S.info.ls_trials))) return rc;
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
   if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
+  S.cstart.assign(S.P + 1, 0);
+  for (int c = 0; c <= S.P; ++c) S.cstart[c] = (int)(((int64_t)c * L.T) / S.P);
+  HIP_TRY(hipMalloc((void**)&S.d_cstart, (S.P + 1) * sizeof(int)));
+  HIP_TRY(hipMemcpy(S.d_cstart, S.cstart.data(), (S.P + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(&S.csum, lanes * (size_t)S.P * S.info.chunk_sum_size))) return rc;
+  if ((rc = dev_alloc(&S.sfac, lanes * (size_t)S.P * S.info.sep_fac_size))) return rc;
+  if ((rc = dev_alloc(&S.xsep, lanes * (size_t)S.P * S.info.nx))) return rc;
+  if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P * 4))) return rc;
   S.h_scal.assign(lanes * S.info.nscal, 0.0);
   return DTO_OK;
 }
@@ -156,6 +178,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
+  a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc;
   a.opt = S.opt;
 }
 
@@ -305,10 +328,26 @@ int dto_solver_stats(dto_problem* h, int32_t* status, int32_t* iterations, doubl
 int dto_solver_launch_op(dto_problem* h, int op, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin has not been called");
-  if (op < DTO_KKT_EVAL || op > DTO_KKT_UPDATE) return set_error(DTO_ERR_INVALID, "op out of range");
+  if (op < DTO_KKT_EVAL || op >= DTO_KKT_OP_COUNT) return set_error(DTO_ERR_INVALID, "op out of range");
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
   return dto::kkt_launch(p, op, a, (hipStream_t)stream);
+}
+
+int dto_solver_set_partitions(dto_problem* h, int partitions) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || partitions < 0 || partitions > 64) return set_error(DTO_ERR_INVALID, "partitions must be in [0, 64]");
+  if (partitions > p->L.T) return set_error(DTO_ERR_INVALID, "more partitions than stages");
+  if (!p->solver) p->solver = new SolverState();
+  p->solver->forced_P = partitions;
+  return DTO_OK;
+}
+
+int dto_solver_partitions(dto_problem* h, int* partitions) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !partitions) return set_error(DTO_ERR_INVALID, "no solver state");
+  *partitions = p->solver->P;
+  return DTO_OK;
 }
 
 int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni) {

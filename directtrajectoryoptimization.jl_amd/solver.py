@@ -336,7 +336,17 @@ class Solver:
         names = ["objective", "constr_viol", "dual_inf", "mu", "delta_w", "alpha"]
         return dict(status=st, iterations=it, **dict(zip(names, arrs)))
 
-    KKT_OPS = dict(eval=3, conv=4, factor_solve=5, linesearch=6, ls_reduce=7, update=8)
+    KKT_OPS = dict(eval=3, conv=4, factor_solve=5, linesearch=6, ls_reduce=7, update=8, kkt_fwd=9, kkt_sep=10, kkt_bwd=11,
+                   kkt_post=12)
+
+    def set_partitions(self, partitions: int):
+        """Chunks of the time-partitioned factorisation (0 = automatic, 1 = sequential)."""
+        capi.check(self.nlp._lib.dto_solver_set_partitions(self.nlp._h, int(partitions)))
+
+    def partitions(self) -> int:
+        v = C.c_int(0)
+        capi.check(self.nlp._lib.dto_solver_partitions(self.nlp._h, C.byref(v)))
+        return v.value
 
     def launch_op(self, name: str, stream=0):
         capi.check(self.nlp._lib.dto_solver_launch_op(self.nlp._h, self.KKT_OPS[name], stream or None))

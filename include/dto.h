@@ -184,6 +184,10 @@ int dto_solver_stats(dto_problem* p, int32_t* status, int32_t* iterations, doubl
 /* diagnostic: launch ONE kernel of the iteration (enum dto_kkt_op in csrc/dto_kkt_kernels.hpp: 3 EVAL, 4 CONV,
  * 5 FACTOR_SOLVE, 6 LINESEARCH, 7 LS_REDUCE, 8 UPDATE) so a caller can time it with events on `stream` */
 int dto_solver_launch_op(dto_problem* p, int op, void* stream);
+/* chunks of the time-partitioned block-tridiagonal factorisation: 0 = chosen from the batch size so that
+ * tiles x chunks fills the GPU's SIMDs; 1 = plain sequential sweep.  Takes effect at the next begin/step. */
+int dto_solver_set_partitions(dto_problem* p, int partitions);
+int dto_solver_partitions(dto_problem* p, int* partitions);
 /* per-instance footprint of the solver state in doubles: stage records, factors (for roofline arithmetic) */
 int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* factor_doubles, int64_t* num_slacks);
 /* diagnostic: one per-instance scalar slot of the device state (enum dto_scal in csrc/dto_kkt_kernels.hpp), HOST [B] */

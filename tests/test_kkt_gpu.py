@@ -60,6 +60,42 @@ def test_kkt_step_matches_dense_solve(model, T, B, dw):
     assert ok
 
 
+@pytest.mark.parametrize("model,T,dw", [("pendulum", 50, 30.0), ("acrobot", 70, 60.0), ("car", 51, 10.0), ("cartpole", 40, 400.0)])
+@pytest.mark.parametrize("partitions", [1, 2, 3, 7, 16])
+def test_time_partitioned_factorisation_matches_dense_solve(model, T, dw, partitions):
+    """The parallel-in-time factorisation (chunks + spikes + separator system) solves the same system as the
+    sequential sweep and as numpy's dense solve, for any number of chunks (including chunk lengths that do
+    not divide T and chunks that start at a constrained stage)."""
+    import torch
+    from oracle import dto_oracle as O, sympy_models as S
+    s, _ = product_solver(model, T)
+    n = s.nlp
+    p = S.build(model, T, evaluate_hessian=True)
+    onlp = O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True)
+    nz, nc = n.num_variables, n.num_constraint
+    rng = np.random.default_rng(7 * T + partitions)
+    B = 2
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    dz, dmu = torch.tensor(Z, device="cuda"), torch.tensor(MU, device="cuda")
+    dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    s.set_partitions(partitions)
+    try:
+        ok = s.kkt_step_batch(dz.data_ptr(), B, nz, dmu.data_ptr(), nc, dw, 1e-5, dx.data_ptr(), nz, dl.data_ptr(), nc)
+        assert s.partitions() == partitions
+    finally:
+        s.set_partitions(0)
+    torch.cuda.synchronize()
+    dx, dl = dx.cpu().numpy(), dl.cpu().numpy()
+    for b in range(B):
+        rx, rl, inertia, cond = dense_kkt_solve(onlp, Z[b], MU[b], dw, 1e-5)
+        assert inertia == (nz, nc)
+        scale = max(np.max(np.abs(rx)), np.max(np.abs(rl)))
+        assert np.max(np.abs(dx[b] - rx)) <= 1e-8 * scale, (np.max(np.abs(dx[b] - rx)), scale, cond)
+        assert np.max(np.abs(dl[b] - rl)) <= 1e-8 * scale, (np.max(np.abs(dl[b] - rl)), scale, cond)
+    assert ok
+
+
 def test_inertia_flag_matches_dense_inertia():
     """The negative-pivot count of the block-tridiagonal LDL^T (Sylvester) must agree with the dense
     eigenvalue inertia of the same matrix: correct for small multipliers, wrong once the constraint
