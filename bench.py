@@ -121,35 +121,46 @@ def main():
         dt = float(tmax[0])
         iters_done, facts_done = float(tt[1]), float(tt[2])
 
-    # ---- per-kernel time of one iteration (HIP events on the launch stream), dominant kernel roofline
-    ops = ["eval", "conv", "factor_solve", "linesearch", "ls_reduce", "update"]
-    op_ms = {}
-    reps = 3
-    acc = {o: 0.0 for o in ops}
-    for _ in range(reps):
-        for o in ops:
-            acc[o] += event_time_ms(lambda: s.launch_op(o, stream=st), 1)
-    op_ms = {o: acc[o] / reps for o in ops}
+    # ---- per-kernel durations (HIP events on the launch stream): the launch sequence of an iteration is
+    #      replayed kernel by kernel for a few more iterations; averages are over ALL launches of a kernel,
+    #      including the rounds of k_kkt_fwd/k_kkt_sep that exit at once -- what `rocprofv3 --stats` reports.
     fp = s.footprint()
+    rounds = fp["factor_rounds"]
+    seq = (["eval", "conv"] + ["kkt_fwd", "kkt_sep"] * rounds + ["kkt_bwd", "kkt_post", "linesearch", "ls_reduce", "update"])
+    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd", kkt_sep="k_kkt_sep", kkt_bwd="k_kkt_bwd",
+                 kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update")
+    tot = {k: 0.0 for k in kname}
+    cnt = {k: 0 for k in kname}
+    reps = 3
+    nf_a = float(np.sum(s.scalar_batch("nfact")))
+    it_a = float(np.sum(s.scalar_batch("iter")))
+    for _ in range(reps):
+        for o in seq:
+            tot[o] += event_time_ms(lambda: s.launch_op(o, stream=st), 1)
+            cnt[o] += 1
+    nf_b = float(np.sum(s.scalar_batch("nfact")))
+    it_b = float(np.sum(s.scalar_batch("iter")))
+    avg_ms = {k: tot[k] / cnt[k] for k in kname}
+    per_iter_ms = {k: tot[k] / reps for k in kname}
     nfact_per_iter = facts_done / max(iters_done, 1.0)
-    nnz_K = nj + (nh + nz) // 2 + nc                     # structural lower-triangular KKT entries
-    alg_bytes = {
-        # fused KKT value scatter = 8 (Nz + Nw + Nc + 1) + 8 nnz_K
-        "eval": 8 * (nz + nc + 1) + 8 * nnz_K,
-        # factor + solve: read K once, write the factors once, read them once, read rhs, write the step
-        "factor_solve": 8 * (nnz_K + 2 * fp["factor_doubles"] + 2 * (nz + nc)),
-        "linesearch": 8 * (2 * nz + 1) + 8 * 16,
-        "update": 8 * 3 * (nz + nc),
-        "conv": 8 * 9 * T, "ls_reduce": 8 * 16 * T,
-    }
-    dom = max(op_ms, key=op_ms.get)
-    achieved = B * alg_bytes[dom] / (op_ms[dom] * 1e-3) / 1e9
-    roofline = dict(kernel={"eval": "k_stage_eval", "factor_solve": "k_kkt", "linesearch": "k_linesearch",
-                            "update": "k_update", "conv": "k_conv", "ls_reduce": "k_ls_reduce"}[dom],
-                    bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+    working = (nf_b - nf_a) / max(B * reps * rounds, 1)         # fraction of k_kkt_fwd launches x lanes that factorised
+    nnz_K = nj + (nh + nz) // 2 + nc                           # structural lower-triangular KKT entries
+    fac_d = fp["factor_doubles"]
+    alg_bytes = dict(                                          # per instance and per launch
+        eval=8 * (nz + nc + 1) + 8 * nnz_K,                    # fused KKT value scatter
+        kkt_fwd=working * 8 * (nnz_K + fac_d),                 # read K, write the factors (working launches only)
+        kkt_bwd=8 * (fac_d + nz + nc) + 8 * (nz + nc),         # read the factors + rhs, write the step
+        linesearch=8 * (2 * nz) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 9 * T, ls_reduce=8 * 16 * T,
+        kkt_sep=8 * 64, kkt_post=8 * 4)
+    dom = max(per_iter_ms, key=per_iter_ms.get)
+    achieved = B * alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    roofline = dict(kernel=kname[dom], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                    avg_launch_ms=round(op_ms[dom], 4), algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
-                    step_kernel_ms={k: round(v, 4) for k, v in op_ms.items()})
+                    avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
+                    algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
+                    working_fraction_of_launches=round(working, 4),
+                    kernel_ms_per_iteration={kname[k]: round(v, 4) for k, v in per_iter_ms.items()},
+                    kernel_avg_launch_ms={kname[k]: round(v, 5) for k, v in avg_ms.items()})
 
     # ---- Jacobian assembly (the MOI callback, instance-major, reference COO order)
     jout = torch.empty((B, nj), device=dev, dtype=torch.float64)
@@ -190,7 +201,7 @@ def main():
                         horizon=T, instances_per_gpu=B, instances_total=B * world, num_variables=nz, num_constraint=nc,
                         jacobian_nnz=nj, hessian_key=nh, parallelism=f"instance sharding x{world}, all-gather of trajectories"),
             jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
-            factorizations_per_iteration=round(nfact_per_iter, 3),
+            factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=s.partitions(),
             gathered_trajectories=int(gathered.shape[0]),
             roofline=roofline, cpu_baseline=cpu,
         )

@@ -350,12 +350,13 @@ int dto_solver_partitions(dto_problem* h, int* partitions) {
   return DTO_OK;
 }
 
-int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni) {
+int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni, int* rounds) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
   if (rec) *rec = p->solver->rec_total;
   if (fac) *fac = p->solver->fac_total;
   if (ni) *ni = p->solver->Ni;
+  if (rounds) *rounds = p->solver->opt.newton_only ? 1 : p->solver->opt.max_refactor + 1;
   return DTO_OK;
 }
 

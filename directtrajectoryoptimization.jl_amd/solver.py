@@ -352,9 +352,9 @@ class Solver:
         capi.check(self.nlp._lib.dto_solver_launch_op(self.nlp._h, self.KKT_OPS[name], stream or None))
 
     def footprint(self):
-        r, f, n = C.c_int64(), C.c_int64(), C.c_int64()
-        capi.check(self.nlp._lib.dto_solver_footprint(self.nlp._h, C.byref(r), C.byref(f), C.byref(n)))
-        return dict(record_doubles=r.value, factor_doubles=f.value, num_slacks=n.value)
+        r, f, n, k = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        capi.check(self.nlp._lib.dto_solver_footprint(self.nlp._h, C.byref(r), C.byref(f), C.byref(n), C.byref(k)))
+        return dict(record_doubles=r.value, factor_doubles=f.value, num_slacks=n.value, factor_rounds=k.value)
 
     def scalar_batch(self, name: str):
         out = np.zeros(self._B)

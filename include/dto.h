@@ -189,7 +189,8 @@ int dto_solver_launch_op(dto_problem* p, int op, void* stream);
 int dto_solver_set_partitions(dto_problem* p, int partitions);
 int dto_solver_partitions(dto_problem* p, int* partitions);
 /* per-instance footprint of the solver state in doubles: stage records, factors (for roofline arithmetic) */
-int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* factor_doubles, int64_t* num_slacks);
+int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* factor_doubles, int64_t* num_slacks,
+                         int* factor_rounds /* (k_kkt_fwd, k_kkt_sep) launch pairs per iteration */);
 /* diagnostic: one per-instance scalar slot of the device state (enum dto_scal in csrc/dto_kkt_kernels.hpp), HOST [B] */
 int dto_solver_scalar(dto_problem* p, int slot, double* out);
 int dto_solver_end(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream);
