@@ -131,25 +131,30 @@ struct KindDims {
   static constexpr int QI = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NI; else return 0; }();
   static constexpr int NY = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NY; else return 0; }();
   static constexpr int BD = NP + Q + NY;
-  // record layout
-  static constexpr int R_W = 0;                          // sigma * objective Hessian (packed lower)
-  static constexpr int R_WD = R_W + NP * (NP + 1) / 2;   // curvature of lam'd + nu'c, pp block (packed lower)
-  static constexpr int R_V = R_WD + NP * (NP + 1) / 2;
-  static constexpr int R_YY = R_V + NP * NY;
-  static constexpr int R_F = R_YY + NY * (NY + 1) / 2;
-  static constexpr int R_E = R_F + NY * NP;
-  static constexpr int R_G = R_E + NY * NY;
-  static constexpr int R_RP = R_G + Q * NP;
+  // record layout: STRUCTURAL nonzeros only (what the reference's nzval vectors hold), scattered into the
+  // dense stage blocks inside the factor kernel
+  static constexpr int N_CH = C::NHL;   // objective Hessian, lower triangle
+  static constexpr int N_DJ = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NJ; else return 0; }();
+  static constexpr int N_DH = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NHL; else return 0; }();
+  static constexpr int N_KJ = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NJ; else return 0; }();
+  static constexpr int N_KH = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NHL; else return 0; }();
+  static constexpr int R_CH = 0;
+  static constexpr int R_DJ = R_CH + N_CH;
+  static constexpr int R_DH = R_DJ + N_DJ;
+  static constexpr int R_KJ = R_DH + N_DH;
+  static constexpr int R_KH = R_KJ + N_KJ;
+  static constexpr int R_RP = R_KH + N_KH;
   static constexpr int R_D = R_RP + NP;
   static constexpr int R_C = R_D + NY;
   static constexpr int REC = R_C + Q;
-  // factor layout
-  static constexpr int F_L = 0;                       // strict lower, row-major packed: (i,j) at i(i-1)/2 + j
-  static constexpr int F_DI = F_L + BD * (BD - 1) / 2;  // 1/d_i
-  static constexpr int F_X = F_DI + BD;               // BD x NY
-  static constexpr int F_W = F_X + BD * NY;           // BD
-  static constexpr int F_Z = F_W + BD;                // BD x NX spike (chunks p >= 1)
-  static constexpr int FAC = F_Z + BD * NX;
+  // "factor" record: only what the forward recursion hands from stage to stage (the carry-in of this stage).
+  // The stage's L, D, X, w, Z are NOT stored: the backward sweep rebuilds them from the stage record and
+  // this carry -- a 9x9..13x13 LDL^T is ~0.4 us of arithmetic, the 162 doubles it replaces are 83 KB of HBM
+  // writes + reads per wave and stage (measured: the stored-factor version was write-bandwidth bound).
+  static constexpr int F_P = 0;                          // Schur complement on x_t from stage t-1 (packed lower)
+  static constexpr int F_PY = F_P + NX * (NX + 1) / 2;   // rhs carry
+  static constexpr int F_CX = F_PY + NX;                 // coupling of x_t to the chunk's left separator (NX x NX)
+  static constexpr int FAC = F_CX + NX * NX;
   __host__ __device__ static constexpr bool ineq(int j) {
     if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::ineq(j); else return false;
   }
@@ -349,9 +354,6 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     arr<CO::NW> wc;
     gmem_load(wc, a.params + a.woff[t]);
 
-    arr<D::NP*(D::NP + 1) / 2> W, WD;
-#pragma unroll
-    for (int i = 0; i < D::NP * (D::NP + 1) / 2; ++i) W[i] = WD[i] = 0.0;
     arr<D::NP> rp;
     double cost_val;
     {
@@ -361,8 +363,11 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
       if constexpr (CO::NH > 0) {
         arr<CO::NH> hv;
+        arr<CO::NHL> hl;
         CO::hess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
-        CO::scatter_hess(hv.data(), W.data());
+        CO::pack_hess_lower(hv.data(), hl.data());
+#pragma unroll
+        for (int i = 0; i < CO::NHL; ++i) put(D::R_CH + i, hl[i]);
       }
     }
     double th1 = 0.0, thinf = 0.0, sumlam = 0.0;
@@ -380,33 +385,17 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       DY::eval(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data());
       arr<DY::NJ> jv;
       DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jv.data());
-      arr<DY::NY * D::NP> F;
-      arr<DY::NY * DY::NY> E;
-#pragma unroll
-      for (int i = 0; i < DY::NY * D::NP; ++i) F[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < DY::NY * DY::NY; ++i) E[i] = 0.0;
-      DY::scatter_jac(jv.data(), F.data(), E.data());
       DY::jtlam(jv.data(), lam.data(), rp.data());
-      arr<D::NP * DY::NY> V;
-      arr<DY::NY*(DY::NY + 1) / 2> YY;
 #pragma unroll
-      for (int i = 0; i < D::NP * DY::NY; ++i) V[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < DY::NY * (DY::NY + 1) / 2; ++i) YY[i] = 0.0;
+      for (int i = 0; i < DY::NJ; ++i) put(D::R_DJ + i, jv[i]);
       if constexpr (DY::NH > 0) {
         arr<DY::NH> hv;
+        arr<DY::NHL> hl;
         DY::hess(p.data(), p.data() + DY::NX, y.data(), w.data(), lam.data(), hv.data());
-        DY::scatter_hess(hv.data(), WD.data(), V.data(), YY.data());
+        DY::pack_hess_lower(hv.data(), hl.data());
+#pragma unroll
+        for (int i = 0; i < DY::NHL; ++i) put(D::R_DH + i, hl[i]);
       }
-#pragma unroll
-      for (int i = 0; i < D::NP * DY::NY; ++i) put(D::R_V + i, V[i]);
-#pragma unroll
-      for (int i = 0; i < DY::NY * (DY::NY + 1) / 2; ++i) put(D::R_YY + i, YY[i]);
-#pragma unroll
-      for (int i = 0; i < DY::NY * D::NP; ++i) put(D::R_F + i, F[i]);
-#pragma unroll
-      for (int i = 0; i < DY::NY * DY::NY; ++i) put(D::R_E + i, E[i]);
 #pragma unroll
       for (int i = 0; i < DY::NY; ++i) {
         put(D::R_D + i, d[i]);
@@ -424,18 +413,17 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
       C::jac(p.data(), p.data() + C::NX, w.data(), jv.data());
-      arr<C::NC * D::NP> G;
-#pragma unroll
-      for (int i = 0; i < C::NC * D::NP; ++i) G[i] = 0.0;
-      C::scatter_jac(jv.data(), G.data());
       C::jtlam(jv.data(), nu.data(), rp.data());
+#pragma unroll
+      for (int i = 0; i < C::NJ; ++i) put(D::R_KJ + i, jv[i]);
       if constexpr (C::NH > 0) {
         arr<C::NH> hv;
+        arr<C::NHL> hl;
         C::hess(p.data(), p.data() + C::NX, w.data(), nu.data(), hv.data());
-        C::scatter_hess(hv.data(), WD.data());
-      }
+        C::pack_hess_lower(hv.data(), hl.data());
 #pragma unroll
-      for (int i = 0; i < C::NC * D::NP; ++i) put(D::R_G + i, G[i]);
+        for (int i = 0; i < C::NHL; ++i) put(D::R_KH + i, hl[i]);
+      }
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
         double r = c[j];
@@ -466,11 +454,6 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, a.cdoff[t - 1] + i);
       DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
       DP::etlam(jv.data(), lamp.data(), rp.data());
-    }
-#pragma unroll
-    for (int i = 0; i < D::NP * (D::NP + 1) / 2; ++i) {
-      put(D::R_W + i, W[i]);
-      put(D::R_WD + i, WD[i]);
     }
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
@@ -640,25 +623,75 @@ struct Spike {
   double rL[M::MAX_NX];                          // separator rhs contribution
 };
 
+// Build the stage block S_t (with the carry-in P_t, py and, in chunks p >= 1, the spike coupling Cx), factorise
+// it and run the forward substitutions.  On return S holds L (strict lower), dinv = 1/D, X = L^-1 O, y = w,
+// Z = L^-1 C.  Used by BOTH sweeps: the backward sweep recomputes instead of reading stored factors.
 template <class M, int K, bool SPK>
-__device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
-                                              double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
-                                              bool& ok, int& nneg) {
+__device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
+                                             bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
+                                             double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
+                                             bool& ok, int& nneg) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
   const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
-  double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
   auto R = [&](int e) { return rec[(int64_t)e << 6]; };
   const int z0 = a.zoff[t];
 
-  double S[BD * (BD + 1) / 2];
-  double y[BD];
-  // --- primal block
+  using KD = typename D::KD;
+  using CO = typename M::template Cost<KD::COST>;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
+  for (int i = 0; i < BD * (BD + 1) / 2; ++i) S[i] = 0.0;
 #pragma unroll
-    for (int j = 0; j <= i; ++j) S[tri(i, j)] = R(D::R_W + tri(i, j)) + gam * R(D::R_WD + tri(i, j));
+  for (int i = 0; i < BD * (NY > 0 ? NY : 1); ++i) X[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (NY > 0 ? NY * (NY + 1) / 2 : 1); ++i) YYl[i] = 0.0;
+  // --- scatter the structural nonzeros into the dense blocks (literal indices: registers only)
+  if constexpr (CO::NHL > 0) {
+    double hl[CO::NHL];
+#pragma unroll
+    for (int i = 0; i < CO::NHL; ++i) hl[i] = R(D::R_CH + i);
+    CO::scatter_hess_lower(hl, S);  // the pp block of S is packed exactly like W
+  }
+  if constexpr (KD::DYN >= 0) {
+    using DY = typename M::template Dyn<KD::DYN>;
+    double jv[DY::NJ], F[NY * NP];
+#pragma unroll
+    for (int i = 0; i < DY::NJ; ++i) jv[i] = R(D::R_DJ + i);
+#pragma unroll
+    for (int i = 0; i < NY * NP; ++i) F[i] = 0.0;
+    DY::scatter_jac(jv, F, X + (NP + Q) * NY);  // E rows of the coupling block
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[tri(NP + Q + k, i)] = F[k * NP + i];
+    }
+    if constexpr (DY::NHL > 0) {
+      double hl[DY::NHL];
+#pragma unroll
+      for (int i = 0; i < DY::NHL; ++i) hl[i] = R(D::R_DH + i);
+      DY::scatter_hess_lower(hl, gam, S, X, YYl);  // W_D -> pp block, V -> p rows of the coupling block
+    }
+  }
+  if constexpr (KD::CON >= 0) {
+    using CN = typename M::template Con<KD::CON>;
+    double jv[CN::NJ > 0 ? CN::NJ : 1], G[Q * NP > 0 ? Q * NP : 1];
+#pragma unroll
+    for (int i = 0; i < CN::NJ; ++i) jv[i] = R(D::R_KJ + i);
+#pragma unroll
+    for (int i = 0; i < Q * NP; ++i) G[i] = 0.0;
+    CN::scatter_jac(jv, G);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[tri(NP + j, i)] = G[j * NP + i];
+    }
+    if constexpr (CN::NHL > 0) {
+      double hl[CN::NHL];
+#pragma unroll
+      for (int i = 0; i < CN::NHL; ++i) hl[i] = R(D::R_KH + i);
+      CN::scatter_hess_lower(hl, gam, S);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
@@ -695,10 +728,6 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   // --- stage-constraint rows
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) S[tri(NP + j, i)] = R(D::R_G + j * NP + i);
-#pragma unroll
-    for (int k = 0; k < j; ++k) S[tri(NP + j, NP + k)] = 0.0;
     double dc = o.delta_c;
     double r = R(D::R_C + j);
     if (!o.newton_only && D::ineq(j)) {
@@ -714,29 +743,8 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   // --- dynamics rows
 #pragma unroll
   for (int k = 0; k < NY; ++k) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) S[tri(NP + Q + k, i)] = R(D::R_F + k * NP + i);
-#pragma unroll
-    for (int j = 0; j < Q + k; ++j) S[tri(NP + Q + k, NP + j)] = 0.0;
     S[tri(NP + Q + k, NP + Q + k)] = -o.delta_c;
     y[NP + Q + k] = -R(D::R_D + k);
-  }
-  // --- coupling O = [V; 0; E]
-  double X[BD * (NY > 0 ? NY : 1)];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-#pragma unroll
-    for (int c = 0; c < NY; ++c) X[i * NY + c] = gam * R(D::R_V + i * NY + c);
-  }
-#pragma unroll
-  for (int j = 0; j < Q; ++j) {
-#pragma unroll
-    for (int c = 0; c < NY; ++c) X[(NP + j) * NY + c] = 0.0;
-  }
-#pragma unroll
-  for (int k = 0; k < NY; ++k) {
-#pragma unroll
-    for (int c = 0; c < NY; ++c) X[(NP + Q + k) * NY + c] = R(D::R_E + k * NY + c);
   }
   // --- fixed variables: identity rows/columns
 #pragma unroll
@@ -754,8 +762,6 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
     }
   }
   // --- spike: coupling of this stage to the chunk's left separator x_L
-  double Z[SPK ? BD * NX : 1];
-  double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
   if constexpr (SPK) {
 #pragma unroll
     for (int i = 0; i < (NY > 0 ? NY : 1) * NX; ++i) cx_direct[i] = 0.0;
@@ -799,7 +805,6 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
     }
   }
   // --- factor
-  double dinv[BD];
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
   // --- X = L^-1 O, w = L^-1 y, Z = L^-1 C
 #pragma unroll
@@ -816,12 +821,40 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       }
     }
   }
+}
+
+template <class M, int K, bool SPK>
+__device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
+                                              double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
+                                              bool& ok, int& nneg) {
+  using D = KindDims<M, K>;
+  constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
+  double S[BD * (BD + 1) / 2];
+  double y[BD];
+  double X[BD * (NY > 0 ? NY : 1)];
+  double YYl[NY > 0 ? NY * (NY + 1) / 2 : 1];
+  double Z[SPK ? BD * NX : 1];
+  double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
+  double dinv[BD];
+  // --- carry-in of this stage is all the backward sweep needs besides the stage record
+  if (need) {
+    double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NX * (NX + 1) / 2; ++i) fac[(int64_t)(D::F_P + i) << 6] = cy.P[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) fac[(int64_t)(D::F_PY + i) << 6] = cy.py[i];
+    if constexpr (SPK) {
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) fac[(int64_t)(D::F_CX + i) << 6] = sp.Cx[i];
+    }
+  }
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg);
   // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w
 #pragma unroll
   for (int c = 0; c < NY; ++c) {
 #pragma unroll
     for (int e = 0; e <= c; ++e) {
-      double acc = gam * R(D::R_YY + tri(c, e));
+      double acc = YYl[tri(c, e)];
 #pragma unroll
       for (int i = 0; i < BD; ++i) acc -= X[i * NY + c] * X[i * NY + e] * dinv[i];
       cy.P[tri(c, e)] = acc;
@@ -855,25 +888,6 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
 #pragma unroll
         for (int i = 0; i < BD; ++i) acc -= X[i * NY + aa] * dinv[i] * Z[i * NX + c];
         sp.Cx[aa * NX + c] = acc;
-      }
-    }
-  }
-  // --- store factors (only for instances that asked for this factorisation)
-  if (need) {
-#pragma unroll
-    for (int i = 1; i < BD; ++i) {
-#pragma unroll
-      for (int k = 0; k < i; ++k) fac[(int64_t)(D::F_L + i * (i - 1) / 2 + k) << 6] = S[tri(i, k)];
-    }
-#pragma unroll
-    for (int i = 0; i < BD; ++i) {
-      fac[(int64_t)(D::F_DI + i) << 6] = dinv[i];
-      fac[(int64_t)(D::F_W + i) << 6] = y[i];
-#pragma unroll
-      for (int c = 0; c < NY; ++c) fac[(int64_t)(D::F_X + i * NY + c) << 6] = X[i * NY + c];
-      if constexpr (SPK) {
-#pragma unroll
-        for (int c = 0; c < NX; ++c) fac[(int64_t)(D::F_Z + i * NX + c) << 6] = Z[i * NX + c];
       }
     }
   }
@@ -1113,30 +1127,51 @@ struct StepAcc {
 
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
-                                               bool first, const double* xL, double* xn, StepAcc& acc) {
+                                               double dw, double gam, bool first, const double* xL, double* xn,
+                                               StepAcc& acc) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
   const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
   const double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
   auto R = [&](int e) { return rec[(int64_t)e << 6]; };
-  auto Fv = [&](int e) { return fac[(int64_t)e << 6]; };
+  // --- rebuild this stage's factorisation from its record and the stored carry-in
+  Carry<M> cy;
+  Spike<M> sp;
+#pragma unroll
+  for (int i = 0; i < NX * (NX + 1) / 2; ++i) cy.P[i] = fac[(int64_t)(D::F_P + i) << 6];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) cy.py[i] = fac[(int64_t)(D::F_PY + i) << 6];
+  if constexpr (SPK) {
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) sp.Cx[i] = fac[(int64_t)(D::F_CX + i) << 6];
+  }
+  double S[BD * (BD + 1) / 2];
+  double w[BD];
+  double X[BD * (NY > 0 ? NY : 1)];
+  double YYl[NY > 0 ? NY * (NY + 1) / 2 : 1];
+  double Z[SPK ? BD * NX : 1];
+  double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
+  double dinv[BD];
+  bool ok_unused = true;
+  int nneg_unused = 0;
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused);
   double v[BD];
 #pragma unroll
   for (int i = 0; i < BD; ++i) {
-    double r = Fv(D::F_W + i);
+    double r = w[i];
 #pragma unroll
-    for (int c = 0; c < NY; ++c) r -= Fv(D::F_X + i * NY + c) * xn[c];
+    for (int c = 0; c < NY; ++c) r -= X[i * NY + c] * xn[c];
     if constexpr (SPK) {
 #pragma unroll
-      for (int c = 0; c < NX; ++c) r -= Fv(D::F_Z + i * NX + c) * xL[c];
+      for (int c = 0; c < NX; ++c) r -= Z[i * NX + c] * xL[c];
     }
-    v[i] = r * Fv(D::F_DI + i);
+    v[i] = r * dinv[i];
   }
 #pragma unroll
   for (int i = BD - 1; i >= 1; --i) {
 #pragma unroll
-    for (int k = 0; k < i; ++k) v[k] -= Fv(D::F_L + i * (i - 1) / 2 + k) * v[i];
+    for (int k = 0; k < i; ++k) v[k] -= S[tri(i, k)] * v[i];
   }
   if constexpr (SPK) {
     if (first) {
@@ -1219,6 +1254,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
   constexpr int N = M::MAX_NX;
   const double mu = sc[SC_MU << 6];
   const double tau = fmax(o.tau_min, 1.0 - mu);
+  const double dw = sc[SC_DELTA_W << 6], gam = sc[SC_GAMMA << 6];  // the accepted factorisation
   const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
   double xL[N], xn[N];
 #pragma unroll
@@ -1230,13 +1266,13 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
   if (p == 0) {
     for (int t = t1 - 1; t >= t0; --t)
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, false, xL, xn, acc);
+        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
       });
   } else {
     for (int t = t1 - 1; t >= t0; --t)
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, t == t0, xL, xn, acc);
+          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc);
       });
   }
   double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;

@@ -27,7 +27,7 @@ from .symbolic.codegen import emit_body
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PLUGIN_DIR = os.path.join(_HERE, "_plugins")
-GENERATOR_VERSION = "5"
+GENERATOR_VERSION = "6"
 
 
 class Structure:
@@ -155,6 +155,26 @@ def _scatter_dyn(d: Dynamics, h: bool) -> str:
             else:
                 body.append(f"    YY[{_tri(r - npd, c - npd)}] += hv[{k}];")
     out.append(_fn("scatter_hess", "const double* hv, double* W, double* V, double* YY", "\n".join(body) or "    (void)hv;"))
+    # lower-triangle packing used by the solver's stage records (structural nonzeros only)
+    pack, scat = [], []
+    j = 0
+    if h:
+        for k, (r, c) in enumerate(zip(*d.hessian_sparsity)):
+            r, c = r - 1, c - 1
+            if r < c:
+                continue
+            pack.append(f"    hl[{j}] = hv[{k}];")
+            if r < npd:
+                scat.append(f"    W[{_tri(r, c)}] += gam * hl[{j}];")
+            elif c < npd:
+                scat.append(f"    V[{c * ny + (r - npd)}] += gam * hl[{j}];")
+            else:
+                scat.append(f"    YY[{_tri(r - npd, c - npd)}] += gam * hl[{j}];")
+            j += 1
+    out.append(f"  static constexpr int NHL = {j};\n")
+    out.append(_fn("pack_hess_lower", "const double* hv, double* hl", "\n".join(pack) or "    (void)hv;"))
+    out.append(_fn("scatter_hess_lower", "const double* hl, double gam, double* W, double* V, double* YY",
+                   "\n".join(scat) or "    (void)hl;"))
     return "".join(out)
 
 
@@ -164,7 +184,19 @@ def _scatter_cost(c: Cost, h: bool) -> str:
         for k, (r, q) in enumerate(zip(*c.sparsity)):
             if r >= q:
                 body.append(f"    W[{_tri(r - 1, q - 1)}] += hv[{k}];")
-    return _fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;")
+    out = [_fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;")]
+    pack, scat = [], []
+    j = 0
+    if h:
+        for k, (r, q) in enumerate(zip(*c.sparsity)):
+            if r >= q:
+                pack.append(f"    hl[{j}] = hv[{k}];")
+                scat.append(f"    W[{_tri(r - 1, q - 1)}] += hl[{j}];")
+                j += 1
+    out.append(f"  static constexpr int NHL = {j};\n")
+    out.append(_fn("pack_hess_lower", "const double* hv, double* hl", "\n".join(pack) or "    (void)hv;"))
+    out.append(_fn("scatter_hess_lower", "const double* hl, double* W", "\n".join(scat) or "    (void)hl;"))
+    return "".join(out)
 
 
 def _scatter_con(c: Constraint, h: bool) -> str:
@@ -180,6 +212,17 @@ def _scatter_con(c: Constraint, h: bool) -> str:
             if r >= q:
                 body.append(f"    W[{_tri(r - 1, q - 1)}] += hv[{k}];")
     out.append(_fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;"))
+    pack, scat = [], []
+    j = 0
+    if h:
+        for k, (r, q) in enumerate(zip(*c.hessian_sparsity)):
+            if r >= q:
+                pack.append(f"    hl[{j}] = hv[{k}];")
+                scat.append(f"    W[{_tri(r - 1, q - 1)}] += gam * hl[{j}];")
+                j += 1
+    out.append(f"  static constexpr int NHL = {j};\n")
+    out.append(_fn("pack_hess_lower", "const double* hv, double* hl", "\n".join(pack) or "    (void)hv;"))
+    out.append(_fn("scatter_hess_lower", "const double* hl, double gam, double* W", "\n".join(scat) or "    (void)hl;"))
     return "".join(out)
 
 
