@@ -64,12 +64,46 @@ __device__ __forceinline__ void gmem_load(arr<N>& dst, const double* src) {
   for (int i = 0; i < N; ++i) dst[i] = src[i];
 }
 
-// cooperative, coalesced copies between HBM and the wave's LDS image
+// cooperative, coalesced copies between HBM and the wave's LDS image: 16 bytes per lane (1 KiB per
+// wave-instruction) on the 16-byte-aligned body, scalar head/tail.  `lds` must be 16-byte aligned.
 __device__ __forceinline__ void wave_load(double* lds, const double* g, int count) {
-  for (int i = threadIdx.x; i < count; i += WAVE) lds[i] = g[i];
+  // shift so that the GLOBAL address of the vector body is 16-byte aligned; the LDS image keeps the same
+  // element offsets, so lds + head is 16-byte aligned only if head is even -- handled by the (lds) parity test
+  const int head = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);
+  if (head == 0 && (count >= 2)) {
+    const int nv = count >> 1;
+    const double2* gv = reinterpret_cast<const double2*>(g);
+    double2* lv = reinterpret_cast<double2*>(lds);
+    for (int i = threadIdx.x; i < nv; i += WAVE) lv[i] = gv[i];
+    if ((count & 1) && threadIdx.x == 0) lds[count - 1] = g[count - 1];
+  } else {
+    for (int i = threadIdx.x; i < count; i += WAVE) lds[i] = g[i];
+  }
 }
 __device__ __forceinline__ void wave_store(double* g, const double* lds, int count) {
-  for (int i = threadIdx.x; i < count; i += WAVE) g[i] = lds[i];
+  const int head = (int)((reinterpret_cast<uintptr_t>(g) >> 3) & 1);
+  if (head == 0 && (count >= 2)) {
+    const int nv = count >> 1;
+    double2* gv = reinterpret_cast<double2*>(g);
+    const double2* lv = reinterpret_cast<const double2*>(lds);
+    for (int i = threadIdx.x; i < nv; i += WAVE) gv[i] = lv[i];
+    if ((count & 1) && threadIdx.x == 0) g[count - 1] = lds[count - 1];
+  } else {
+    for (int i = threadIdx.x; i < count; i += WAVE) g[i] = lds[i];
+  }
+}
+
+// stream a wave's LDS image to HBM: 16 bytes per lane where the destination is 16-byte aligned
+__device__ __forceinline__ void wave_store_image(double* g, const double* l, int count, int lane) {
+  if (((reinterpret_cast<uintptr_t>(g) >> 3) & 1) == 0) {
+    const int nv = count >> 1;
+    double2* gv = reinterpret_cast<double2*>(g);
+    const double2* lv = reinterpret_cast<const double2*>(l);
+    for (int i = lane; i < nv; i += WAVE) gv[i] = lv[i];
+    if ((count & 1) && lane == 0) g[count - 1] = l[count - 1];
+  } else {
+    for (int i = lane; i < count; i += WAVE) g[i] = l[i];
+  }
 }
 
 // LDS needed to stage z for 64(+1) knots
@@ -81,7 +115,7 @@ constexpr int z_stage_len() { return (WAVE + 1) * M::MAX_NXU + M::MAX_NX; }
 // ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_obj(dto_eval_args a) {
-  __shared__ double s_z[z_stage_len<M>()];
+  __shared__ __attribute__((aligned(16))) double s_z[z_stage_len<M>()];
   const int wpi = (a.T + WAVE - 1) / WAVE;
   const int64_t b = blockIdx.x / wpi;
   const int t0 = (blockIdx.x % wpi) * WAVE;
@@ -122,8 +156,8 @@ static __global__ __launch_bounds__(WAVE) void k_sum_rows(const double* rows, in
 // ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_grad(dto_eval_args a) {
-  __shared__ double s_z[z_stage_len<M>()];
-  __shared__ double s_o[WAVE * M::MAX_NXU];
+  __shared__ __attribute__((aligned(16))) double s_z[z_stage_len<M>()];
+  __shared__ __attribute__((aligned(16))) double s_o[WAVE * M::MAX_NXU];
   const int wpi = (a.T + WAVE - 1) / WAVE;
   const int64_t b = blockIdx.x / wpi;
   const int t0 = (blockIdx.x % wpi) * WAVE;
@@ -155,127 +189,133 @@ __global__ __launch_bounds__(WAVE) void k_grad(dto_eval_args a) {
 // constraints: dynamics rows then stage rows
 // ------------------------------------------------------------------------------------------------
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_con(dto_eval_args a) {
-  __shared__ double s_z[z_stage_len<M>()];
-  __shared__ double s_d[WAVE * M::MAX_DYN_NC + 1];
-  __shared__ double s_c[WAVE * M::MAX_CON_NC + 1];
+__global__ __launch_bounds__(4 * WAVE) void k_con(dto_eval_args a) {
+  // same mapping as k_jac: direct reads, LDS-transposed full-line stores for the dynamics rows, 4 waves/workgroup
+  __shared__ __attribute__((aligned(16))) double s_d[4][WAVE * M::MAX_DYN_NC + 2];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpi = (a.T + WAVE - 1) / WAVE;
-  const int64_t b = blockIdx.x / wpi;
-  const int t0 = (blockIdx.x % wpi) * WAVE;
-  const int tend = min(t0 + WAVE, a.T);
-  const int z0 = a.zoff[t0];
-  const int zend = a.zoff[min(tend + 1, a.T)];
-  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
-  __syncthreads();
-  const int t = t0 + threadIdx.x;
-  const int d0 = a.cdoff[t0], c0 = a.ccoff[t0];
-  if (t < a.T) {
+  const int bpi = (wpi + 3) / 4;
+  const int64_t b = blockIdx.x / bpi;
+  const int t0 = ((blockIdx.x % bpi) * 4 + wv) * WAVE;
+  const bool live_wave = t0 < a.T;
+  const int tend = live_wave ? min(t0 + WAVE, a.T) : 0;
+  const int t = t0 + lane;
+  double* ob = a.out + b * a.ldout;
+  const int d0 = live_wave ? a.cdoff[t0] : 0;
+  if (live_wave && t < a.T) {
+    const double* zs = a.z + b * a.ldz + a.zoff[t];
+    const double* wp = a.w + b * a.ldw + a.woff[t];
     dispatch_kind<M>(a.kind[t], [&](auto kc) {
       using KD = typename M::template Kind<decltype(kc)::value>;
-      const double* zs = s_z + (a.zoff[t] - z0);
-      const double* wp = a.w + b * a.ldw + a.woff[t];
       if constexpr (KD::DYN >= 0) {
         using D = typename M::template Dyn<KD::DYN>;
         arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NY> o;
-        lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+        gmem_load(x, zs); gmem_load(u, zs + D::NX); gmem_load(y, zs + D::NX + D::NU);
         gmem_load(w, wp);
         D::eval(x.data(), u.data(), y.data(), w.data(), o.data());
         const int off = a.cdoff[t] - d0;
 #pragma unroll
-        for (int i = 0; i < D::NY; ++i) s_d[off + i] = o[i];
+        for (int i = 0; i < D::NY; ++i) s_d[wv][off + i] = o[i];
       }
       if constexpr (KD::CON >= 0) {
         using C = typename M::template Con<KD::CON>;
         arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NC> o;
-        lds_load(x, zs); lds_load(u, zs + C::NX);
+        gmem_load(x, zs); gmem_load(u, zs + C::NX);
         gmem_load(w, wp);
         C::eval(x.data(), u.data(), w.data(), o.data());
-        const int off = a.ccoff[t] - c0;
+        double* dst = ob + a.ccoff[t];
 #pragma unroll
-        for (int i = 0; i < C::NC; ++i) s_c[off + i] = o[i];
+        for (int i = 0; i < C::NC; ++i) dst[i] = o[i];
       }
     });
   }
   __syncthreads();
-  double* ob = a.out + b * a.ldout;
-  wave_store(ob + d0, s_d, a.cdoff[tend] - d0);
-  wave_store(ob + c0, s_c, a.ccoff[tend] - c0);
+  if (live_wave) wave_store_image(ob + d0, s_d[wv], a.cdoff[tend] - d0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // constraint Jacobian nonzeros, reference COO order (dynamics block then stage block)
 // ------------------------------------------------------------------------------------------------
+constexpr int JAC_WAVES = 4;  // wavefronts per workgroup (each owns 64 consecutive knots of one instance)
+
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_jac(dto_eval_args a) {
-  __shared__ double s_z[z_stage_len<M>()];
-  __shared__ double s_d[WAVE * M::MAX_DYN_NJ + 1];
-  __shared__ double s_c[WAVE * M::MAX_CON_NJ + 1];
-  const int wpi = (a.T + WAVE - 1) / WAVE;
-  const int64_t b = blockIdx.x / wpi;
-  const int t0 = (blockIdx.x % wpi) * WAVE;
-  const int tend = min(t0 + WAVE, a.T);
-  const int z0 = a.zoff[t0];
-  const int zend = a.zoff[min(tend + 1, a.T)];
-  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
-  __syncthreads();
-  const int t = t0 + threadIdx.x;
-  const int d0 = a.jdoff[t0], c0 = a.jcoff[t0];
-  if (t < a.T) {
+__global__ __launch_bounds__(JAC_WAVES * WAVE) void k_jac(dto_eval_args a) {
+  // wave = 64 consecutive knots of ONE instance (so its dynamics nonzeros are one contiguous output range).
+  //  * reads: straight from global -- a lane's (x_t,u_t,x_{t+1}) are contiguous and overlap the neighbour's, the
+  //    vector L1 serves the 40-byte-stride pattern; no input staging, no barrier before the arithmetic;
+  //  * writes: lanes deposit their NJ values into the wave's LDS image, the wave streams the image out with
+  //    16-byte-per-lane stores (1 KiB per wave-instruction, full lines).  Measured on MI355X: full-line stores
+  //    reach 5.2-5.5 TB/s, the direct "26 contiguous doubles per lane" pattern tops out at 2.7-3.5 TB/s even
+  //    without any arithmetic (tools/micro/store_ceiling.hip), and non-temporal stores are 7x slower;
+  //  * only the output image lives in LDS (13 KiB per wave for the acrobot): 12 waves per CU instead of 8;
+  //    the (rare) stage-constraint nonzeros are written directly.
+  __shared__ __attribute__((aligned(16))) double s_d[JAC_WAVES][WAVE * M::MAX_DYN_NJ + 2];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpi = (a.T + WAVE - 1) / WAVE;                    // wave tiles per instance
+  const int bpi = (wpi + JAC_WAVES - 1) / JAC_WAVES;          // workgroups per instance
+  const int64_t b = blockIdx.x / bpi;
+  const int tile = (blockIdx.x % bpi) * JAC_WAVES + wv;
+  const int t0 = tile * WAVE;
+  const bool live_wave = t0 < a.T;
+  const int tend = live_wave ? min(t0 + WAVE, a.T) : 0;
+  const int t = t0 + lane;
+  double* ob = a.out + b * a.ldout;
+  const int d0 = live_wave ? a.jdoff[t0] : 0;
+  if (live_wave && t < a.T) {
+    const double* zs = a.z + b * a.ldz + a.zoff[t];
+    const double* wp = a.w + b * a.ldw + a.woff[t];
     dispatch_kind<M>(a.kind[t], [&](auto kc) {
       using KD = typename M::template Kind<decltype(kc)::value>;
-      const double* zs = s_z + (a.zoff[t] - z0);
-      const double* wp = a.w + b * a.ldw + a.woff[t];
       if constexpr (KD::DYN >= 0) {
         using D = typename M::template Dyn<KD::DYN>;
         arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NJ> o;
-        lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+        gmem_load(x, zs); gmem_load(u, zs + D::NX); gmem_load(y, zs + D::NX + D::NU);
         gmem_load(w, wp);
         D::jac(x.data(), u.data(), y.data(), w.data(), o.data());
         const int off = a.jdoff[t] - d0;
 #pragma unroll
-        for (int i = 0; i < D::NJ; ++i) s_d[off + i] = o[i];
+        for (int i = 0; i < D::NJ; ++i) s_d[wv][off + i] = o[i];
       }
       if constexpr (KD::CON >= 0) {
         using C = typename M::template Con<KD::CON>;
         arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NJ> o;
-        lds_load(x, zs); lds_load(u, zs + C::NX);
+        gmem_load(x, zs); gmem_load(u, zs + C::NX);
         gmem_load(w, wp);
         C::jac(x.data(), u.data(), w.data(), o.data());
-        const int off = a.jcoff[t] - c0;
+        double* dst = ob + a.jcoff[t];
 #pragma unroll
-        for (int i = 0; i < C::NJ; ++i) s_c[off + i] = o[i];
+        for (int i = 0; i < C::NJ; ++i) dst[i] = o[i];
       }
     });
   }
   __syncthreads();
-  double* ob = a.out + b * a.ldout;
-  wave_store(ob + d0, s_d, a.jdoff[tend] - d0);
-  wave_store(ob + c0, s_c, a.jcoff[tend] - c0);
+  if (live_wave) wave_store_image(ob + d0, s_d[wv], a.jdoff[tend] - d0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Hessian of the Lagrangian, reference key order (row-major sorted unique, both triangles)
 // ------------------------------------------------------------------------------------------------
 constexpr int HOWN = WAVE - 1;  // stages owned by one wave; lane 0 is the halo (stage t0-1)
+constexpr int HESS_WAVES = 2;   // wavefronts per workgroup (the output image is ~21 KiB per wave)
 
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
-  __shared__ double s_z[z_stage_len<M>()];
-  __shared__ double s_o[HOWN * M::MAX_KEY + 1];
+__global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
+  __shared__ __attribute__((aligned(16))) double s_img[HESS_WAVES][HOWN * M::MAX_KEY + 2];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* s_o = s_img[wv];
   const int wpi = (a.T + HOWN - 1) / HOWN;
-  const int64_t b = blockIdx.x / wpi;
-  const int t0 = (blockIdx.x % wpi) * HOWN;      // first owned stage
-  const int tend = min(t0 + HOWN, a.T);          // one past the last owned stage
-  const int tlo = max(t0 - 1, 0);                // first staged stage (halo)
-  const int z0 = a.zoff[tlo];
-  const int zend = a.zoff[min(tend + 1, a.T)];
-  const int h0 = a.hoff[t0];
-  const int hlen = a.hoff[tend] - h0;
-  wave_load(s_z, a.z + b * a.ldz + z0, zend - z0);
-  for (int i = threadIdx.x; i < hlen; i += WAVE) s_o[i] = 0.0;
+  const int bpi = (wpi + HESS_WAVES - 1) / HESS_WAVES;
+  const int64_t b = blockIdx.x / bpi;
+  const int tile = (blockIdx.x % bpi) * HESS_WAVES + wv;
+  const int t0 = tile * HOWN;                    // first owned stage
+  const bool live_wave = t0 < a.T;
+  const int tend = live_wave ? min(t0 + HOWN, a.T) : 0;  // one past the last owned stage
+  const int h0 = live_wave ? a.hoff[t0] : 0;
+  const int hlen = live_wave ? a.hoff[tend] - h0 : 0;
+  for (int i = lane; i < hlen; i += WAVE) s_o[i] = 0.0;
   __syncthreads();
-  const int s = t0 - 1 + (int)threadIdx.x;       // this lane's stage
-  const bool live = (s >= 0) && (s < tend);
+  const int s = t0 - 1 + lane;                   // this lane's stage (lane 0 is the halo)
+  const bool live = live_wave && (s >= 0) && (s < tend);
   const bool own = live && (s >= t0);
   const double* mu = a.mu + b * a.ldmu;
   const int kind = live ? a.kind[s] : -1;
@@ -285,7 +325,7 @@ __global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
   if (live) {
     dispatch_kind<M>(kind, [&](auto kc) {
       using KD = typename M::template Kind<decltype(kc)::value>;
-      const double* zs = s_z + (a.zoff[s] - z0);
+      const double* zs = a.z + b * a.ldz + a.zoff[s];  // direct reads: contiguous per lane, L1-served overlap
       const double* wp = a.w + b * a.ldw + a.woff[s];
       const int base = a.hoff[s] - h0;
       const int* mrow = nullptr;
@@ -293,7 +333,7 @@ __global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
         using C = typename M::template Cost<KD::COST>;
         if (own) {
           arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NH> o;
-          lds_load(x, zs); lds_load(u, zs + C::NX); gmem_load(w, wp);
+          gmem_load(x, zs); gmem_load(u, zs + C::NX); gmem_load(w, wp);
           C::hess(x.data(), u.data(), w.data(), o.data());
           mrow = a.hmap_cost + decltype(kc)::value * a.hmap_stride;
 #pragma unroll
@@ -304,7 +344,7 @@ __global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
         using D = typename M::template Dyn<KD::DYN>;
         if constexpr (D::NH > 0) {
           arr<D::NX> x; arr<D::NU> u; arr<D::NY> y; arr<D::NW> w; arr<D::NY> lam; arr<D::NH> o;
-          lds_load(x, zs); lds_load(u, zs + D::NX); lds_load(y, zs + D::NX + D::NU);
+          gmem_load(x, zs); gmem_load(u, zs + D::NX); gmem_load(y, zs + D::NX + D::NU);
           gmem_load(w, wp); gmem_load(lam, mu + a.cdoff[s]);
           D::hess(x.data(), u.data(), y.data(), w.data(), lam.data(), o.data());
           nh_dyn = D::NH;
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
         if constexpr (C::NH > 0) {
           if (own) {
             arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NC> lam; arr<C::NH> o;
-            lds_load(x, zs); lds_load(u, zs + C::NX); gmem_load(w, wp);
+            gmem_load(x, zs); gmem_load(u, zs + C::NX); gmem_load(w, wp);
             gmem_load(lam, mu + a.ccoff[s]);
             C::hess(x.data(), u.data(), w.data(), lam.data(), o.data());
             mrow = a.hmap_con + decltype(kc)::value * a.hmap_stride;
@@ -350,7 +390,7 @@ __global__ __launch_bounds__(WAVE) void k_hess(dto_eval_args a) {
     }
   }
   __syncthreads();
-  wave_store(a.out + b * a.ldout + h0, s_o, hlen);
+  if (live_wave) wave_store_image(a.out + b * a.ldout + h0, s_o, hlen, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,11 +434,16 @@ int launch_eval(int op, const dto_eval_args* args, void* stream_) {
       hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)a.B), dim3(WAVE), 0, stream, (const double*)a.scratch, (int64_t)a.T, a.T, a.out);
       break;
     case DTO_OP_GRAD: hipLaunchKernelGGL(k_grad<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
-    case DTO_OP_CON: hipLaunchKernelGGL(k_con<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
-    case DTO_OP_JAC: hipLaunchKernelGGL(k_jac<M>, dim3(grid), dim3(WAVE), 0, stream, a); break;
+    case DTO_OP_CON: hipLaunchKernelGGL(k_con<M>, dim3((unsigned)(a.B * ((wpi + 3) / 4))), dim3(4 * WAVE), 0, stream, a); break;
+    case DTO_OP_JAC: {
+      const int bpi = (wpi + JAC_WAVES - 1) / JAC_WAVES;
+      hipLaunchKernelGGL(k_jac<M>, dim3((unsigned)(a.B * bpi)), dim3(JAC_WAVES * WAVE), 0, stream, a);
+      break;
+    }
     case DTO_OP_HESS: {
       const int wph = (a.T + HOWN - 1) / HOWN;
-      hipLaunchKernelGGL(k_hess<M>, dim3((unsigned)(a.B * wph)), dim3(WAVE), 0, stream, a);
+      const int bph = (wph + HESS_WAVES - 1) / HESS_WAVES;
+      hipLaunchKernelGGL(k_hess<M>, dim3((unsigned)(a.B * bph)), dim3(HESS_WAVES * WAVE), 0, stream, a);
       break;
     }
     case DTO_OP_GENERAL_CON:

@@ -105,6 +105,7 @@ struct dto_kkt_args {
   int P;               // chunks of the time-partitioned factorisation
   const int* cstart;   // [P+1] first stage of every chunk
   double* csum; double* sfac; double* xsep; double* cacc;  // chunk summaries, separator factors/solutions, step partials
+  double* cpart;       // [G][P][16][64] chunk-level partial reductions (k_part_reduce)
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -492,6 +493,32 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// first level of the deterministic reductions: every (tile, chunk) wave folds the per-stage partials of its
+// chunk in stage order (sum, or max for the slots in `maxmask`); k_conv / k_ls_reduce then fold P chunk rows
+// instead of T stage rows.  grid = G*P waves.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, const double* in, unsigned maxmask) {
+  const int64_t g = blockIdx.x / a.P;
+  const int p = blockIdx.x % a.P;
+  if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  for (int t = a.cstart[p]; t < a.cstart[p + 1]; ++t) {
+    const double* row = in + (((g * a.T + t) * NV) << 6) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double v = row[(int64_t)k << 6];
+      acc[k] = ((maxmask >> k) & 1u) ? fmax(acc[k], v) : acc[k] + v;
+    }
+  }
+  double* out = a.cpart + (((g * a.P + p) * 16) << 6) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[(int64_t)k << 6] = acc[k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // reduce the stage partials in stage order (deterministic), test convergence, update mu.
 // grid = G waves.
 // ------------------------------------------------------------------------------------------------
@@ -501,8 +528,8 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double f = 0, th1 = 0, thinf = 0, dinf = 0, c0 = 0, cmu = 0, slam = 0, sz = 0, lb = 0;
-  for (int t = 0; t < a.T; ++t) {
-    const double* part = a.part + (((g * a.T + t) * DTO_NPART) << 6) + threadIdx.x;
+  for (int c = 0; c < a.P; ++c) {
+    const double* part = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
     f += part[0 << 6];
     th1 += part[1 << 6];
     thinf = fmax(thinf, part[2 << 6]);
@@ -635,7 +662,12 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
   const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
-  auto R = [&](int e) { return rec[(int64_t)e << 6]; };
+  // the whole structural record of the stage is requested up front (all loads in flight at once: with one
+  // wave per SIMD nothing else hides HBM latency), then consumed from registers
+  double rr[D::REC > 0 ? D::REC : 1];
+#pragma unroll
+  for (int i = 0; i < D::REC; ++i) rr[i] = rec[(int64_t)i << 6];
+  auto R = [&](int e) { return rr[e]; };
   const int z0 = a.zoff[t];
 
   using KD = typename D::KD;
@@ -1395,8 +1427,8 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
   double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
 #pragma unroll
   for (int k = 0; k < DTO_LS_TRIALS; ++k) phi[k] = th[k] = 0.0;
-  for (int t = 0; t < a.T; ++t) {
-    const double* in = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
+  for (int c = 0; c < a.P; ++c) {
+    const double* in = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < DTO_LS_TRIALS; ++k) {
       phi[k] += in[(int64_t)(2 * k) << 6];
@@ -1573,7 +1605,12 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       }
       case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_CONV: hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd); break;
+      case DTO_KKT_CONV:
+        // slots 2..5 (theta_inf, dual inf, complementarity x2) are maxima, the others sums
+        hipLaunchKernelGGL(k_part_reduce<DTO_NPART>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
+                           (const double*)a.part, 0x3Cu);
+        hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd);
+        break;
       case DTO_KKT_FACTOR_SOLVE: {
         const unsigned gp = (unsigned)((int64_t)a.G * a.P);
         const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
@@ -1590,7 +1627,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_BWD: hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_LS_REDUCE: hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_LS_REDUCE:
+        hipLaunchKernelGGL(k_part_reduce<2 * DTO_LS_TRIALS>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
+                           (const double*)a.lspart, 0u);
+        hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        break;
       case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       default: return -1;
     }

@@ -36,7 +36,7 @@ struct SolverState {
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
-  double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr;
+  double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr, *cpart = nullptr;
   int P = 1;            // chunks of the time-partitioned factorisation
   int forced_P = 0;     // 0 = choose from the batch size
   std::vector<int> cstart;
@@ -51,11 +51,11 @@ struct SolverState {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
-                    (void*)cacc, (void*)d_cstart})
+                    (void*)cacc, (void*)cpart, (void*)d_cstart})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    csum = sfac = xsep = cacc = nullptr; d_cstart = nullptr;
+    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr;
     B = 0; G = 0;
   }
 };
@@ -160,6 +160,7 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.sfac, lanes * (size_t)S.P * S.info.sep_fac_size))) return rc;
   if ((rc = dev_alloc(&S.xsep, lanes * (size_t)S.P * S.info.nx))) return rc;
   if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P * 4))) return rc;
+  if ((rc = dev_alloc(&S.cpart, lanes * (size_t)S.P * 16))) return rc;
   S.h_scal.assign(lanes * S.info.nscal, 0.0);
   return DTO_OK;
 }
@@ -178,7 +179,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
-  a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc;
+  a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
   a.opt = S.opt;
 }
 

@@ -311,6 +311,7 @@ class Solver:
         """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays."""
         b = self.nlp._batch(x0_ptr, B, ldx, stream)
         co = _c_options(self.options, check_every)
+        self._B = B
         status = np.zeros(B, dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
         capi.check(self.nlp._lib.dto_solve_batch(self.nlp._h, C.byref(co), C.byref(b), x_out_ptr, ldxo,
