@@ -131,7 +131,7 @@ def main():
                  kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update")
     tot = {k: 0.0 for k in kname}
     cnt = {k: 0 for k in kname}
-    reps = 3
+    reps = 8
     nf_a = float(np.sum(s.scalar_batch("nfact")))
     it_a = float(np.sum(s.scalar_batch("iter")))
     for _ in range(reps):
@@ -146,16 +146,25 @@ def main():
     working = (nf_b - nf_a) / max(B * reps * rounds, 1)         # fraction of k_kkt_fwd launches x lanes that factorised
     nnz_K = nj + (nh + nz) // 2 + nc                           # structural lower-triangular KKT entries
     fac_d = fp["factor_doubles"]
+    rec_d = fp["record_doubles"]                               # structural stage records (Jacobian nnz + lower Hessian nnz + residuals)
     alg_bytes = dict(                                          # per instance and per launch
         eval=8 * (nz + nc + 1) + 8 * nnz_K,                    # fused KKT value scatter
-        kkt_fwd=working * 8 * (nnz_K + fac_d),                 # read K, write the factors (working launches only)
-        kkt_bwd=8 * (fac_d + nz + nc) + 8 * (nz + nc),         # read the factors + rhs, write the step
+        # forward chunk sweep: read the KKT values once, write the per-stage carries (working launches only)
+        kkt_fwd=working * 8 * (nnz_K + (nz + nc) + fac_d),
+        # backward sweep: re-read the KKT values + carries (the factors are recomputed, not stored), write the step
+        kkt_bwd=8 * (nnz_K + (nz + nc) + fac_d) + 8 * (nz + nc),
         linesearch=8 * (2 * nz) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 9 * T, ls_reduce=8 * 16 * T,
         kkt_sep=8 * 64, kkt_post=8 * 4)
     dom = max(per_iter_ms, key=per_iter_ms.get)
     achieved = B * alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/, tools/pmc_summary.py)
+        with open(os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_acrobot_T{T}_B{B}.json")) as f:
+            traffic = json.load(f)["kernels"][kname[dom]]["hbm_bytes_per_launch_mean"]
+    except Exception:
+        traffic = None
     roofline = dict(kernel=kname[dom], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
                     algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
                     working_fraction_of_launches=round(working, 4),

@@ -19,9 +19,13 @@ def all_structures():
         ("ref_dynamics", P.build_ref_dynamics, {}),
         ("ref_constraints", P.build_ref_constraints, {}),
         ("ref_hesslag", P.build_ref_hesslag, {}),
+        ("ref_general", P.build_ref_general, dict(user_jacobian=False)),
+        ("ref_general", P.build_ref_general, dict(user_jacobian=True)),
+        ("param_pendulum", P.build_param_pendulum, dict(T=8)),
     ]:
         p = builder(**kw)
-        out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], None, p["evaluate_hessian"])))
+        out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], p.get("general_constraint"),
+                                    p["evaluate_hessian"])))
     return out
 
 

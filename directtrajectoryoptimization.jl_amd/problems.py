@@ -292,3 +292,52 @@ def build_ref_hesslag():
     conT = Constraint(cTf, n, 0, evaluate_hessian=True)
     return dict(dynamics=[dt] * 2, objective=[objt, objt, objT], constraints=[cont, cont, conT],
                 bounds=[Bound(n, m)] * 2 + [Bound(n, 0)], T=T, n=n, m=m, evaluate_hessian=True)
+
+
+def build_ref_general(user_jacobian=False):
+    """test/solve.jl:140-296: double integrator, T = 11; (a) user-provided dense dynamics Jacobian
+    (test/solve.jl:149-183), (b) GeneralConstraint z[end-1:end] - xT over the whole decision vector
+    (test/solve.jl:273-274)."""
+    from .model import GeneralConstraint
+    T, n, m = 11, 2, 1
+    x1 = np.array([0.0, 0.0])
+    xT = np.array([1.0, 0.0])
+    if user_jacobian:
+        dt = Dynamics(double_integrator, double_integrator_grad, n, n, m)
+        eh = False
+    else:
+        dt = Dynamics(double_integrator, n, n, m, evaluate_hessian=True)
+        eh = True
+    ct = Cost(lambda x, u, w: 0.1 * dot(x, x) + 0.1 * dot(u, u), n, m, evaluate_hessian=eh)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x, x), n, 0, evaluate_hessian=eh)
+    nz = n * T + m * (T - 1)
+    gc = GeneralConstraint(lambda z, w: z[nz - 2:nz] - xT, nz, 0, evaluate_hessian=eh)
+    bounds = [Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2) + [Bound(n, 0)]
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
+                bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=eh)
+
+
+def build_param_pendulum(T=8):
+    """Per-stage parameters w_t (src/solver.jl:10 `parameters` kwarg): pendulum whose mass and goal angle are
+    parameters; exercises num_parameter > 0 in Dynamics, Cost and Constraint."""
+    n, m, nw = 2, 1, 2
+
+    def pend(x, u, w):
+        mass, length_com, gravity, damping = w[0], 0.5, 9.81, 0.1
+        return np.array([x[1], u[0] / (mass * length_com * length_com) - gravity * np.sin(x[0]) / length_com
+                         - damping * x[1] / (mass * length_com * length_com)], dtype=object)
+
+    def dyn(y, x, u, w, h=0.05):
+        return y - (x + h * pend(0.5 * (x + y), u, w))
+
+    dt = Dynamics(dyn, n, n, m, num_parameter=nw, evaluate_hessian=True)
+    ct = Cost(lambda x, u, w: 0.1 * (x[0] - w[1]) * (x[0] - w[1]) + 0.1 * x[1] * x[1] + 0.1 * dot(u, u), n, m,
+              num_parameter=nw, evaluate_hessian=True)
+    cT = Cost(lambda x, u, w: 10.0 * (x[0] - w[1]) * (x[0] - w[1]), n, 0, num_parameter=nw, evaluate_hessian=True)
+    con = Constraint(lambda x, u, w: np.array([x[0] * x[0] + u[0] - w[0]], dtype=object), n, m, num_parameter=nw,
+                     indices_inequality=[1], evaluate_hessian=True)
+    conT = Constraint(lambda x, u, w: np.array([x[0] - w[1]], dtype=object), n, 0, num_parameter=nw, evaluate_hessian=True)
+    rng = np.random.Generator(np.random.PCG64(99))
+    params = [np.array([1.0 + 0.5 * rng.random(), 3.0 * rng.random()]) for _ in range(T)]
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[con] * (T - 1) + [conT],
+                bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], parameters=params, T=T, n=n, m=m, evaluate_hessian=True)

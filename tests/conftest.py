@@ -29,7 +29,11 @@ def product_solver(model, T, evaluate_hessian=True):
     from dto_amd import problems as P
     key = (model, T, evaluate_hessian)
     if key not in _PRODUCT_CACHE:
-        if model.startswith("ref_"):
+        if model == "ref_general":
+            p = P.build_ref_general(user_jacobian=not evaluate_hessian)
+        elif model == "param_pendulum":
+            p = P.build_param_pendulum(T)
+        elif model.startswith("ref_"):
             p = getattr(P, f"build_{model}")()
             assert p["T"] == T and p["evaluate_hessian"] == evaluate_hessian
         elif model == "acrobot_bounds":
@@ -37,7 +41,8 @@ def product_solver(model, T, evaluate_hessian=True):
         else:
             p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=evaluate_hessian)
         s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"],
-                           evaluate_hessian=evaluate_hessian, name=model)
+                           evaluate_hessian=evaluate_hessian, general_constraint=p.get("general_constraint"),
+                           parameters=p.get("parameters"), name=model)
         _PRODUCT_CACHE[key] = (s, p)
     return _PRODUCT_CACHE[key]
 
