@@ -54,7 +54,7 @@ enum dto_scal {
   SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed
   SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
-  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT,
+  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET,
   SC_COUNT
 };
 
@@ -139,8 +139,18 @@ struct KindDims {
   static constexpr int N_DH = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NHL; else return 0; }();
   static constexpr int N_KJ = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NJ; else return 0; }();
   static constexpr int N_KH = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NHL; else return 0; }();
+  // quasi-Newton mode (problem built with evaluate_hessian=false, the reference default under which Ipopt uses a
+  // limited-memory BFGS Hessian): a partitioned, Powell-damped BFGS approximation B_t of the ELEMENT Hessian
+  // d^2/d(p_t,x_{t+1})^2 [ l_t + lam_t'd_t + nu_t'c_t ] is kept per stage (block structure preserved), together
+  // with the previous objective gradient for the secant pair.
+  static constexpr bool QN = (M::EVALUATE_HESSIAN == 0);
+  static constexpr int NE = NP + NY;
+  static constexpr int N_B = QN ? NE * (NE + 1) / 2 : 0;
+  static constexpr int N_GC = QN ? NP : 0;
   static constexpr int R_CH = 0;
-  static constexpr int R_DJ = R_CH + N_CH;
+  static constexpr int R_B = R_CH + N_CH;
+  static constexpr int R_GC = R_B + N_B;
+  static constexpr int R_DJ = R_GC + N_GC;
   static constexpr int R_DH = R_DJ + N_DJ;
   static constexpr int R_KJ = R_DH + N_DH;
   static constexpr int R_KH = R_KJ + N_KJ;
@@ -191,7 +201,7 @@ void fill_info(dto_kkt_info* o) {
 
 template <class M>
 int kkt_info(dto_kkt_info* out) {
-  out->supported = (M::EVALUATE_HESSIAN != 0 && M::N_KIND <= 16 && !M::HAS_GENERAL) ? 1 : 0;
+  out->supported = (M::N_KIND <= 16 && !M::HAS_GENERAL) ? 1 : 0;
   out->n_kind = M::N_KIND;
   for (int i = 0; i < 16; ++i) out->rec_size[i] = out->fac_size[i] = out->n_ineq[i] = 0;
   fill_info<M>(out);
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_THETA_MIN) = -1.0;
     *soa(a.scal, g, SC_COUNT, SC_FILTER_N) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_LS_KIND) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_QN_RESET) = 1.0;  // quasi-Newton blocks start from the objective Hessian
   }
 }
 
@@ -355,6 +366,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     arr<CO::NW> wc;
     gmem_load(wc, a.params + a.woff[t]);
 
+    // quasi-Newton mode: last iteration's Jacobian nonzeros (still in the record) for the secant pair
+    double qn_old_dj[D::QN && D::N_DJ > 0 ? D::N_DJ : 1], qn_old_kj[D::QN && D::N_KJ > 0 ? D::N_KJ : 1];
+    if constexpr (D::QN) {
+#pragma unroll
+      for (int i = 0; i < D::N_DJ; ++i) qn_old_dj[i] = rec[(int64_t)(D::R_DJ + i) << 6];
+#pragma unroll
+      for (int i = 0; i < D::N_KJ; ++i) qn_old_kj[i] = rec[(int64_t)(D::R_KJ + i) << 6];
+    }
     arr<D::NP> rp;
     double cost_val;
     {
@@ -362,10 +381,10 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       CO::eval(p.data(), p.data() + CO::NX, wc.data(), o1);
       cost_val = o1[0];
       CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
-      if constexpr (CO::NH > 0) {
-        arr<CO::NH> hv;
+      if constexpr (CO::SNH > 0) {
+        arr<CO::SNH> hv;
         arr<CO::NHL> hl;
-        CO::hess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
+        CO::shess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
         CO::pack_hess_lower(hv.data(), hl.data());
 #pragma unroll
         for (int i = 0; i < CO::NHL; ++i) put(D::R_CH + i, hl[i]);
@@ -455,6 +474,98 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, a.cdoff[t - 1] + i);
       DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
       DP::etlam(jv.data(), lamp.data(), rp.data());
+    }
+    if constexpr (D::QN) {
+      // ---- partitioned SR1 on the element Hessian of this stage
+      constexpr int NE = D::NE, NBQ = NE * (NE + 1) / 2;
+      const bool reset = (*soa(a.scal, g, SC_COUNT, SC_QN_RESET) != 0.0);
+      const double alpha = *soa(a.scal, g, SC_COUNT, SC_ALPHA);
+      double B[NBQ > 0 ? NBQ : 1];
+      // new and old element gradients, both with the CURRENT multipliers (Ipopt's L-BFGS secant pair)
+      double gn[NE > 0 ? NE : 1], go[NE > 0 ? NE : 1], sv[NE > 0 ? NE : 1];
+#pragma unroll
+      for (int i = 0; i < NE; ++i) gn[i] = go[i] = sv[i] = 0.0;
+      {
+        arr<D::NP> gc;
+        CO::grad(p.data(), p.data() + CO::NX, wc.data(), gc.data());
+#pragma unroll
+        for (int i = 0; i < D::NP; ++i) {
+          gn[i] = gc[i];
+          go[i] = rec[(int64_t)(D::R_GC + i) << 6];
+          put(D::R_GC + i, gc[i]);
+          sv[i] = alpha * *soa(a.dz, g, a.Nz, z0 + i);
+        }
+      }
+      if constexpr (KD::DYN >= 0) {
+        using DY = typename M::template Dyn<KD::DYN>;
+        arr<DY::NY> y, lam; arr<DY::NW> w; arr<DY::NJ> jn, jo;
+        gmem_load(w, a.params + a.woff[t]);
+#pragma unroll
+        for (int i = 0; i < DY::NY; ++i) {
+          y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
+          lam[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
+          sv[D::NP + i] = alpha * *soa(a.dz, g, a.Nz, a.zoff[t + 1] + i);
+        }
+        DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jn.data());
+#pragma unroll
+        for (int i = 0; i < DY::NJ; ++i) jo[i] = qn_old_dj[i];
+        DY::jtlam(jn.data(), lam.data(), gn);
+        DY::etlam(jn.data(), lam.data(), gn + D::NP);
+        DY::jtlam(jo.data(), lam.data(), go);
+        DY::etlam(jo.data(), lam.data(), go + D::NP);
+      }
+      if constexpr (KD::CON >= 0) {
+        using C = typename M::template Con<KD::CON>;
+        arr<C::NW> w; arr<C::NC> nu; arr<C::NJ> jn, jo;
+        gmem_load(w, a.params + a.woff[t]);
+#pragma unroll
+        for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+        C::jac(p.data(), p.data() + C::NX, w.data(), jn.data());
+#pragma unroll
+        for (int i = 0; i < C::NJ; ++i) jo[i] = qn_old_kj[i];
+        C::jtlam(jn.data(), nu.data(), gn);
+        C::jtlam(jo.data(), nu.data(), go);
+      }
+      if (reset) {
+        // start from the (exact) objective Hessian plus a small multiple of the identity
+#pragma unroll
+        for (int i = 0; i < NBQ; ++i) B[i] = 0.0;
+        if constexpr (CO::SNH > 0) {
+          arr<CO::SNH> hv; arr<CO::NHL> hl;
+          CO::shess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
+          CO::pack_hess_lower(hv.data(), hl.data());
+          CO::scatter_hess_lower(hl.data(), B);
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) B[tri(i, i)] += 1e-8;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NBQ; ++i) B[i] = rec[(int64_t)(D::R_B + i) << 6];
+        // symmetric rank-one update: element Hessians of lam'd are indefinite, which SR1 can represent (BFGS cannot);
+        // the inertia ladder of the factorization takes care of the resulting indefinite reduced Hessians
+        double v[NE > 0 ? NE : 1];
+        double vs = 0.0, vv = 0.0, ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < NE; ++j) acc += B[i >= j ? tri(i, j) : tri(j, i)] * sv[j];
+          v[i] = (gn[i] - go[i]) - acc;
+          vs += v[i] * sv[i];
+          vv += v[i] * v[i];
+          ss += sv[i] * sv[i];
+        }
+        if (ss > 1e-24 && fabs(vs) > 1e-8 * sqrt(vv * ss)) {
+          const double ivs = 1.0 / vs;
+#pragma unroll
+          for (int i = 0; i < NE; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) B[tri(i, j)] += v[i] * v[j] * ivs;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NBQ; ++i) put(D::R_B + i, B[i]);
     }
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
@@ -684,6 +795,24 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 #pragma unroll
     for (int i = 0; i < CO::NHL; ++i) hl[i] = R(D::R_CH + i);
     CO::scatter_hess_lower(hl, S);  // the pp block of S is packed exactly like W
+  }
+  if constexpr (D::QN) {
+    // element BFGS block B over (p_t, x_{t+1}): pp part -> S, (x_{t+1}, p) part -> coupling rows, x_{t+1} part -> YY.
+    // gam = 0 (inertia fallback) keeps only the objective Hessian scattered above.
+    if (gam != 0.0) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) S[tri(i, j)] = R(D::R_B + tri(i, j));
+      }
+#pragma unroll
+      for (int c = 0; c < NY; ++c) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) X[i * NY + c] = R(D::R_B + tri(NP + c, i));
+#pragma unroll
+        for (int e = 0; e <= c; ++e) YYl[tri(c, e)] = R(D::R_B + tri(NP + c, NP + e));
+      }
+    }
   }
   if constexpr (KD::DYN >= 0) {
     using DY = typename M::template Dyn<KD::DYN>;
@@ -1131,6 +1260,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
     if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
     if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
     sc[SC_LS_FAIL << 6] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
+    sc[SC_QN_RESET << 6] = (gam == 0.0) ? 1.0 : 0.0;  // quasi-Newton: restart the element blocks after a fallback
     return;
   }
   if (gam != 0.0) {
@@ -1582,7 +1712,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   const dto_kkt_args& a = *args;
   const unsigned gt = (unsigned)((int64_t)a.G * a.T);
-  if constexpr (M::EVALUATE_HESSIAN == 0 || M::HAS_GENERAL) {
+  if constexpr (M::HAS_GENERAL) {
     return (int)hipErrorNotSupported;
   } else {
     switch (op) {

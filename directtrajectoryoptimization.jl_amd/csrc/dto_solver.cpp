@@ -109,7 +109,7 @@ static int ensure_state(Problem* p, int64_t B) {
   p->vt->kkt_info(&S.info);
   if (!S.info.supported)
     return set_error(DTO_ERR_UNSUPPORTED,
-                     "the KKT/solver path needs evaluate_hessian=true objects and no GeneralConstraint (DESIGN.md)");
+                     "the KKT/solver path does not support a GeneralConstraint yet (bordered system, DESIGN.md section 8)");
   for (int t = 1; t < L.T; ++t)
     if (L.nx[t] != L.nx[0]) return set_error(DTO_ERR_UNSUPPORTED, "the solver path needs a uniform state dimension");
   S.B = B;

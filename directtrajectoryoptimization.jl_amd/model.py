@@ -67,6 +67,12 @@ class Cost:
             self.sparsity = [[], []]
             self.num_hessian = 0
         self.evaluate_hessian = evaluate_hessian
+        # The GPU solver always has the objective Hessian: with evaluate_hessian=false (where the reference lets
+        # Ipopt use a limited-memory Hessian) it is the starting point of the per-stage SR1
+        # blocks and what remains in the Gauss-Newton inertia fallback.
+        r, c, v = D.sparse_hessian(ev[0], wrt)
+        self.solver_hessian_expr = v
+        self.solver_sparsity = [_one_based(r), _one_based(c)]
 
 
 class Dynamics:

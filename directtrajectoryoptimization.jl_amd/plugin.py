@@ -27,7 +27,7 @@ from .symbolic.codegen import emit_body
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PLUGIN_DIR = os.path.join(_HERE, "_plugins")
-GENERATOR_VERSION = "6"
+GENERATOR_VERSION = "7"
 
 
 class Structure:
@@ -185,14 +185,14 @@ def _scatter_cost(c: Cost, h: bool) -> str:
             if r >= q:
                 body.append(f"    W[{_tri(r - 1, q - 1)}] += hv[{k}];")
     out = [_fn("scatter_hess", "const double* hv, double* W", "\n".join(body) or "    (void)hv;")]
+    # lower-triangle packing of the SOLVER's objective Hessian (always generated)
     pack, scat = [], []
     j = 0
-    if h:
-        for k, (r, q) in enumerate(zip(*c.sparsity)):
-            if r >= q:
-                pack.append(f"    hl[{j}] = hv[{k}];")
-                scat.append(f"    W[{_tri(r - 1, q - 1)}] += hl[{j}];")
-                j += 1
+    for k, (r, q) in enumerate(zip(*c.solver_sparsity)):
+        if r >= q:
+            pack.append(f"    hl[{j}] = hv[{k}];")
+            scat.append(f"    W[{_tri(r - 1, q - 1)}] += hl[{j}];")
+            j += 1
     out.append(f"  static constexpr int NHL = {j};\n")
     out.append(_fn("pack_hess_lower", "const double* hv, double* hl", "\n".join(pack) or "    (void)hv;"))
     out.append(_fn("scatter_hess_lower", "const double* hl, double* W", "\n".join(scat) or "    (void)hl;"))
@@ -296,6 +296,9 @@ def generate_source(st: Structure, name: str) -> str:
         out.append(_fn("grad", sig, emit_body(c.gradient_expr, "out", va)))
         if nh:
             out.append(_fn("hess", sig, emit_body(c.hessian_expr, "out", va)))
+        # objective Hessian for the solver (always available: Gauss-Newton mode when evaluate_hessian=false)
+        out.append(f"  static constexpr int SNH = {len(c.solver_hessian_expr)};\n")
+        out.append(_fn("shess", sig, emit_body(c.solver_hessian_expr, "out", va) if c.solver_hessian_expr else "    (void)x;"))
         out.append(_scatter_cost(c, h))
         out.append("};")
         tables.append(_int_array(f"cost{i}_hr", c.sparsity[0] if h else []))

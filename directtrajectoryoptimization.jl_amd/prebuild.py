@@ -15,6 +15,8 @@ def all_structures():
         ("acrobot_bounds", P.build_acrobot, dict(T=4, evaluate_hessian=True, endpoint="bounds")),
         ("car", P.build_car, dict(T=6, evaluate_hessian=True)),
         ("car", P.build_car, dict(T=6, evaluate_hessian=False)),
+        ("cartpole", P.build_cartpole, dict(T=5, evaluate_hessian=False)),
+        ("pendulum", P.build_pendulum, dict(T=6, evaluate_hessian=False)),
         ("ref_objective", P.build_ref_objective, {}),
         ("ref_dynamics", P.build_ref_dynamics, {}),
         ("ref_constraints", P.build_ref_constraints, {}),

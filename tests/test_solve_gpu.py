@@ -122,3 +122,24 @@ def test_single_instance_host_solve_matches_batched():
     assert len(x_sol) == 50 and len(u_sol) == 49
     z = np.concatenate([np.concatenate([x_sol[t], u_sol[t]]) for t in range(49)] + [x_sol[49]])
     assert np.array_equal(z, Z[1]) and s.iterations == iters[1]
+
+
+def test_default_mode_without_exact_hessians():
+    """The reference default: Solver(...) without evaluate_hessian (src/solver.jl:7) -- Ipopt then uses a
+    limited-memory Hessian.  Here the solver keeps a partitioned SR1 approximation of each stage's element
+    Hessian (csrc/dto_kkt_kernels.hpp, k_stage_eval); the MOI Hessian callback stays unavailable exactly as in the
+    reference (features_available == [:Grad, :Jac]).  The quasi-Newton path must stay within a small factor of
+    the exact-Hessian iteration counts on these models (pendulum 11-13, car ~30)."""
+    import torch
+    import dto_amd
+    for model, T, cap in (("car", 51, 80), ("pendulum", 50, 40)):
+        s, p = product_solver(model, T, evaluate_hessian=False)
+        assert s.nlp.features_available() == ["Grad", "Jac"]
+        rng = np.random.Generator(np.random.PCG64(0))
+        xs, us = p["guess"](rng)
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, us)
+        assert dto_amd.solve(s) == 1, (model, s.status, s.iterations)
+        assert s.iterations <= cap, (model, s.iterations)
+        x_sol, u_sol = dto_amd.get_trajectory(s)
+        assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3

@@ -14,8 +14,9 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 60
 kw = dict(endpoint="bounds") if model == "acrobot_bounds" else {}
-p = getattr(P, "build_acrobot" if model.startswith("acrobot") else f"build_{model}")(T=T, evaluate_hessian=True, **kw)
-s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name=model)
+EH = os.environ.get("DBG_EH", "1") == "1"
+p = getattr(P, "build_acrobot" if model.startswith("acrobot") else f"build_{model}")(T=T, evaluate_hessian=EH, **kw)
+s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=EH, name=model)
 n = s.nlp
 nz = n.num_variables
 Z = np.zeros((B, nz))
