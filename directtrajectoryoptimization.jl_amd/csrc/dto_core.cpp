@@ -111,6 +111,9 @@ void Problem::fill_args(dto_eval_args& a, int64_t B, const double* z, int64_t ld
 }
 
 int Problem::launch(int op, const dto_eval_args& a, hipStream_t s) {
+  if (!vt->launch)
+    return set_error(DTO_ERR_UNSUPPORTED,
+                     "wide-stage model: the evaluator callbacks are not built for it yet, only the KKT step (DESIGN.md)");
   const int rc = vt->launch(op, &a, (void*)s);
   if (rc != 0) return hip_fail((hipError_t)rc, "kernel launch");
   return DTO_OK;
@@ -120,8 +123,9 @@ Problem::~Problem() {
   for (int* p : {d_kind, d_zoff, d_woff, d_cdoff, d_ccoff, d_jdoff, d_jcoff, d_hoff, d_hmap_cost, d_hmap_dyn_own,
                  d_hmap_dyn_next, d_hmap_con})
     if (p) (void)hipFree(p);
-  for (double* p : {d_params, d_x1, d_mu1, d_out1, d_scratch})
+  for (double* p : {d_params, d_x1, d_mu1, d_out1, d_scratch, wide_fac})
     if (p) (void)hipFree(p);
+  if (wide_flags) (void)hipFree(wide_flags);
   free_solver();
   if (stream) (void)hipStreamDestroy(stream);
   if (dl) dlclose(dl);

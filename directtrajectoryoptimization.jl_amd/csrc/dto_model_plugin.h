@@ -13,7 +13,7 @@
 
 #include <stdint.h>
 
-#define DTO_PLUGIN_ABI 3
+#define DTO_PLUGIN_ABI 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -99,6 +99,8 @@ typedef struct dto_eval_args {
 
 struct dto_kkt_args;
 struct dto_kkt_info;
+struct dto_wide_args;
+struct dto_wide_info;
 
 typedef struct dto_model_vtable {
   int abi;            /* DTO_PLUGIN_ABI */
@@ -116,6 +118,10 @@ typedef struct dto_model_vtable {
   /* KKT / solver kernels (dto_kkt_kernels.hpp), same convention */
   int (*launch_kkt)(int op, const struct dto_kkt_args* args, void* stream);
   int (*kkt_info)(struct dto_kkt_info* out);
+  /* wide-stage (tile / MFMA) KKT kernels of dto_wide_kernels.hpp; NULL for register-path models, and then
+   * `launch`/`launch_kkt` are NULL for wide models */
+  int (*launch_wide)(int op, const struct dto_wide_args* args, void* stream);
+  int (*wide_info)(struct dto_wide_info* out);
 } dto_model_vtable;
 
 /* the one symbol every plugin exports */

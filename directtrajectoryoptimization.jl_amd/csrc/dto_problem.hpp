@@ -31,6 +31,11 @@ struct Problem {
   size_t scratch_len = 0;
   hipStream_t stream = nullptr;
   SolverState* solver = nullptr;
+  // factor storage and inertia flags of the wide-stage KKT kernels
+  double* wide_fac = nullptr;
+  size_t wide_fac_len = 0;
+  int* wide_flags = nullptr;
+  size_t wide_flags_len = 0;
 
   int ensure_device();
   int ensure_scratch(int64_t B);

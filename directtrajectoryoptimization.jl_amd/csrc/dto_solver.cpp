@@ -14,6 +14,7 @@
 
 #include "../../include/dto.h"
 #include "dto_kkt_kernels.hpp"
+#include "dto_wide_kernels.hpp"
 #include "dto_problem.hpp"
 
 #define HIP_TRY(expr)                                       \
@@ -80,6 +81,49 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.eta_armijo = 1e-4; o.rho_penalty = 0.1; o.piv_tol = 1e-9;
   o.max_refactor = 9;
   o.newton_only = 0; o.fixed_delta_w = 0.0;
+}
+
+// ---- wide-stage models (dto_wide_kernels.hpp): one workgroup per instance, AoS buffers used as they are
+static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, double delta_w, double delta_c,
+                     double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok) {
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  dto_wide_info info;
+  p->vt->wide_info(&info);
+  const Layout& L = p->L;
+  if (L.Nstage != 0 || L.Ngen != 0) return set_error(DTO_ERR_UNSUPPORTED, "wide-stage models: dynamics rows and bounds only");
+  hipStream_t st = (hipStream_t)b->stream;
+  const size_t need = (size_t)b->B * (size_t)L.T * (size_t)info.fac_stage;
+  if (p->wide_fac_len < need) {
+    if (p->wide_fac) (void)hipFree(p->wide_fac);
+    p->wide_fac = nullptr; p->wide_fac_len = 0;
+    HIP_TRY(hipMalloc((void**)&p->wide_fac, need * sizeof(double)));
+    p->wide_fac_len = need;
+  }
+  if (p->wide_flags_len < (size_t)b->B) {
+    if (p->wide_flags) (void)hipFree(p->wide_flags);
+    p->wide_flags = nullptr; p->wide_flags_len = 0;
+    HIP_TRY(hipMalloc((void**)&p->wide_flags, (size_t)b->B * sizeof(int)));
+    p->wide_flags_len = (size_t)b->B;
+  }
+  dto_wide_args a;
+  a.T = L.T; a.B = b->B;
+  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff;
+  a.params = p->d_params;
+  a.z = b->x; a.ldz = b->ldx; a.mu = mu; a.ldmu = ldmu;
+  a.delta_w = delta_w; a.delta_c = delta_c; a.piv_tol = 1e-9;
+  a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
+  a.fac = p->wide_fac; a.flags = p->wide_flags; a.Nc = L.Nc;
+  const int lrc = p->vt->launch_wide(DTO_WIDE_STEP, &a, (void*)st);
+  if (lrc != 0) return hip_fail((hipError_t)lrc, "wide kernel launch");
+  if (inertia_ok) {
+    std::vector<int> fl((size_t)b->B);
+    HIP_TRY(hipMemcpyAsync(fl.data(), p->wide_flags, fl.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *inertia_ok = 1;
+    for (int v : fl) if (!v) *inertia_ok = 0;
+  }
+  return DTO_OK;
 }
 
 template <class T>
@@ -232,6 +276,7 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   if (!p || !b || !b->x || !mu || !dx || !dmu) return set_error(DTO_ERR_INVALID, "null argument");
   if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported on the KKT path yet");
   if (b->ldx < p->L.Nz || ldmu < p->L.Nc || lddx < p->L.Nz || lddmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  if (p->vt->launch_wide) return dto::wide_step(p, b, mu, ldmu, delta_w, delta_c, dx, lddx, dmu, lddmu, inertia_ok);
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;

@@ -1,0 +1,661 @@
+// Wide-stage KKT kernels: block-tridiagonal LDL^T with DENSE per-stage blocks on the f64 matrix cores.
+//
+// The lane-per-instance kernels of dto_kkt_kernels.hpp keep a whole stage block in registers, which stops
+// working when state + action dimension reaches MFMA tile sizes (BASELINE.json configs[4]: acrobot embedded in
+// n = 64 states, blocks of n + m + n = 129).  Here ONE WORKGROUP owns one
+// problem instance and walks the horizon; the stage blocks live in LDS as 16 x 16 tiles and every O(n^3)
+// operation is a v_mfma_f64_16x16x4_f64 tile product.
+//
+// System solved (the reference's in-tree KKT sketch, examples/pendulum/pendulum.jl:138-198):
+//     [ H + dw I   J' ] [dz ]     [ grad f + J' mu ]
+//     [ J      -dc I  ] [dmu] = - [ c              ]
+// Stage t couples (x_t, u_t, lam_t) with y = x_{t+1}.  Elimination order inside a stage: u (scalar pivots),
+// x (A = L_A D_A L_A'), lam (-(D + F~ D_A^-1 F~') = -L_M D_M L_M'); the Schur complement
+//     P' = YY - V~' D_A^-1 V~ + E~' D_M^-1 E~          (F~ = F L_A^-T, V~ = L_A^-1 V, E~ = L_M^-1 (E - F~ D_A^-1 V~))
+// is carried to stage t+1.  Factors go to HBM for the backward sweep (same kernel, same workgroup).
+// Inertia = number of negative pivots (Sylvester), must equal the number of constraints.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dto_model_plugin.h"
+
+enum dto_wide_op { DTO_WIDE_STEP = 0 };
+
+struct dto_wide_info {
+  int supported;
+  int n, nu;
+  int64_t fac_stage;  // doubles of factor storage per stage and instance
+  int lds_bytes;
+};
+
+struct dto_wide_args {
+  int T;
+  int64_t B;
+  const int* kind;   // [T]
+  const int* zoff;   // [T+1]
+  const int* woff;   // [T+1]
+  const int* cdoff;  // [T+1]
+  const double* params;
+  const double* z; int64_t ldz;
+  const double* mu; int64_t ldmu;
+  double delta_w, delta_c, piv_tol;
+  double* dz; int64_t lddz;
+  double* dmu; int64_t lddmu;
+  double* fac;   // [B][T][fac_stage]
+  int* flags;    // [B]: 1 = inertia (n, m, 0) and no tiny pivot
+  int64_t Nc;
+};
+
+namespace dto {
+namespace wide {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG = 256;  // 4 wavefronts
+constexpr int TB = 16;   // MFMA tile edge
+
+template <int N>
+struct Dims {
+  static constexpr int LD = N + 1;             // row stride of the LDS matrices (odd: column walks are conflict free)
+  static constexpr int MAT = N * LD;           // doubles per matrix
+  static constexpr int NT = N / TB;            // tiles per edge
+  static constexpr int LI_LD = TB + 1;
+  static constexpr int LI = NT * TB * LI_LD;   // inverses of the unit-lower diagonal tiles
+  // factor record of one stage in HBM
+  static constexpr int F_LA = 0, F_FT = MAT, F_VT = 2 * MAT, F_LM = 3 * MAT, F_ET = 4 * MAT, F_VEC = 5 * MAT;
+  static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = 5 * N, V_VU = 6 * N, V_SC = 7 * N;
+  static constexpr int FAC = F_VEC + 7 * N + 8;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- 16x16 tile <-> accumulator (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 j)
+__device__ __forceinline__ d4 tile_load(const double* Mx, int ld, int m0, int n0) {
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  d4 c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = Mx[(m0 + q + 4 * j) * ld + n0 + r];
+  return c;
+}
+__device__ __forceinline__ void tile_store(double* Mx, int ld, int m0, int n0, d4 c) {
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) Mx[(m0 + q + 4 * j) * ld + n0 + r] = c[j];
+}
+
+// C(m,n) += sum_k A[m0+m][k] * s[k] * B[n0+n][k]        (A, B row-major; "NT")
+__device__ __forceinline__ d4 mm_nt(d4 c, const double* A, int lda, int m0, const double* Bm, int ldb, int n0, int k0,
+                                    int k1, const double* s, double sgn) {
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  for (int k = k0; k < k1; k += 4) {
+    double a = A[(m0 + r) * lda + k + q];
+    if (s) a *= s[k + q];
+    const double b = Bm[(n0 + r) * ldb + k + q];
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * a, b, c, 0, 0, 0);
+  }
+  return c;
+}
+// C(m,n) += sum_k A[m0+m][k] * s[k] * B[k][n0+n]          ("NN")
+__device__ __forceinline__ d4 mm_nn(d4 c, const double* A, int lda, int m0, const double* Bm, int ldb, int n0, int k0,
+                                    int k1, const double* s, double sgn, int ka0 = -1) {
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  // ka0: column offset of A for k = k0 (A may be a small tile whose columns start at 0)
+  const int ka = (ka0 < 0) ? k0 : ka0;
+  for (int k = k0; k < k1; k += 4) {
+    double a = A[(m0 + r) * lda + (k - k0 + ka) + q];
+    if (s) a *= s[k + q];
+    const double b = Bm[(k + q) * ldb + n0 + r];
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * a, b, c, 0, 0, 0);
+  }
+  return c;
+}
+// C(m,n) += sum_k A[k][m0+m] * s[k] * B[k][n0+n]          ("TN")
+__device__ __forceinline__ d4 mm_tn(d4 c, const double* A, int lda, int m0, const double* Bm, int ldb, int n0, int k0,
+                                    int k1, const double* s, double sgn) {
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  for (int k = k0; k < k1; k += 4) {
+    double a = A[(k + q) * lda + m0 + r];
+    if (s) a *= s[k + q];
+    const double b = Bm[(k + q) * ldb + n0 + r];
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * a, b, c, 0, 0, 0);
+  }
+  return c;
+}
+
+// ---- unblocked LDL^T of the 16x16 diagonal tile at (o, o), one wavefront (lanes 0..15 = rows), then the inverse
+//      of its unit-lower factor.  d/dinv get the pivots; cnt[0] += negative pivots, cnt[1] |= tiny pivot seen.
+__device__ __forceinline__ void diag_tile(double* Mx, int ld, int o, double* d, double* dinv, double* LIk, int li_ld,
+                                          double piv_tol, int* cnt) {
+  const int l = lane_id();
+  int nneg = 0, tiny = 0;
+  for (int j = 0; j < TB; ++j) {
+    const double dj = Mx[(o + j) * ld + o + j];
+    double colmax = (l > j && l < TB) ? fabs(Mx[(o + l) * ld + o + j]) : 0.0;
+#pragma unroll
+    for (int sft = 8; sft >= 1; sft >>= 1) colmax = fmax(colmax, __shfl_xor(colmax, sft));
+    if (!(fabs(dj) > piv_tol * fmax(1.0, colmax))) tiny = 1;
+    if (dj < 0.0) ++nneg;
+    const double idj = 1.0 / dj;
+    if (l > j && l < TB) {
+      const double aij = Mx[(o + l) * ld + o + j];
+      const double lij = aij * idj;
+      for (int c = j + 1; c <= l; ++c) Mx[(o + l) * ld + o + c] -= lij * Mx[(o + c) * ld + o + j];
+      Mx[(o + l) * ld + o + j] = lij;
+    }
+    if (l == 0) { d[o + j] = dj; dinv[o + j] = idj; }
+  }
+  if (l == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
+  // inverse of the unit-lower tile, lane c = column c
+  if (l < TB) {
+    double X[TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc += Mx[(o + i) * ld + o + k] * X[k];
+      X[i] = (i == l) ? 1.0 : (i > l ? -sacc : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < TB; ++i) LIk[i * li_ld + l] = X[i];
+  }
+}
+
+// ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
+//      On exit: strict lower part = L, d/dinv = pivots, LI = inverses of the unit-lower diagonal tiles.
+template <int N>
+__device__ void ldl_blocked(double* Mx, double* d, double* dinv, double* LI, double piv_tol, int* cnt) {
+  using D = Dims<N>;
+  constexpr int LD = D::LD, NT = D::NT;
+  const int w = wave_id();
+  for (int kb = 0; kb < NT; ++kb) {
+    const int o = kb * TB;
+    double* LIk = LI + kb * TB * D::LI_LD;
+    if (w == 0) diag_tile(Mx, LD, o, d, dinv, LIk, D::LI_LD, piv_tol, cnt);
+    __syncthreads();
+    // panel: L(ib,kb) = A(ib,kb) * Linv' * D^-1
+    for (int ib = kb + 1 + w; ib < NT; ib += 4) {
+      d4 c = {0.0, 0.0, 0.0, 0.0};
+      c = mm_nt(c, Mx + o, LD, ib * TB, LIk, D::LI_LD, 0, 0, TB, nullptr, 1.0);
+      const double sc = dinv[o + (lane_id() & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] *= sc;
+      tile_store(Mx, LD, ib * TB, o, c);
+    }
+    __syncthreads();
+    // trailing update of the lower tiles: A(ib,jb) -= L(ib,kb) D_kb L(jb,kb)'
+    int idx = 0;
+    for (int ib = kb + 1; ib < NT; ++ib) {
+      for (int jb = kb + 1; jb <= ib; ++jb, ++idx) {
+        if ((idx & 3) != w) continue;
+        d4 c = tile_load(Mx, LD, ib * TB, jb * TB);
+        c = mm_nt(c, Mx + o, LD, ib * TB, Mx + o, LD, jb * TB, 0, TB, d + o, -1.0);
+        tile_store(Mx, LD, ib * TB, jb * TB, c);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// X <- X * L^-T for row-tile `ib` of X (one wavefront; tiles of one row depend only on each other)
+template <int N>
+__device__ __forceinline__ void trsm_right_rowtile(double* X, const double* Lm, const double* LI, int ib) {
+  using D = Dims<N>;
+  constexpr int LD = D::LD;
+  for (int jb = 0; jb < D::NT; ++jb) {
+    d4 c = tile_load(X, LD, ib * TB, jb * TB);
+    if (jb > 0) c = mm_nt(c, X, LD, ib * TB, Lm, LD, jb * TB, 0, jb * TB, nullptr, -1.0);
+    tile_store(X, LD, ib * TB, jb * TB, c);
+    d4 c2 = {0.0, 0.0, 0.0, 0.0};
+    c2 = mm_nt(c2, X + jb * TB, LD, ib * TB, LI + jb * TB * D::LI_LD, D::LI_LD, 0, 0, TB, nullptr, 1.0);
+    tile_store(X, LD, ib * TB, jb * TB, c2);
+  }
+}
+
+// X <- L^-1 X for column-tile `jb` of X (one wavefront)
+template <int N>
+__device__ __forceinline__ void trsm_left_coltile(double* X, const double* Lm, const double* LI, int jb) {
+  using D = Dims<N>;
+  constexpr int LD = D::LD;
+  for (int ib = 0; ib < D::NT; ++ib) {
+    d4 c = tile_load(X, LD, ib * TB, jb * TB);
+    if (ib > 0) c = mm_nn(c, Lm, LD, ib * TB, X, LD, jb * TB, 0, ib * TB, nullptr, -1.0);
+    tile_store(X, LD, ib * TB, jb * TB, c);
+    d4 c2 = {0.0, 0.0, 0.0, 0.0};
+    c2 = mm_nn(c2, LI + ib * TB * D::LI_LD, D::LI_LD, 0, X, LD, jb * TB, ib * TB, ib * TB + TB, nullptr, 1.0, 0);
+    tile_store(X, LD, ib * TB, jb * TB, c2);
+  }
+}
+
+// v <- L^-1 v (unit lower, strict lower part of Lm), one wavefront, lanes = rows
+template <int N>
+__device__ __forceinline__ void trsv_lower(const double* Lm, double* v) {
+  constexpr int LD = Dims<N>::LD;
+  const int l = lane_id();
+  double mine = (l < N) ? v[l] : 0.0;
+  for (int k = 0; k < N - 1; ++k) {
+    const double vk = __shfl(mine, k);
+    if (l > k && l < N) mine -= Lm[l * LD + k] * vk;
+  }
+  if (l < N) v[l] = mine;
+}
+// v <- L^-T v, one wavefront
+template <int N>
+__device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
+  constexpr int LD = Dims<N>::LD;
+  const int l = lane_id();
+  double mine = (l < N) ? v[l] : 0.0;
+  for (int k = N - 1; k >= 1; --k) {
+    const double vk = __shfl(mine, k);
+    if (l < k) mine -= Lm[k * LD + l] * vk;
+  }
+  if (l < N) v[l] = mine;
+}
+
+template <class M, int WKI>
+struct WK {
+  using KD = typename M::template WKind<WKI>;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// the kernel: forward factor/solve sweep, terminal solve, backward sweep.  grid = B, block = 256.
+// ---------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
+  constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+  static_assert(N == 64, "wide path is built for 64 states (one wavefront of rows, 4 x 4 tiles)");
+  static_assert(NU == 1, "wide path eliminates one action per stage");
+  using D = Dims<N>;
+  constexpr int LD = D::LD, MAT = D::MAT, NT = D::NT;
+  extern __shared__ double sm[];
+  double* MA = sm;
+  double* MF = MA + MAT;
+  double* MV = MF + MAT;
+  double* ME = MV + MAT;
+  double* LI = ME + MAT;
+  double* vec = LI + D::LI;
+  double* xv = vec;            // [N]
+  double* yv = xv + N;         // [N]
+  double* lamv = yv + N;       // [N]
+  double* au = lamv + N;       // A_xu
+  double* fu = au + N;         // F_u
+  double* vu = fu + N;         // V_u (u-y coupling)
+  double* bx = vu + N;
+  double* bd = bx + N;
+  double* byc = bd + N;        // carried right-hand side for the next x
+  double* byn = byc + N;
+  double* gyp = byn + N;       // E_{t-1}' lam_{t-1}
+  double* gyn = gyp + N;
+  double* dA = gyn + N;
+  double* dAi = dA + N;
+  double* dM = dAi + N;
+  double* dMi = dM + N;
+  double* nlf = dMi + N;       // nonlinear remainder of the residual, scattered to rows
+  double* gc = nlf + N;        // cost gradient [N + NU]
+  double* tmp = gc + N + 8;    // [N]
+  double* hv = tmp + N;        // dynamics Hessian values [MAX_NH]
+  double* chv = hv + M::MAX_NH;  // cost Hessian values [MAX_SNH]
+  double* jvv = chv + M::MAX_SNH;  // variable Jacobian entries [MAX_NJV]
+  double* sc = jvv + M::MAX_NJV;   // scalars: 0 uv, 1 auu, 2 bu, 3 piv
+  int* cnt = (int*)(sc + 8);       // 0 nneg, 1 tiny
+
+  const int tid = threadIdx.x, w = wave_id(), l = lane_id();
+  const int64_t b = blockIdx.x;
+  const double* z = a.z + b * a.ldz;
+  const double* mu = a.mu + b * a.ldmu;
+  double* facb = a.fac + b * (int64_t)a.T * D::FAC;
+  const double dw = a.delta_w, dc = a.delta_c;
+
+  for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
+  if (tid < N) { byc[tid] = 0.0; gyp[tid] = 0.0; }
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  __syncthreads();
+
+  for (int t = 0; t < a.T - 1; ++t) {
+    double* fac = facb + (int64_t)t * D::FAC;
+    const int wk = M::wk_of_kind(a.kind[t]);
+    M::dispatch_wk(wk, [&](auto wkc) {
+      constexpr int WKI = decltype(wkc)::value;
+      using KD = typename M::template WKind<WKI>;
+      if constexpr (KD::DYN >= 0) {
+        using DY = typename M::template Dyn<KD::DYN>;
+        using CO = typename M::template Cost<KD::COST>;
+        static_assert(DY::NX == N && DY::NY == N && DY::NU == NU, "uniform wide stages expected");
+        const double* wp = a.params + a.woff[t];
+        // ---- phase 0: the point, constant Jacobian part
+        if (tid < N) {
+          xv[tid] = z[a.zoff[t] + tid];
+          yv[tid] = z[a.zoff[t + 1] + tid];
+          lamv[tid] = mu[a.cdoff[t] + tid];
+          au[tid] = 0.0; vu[tid] = 0.0; nlf[tid] = 0.0;
+          MA[tid * LD + tid] += dw;
+        }
+        if (tid == 0) { sc[0] = z[a.zoff[t] + N]; sc[1] = 0.0; }
+        {
+          constexpr int NC = 2 * N + NU;
+          const double* fe = DY::fe_const();
+          for (int i = tid; i < N * NC; i += WG) {
+            const int r = i / NC, c = i - r * NC;
+            const double v = fe[i];
+            if (c < N) MF[r * LD + c] = v;
+            else if (c < N + NU) fu[r] = v;
+            else ME[r * LD + c - N - NU] = v;
+          }
+          for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
+        }
+        __syncthreads();
+        // ---- phase 1: model code (wave-uniform values, one wavefront per function)
+        if (w == 0) {
+          DY::eval_nl(xv, sc, yv, wp, tmp);
+          if (l < DY::NNL) nlf[DY::nl_row(l)] = tmp[l];
+        } else if (w == 1) {
+          DY::jac_var(xv, sc, yv, wp, jvv);
+        } else if (w == 2) {
+          if constexpr (DY::NH > 0) DY::hess(xv, sc, yv, wp, lamv, hv);
+        } else {
+          CO::grad(xv, sc, wp, gc);
+          if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
+        }
+        __syncthreads();
+        // ---- phase 2: residual from the constant part (variable Jacobian entries are still zero in MF/ME/fu)
+        if (tid < N) {
+          double acc = nlf[tid] + fu[tid] * sc[0];
+          for (int c = 0; c < N; ++c) acc += MF[tid * LD + c] * xv[c] + ME[tid * LD + c] * yv[c];
+          bd[tid] = -acc;
+        }
+        __syncthreads();
+        // ---- phase 3: variable Jacobian entries, Hessian blocks
+        if (tid < DY::NJV) {
+          const int r = DY::jv_row(tid), c = DY::jv_col(tid);
+          const double v = jvv[tid];
+          if (c < N) MF[r * LD + c] = v;
+          else if (c < N + NU) fu[r] = v;
+          else ME[r * LD + c - N - NU] = v;
+        }
+        if constexpr (CO::SNH > 0) {
+          if (tid < CO::SNH) {
+            const int r = CO::sh_row(tid), c = CO::sh_col(tid);
+            const double v = chv[tid];
+            if (r < N && c < N) MA[r * LD + c] += v;
+            else if (r < N && c >= N) au[r] += v;
+            else if (r >= N && c >= N) sc[1] += v;
+          }
+        }
+        __syncthreads();
+        if constexpr (DY::NH > 0) {
+          if (tid < DY::NH) {
+            const int r = DY::h_row(tid), c = DY::h_col(tid);
+            const double v = hv[tid];
+            if (r < N) {
+              if (c < N) MA[r * LD + c] += v;
+              else if (c < N + NU) au[r] += v;
+              else MV[r * LD + c - N - NU] += v;
+            } else if (r < N + NU) {
+              if (c >= N && c < N + NU) sc[1] += v;
+              else if (c >= N + NU) vu[c - N - NU] += v;
+            }
+          }
+        }
+        __syncthreads();
+        // ---- phase 4: gradient of the Lagrangian -> right-hand sides
+        if (tid < N) {
+          double acc = gc[tid] + gyp[tid];
+          for (int r = 0; r < N; ++r) acc += MF[r * LD + tid] * lamv[r];
+          bx[tid] = -acc + byc[tid];
+        } else if (tid < 2 * N) {
+          const int j = tid - N;
+          double acc = 0.0;
+          for (int r = 0; r < N; ++r) acc += ME[r * LD + j] * lamv[r];
+          gyn[j] = acc;
+        } else if (tid == 2 * N) {
+          double acc = gc[N];
+          for (int r = 0; r < N; ++r) acc += fu[r] * lamv[r];
+          sc[2] = -acc;
+          sc[3] = sc[1] + dw;
+        }
+        __syncthreads();
+        // ---- phase 5: eliminate u
+        const double piv = sc[3], ip = 1.0 / piv, bu = sc[2];
+        for (int i = tid; i < N * N; i += WG) {
+          const int r = i >> 6, c = i & 63;
+          MA[r * LD + c] -= au[r] * au[c] * ip;
+          MF[r * LD + c] -= fu[r] * au[c] * ip;
+          MV[r * LD + c] -= au[r] * vu[c] * ip;
+          ME[r * LD + c] -= fu[r] * vu[c] * ip;
+        }
+        if (tid < N) {
+          bx[tid] -= au[tid] * bu * ip;
+          bd[tid] -= fu[tid] * bu * ip;
+          byn[tid] = -vu[tid] * bu * ip;
+        }
+        if (tid == 0) {
+          if (piv < 0.0) cnt[0] += 1;
+          if (!(fabs(piv) > a.piv_tol)) cnt[1] |= 1;
+        }
+        __syncthreads();
+        // ---- phase 6: A = L_A D_A L_A'
+        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
+        // ---- phase 7: F~ = F L_A^-T (row tiles), V~ = L_A^-1 V (column tiles), bx~ = L_A^-1 bx
+        if (w == 0) trsv_lower<N>(MA, bx);
+        trsm_right_rowtile<N>(MF, MA, LI, w);
+        trsm_left_coltile<N>(MV, MA, LI, w);
+        __syncthreads();
+        // ---- phase 8: M = D + F~ D_A^-1 F~' (registers), E'' = E - F~ D_A^-1 V~ (in place), bd~
+        d4 macc[NT];
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) {
+          const int r = l & 15, q = l >> 4;
+          d4 c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = w * TB + q + 4 * j, col = jb * TB + r;
+            c[j] = (row == col ? dc : 0.0) + fu[row] * fu[col] * ip;
+          }
+          macc[jb] = mm_nt(c, MF, LD, w * TB, MF, LD, jb * TB, 0, N, dAi, 1.0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) {
+          d4 c = tile_load(ME, LD, w * TB, jb * TB);
+          c = mm_nn(c, MF, LD, w * TB, MV, LD, jb * TB, 0, N, dAi, -1.0);
+          tile_store(ME, LD, w * TB, jb * TB, c);
+        }
+        if (tid < N) {
+          double acc = bd[tid];
+          for (int k = 0; k < N; ++k) acc -= MF[tid * LD + k] * bx[k] * dAi[k];
+          tmp[tid] = acc;
+        }
+        for (int i = tid; i < MAT; i += WG) fac[D::F_LA + i] = MA[i];
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
+        if (tid < N) bd[tid] = tmp[tid];
+        __syncthreads();
+        // ---- phase 9: M = L_M D_M L_M'   (the KKT pivots of this block are -D_M)
+        if (tid == 0) cnt[0] += N;  // N negative pivots if every D_M entry is positive; corrected below
+        __syncthreads();
+        {
+          int* cm = cnt + 2;  // scratch counters for M
+          if (tid == 0) { cm[0] = 0; cm[1] = 0; }
+          __syncthreads();
+          ldl_blocked<N>(MA, dM, dMi, LI, a.piv_tol, cm);
+          if (tid == 0) { cnt[0] -= cm[0]; cnt[1] |= cm[1]; }
+        }
+        // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
+        if (w == 0) trsv_lower<N>(MA, bd);
+        trsm_left_coltile<N>(ME, MA, LI, w);
+        __syncthreads();
+        // ---- phase 11: P' = -V~' D_A^-1 V~ + E~' D_M^-1 E~ (registers), carried right-hand side
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) {
+          d4 c = {0.0, 0.0, 0.0, 0.0};
+          c = mm_tn(c, MV, LD, w * TB, MV, LD, jb * TB, 0, N, dAi, -1.0);
+          macc[jb] = mm_tn(c, ME, LD, w * TB, ME, LD, jb * TB, 0, N, dMi, 1.0);
+        }
+        if (tid < N) {
+          double acc = byn[tid];
+          for (int k = 0; k < N; ++k) acc += -MV[k * LD + tid] * bx[k] * dAi[k] + ME[k * LD + tid] * bd[k] * dMi[k];
+          tmp[tid] = acc;
+        }
+        for (int i = tid; i < MAT; i += WG) {
+          fac[D::F_LM + i] = MA[i];
+          fac[D::F_FT + i] = MF[i];
+          fac[D::F_VT + i] = MV[i];
+          fac[D::F_ET + i] = ME[i];
+        }
+        if (tid < N) {
+          double* fv = fac + D::F_VEC;
+          fv[D::V_DA + tid] = dAi[tid];
+          fv[D::V_DM + tid] = dMi[tid];
+          fv[D::V_BX + tid] = bx[tid];
+          fv[D::V_BD + tid] = bd[tid];
+          fv[D::V_AU + tid] = au[tid];
+          fv[D::V_FU + tid] = fu[tid];
+          fv[D::V_VU + tid] = vu[tid];
+        }
+        if (tid == 0) { fac[D::F_VEC + D::V_SC + 0] = ip; fac[D::F_VEC + D::V_SC + 1] = bu; }
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
+        if (tid < N) { byc[tid] = tmp[tid]; gyp[tid] = gyn[tid]; }
+        __syncthreads();
+        // the y-y part of this stage's Hessian and the u rank-one term complete P'
+        for (int i = tid; i < N * N; i += WG) {
+          const int r = i >> 6, c = i & 63;
+          MA[r * LD + c] -= vu[r] * vu[c] * ip;
+        }
+        __syncthreads();
+        if constexpr (DY::NH > 0) {
+          if (tid < DY::NH) {
+            const int r = DY::h_row(tid), c = DY::h_col(tid);
+            if (r >= N + NU && c >= N + NU) MA[(r - N - NU) * LD + c - N - NU] += hv[tid];
+          }
+        }
+        __syncthreads();
+      }
+    });
+  }
+  // ---- terminal stage: (W_T + dw I + P') x = -(grad + E' lam) + by
+  {
+    const int t = a.T - 1;
+    const int wk = M::wk_of_kind(a.kind[t]);
+    M::dispatch_wk(wk, [&](auto wkc) {
+      constexpr int WKI = decltype(wkc)::value;
+      using KD = typename M::template WKind<WKI>;
+      if constexpr (KD::DYN < 0) {
+        using CO = typename M::template Cost<KD::COST>;
+        const double* wp = a.params + a.woff[t];
+        if (tid < N) xv[tid] = z[a.zoff[t] + tid];
+        __syncthreads();
+        if (w == 0) {
+          CO::grad(xv, sc, wp, gc);
+          if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
+        }
+        __syncthreads();
+        if constexpr (CO::SNH > 0) {
+          if (tid < CO::SNH) MA[CO::sh_row(tid) * LD + CO::sh_col(tid)] += chv[tid];
+        }
+        __syncthreads();
+        if (tid < N) {
+          MA[tid * LD + tid] += dw;
+          bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid];
+        }
+        __syncthreads();
+        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
+        if (w == 0) {
+          trsv_lower<N>(MA, bx);
+          if (l < N) bx[l] *= dAi[l];
+          trsv_lower_t<N>(MA, bx);
+          if (l < N) {
+            yv[l] = bx[l];
+            a.dz[b * a.lddz + a.zoff[t] + l] = bx[l];
+          }
+        }
+        __syncthreads();
+      }
+    });
+  }
+  if (tid == 0) a.flags[b] = (cnt[0] == (int)a.Nc && cnt[1] == 0) ? 1 : 0;
+  // ---- backward sweep: y = x_{t+1} is in yv
+  for (int t = a.T - 2; t >= 0; --t) {
+    const double* fac = facb + (int64_t)t * D::FAC;
+    const double* fv = fac + D::F_VEC;
+    for (int i = tid; i < MAT; i += WG) {
+      ME[i] = fac[D::F_ET + i];
+      MA[i] = fac[D::F_LM + i];
+      MF[i] = fac[D::F_FT + i];
+      MV[i] = fac[D::F_VT + i];
+    }
+    if (tid < N) {
+      dAi[tid] = fv[D::V_DA + tid];
+      dMi[tid] = fv[D::V_DM + tid];
+      bx[tid] = fv[D::V_BX + tid];
+      bd[tid] = fv[D::V_BD + tid];
+      au[tid] = fv[D::V_AU + tid];
+      fu[tid] = fv[D::V_FU + tid];
+      vu[tid] = fv[D::V_VU + tid];
+    }
+    __syncthreads();
+    // lam = L_M^-T D_M^-1 (E~ y - bd^)
+    if (tid < N) {
+      double acc = -bd[tid];
+      for (int c = 0; c < N; ++c) acc += ME[tid * LD + c] * yv[c];
+      lamv[tid] = acc * dMi[tid];
+    }
+    __syncthreads();
+    if (w == 0) trsv_lower_t<N>(MA, lamv);
+    __syncthreads();
+    // x = L_A^-T D_A^-1 (bx~ - F~' lam - V~ y)
+    if (tid < N) {
+      double acc = bx[tid];
+      for (int r = 0; r < N; ++r) acc -= MF[r * LD + tid] * lamv[r];
+      for (int c = 0; c < N; ++c) acc -= MV[tid * LD + c] * yv[c];
+      xv[tid] = acc * dAi[tid];
+    }
+    __syncthreads();
+    for (int i = tid; i < MAT; i += WG) MA[i] = fac[D::F_LA + i];
+    __syncthreads();
+    if (w == 0) trsv_lower_t<N>(MA, xv);
+    __syncthreads();
+    if (tid < N) {
+      a.dz[b * a.lddz + a.zoff[t] + tid] = xv[tid];
+      a.dmu[b * a.lddmu + a.cdoff[t] + tid] = lamv[tid];
+    }
+    if (w == 1) {
+      // u = (bu - au'x - fu'lam - vu'y) / piv
+      double part = (l < N) ? (au[l] * xv[l] + fu[l] * lamv[l] + vu[l] * yv[l]) : 0.0;
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) part += __shfl_xor(part, sft);
+      if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
+    }
+    __syncthreads();
+    if (tid < N) yv[tid] = xv[tid];
+    __syncthreads();
+  }
+}
+
+template <class M>
+int wide_info(dto_wide_info* out) {
+  using D = Dims<M::WIDE_N>;
+  out->supported = 1;
+  out->n = M::WIDE_N;
+  out->nu = M::WIDE_NU;
+  out->fac_stage = D::FAC;
+  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4);
+  return 0;
+}
+
+template <class M>
+int launch_wide(int op, const dto_wide_args* a, void* stream) {
+  if (op != DTO_WIDE_STEP) return (int)hipErrorInvalidValue;
+  dto_wide_info info;
+  wide_info<M>(&info);
+  hipError_t e = hipFuncSetAttribute((const void*)k_wide_step<M>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_wide_step<M>, dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace wide
+}  // namespace dto

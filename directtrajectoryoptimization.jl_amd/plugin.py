@@ -23,11 +23,14 @@ from typing import Dict, List, Sequence, Tuple
 
 from .model import Constraint, Cost, Dynamics, GeneralConstraint
 from .symbolic.codegen import emit_body
+from .symbolic import expr as E
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PLUGIN_DIR = os.path.join(_HERE, "_plugins")
-GENERATOR_VERSION = "7"
+GENERATOR_VERSION = "8"
+WIDE_MIN_STATE = 17   # above this the lane-per-instance register kernels give way to the tile (MFMA) kernels
+WIDE_STATE = 64       # the state dimension the tile kernels are built for
 
 
 class Structure:
@@ -77,6 +80,15 @@ class Structure:
                 raise ValueError(f"stage {t + 1}: cost dims {self.cost[c].num_state, self.cost[c].num_action} != {(nx, nu)}")
             if kc >= 0 and (self.con[kc].num_state, self.con[kc].num_action) != (nx, nu):
                 raise ValueError(f"stage {t + 1}: constraint dims != {(nx, nu)}")
+        max_nx = max([d.num_state for d in self.dyn] + [c.num_state for c in self.cost])
+        self.wide = max_nx >= WIDE_MIN_STATE
+        if self.wide:
+            ok = (all(d.num_state == WIDE_STATE and d.num_next_state == WIDE_STATE and d.num_action == 1 for d in self.dyn)
+                  and not self.con and self.general is None and self.evaluate_hessian
+                  and all(d.num_parameter == 0 for d in self.dyn))
+            if not ok:
+                raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
+                                 f"{WIDE_STATE} states, one action, exact Hessians and bound-only stage constraints")
         if self.evaluate_hessian:
             # all objects must agree on the flag
             for o in list(self.dyn) + list(self.cost) + list(self.con):
@@ -226,7 +238,141 @@ def _scatter_con(c: Constraint, h: bool) -> str:
     return "".join(out)
 
 
+def _dev_int_array(name: str, vals: Sequence[int]) -> str:
+    body = ", ".join(str(int(v)) for v in vals) if len(vals) else "0"
+    return f"__device__ const int {name}[] = {{{body}}};"
+
+
+def _lookup(fn: str, table: str) -> str:
+    return f"  static __device__ __forceinline__ int {fn}(int k) {{ return {table}[k]; }}\n"
+
+
+def generate_wide_source(st: Structure, name: str) -> str:
+    """Plugin for wide stages (csrc/dto_wide_kernels.hpp): the stage Jacobian is split into a constant dense table and
+    the few state-dependent entries; the residual is the constant part times [x; u; y] plus a nonlinear remainder."""
+    from .symbolic.codegen import _lit
+    out: List[str] = []
+    out.append(f"// generated by directtrajectoryoptimization.jl_amd/plugin.py (v{GENERATOR_VERSION}, wide) -- do not edit")
+    out.append("#include <type_traits>")
+    out.append('#include "dto_wide_kernels.hpp"')
+    out.append("namespace {")
+    wkinds: List[Tuple[int, int]] = []
+    wk_of_kind = []
+    for (d, p, c, kc) in st.kinds:
+        if (d, c) not in wkinds:
+            wkinds.append((d, c))
+        wk_of_kind.append(wkinds.index((d, c)))
+    dev_tables: List[str] = []
+    host_tables: List[str] = []
+    classes: List[str] = []
+    max_njv, max_nh, max_snh = 1, 1, 1
+    for i, d in enumerate(st.dyn):
+        nx, nu, ny = d.num_state, d.num_action, d.num_next_state
+        ncol = nx + nu + ny
+        x = E.variables("x", nx); u = E.variables("u", nu); y = E.variables("y", ny)
+        wrt = list(x) + list(u) + list(y)
+        fe = [0.0] * (ny * ncol)
+        var_idx = []
+        const_cols: Dict[int, List[int]] = {r: [] for r in range(ny)}
+        for k, (r1, c1, e) in enumerate(zip(d.jacobian_sparsity[0], d.jacobian_sparsity[1], d.jacobian_expr)):
+            r, c = r1 - 1, c1 - 1
+            if e.is_const:
+                fe[r * ncol + c] = float(e.value)
+                const_cols[r].append(c)
+            else:
+                var_idx.append(k)
+        # nonlinear remainder of row r: the residual with every constant-coefficient variable set to zero
+        rem = []
+        for r in range(ny):
+            rem.append(E.substitute([d.evaluate_expr[r]], {wrt[c]: E.const(0.0) for c in const_cols[r]})[0])
+        nl_rows = [r for r in range(ny) if not rem[r].is_zero()]
+        va = {"x": "x", "u": "u", "y": "y", "w": "w", "lam": "lam"}
+        sig = "const double* x, const double* u, const double* y, const double* w, double* out"
+        sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
+        nh = d.num_hessian
+        max_njv, max_nh = max(max_njv, len(var_idx)), max(max_nh, nh)
+        cl = [f"template <> struct Model::Dyn<{i}> {{"]
+        cl.append(f"  static constexpr int NX = {nx}, NU = {nu}, NY = {ny}, NW = {d.num_parameter}, NJ = {d.num_jacobian}, "
+                  f"NH = {nh}, NJV = {len(var_idx)}, NNL = {len(nl_rows)};")
+        cl.append(f"  static __device__ __forceinline__ const double* fe_const() {{ return dyn{i}_fe; }}")
+        cl.append(_fn("eval_nl", sig, emit_body([rem[r] for r in nl_rows], "out", va) if nl_rows else "    (void)x;"))
+        cl.append(_fn("jac_var", sig, emit_body([d.jacobian_expr[k] for k in var_idx], "out", va) if var_idx else "    (void)x;"))
+        if nh:
+            cl.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+        cl.append(_lookup("nl_row", f"dyn{i}_nlr") + _lookup("jv_row", f"dyn{i}_jvr") + _lookup("jv_col", f"dyn{i}_jvc")
+                  + _lookup("h_row", f"dyn{i}_hr0") + _lookup("h_col", f"dyn{i}_hc0"))
+        cl.append("};")
+        classes.append("\n".join(cl))
+        dev_tables.append(f"__device__ const double dyn{i}_fe[] = {{" + ", ".join(_lit(v) for v in fe) + "};")
+        dev_tables.append(_dev_int_array(f"dyn{i}_nlr", nl_rows))
+        dev_tables.append(_dev_int_array(f"dyn{i}_jvr", [d.jacobian_sparsity[0][k] - 1 for k in var_idx]))
+        dev_tables.append(_dev_int_array(f"dyn{i}_jvc", [d.jacobian_sparsity[1][k] - 1 for k in var_idx]))
+        dev_tables.append(_dev_int_array(f"dyn{i}_hr0", [r - 1 for r in d.hessian_sparsity[0]]))
+        dev_tables.append(_dev_int_array(f"dyn{i}_hc0", [c - 1 for c in d.hessian_sparsity[1]]))
+        host_tables.append(_int_array(f"dyn{i}_jr", d.jacobian_sparsity[0]))
+        host_tables.append(_int_array(f"dyn{i}_jc", d.jacobian_sparsity[1]))
+        host_tables.append(_int_array(f"dyn{i}_hr", d.hessian_sparsity[0]))
+        host_tables.append(_int_array(f"dyn{i}_hc", d.hessian_sparsity[1]))
+    for i, c in enumerate(st.cost):
+        va = {"x": "x", "u": "u", "w": "w"}
+        sig = "const double* x, const double* u, const double* w, double* out"
+        snh = len(c.solver_hessian_expr)
+        max_snh = max(max_snh, snh)
+        cl = [f"template <> struct Model::Cost<{i}> {{"]
+        cl.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, NH = {c.num_hessian}, SNH = {snh};")
+        cl.append(_fn("eval", sig, emit_body(c.evaluate_expr, "out", va)))
+        cl.append(_fn("grad", sig, emit_body(c.gradient_expr, "out", va)))
+        cl.append(_fn("shess", sig, emit_body(c.solver_hessian_expr, "out", va) if snh else "    (void)x;"))
+        cl.append(_lookup("sh_row", f"cost{i}_sr0") + _lookup("sh_col", f"cost{i}_sc0"))
+        cl.append("};")
+        classes.append("\n".join(cl))
+        dev_tables.append(_dev_int_array(f"cost{i}_sr0", [r - 1 for r in c.solver_sparsity[0]]))
+        dev_tables.append(_dev_int_array(f"cost{i}_sc0", [q - 1 for q in c.solver_sparsity[1]]))
+        host_tables.append(_int_array(f"cost{i}_hr", c.sparsity[0]))
+        host_tables.append(_int_array(f"cost{i}_hc", c.sparsity[1]))
+    out.extend(dev_tables)
+    out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
+    out.append("struct Model {")
+    out.append(f"  static constexpr int WIDE_N = {WIDE_STATE}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
+    out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = 1;")
+    out.append("  template <int K> struct WKind;")
+    out.append("  template <int C> struct Dyn;")
+    out.append("  template <int C> struct Cost;")
+    out.append("  static __device__ __forceinline__ int wk_of_kind(int k) { return k_wk_of_kind[k]; }")
+    out.append("  template <class F> static __device__ __forceinline__ void dispatch_wk(int wk, F&& f) {")
+    for i in range(len(wkinds)):
+        out.append(f"    if (wk == {i}) {{ f(std::integral_constant<int, {i}>{{}}); return; }}")
+    out.append("  }")
+    out.append("};")
+    for i, (d, c) in enumerate(wkinds):
+        out.append(f"template <> struct Model::WKind<{i}> {{ static constexpr int DYN = {d}, COST = {c}; }};")
+    out.extend(classes)
+    out.extend(host_tables)
+    rows = []
+    for i, d in enumerate(st.dyn):
+        rows.append(f"  {{{d.num_next_state}, {d.num_state}, {d.num_action}, {d.num_parameter}, {d.num_jacobian}, {d.num_hessian}, "
+                    f"dyn{i}_jr, dyn{i}_jc, dyn{i}_hr, dyn{i}_hc}}")
+    out.append("static const dto_dyn_class k_dyn[] = {\n" + ",\n".join(rows) + "\n};")
+    rows = [f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_hessian}, cost{i}_hr, cost{i}_hc}}" for i, c in enumerate(st.cost)]
+    out.append("static const dto_cost_class k_cost[] = {\n" + ",\n".join(rows) + "\n};")
+    out.append("static const dto_con_class k_con[] = {\n  {0}\n};")
+    rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
+    out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
+    out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
+    out.append("static const dto_model_vtable k_vtable = {")
+    out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
+    out.append("  k_dyn, k_cost, k_con, k_kinds, nullptr, 1,")
+    max_key = max([1] + [st.key_slots(k) for k in st.kinds])
+    out.append(f"  {max_key}, nullptr, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>")
+    out.append("};")
+    out.append("}  // namespace")
+    out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')
+    return "\n".join(out) + "\n"
+
+
 def generate_source(st: Structure, name: str) -> str:
+    if st.wide:
+        return generate_wide_source(st, name)
     h = st.evaluate_hessian
     out: List[str] = []
     out.append(f"// generated by directtrajectoryoptimization.jl_amd/plugin.py (v{GENERATOR_VERSION}) -- do not edit")
@@ -379,7 +525,7 @@ def generate_source(st: Structure, name: str) -> str:
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, {'&k_general' if g is not None else 'nullptr'}, {1 if h else 0},")
-    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>")
+    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>, nullptr, nullptr")
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')

@@ -110,6 +110,30 @@ def acrobot_midpoint(y, x, u, w, h=0.05):
     return y - (x + h * acrobot(0.5 * (x + y), u, w))
 
 
+# ----------------------------------------------------------------------------- acrobot embedded in n states (cfg5)
+def padded_mixing(n=64, m=1, seed=64):
+    """Dense (n x (n+m)) mixing matrix of the synthetic cfg5 model: fixed by the seed so that
+    every rank, the oracle and the fixtures see the same numbers."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.standard_normal((n, n + m)) / np.sqrt(n + m)
+
+
+def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64):
+    """y - x - h*f(0.5(x+y), u) with f = [acrobot(x[0:4], u); 0] + eps * M [xm; u]: the four physical states keep the
+    acrobot dynamics, the padding states are a stable-ish dense linear system, and every residual row depends on every
+    column of [x; u], so the stage Jacobian block is structurally dense (blocks of n + m + n = 129 for n = 64)."""
+    M = padded_mixing(n, 1, seed)
+
+    def f(y, x, u, w):
+        xm = 0.5 * (x + y)
+        phys = acrobot(xm[0:4], u, w)
+        lin = M @ np.concatenate([xm, u])
+        rhs = np.array([(phys[i] if i < 4 else 0.0) + eps * lin[i] for i in range(n)], dtype=object)
+        return y - (x + h * rhs)
+
+    return f
+
+
 # ----------------------------------------------------------------------------- car
 def car(x, u, w):
     return np.array([u[0] * np.cos(x[2]), u[0] * np.sin(x[2]), u[1]], dtype=object)
@@ -209,6 +233,29 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
         dynamics=[dt] * (T - 1),
         objective=[ct] * (T - 1) + [cT],
         constraints=constraints, bounds=bounds,
+        x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
+    )
+
+
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True):
+    """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
+    blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does)."""
+    m = 1
+    x1 = np.zeros(n)
+    xT = np.zeros(n)
+    xT[0] = PI
+    dt = Dynamics(acrobot_padded_midpoint(n), n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]), n, 0, evaluate_hessian=evaluate_hessian)
+    b1 = Bound(n, m, state_lower=x1, state_upper=x1)
+    bt = Bound(n, m)
+    bT = Bound(n, 0, state_lower=xT, state_upper=xT)
+    return dict(
+        dynamics=[dt] * (T - 1),
+        objective=[ct] * (T - 1) + [cT],
+        constraints=[Constraint() for _ in range(T)],
+        bounds=[b1] + [bt] * (T - 2) + [bT],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )

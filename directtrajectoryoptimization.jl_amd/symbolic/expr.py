@@ -395,3 +395,33 @@ def topo_order(roots: Iterable[Expr]) -> List[Expr]:
                     seen.add(node.id)
                     out.append(node)
     return out
+
+
+def substitute(roots: Sequence[Expr], mapping: Dict[Expr, Expr]) -> List[Expr]:
+    """Rebuild `roots` with the nodes in `mapping` replaced (folding rules re-applied on the way up)."""
+    memo: Dict[int, Expr] = {}
+    for node in topo_order(roots):
+        if node in mapping:
+            new = mapping[node]
+        elif node.op in (CONST, VAR):
+            new = node
+        else:
+            args = [memo[a.id] for a in node.args]
+            if node.op == ADD:
+                new = add(args[0], args[1])
+            elif node.op == SUB:
+                new = sub(args[0], args[1])
+            elif node.op == MUL:
+                new = mul(args[0], args[1])
+            elif node.op == DIV:
+                new = div(args[0], args[1])
+            elif node.op == NEG:
+                new = neg(args[0])
+            elif node.op == POWI:
+                new = power(args[0], node.value)
+            elif node.op == POW:
+                new = power(args[0], args[1])
+            else:
+                new = func(node.fn, args[0])
+        memo[node.id] = new
+    return [memo[r.id] for r in roots]

@@ -1,0 +1,112 @@
+"""ORACLE (test infrastructure): the synthetic cfg5 model -- acrobot embedded in n = 64 states -- and its dense KKT system.
+
+BASELINE.json configs[4] / SURVEY.md section 8(d) define the model only in words ("acrobot dynamics embedded in n=64 ...
+padding rows y_i - x_i plus a small dense linear mixing so the Jacobian block is structurally dense"); the exact
+definition used by this repository is
+
+    d(y, x, u) = y - x - h * ( [acrobot(xm[0:4], u); 0] + eps * M [xm; u] ),   xm = (x + y) / 2,  h = 0.05,  eps = 0.05,
+    M = PCG64(64).standard_normal((n, n + 1)) / sqrt(n + 1),
+    cost_t = 0.1 |x[2:n]|^2 + 0.1 u^2,   cost_T = 0.1 |x[2:n]|^2.
+
+Restatement strategy: the nonlinear part is the 4-state acrobot midpoint residual, whose value / Jacobian / Hessian come
+from the pinned sympy oracle objects (oracle/sympy_models.py, checked against the reference's KATs in
+tests/test_oracle_kat.py); the linear mixing is added in numpy.  Nothing here imports product code.
+
+The KKT system is the one sketched in the reference at examples/pendulum/pendulum.jl:138-198.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import sympy_models as S
+
+H_STEP, EPS, SEED = 0.05, 0.05, 64
+
+
+def mixing(n=64, m=1):
+    rng = np.random.Generator(np.random.PCG64(SEED))
+    return rng.standard_normal((n, n + m)) / np.sqrt(n + m)
+
+
+class PaddedAcrobot:
+    def __init__(self, n=64):
+        self.n, self.m = n, 1
+        self.M = mixing(n, 1)
+        self.phys = S.Dynamics(S.acrobot_midpoint, 4, 4, 1, evaluate_hessian=True)
+        # local variable order of the small object: [x(4); u(1); y(4)] -> positions in [x(n); u; y(n)]
+        self.emb = np.array([0, 1, 2, 3, n, n + 1, n + 2, n + 3, n + 4])
+
+    def _lin_blocks(self):
+        n, M = self.n, self.M
+        Fx = -np.eye(n) - H_STEP * EPS * 0.5 * M[:, :n]
+        Fu = -H_STEP * EPS * M[:, n:]
+        E = np.eye(n) - H_STEP * EPS * 0.5 * M[:, :n]
+        return Fx, Fu, E
+
+    def residual(self, x, u, y):
+        n = self.n
+        xm = 0.5 * (x + y)
+        d = y - x - H_STEP * EPS * (self.M @ np.concatenate([xm, u]))
+        # the small object returns y4 - x4 - h acrobot(xm4, u): take only its -h acrobot(...) part
+        small = self.phys.evaluate(list(y[:4]), list(x[:4]), list(u), [])
+        d[:4] += small - (y[:4] - x[:4])
+        return d
+
+    def jacobian(self, x, u, y):
+        """dense n x (2n + 1) over [x; u; y]"""
+        n = self.n
+        Fx, Fu, E = self._lin_blocks()
+        J = np.hstack([Fx, Fu, E])
+        vals = self.phys.jacobian(list(y[:4]), list(x[:4]), list(u), [])
+        Js = np.zeros((4, 9))
+        for r, c, v in zip(self.phys.jacobian_sparsity[0], self.phys.jacobian_sparsity[1], vals):
+            Js[r - 1, c - 1] = v
+        # remove the y - x part of the small object (already in the linear blocks), keep -h d acrobot
+        Js[:, 0:4] += np.eye(4)
+        Js[:, 5:9] -= np.eye(4)
+        J[:4][:, self.emb] += Js
+        return J
+
+    def hessian(self, x, u, y, lam):
+        """dense (2n+1) x (2n+1) Hessian of lam' d over [x; u; y]"""
+        n = self.n
+        vals = self.phys.hessian(list(y[:4]), list(x[:4]), list(u), [], list(lam[:4]))
+        H = np.zeros((2 * n + 1, 2 * n + 1))
+        for r, c, v in zip(self.phys.hessian_sparsity[0], self.phys.hessian_sparsity[1], vals):
+            H[self.emb[r - 1], self.emb[c - 1]] += v
+        return H
+
+    def cost_grad_hess(self, x, u):
+        n = self.n
+        g = np.zeros(n + len(u))
+        g[2:n] = 0.2 * x[2:n]
+        W = np.zeros((n + len(u), n + len(u)))
+        W[np.arange(2, n), np.arange(2, n)] = 0.2
+        if len(u):
+            g[n] = 0.2 * u[0]
+            W[n, n] = 0.2
+        return g, W
+
+
+def dense_kkt(model: PaddedAcrobot, T: int, z, mu, dw, dc):
+    """K and right-hand side of the regularised Newton-KKT system at (z, mu); z = [x1; u1; ...; xT], mu = dynamics rows."""
+    n, m = model.n, model.m
+    nz, nc = (T - 1) * (n + m) + n, (T - 1) * n
+    H = np.zeros((nz, nz)); J = np.zeros((nc, nz)); g = np.zeros(nz); c = np.zeros(nc)
+    for t in range(T):
+        o = t * (n + m)
+        x = z[o:o + n]
+        u = z[o + n:o + n + m] if t < T - 1 else np.zeros(0)
+        gt, Wt = model.cost_grad_hess(x, u)
+        npv = n + len(u)
+        g[o:o + npv] += gt
+        H[o:o + npv, o:o + npv] += Wt
+        if t < T - 1:
+            y = z[o + n + m:o + 2 * n + m]
+            lam = mu[t * n:(t + 1) * n]
+            c[t * n:(t + 1) * n] = model.residual(x, u, y)
+            J[t * n:(t + 1) * n, o:o + 2 * n + m] = model.jacobian(x, u, y)
+            H[o:o + 2 * n + m, o:o + 2 * n + m] += model.hessian(x, u, y, lam)
+    K = np.block([[H + dw * np.eye(nz), J.T], [J, -dc * np.eye(nc)]])
+    rhs = -np.concatenate([g + J.T @ mu, c])
+    return K, rhs

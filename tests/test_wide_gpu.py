@@ -1,0 +1,104 @@
+"""Wide-stage (dense 129 x 129 blocks, f64 MFMA) KKT step of BASELINE configs[4] -- acrobot embedded in 64 states --
+against numpy's dense solve of the same system built by the ORACLE (oracle/padded_model.py).
+
+System: examples/pendulum/pendulum.jl:138-198, [H + dw I, J'; J, -dc I] [dz; dmu] = -[grad f + J' mu; c].
+Tolerance 1e-8 relative to the solution norm ("entries and iterates within 1e-8 relative").
+At the full horizon (T = 2000) the dense matrix is out of reach; there the check is the size-independent one:
+the residual of the block equations, evaluated with the oracle's stage blocks.
+"""
+import numpy as np
+import pytest
+
+from conftest import product_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _kkt_step(s, Z, MU, dw, dc):
+    import torch
+    B, nz = Z.shape
+    nc = MU.shape[1]
+    dz, dmu = torch.tensor(Z, device="cuda"), torch.tensor(MU, device="cuda")
+    dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    ok = s.kkt_step_batch(dz.data_ptr(), B, nz, dmu.data_ptr(), nc, dw, dc, dx.data_ptr(), nz, dl.data_ptr(), nc)
+    torch.cuda.synchronize()
+    return dx.cpu().numpy(), dl.cpu().numpy(), ok
+
+
+@pytest.mark.parametrize("T,B,dw", [(2, 2, 2.0), (5, 3, 2.0), (9, 2, 30.0)])
+def test_wide_kkt_step_matches_dense_solve(T, B, dw):
+    from oracle.padded_model import PaddedAcrobot, dense_kkt
+    s, _ = product_solver("acrobot_padded", T)
+    om = PaddedAcrobot(64)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    assert (nz, nc) == ((T - 1) * 65 + 64, (T - 1) * 64)
+    rng = np.random.default_rng(5 + T)
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    dc = 1e-5
+    dx, dl, ok = _kkt_step(s, Z, MU, dw, dc)
+    for b in range(B):
+        K, rhs = dense_kkt(om, T, Z[b], MU[b], dw, dc)
+        eig = np.linalg.eigvalsh(K)
+        assert (int(np.sum(eig > 0)), int(np.sum(eig < 0))) == (nz, nc), "test point must be quasi-definite; raise dw"
+        sol = np.linalg.solve(K, rhs)
+        scale = np.max(np.abs(sol))
+        assert np.max(np.abs(dx[b] - sol[:nz])) <= 1e-8 * scale, (np.max(np.abs(dx[b] - sol[:nz])), scale)
+        assert np.max(np.abs(dl[b] - sol[nz:])) <= 1e-8 * scale, (np.max(np.abs(dl[b] - sol[nz:])), scale)
+    assert ok
+
+
+def test_wide_inertia_flag_matches_eigenvalues():
+    """delta_w = 0 with multipliers of order 10: the Hessian of the Lagrangian is indefinite on the null space of J."""
+    from oracle.padded_model import PaddedAcrobot, dense_kkt
+    T, B = 4, 4
+    s, _ = product_solver("acrobot_padded", T)
+    om = PaddedAcrobot(64)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(99)
+    Z = rng.random((B, nz))
+    MU = 40.0 * (rng.random((B, nc)) - 0.5)
+    for dw in (0.0, 50.0):
+        want = True
+        for b in range(B):
+            K, _ = dense_kkt(om, T, Z[b], MU[b], dw, 1e-5)
+            eig = np.linalg.eigvalsh(K)
+            want = want and (int(np.sum(eig > 0)), int(np.sum(eig < 0))) == (nz, nc)
+        _, _, ok = _kkt_step(s, Z, MU, dw, 1e-5)
+        assert bool(ok) == want, (dw, ok, want)
+
+
+def test_wide_full_horizon_residual():
+    """T = 2000 (the configs[4] horizon): K [dz; dmu] + [grad L; c] = 0 block row by block row."""
+    from oracle.padded_model import PaddedAcrobot
+    T, B, dw, dc = 2000, 2, 2.0, 1e-5
+    s, _ = product_solver("acrobot_padded", T)
+    om = PaddedAcrobot(64)
+    n, m = 64, 1
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(2000)
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    dx, dl, ok = _kkt_step(s, Z, MU, dw, dc)
+    assert ok
+    for b in range(B):
+        z, mu, d, dlam = Z[b], MU[b], dx[b], dl[b]
+        r1 = dw * d.copy()          # (H + dw I) dz + J' dmu + grad L
+        r2 = -dc * dlam.copy()      # J dz - dc dmu + c
+        for t in range(T):
+            o = t * (n + m)
+            x = z[o:o + n]
+            u = z[o + n:o + n + m] if t < T - 1 else np.zeros(0)
+            g, W = om.cost_grad_hess(x, u)
+            npv = n + len(u)
+            r1[o:o + npv] += W @ d[o:o + npv] + g
+            if t < T - 1:
+                y = z[o + npv:o + npv + n]
+                sl = slice(o, o + 2 * n + m)
+                rows = slice(t * n, (t + 1) * n)
+                J = om.jacobian(x, u, y)
+                Hd = om.hessian(x, u, y, mu[rows])
+                r1[sl] += Hd @ d[sl] + J.T @ (dlam[rows] + mu[rows])
+                r2[rows] += J @ d[sl] + om.residual(x, u, y)
+        scale = max(np.max(np.abs(d)), np.max(np.abs(dlam)), 1.0)
+        assert np.max(np.abs(r1)) <= 1e-8 * scale, (np.max(np.abs(r1)), scale)
+        assert np.max(np.abs(r2)) <= 1e-8 * scale, (np.max(np.abs(r2)), scale)
