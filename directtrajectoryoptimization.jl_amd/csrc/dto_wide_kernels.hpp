@@ -46,6 +46,7 @@ struct dto_wide_args {
   double* fac;   // [B][T][fac_stage]
   int* flags;    // [B]: 1 = inertia (n, m, 0) and no tiny pivot
   int64_t Nc;
+  long long* prof;  // optional [32] cycle counters of workgroup 0 (tools/wide_profile.py), else NULL
 };
 
 namespace dto {
@@ -125,56 +126,96 @@ __device__ __forceinline__ d4 mm_tn(d4 c, const double* A, int lda, int m0, cons
   return c;
 }
 
-// ---- unblocked LDL^T of the 16x16 diagonal tile at (o, o), one wavefront (lanes 0..15 = rows), then the inverse
-//      of its unit-lower factor.  d/dinv get the pivots; cnt[0] += negative pivots, cnt[1] |= tiny pivot seen.
+// ---- one tile-row (four 16x16 tiles) of a 64-deep product, k outermost: per k-step one A fragment feeds four
+//      independent accumulators, so the matrix pipe always has an MFMA to issue while the next fragments load.
+//      MODE 0: C += A s B'   (A[(m0+m)][k], B[(n)][k]);  1: C += A s B  (A[(m0+m)][k], B[k][n]);  2: C += A' s B  (A[k][m0+m], B[k][n])
+template <int MODE, int N>
+__device__ __forceinline__ void mm_row4(d4 (&c)[4], const double* A, int m0, const double* Bm, const double* s, double sgn) {
+  constexpr int LD = Dims<N>::LD;
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+#pragma unroll 4
+  for (int k = 0; k < N; k += 4) {
+    double a = (MODE == 2) ? A[(k + q) * LD + m0 + r] : A[(m0 + r) * LD + k + q];
+    a *= sgn * s[k + q];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const double bv = (MODE == 0) ? Bm[(jb * TB + r) * LD + k + q] : Bm[(k + q) * LD + jb * TB + r];
+      c[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, c[jb], 0, 0, 0);
+    }
+  }
+}
+
+// ---- unblocked LDL^T of the 16x16 diagonal tile at (o, o) by one wavefront: lane i (< 16) holds row i of the
+//      symmetric tile in registers and the pivot row travels by ds_bpermute (no LDS read-modify-write inside the
+//      16-step dependency chain).  Then the inverse of the unit-lower factor, lane c = column c, from broadcast reads
+//      of L (independent loads).  d/dinv get the pivots; cnt[0] += negative pivots, cnt[1] |= tiny pivot seen.
 __device__ __forceinline__ void diag_tile(double* Mx, int ld, int o, double* d, double* dinv, double* LIk, int li_ld,
                                           double piv_tol, int* cnt) {
   const int l = lane_id();
-  int nneg = 0, tiny = 0;
-  for (int j = 0; j < TB; ++j) {
-    const double dj = Mx[(o + j) * ld + o + j];
-    double colmax = (l > j && l < TB) ? fabs(Mx[(o + l) * ld + o + j]) : 0.0;
+  const int i = l & 15;
+  double a[TB];
 #pragma unroll
-    for (int sft = 8; sft >= 1; sft >>= 1) colmax = fmax(colmax, __shfl_xor(colmax, sft));
-    if (!(fabs(dj) > piv_tol * fmax(1.0, colmax))) tiny = 1;
+  for (int c = 0; c < TB; ++c) a[c] = (c <= i) ? Mx[(o + i) * ld + o + c] : Mx[(o + c) * ld + o + i];
+  const double diag0 = fabs(Mx[(o + i) * ld + o + i]);
+  int nneg = 0, tiny = 0;
+  double dj_mine = 0.0, idj_mine = 0.0;
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    double rj[TB];
+#pragma unroll
+    for (int c = j; c < TB; ++c) rj[c] = __shfl(a[c], j);
+    const double d0 = __shfl(diag0, j);
+    const double dj = rj[j];
+    if (!(fabs(dj) > piv_tol * fmax(1.0, d0))) tiny = 1;
     if (dj < 0.0) ++nneg;
     const double idj = 1.0 / dj;
-    if (l > j && l < TB) {
-      const double aij = Mx[(o + l) * ld + o + j];
-      const double lij = aij * idj;
-      for (int c = j + 1; c <= l; ++c) Mx[(o + l) * ld + o + c] -= lij * Mx[(o + c) * ld + o + j];
-      Mx[(o + l) * ld + o + j] = lij;
+    if (l == j) { dj_mine = dj; idj_mine = idj; }
+    const double lij = a[j] * idj;
+    if (i > j) {
+#pragma unroll
+      for (int c = j + 1; c < TB; ++c) a[c] -= lij * rj[c];
+      a[j] = lij;
     }
-    if (l == 0) { d[o + j] = dj; dinv[o + j] = idj; }
+  }
+  if (l < TB) {
+    d[o + l] = dj_mine;
+    dinv[o + l] = idj_mine;
+#pragma unroll
+    for (int k = 0; k < TB - 1; ++k)
+      if (k < l) Mx[(o + l) * ld + o + k] = a[k];
   }
   if (l == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
-  // inverse of the unit-lower tile, lane c = column c
+  // inverse of the unit-lower tile: X[r] = -sum_{k<r} L[r][k] X[k] below the unit diagonal, lane c = column c
   if (l < TB) {
     double X[TB];
 #pragma unroll
-    for (int i = 0; i < TB; ++i) {
+    for (int r = 0; r < TB; ++r) {
       double sacc = 0.0;
 #pragma unroll
-      for (int k = 0; k < i; ++k) sacc += Mx[(o + i) * ld + o + k] * X[k];
-      X[i] = (i == l) ? 1.0 : (i > l ? -sacc : 0.0);
+      for (int k = 0; k < r; ++k) sacc += Mx[(o + r) * ld + o + k] * X[k];
+      X[r] = (r == l) ? 1.0 : (r > l ? -sacc : 0.0);
     }
 #pragma unroll
-    for (int i = 0; i < TB; ++i) LIk[i * li_ld + l] = X[i];
+    for (int r = 0; r < TB; ++r) LIk[r * li_ld + l] = X[r];
   }
 }
 
 // ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
 //      On exit: strict lower part = L, d/dinv = pivots, LI = inverses of the unit-lower diagonal tiles.
 template <int N>
-__device__ void ldl_blocked(double* Mx, double* d, double* dinv, double* LI, double piv_tol, int* cnt) {
+__device__ __forceinline__ void ldl_blocked(double* Mx, double* d, double* dinv, double* LI, double piv_tol, int* cnt, long long* prof = nullptr) {
   using D = Dims<N>;
   constexpr int LD = D::LD, NT = D::NT;
   const int w = wave_id();
   for (int kb = 0; kb < NT; ++kb) {
     const int o = kb * TB;
     double* LIk = LI + kb * TB * D::LI_LD;
+    long long t0_ = 0;
+    if (prof && threadIdx.x == 0) t0_ = clock64();
     if (w == 0) diag_tile(Mx, LD, o, d, dinv, LIk, D::LI_LD, piv_tol, cnt);
+    if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[20] += t1_ - t0_; t0_ = t1_; }
     __syncthreads();
+    if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[21] += t1_ - t0_; t0_ = t1_; }
     // panel: L(ib,kb) = A(ib,kb) * Linv' * D^-1
     for (int ib = kb + 1 + w; ib < NT; ib += 4) {
       d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -185,6 +226,7 @@ __device__ void ldl_blocked(double* Mx, double* d, double* dinv, double* LI, dou
       tile_store(Mx, LD, ib * TB, o, c);
     }
     __syncthreads();
+    if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[22] += t1_ - t0_; t0_ = t1_; }
     // trailing update of the lower tiles: A(ib,jb) -= L(ib,kb) D_kb L(jb,kb)'
     int idx = 0;
     for (int ib = kb + 1; ib < NT; ++ib) {
@@ -196,6 +238,7 @@ __device__ void ldl_blocked(double* Mx, double* d, double* dinv, double* LI, dou
       }
     }
     __syncthreads();
+    if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[23] += t1_ - t0_; t0_ = t1_; }
   }
 }
 
@@ -254,6 +297,61 @@ __device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
   if (l < N) v[l] = mine;
 }
 
+// dot products over N terms, fully unrolled with four independent accumulators (LDS loads all in flight)
+template <int N>
+__device__ __forceinline__ double dot_rr(const double* a, const double* v) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c += 4) {
+    s0 += a[c] * v[c]; s1 += a[c + 1] * v[c + 1]; s2 += a[c + 2] * v[c + 2]; s3 += a[c + 3] * v[c + 3];
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+template <int N>
+__device__ __forceinline__ double dot_rrs(const double* a, const double* v, const double* sc) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c += 4) {
+    s0 += a[c] * v[c] * sc[c]; s1 += a[c + 1] * v[c + 1] * sc[c + 1];
+    s2 += a[c + 2] * v[c + 2] * sc[c + 2]; s3 += a[c + 3] * v[c + 3] * sc[c + 3];
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+// column of a row-major matrix (stride ld) against a vector
+template <int N>
+__device__ __forceinline__ double dot_cr(const double* a, int ld, const double* v) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c += 4) {
+    s0 += a[c * ld] * v[c]; s1 += a[(c + 1) * ld] * v[c + 1]; s2 += a[(c + 2) * ld] * v[c + 2]; s3 += a[(c + 3) * ld] * v[c + 3];
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+template <int N>
+__device__ __forceinline__ double dot_crs(const double* a, int ld, const double* v, const double* sc) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c += 4) {
+    s0 += a[c * ld] * v[c] * sc[c]; s1 += a[(c + 1) * ld] * v[c + 1] * sc[c + 1];
+    s2 += a[(c + 2) * ld] * v[c + 2] * sc[c + 2]; s3 += a[(c + 3) * ld] * v[c + 3] * sc[c + 3];
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+  return v;
+}
+
+#define DTO_WIDE_TICK(slot)                                                       \
+  do {                                                                             \
+    if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {                           \
+      const long long now_ = clock64();                                            \
+      a.prof[slot] += now_ - tick_;                                                \
+      tick_ = now_;                                                                \
+    }                                                                              \
+  } while (0)
+
 template <class M, int WKI>
 struct WK {
   using KD = typename M::template WKind<WKI>;
@@ -308,6 +406,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   double* facb = a.fac + b * (int64_t)a.T * D::FAC;
   const double dw = a.delta_w, dc = a.delta_c;
 
+  long long tick_ = clock64();
   for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
   if (tid < N) { byc[tid] = 0.0; gyp[tid] = 0.0; }
   if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
@@ -336,16 +435,17 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         {
           constexpr int NC = 2 * N + NU;
           const double* fe = DY::fe_const();
-          for (int i = tid; i < N * NC; i += WG) {
-            const int r = i / NC, c = i - r * NC;
-            const double v = fe[i];
-            if (c < N) MF[r * LD + c] = v;
-            else if (c < N + NU) fu[r] = v;
-            else ME[r * LD + c - N - NU] = v;
+#pragma unroll
+          for (int r = w; r < N; r += 4) {
+            const double* row = fe + r * NC;
+            MF[r * LD + l] = row[l];
+            ME[r * LD + l] = row[N + NU + l];
+            if (l < NU) fu[r] = row[N + l];
           }
           for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
         }
         __syncthreads();
+        DTO_WIDE_TICK(0);
         // ---- phase 1: model code (wave-uniform values, one wavefront per function)
         if (w == 0) {
           DY::eval_nl(xv, sc, yv, wp, tmp);
@@ -359,13 +459,14 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
         }
         __syncthreads();
+        DTO_WIDE_TICK(1);
         // ---- phase 2: residual from the constant part (variable Jacobian entries are still zero in MF/ME/fu)
         if (tid < N) {
-          double acc = nlf[tid] + fu[tid] * sc[0];
-          for (int c = 0; c < N; ++c) acc += MF[tid * LD + c] * xv[c] + ME[tid * LD + c] * yv[c];
+          const double acc = nlf[tid] + fu[tid] * sc[0] + dot_rr<N>(MF + tid * LD, xv) + dot_rr<N>(ME + tid * LD, yv);
           bd[tid] = -acc;
         }
         __syncthreads();
+        DTO_WIDE_TICK(2);
         // ---- phase 3: variable Jacobian entries, Hessian blocks
         if (tid < DY::NJV) {
           const int r = DY::jv_row(tid), c = DY::jv_col(tid);
@@ -399,23 +500,21 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
         }
         __syncthreads();
+        DTO_WIDE_TICK(3);
         // ---- phase 4: gradient of the Lagrangian -> right-hand sides
-        if (tid < N) {
-          double acc = gc[tid] + gyp[tid];
-          for (int r = 0; r < N; ++r) acc += MF[r * LD + tid] * lamv[r];
-          bx[tid] = -acc + byc[tid];
-        } else if (tid < 2 * N) {
-          const int j = tid - N;
-          double acc = 0.0;
-          for (int r = 0; r < N; ++r) acc += ME[r * LD + j] * lamv[r];
-          gyn[j] = acc;
-        } else if (tid == 2 * N) {
-          double acc = gc[N];
-          for (int r = 0; r < N; ++r) acc += fu[r] * lamv[r];
-          sc[2] = -acc;
-          sc[3] = sc[1] + dw;
+        if (w == 0) {
+          bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l];
+        } else if (w == 1) {
+          gyn[l] = dot_cr<N>(ME + l, LD, lamv);
+        } else if (w == 2) {
+          const double part = wave_sum(fu[l] * lamv[l]);
+          if (l == 0) {
+            sc[2] = -(gc[N] + part);
+            sc[3] = sc[1] + dw;
+          }
         }
         __syncthreads();
+        DTO_WIDE_TICK(4);
         // ---- phase 5: eliminate u
         const double piv = sc[3], ip = 1.0 / piv, bu = sc[2];
         for (int i = tid; i < N * N; i += WG) {
@@ -435,36 +534,38 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if (!(fabs(piv) > a.piv_tol)) cnt[1] |= 1;
         }
         __syncthreads();
+        DTO_WIDE_TICK(5);
         // ---- phase 6: A = L_A D_A L_A'
-        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
+        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt, blockIdx.x == 0 ? a.prof : nullptr);
+        DTO_WIDE_TICK(6);
         // ---- phase 7: F~ = F L_A^-T (row tiles), V~ = L_A^-1 V (column tiles), bx~ = L_A^-1 bx
         if (w == 0) trsv_lower<N>(MA, bx);
         trsm_right_rowtile<N>(MF, MA, LI, w);
         trsm_left_coltile<N>(MV, MA, LI, w);
         __syncthreads();
+        DTO_WIDE_TICK(7);
         // ---- phase 8: M = D + F~ D_A^-1 F~' (registers), E'' = E - F~ D_A^-1 V~ (in place), bd~
         d4 macc[NT];
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) {
           const int r = l & 15, q = l >> 4;
-          d4 c;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int row = w * TB + q + 4 * j, col = jb * TB + r;
-            c[j] = (row == col ? dc : 0.0) + fu[row] * fu[col] * ip;
+            macc[jb][j] = (row == col ? dc : 0.0) + fu[row] * fu[col] * ip;
           }
-          macc[jb] = mm_nt(c, MF, LD, w * TB, MF, LD, jb * TB, 0, N, dAi, 1.0);
         }
+        mm_row4<0, N>(macc, MF, w * TB, MF, dAi, 1.0);
+        {
+          d4 eacc[NT];
 #pragma unroll
-        for (int jb = 0; jb < NT; ++jb) {
-          d4 c = tile_load(ME, LD, w * TB, jb * TB);
-          c = mm_nn(c, MF, LD, w * TB, MV, LD, jb * TB, 0, N, dAi, -1.0);
-          tile_store(ME, LD, w * TB, jb * TB, c);
+          for (int jb = 0; jb < NT; ++jb) eacc[jb] = tile_load(ME, LD, w * TB, jb * TB);
+          mm_row4<1, N>(eacc, MF, w * TB, MV, dAi, -1.0);
+#pragma unroll
+          for (int jb = 0; jb < NT; ++jb) tile_store(ME, LD, w * TB, jb * TB, eacc[jb]);
         }
         if (tid < N) {
-          double acc = bd[tid];
-          for (int k = 0; k < N; ++k) acc -= MF[tid * LD + k] * bx[k] * dAi[k];
-          tmp[tid] = acc;
+          tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
         }
         for (int i = tid; i < MAT; i += WG) fac[D::F_LA + i] = MA[i];
         __syncthreads();
@@ -472,6 +573,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
         if (tid < N) bd[tid] = tmp[tid];
         __syncthreads();
+        DTO_WIDE_TICK(8);
         // ---- phase 9: M = L_M D_M L_M'   (the KKT pivots of this block are -D_M)
         if (tid == 0) cnt[0] += N;  // N negative pivots if every D_M entry is positive; corrected below
         __syncthreads();
@@ -482,21 +584,19 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           ldl_blocked<N>(MA, dM, dMi, LI, a.piv_tol, cm);
           if (tid == 0) { cnt[0] -= cm[0]; cnt[1] |= cm[1]; }
         }
+        DTO_WIDE_TICK(9);
         // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
         if (w == 0) trsv_lower<N>(MA, bd);
         trsm_left_coltile<N>(ME, MA, LI, w);
         __syncthreads();
+        DTO_WIDE_TICK(10);
         // ---- phase 11: P' = -V~' D_A^-1 V~ + E~' D_M^-1 E~ (registers), carried right-hand side
 #pragma unroll
-        for (int jb = 0; jb < NT; ++jb) {
-          d4 c = {0.0, 0.0, 0.0, 0.0};
-          c = mm_tn(c, MV, LD, w * TB, MV, LD, jb * TB, 0, N, dAi, -1.0);
-          macc[jb] = mm_tn(c, ME, LD, w * TB, ME, LD, jb * TB, 0, N, dMi, 1.0);
-        }
+        for (int jb = 0; jb < NT; ++jb) macc[jb] = d4{0.0, 0.0, 0.0, 0.0};
+        mm_row4<2, N>(macc, MV, w * TB, MV, dAi, -1.0);
+        mm_row4<2, N>(macc, ME, w * TB, ME, dMi, 1.0);
         if (tid < N) {
-          double acc = byn[tid];
-          for (int k = 0; k < N; ++k) acc += -MV[k * LD + tid] * bx[k] * dAi[k] + ME[k * LD + tid] * bd[k] * dMi[k];
-          tmp[tid] = acc;
+          tmp[tid] = byn[tid] - dot_crs<N>(MV + tid, LD, bx, dAi) + dot_crs<N>(ME + tid, LD, bd, dMi);
         }
         for (int i = tid; i < MAT; i += WG) {
           fac[D::F_LM + i] = MA[i];
@@ -520,6 +620,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
         if (tid < N) { byc[tid] = tmp[tid]; gyp[tid] = gyn[tid]; }
         __syncthreads();
+        DTO_WIDE_TICK(11);
         // the y-y part of this stage's Hessian and the u rank-one term complete P'
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
@@ -536,6 +637,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       }
     });
   }
+  DTO_WIDE_TICK(12);
   // ---- terminal stage: (W_T + dw I + P') x = -(grad + E' lam) + by
   {
     const int t = a.T - 1;
@@ -576,8 +678,11 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       }
     });
   }
+  DTO_WIDE_TICK(13);
   if (tid == 0) a.flags[b] = (cnt[0] == (int)a.Nc && cnt[1] == 0) ? 1 : 0;
-  // ---- backward sweep: y = x_{t+1} is in yv
+  // ---- backward sweep: y = x_{t+1} is in yv.  The factor records were written by all threads of this workgroup.
+  __threadfence_block();
+  __syncthreads();
   for (int t = a.T - 2; t >= 0; --t) {
     const double* fac = facb + (int64_t)t * D::FAC;
     const double* fv = fac + D::F_VEC;
@@ -597,21 +702,18 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       vu[tid] = fv[D::V_VU + tid];
     }
     __syncthreads();
+    DTO_WIDE_TICK(14);
     // lam = L_M^-T D_M^-1 (E~ y - bd^)
     if (tid < N) {
-      double acc = -bd[tid];
-      for (int c = 0; c < N; ++c) acc += ME[tid * LD + c] * yv[c];
-      lamv[tid] = acc * dMi[tid];
+      lamv[tid] = (dot_rr<N>(ME + tid * LD, yv) - bd[tid]) * dMi[tid];
     }
     __syncthreads();
     if (w == 0) trsv_lower_t<N>(MA, lamv);
     __syncthreads();
+    DTO_WIDE_TICK(15);
     // x = L_A^-T D_A^-1 (bx~ - F~' lam - V~ y)
     if (tid < N) {
-      double acc = bx[tid];
-      for (int r = 0; r < N; ++r) acc -= MF[r * LD + tid] * lamv[r];
-      for (int c = 0; c < N; ++c) acc -= MV[tid * LD + c] * yv[c];
-      xv[tid] = acc * dAi[tid];
+      xv[tid] = (bx[tid] - dot_cr<N>(MF + tid, LD, lamv) - dot_rr<N>(MV + tid * LD, yv)) * dAi[tid];
     }
     __syncthreads();
     for (int i = tid; i < MAT; i += WG) MA[i] = fac[D::F_LA + i];
@@ -624,14 +726,13 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     }
     if (w == 1) {
       // u = (bu - au'x - fu'lam - vu'y) / piv
-      double part = (l < N) ? (au[l] * xv[l] + fu[l] * lamv[l] + vu[l] * yv[l]) : 0.0;
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) part += __shfl_xor(part, sft);
+      const double part = wave_sum(au[l] * xv[l] + fu[l] * lamv[l] + vu[l] * yv[l]);
       if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
     }
     __syncthreads();
     if (tid < N) yv[tid] = xv[tid];
     __syncthreads();
+    DTO_WIDE_TICK(16);
   }
 }
 
