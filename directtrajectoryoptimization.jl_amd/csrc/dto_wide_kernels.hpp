@@ -736,6 +736,179 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   }
 }
 
+// one wavefront per instance: out[b] = sum_t rows[b][t] in a fixed order (lane-strided partials, then a tree)
+static __global__ __launch_bounds__(64) void k_wide_sum_rows(const double* rows, int64_t ld, int n, double* out) {
+  const int64_t b = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) acc += rows[b * ld + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) out[b] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// evaluator callbacks for wide models (the five MOI methods, src/moi.jl:1-120): one wavefront per knot, the
+// model code runs wave-uniform into LDS, results leave in full-line coalesced stores.  The stage Jacobian is
+// the constant nonzero table (L2 resident) copied to the output plus the few state-dependent entries.
+// ---------------------------------------------------------------------------------------------------
+constexpr int EV_WAVES = 4;
+
+template <class M>
+struct EvalLds {
+  static constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+  static constexpr int PT = 3 * N + NU + 3;                                   // x, u, y, lam
+  static constexpr int OUT = (M::MAX_KEY > N + NU + 8 ? M::MAX_KEY : N + NU + 8) + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8;
+  static constexpr int PER_WAVE = PT + OUT;
+};
+
+template <class M, int OP>
+__global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
+  constexpr int N = M::WIDE_N, NU = M::WIDE_NU, NC = 2 * N + NU;
+  using EL = EvalLds<M>;
+  extern __shared__ double sm[];
+  const int w = wave_id(), l = lane_id();
+  double* mine = sm + w * EL::PER_WAVE;
+  double* xv = mine;            // [N]
+  double* uv = xv + N;          // [NU] (+ pad)
+  double* yv = uv + NU + 1;     // [N]
+  double* lamv = yv + N + 1;    // [N]
+  double* ov = mine + EL::PT;   // outputs / key image
+  double* hv = ov + (M::MAX_KEY > N + NU + 8 ? M::MAX_KEY : N + NU + 8);
+  double* chv = hv + M::MAX_NH;
+  double* jvv = chv + M::MAX_SNH;
+  double* fe_s = sm + EV_WAVES * EL::PER_WAVE;  // [N][NC] constant Jacobian, OP == CON only
+  if constexpr (OP == DTO_OP_CON) {
+    // every dynamics class of a wide model shares one table per class; stage it once per workgroup
+    const double* fe = M::template Dyn<0>::fe_const();
+    for (int i = threadIdx.x; i < N * NC; i += EV_WAVES * 64) fe_s[i] = fe[i];
+    __syncthreads();
+  }
+  const int64_t nknot = a.B * (int64_t)a.T;
+  for (int64_t kn = (int64_t)blockIdx.x * EV_WAVES + w; kn < nknot; kn += (int64_t)gridDim.x * EV_WAVES) {
+    const int64_t b = kn / a.T;
+    const int t = (int)(kn - b * a.T);
+    const double* z = a.z + b * a.ldz;
+    const int kind = a.kind[t];
+    const int wk = M::wk_of_kind(kind);
+    const double* wp = a.w + b * a.ldw + a.woff[t];
+    M::dispatch_wk(wk, [&](auto wkc) {
+      using KD = typename M::template WKind<decltype(wkc)::value>;
+      using CO = typename M::template Cost<KD::COST>;
+      constexpr bool HAS_DYN = KD::DYN >= 0;
+      constexpr int NUK = HAS_DYN ? NU : 0;
+      xv[l] = z[a.zoff[t] + l];
+      if (l < NUK) uv[l] = z[a.zoff[t] + N + l];
+      if constexpr (HAS_DYN) yv[l] = z[a.zoff[t + 1] + l];
+      if constexpr (OP == DTO_OP_OBJ) {
+        CO::eval(xv, uv, wp, ov);
+        if (l == 0) a.scratch[b * a.T + t] = ov[0];
+      } else if constexpr (OP == DTO_OP_GRAD) {
+        CO::grad(xv, uv, wp, ov);
+        double* g = a.out + b * a.ldout + a.zoff[t];
+        g[l] = ov[l];
+        if (l < NUK) g[N + l] = ov[N + l];
+      } else if constexpr (OP == DTO_OP_CON) {
+        if constexpr (HAS_DYN) {
+          using DY = typename M::template Dyn<KD::DYN>;
+          ov[l] = 0.0;
+          DY::eval_nl(xv, uv, yv, wp, hv);
+          if (l < DY::NNL) ov[DY::nl_row(l)] = hv[l];
+          const double* row = fe_s + l * NC;
+          double acc = ov[l] + dot_rr<N>(row, xv) + dot_rr<N>(row + N + NU, yv);
+#pragma unroll
+          for (int j = 0; j < NU; ++j) acc += row[N + j] * uv[j];
+          a.out[b * a.ldout + a.cdoff[t] + l] = acc;
+        }
+      } else if constexpr (OP == DTO_OP_JAC) {
+        if constexpr (HAS_DYN) {
+          using DY = typename M::template Dyn<KD::DYN>;
+          DY::jac_var(xv, uv, yv, wp, jvv);
+          double* o = a.out + b * a.ldout + a.jdoff[t];
+          const double* jc = DY::jc_const();
+          for (int i = l; i < DY::NJ; i += 64) o[i] = jc[i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          if (l < DY::NJV) o[DY::jv_k(l)] = jvv[l];
+        }
+      } else if constexpr (OP == DTO_OP_HESS) {
+        const double* mu = a.mu + b * a.ldmu;
+        const int h0 = a.hoff[t], hlen = a.hoff[t + 1] - h0;
+        for (int i = l; i < hlen; i += 64) ov[i] = 0.0;
+        if constexpr (CO::SNH > 0) {
+          CO::shess(xv, uv, wp, chv);
+          const int* mrow = a.hmap_cost + kind * a.hmap_stride;
+          for (int i = l; i < CO::SNH; i += 64) ov[mrow[i]] += a.sigma * chv[i];
+        }
+        if constexpr (HAS_DYN) {
+          using DY = typename M::template Dyn<KD::DYN>;
+          if constexpr (DY::NH > 0) {
+            lamv[l] = mu[a.cdoff[t] + l];
+            DY::hess(xv, uv, yv, wp, lamv, hv);
+            const int* mrow = a.hmap_dyn_own + kind * a.hmap_stride;
+            for (int i = l; i < DY::NH; i += 64) {
+              const int m = mrow[i];
+              if (m >= 0) ov[m] += hv[i];
+            }
+          }
+        }
+        // rows of this stage also receive the y-rows of the previous stage's dynamics Hessian
+        if (t > 0) {
+          const int wkp = M::wk_of_kind(a.kind[t - 1]);
+          M::dispatch_wk(wkp, [&](auto wkp_c) {
+            using KP = typename M::template WKind<decltype(wkp_c)::value>;
+            if constexpr (KP::DYN >= 0) {
+              using DP = typename M::template Dyn<KP::DYN>;
+              if constexpr (DP::NH > 0) {
+                // previous point: x_{t-1}, u_{t-1}, y = x_t
+                yv[l] = xv[l];
+                xv[l] = z[a.zoff[t - 1] + l];
+                if (l < NU) uv[l] = z[a.zoff[t - 1] + N + l];
+                lamv[l] = mu[a.cdoff[t - 1] + l];
+                DP::hess(xv, uv, yv, a.w + b * a.ldw + a.woff[t - 1], lamv, hv);
+                const int* mrow = a.hmap_dyn_next + kind * a.hmap_stride;
+                for (int i = l; i < DP::NH; i += 64) {
+                  const int m = mrow[i];
+                  if (m >= 0) ov[m] += hv[i];
+                }
+              }
+            }
+          });
+        }
+        double* o = a.out + b * a.ldout + h0;
+        for (int i = l; i < hlen; i += 64) o[i] = ov[i];
+      }
+    });
+  }
+}
+
+template <class M>
+int launch_wide_eval(int op, const dto_eval_args* a, void* stream) {
+  using EL = EvalLds<M>;
+  constexpr int N = M::WIDE_N, NC = 2 * N + M::WIDE_NU;
+  const int64_t nknot = a->B * (int64_t)a->T;
+  const unsigned grid = (unsigned)((nknot + EV_WAVES - 1) / EV_WAVES < 4096 ? (nknot + EV_WAVES - 1) / EV_WAVES : 4096);
+  const int lds = (int)sizeof(double) * EV_WAVES * EL::PER_WAVE;
+  const int lds_con = lds + (int)sizeof(double) * N * NC;
+  hipStream_t st = (hipStream_t)stream;
+  switch (op) {
+    case DTO_OP_OBJ:
+      hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_OBJ>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a);
+      hipLaunchKernelGGL(k_wide_sum_rows, dim3((unsigned)a->B), dim3(64), 0, st, (const double*)a->scratch, (int64_t)a->T, a->T, a->out);
+      break;
+    case DTO_OP_GRAD: hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_GRAD>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a); break;
+    case DTO_OP_CON: {
+      hipError_t e = hipFuncSetAttribute((const void*)k_wide_eval<M, DTO_OP_CON>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_con);
+      if (e != hipSuccess) return (int)e;
+      const unsigned gc = grid < 1024 ? grid : 1024;  // the table staging is per workgroup: fewer, longer-lived workgroups
+      hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_CON>), dim3(gc), dim3(EV_WAVES * 64), lds_con, st, *a);
+      break;
+    }
+    case DTO_OP_JAC: hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_JAC>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a); break;
+    case DTO_OP_HESS: hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_HESS>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  return (int)hipGetLastError();
+}
+
 template <class M>
 int wide_info(dto_wide_info* out) {
   using D = Dims<M::WIDE_N>;

@@ -295,15 +295,20 @@ def generate_wide_source(st: Structure, name: str) -> str:
         cl.append(f"  static constexpr int NX = {nx}, NU = {nu}, NY = {ny}, NW = {d.num_parameter}, NJ = {d.num_jacobian}, "
                   f"NH = {nh}, NJV = {len(var_idx)}, NNL = {len(nl_rows)};")
         cl.append(f"  static __device__ __forceinline__ const double* fe_const() {{ return dyn{i}_fe; }}")
+        cl.append(f"  static __device__ __forceinline__ const double* jc_const() {{ return dyn{i}_jcv; }}")
         cl.append(_fn("eval_nl", sig, emit_body([rem[r] for r in nl_rows], "out", va) if nl_rows else "    (void)x;"))
         cl.append(_fn("jac_var", sig, emit_body([d.jacobian_expr[k] for k in var_idx], "out", va) if var_idx else "    (void)x;"))
         if nh:
             cl.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+        cl.append(_lookup("jv_k", f"dyn{i}_jvk"))
         cl.append(_lookup("nl_row", f"dyn{i}_nlr") + _lookup("jv_row", f"dyn{i}_jvr") + _lookup("jv_col", f"dyn{i}_jvc")
                   + _lookup("h_row", f"dyn{i}_hr0") + _lookup("h_col", f"dyn{i}_hc0"))
         cl.append("};")
         classes.append("\n".join(cl))
         dev_tables.append(f"__device__ const double dyn{i}_fe[] = {{" + ", ".join(_lit(v) for v in fe) + "};")
+        jc = [float(e.value) if e.is_const else 0.0 for e in d.jacobian_expr]
+        dev_tables.append(f"__device__ const double dyn{i}_jcv[] = {{" + ", ".join(_lit(v) for v in jc) + "};")
+        dev_tables.append(_dev_int_array(f"dyn{i}_jvk", var_idx))
         dev_tables.append(_dev_int_array(f"dyn{i}_nlr", nl_rows))
         dev_tables.append(_dev_int_array(f"dyn{i}_jvr", [d.jacobian_sparsity[0][k] - 1 for k in var_idx]))
         dev_tables.append(_dev_int_array(f"dyn{i}_jvc", [d.jacobian_sparsity[1][k] - 1 for k in var_idx]))
@@ -334,7 +339,8 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     out.append("struct Model {")
     out.append(f"  static constexpr int WIDE_N = {WIDE_STATE}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
-    out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = 1;")
+    max_key = max([1] + [st.key_slots(k) for k in st.kinds])
+    out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = 1, MAX_KEY = {max_key};")
     out.append("  template <int K> struct WKind;")
     out.append("  template <int C> struct Dyn;")
     out.append("  template <int C> struct Cost;")
@@ -358,12 +364,12 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("static const dto_con_class k_con[] = {\n  {0}\n};")
     rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
     out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
+    out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::wide::launch_wide_eval<Model>(op, a, s); }")
     out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
     out.append("  k_dyn, k_cost, k_con, k_kinds, nullptr, 1,")
-    max_key = max([1] + [st.key_slots(k) for k in st.kinds])
-    out.append(f"  {max_key}, nullptr, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>")
+    out.append(f"  {max_key}, launch, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>")
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')

@@ -110,3 +110,26 @@ def dense_kkt(model: PaddedAcrobot, T: int, z, mu, dw, dc):
     K = np.block([[H + dw * np.eye(nz), J.T], [J, -dc * np.eye(nc)]])
     rhs = -np.concatenate([g + J.T @ mu, c])
     return K, rhs
+
+
+def dense_derivatives(model: PaddedAcrobot, T: int, z, mu, sigma=1.0):
+    """f, grad f, c, dense J, dense Hessian of sigma f + mu' c (what the five MOI methods return, src/moi.jl:1-120)."""
+    n, m = model.n, model.m
+    nz, nc = (T - 1) * (n + m) + n, (T - 1) * n
+    H = np.zeros((nz, nz)); J = np.zeros((nc, nz)); g = np.zeros(nz); c = np.zeros(nc)
+    f = 0.0
+    for t in range(T):
+        o = t * (n + m)
+        x = z[o:o + n]
+        u = z[o + n:o + n + m] if t < T - 1 else np.zeros(0)
+        gt, Wt = model.cost_grad_hess(x, u)
+        npv = n + len(u)
+        f += 0.1 * float(x[2:n] @ x[2:n]) + 0.1 * float(u @ u)
+        g[o:o + npv] += gt
+        H[o:o + npv, o:o + npv] += sigma * Wt
+        if t < T - 1:
+            y = z[o + n + m:o + 2 * n + m]
+            c[t * n:(t + 1) * n] = model.residual(x, u, y)
+            J[t * n:(t + 1) * n, o:o + 2 * n + m] = model.jacobian(x, u, y)
+            H[o:o + 2 * n + m, o:o + 2 * n + m] += model.hessian(x, u, y, mu[t * n:(t + 1) * n])
+    return f, g, c, J, H
