@@ -825,7 +825,16 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
           DY::jac_var(xv, uv, yv, wp, jvv);
           double* o = a.out + b * a.ldout + a.jdoff[t];
           const double* jc = DY::jc_const();
-          for (int i = l; i < DY::NJ; i += 64) o[i] = jc[i];
+          if ((((uintptr_t)o | (uintptr_t)jc) & 15) == 0) {
+            // 16 B per lane: one full 1 KiB line group per wavefront store
+            const double2* src = reinterpret_cast<const double2*>(jc);
+            double2* dst = reinterpret_cast<double2*>(o);
+#pragma unroll 4
+            for (int i = l; i < DY::NJ / 2; i += 64) dst[i] = src[i];
+            if ((DY::NJ & 1) && l == 0) o[DY::NJ - 1] = jc[DY::NJ - 1];
+          } else {
+            for (int i = l; i < DY::NJ; i += 64) o[i] = jc[i];
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           if (l < DY::NJV) o[DY::jv_k(l)] = jvv[l];
         }

@@ -30,3 +30,16 @@ flop_stage = 2 * 64**3 / 3 + 3 * 64**3 + 4 * 2 * 64**3
 print(json.dumps(dict(T=T, B=B, ok=bool(ok), seconds=round(dt, 4), stages_per_s=round(B * (T - 1) / dt, 1),
                       us_per_stage_per_wg=round(dt / (T - 1) * 1e6, 2), gflops=round(B * (T - 1) * flop_stage / dt / 1e9, 1),
                       factor_bytes_GB=round(B * T * 21256 * 8 / 1e9, 2))))
+
+# ---- evaluator callbacks on the same model: Jacobian nnz/s (HBM-write bound: the stage Jacobian is dense)
+Bj = min(B, 16)
+nj = s.nlp.num_jacobian
+J = torch.empty((Bj, nj), device="cuda", dtype=torch.float64)
+s.nlp.eval_constraint_jacobian_batch(Z.data_ptr(), Bj, nz, J.data_ptr(), nj); torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    e0.record(); s.nlp.eval_constraint_jacobian_batch(Z.data_ptr(), Bj, nz, J.data_ptr(), nj); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e-3)
+dtj = min(ts)
+print(json.dumps(dict(op="jacobian", B=Bj, nnz=nj, seconds=round(dtj, 6), nnz_per_s=round(Bj * nj / dtj, 1),
+                      GBps=round(Bj * (nj + nz) * 8 / dtj / 1e9, 1))))
