@@ -57,6 +57,46 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense FP64 matrix (no local guide figure)
+
+
+def dense_block_measurement(dev, T=2000, B=256):
+    """BASELINE.json configs[4]: acrobot embedded in 64 states, dense 129 x 129 stage blocks, one regularised KKT
+    factor + solve (dto_kkt_step_batch) on the f64 matrix cores; plus the dense-block Jacobian callback.  Flops per stage
+    are SURVEY.md 8(d)'s b^3/3 + 2 b^2 n' + 2 b n'^2 with b = 129, n' = 64."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_acrobot_padded(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    nz, nc, nj = s.nlp.num_variables, s.nlp.num_constraint, s.nlp.num_jacobian
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    Z = torch.rand((B, nz), device=dev, dtype=torch.float64, generator=g)
+    MU = torch.rand((B, nc), device=dev, dtype=torch.float64, generator=g)
+    dx, dl = torch.empty_like(Z), torch.empty_like(MU)
+    st = torch.cuda.current_stream().cuda_stream
+    step = lambda: s.kkt_step_batch(Z.data_ptr(), B, nz, MU.data_ptr(), nc, 2.0, 1e-5, dx.data_ptr(), nz, dl.data_ptr(), nc, stream=st)
+    ok = step()
+    torch.cuda.synchronize()
+    ms = event_time_ms(step, 3)
+    b, npr = 129, 64
+    flop_stage = b ** 3 / 3 + 2 * b * b * npr + 2 * b * npr * npr
+    tflops = B * (T - 1) * flop_stage / (ms * 1e-3) / 1e12
+    Bj = 16
+    J = torch.empty((Bj, nj), device=dev, dtype=torch.float64)
+    jfn = lambda: s.nlp.eval_constraint_jacobian_batch(Z.data_ptr(), Bj, nz, J.data_ptr(), nj, st)
+    jfn()
+    jms = event_time_ms(jfn, 10)
+    jbytes = Bj * 8 * (nj + nz)
+    return dict(workload=f"acrobot embedded in 64 states, T={T}, {B} instances (BASELINE.json configs[4])",
+                kernel="k_wide_step", inertia_ok=bool(ok), avg_launch_ms=round(ms, 3), block=129, stages=B * (T - 1),
+                kkt_steps_per_sec=round(B / (ms * 1e-3), 1),
+                roofline=dict(bound="mfma", achieved=round(tflops, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                              frac=round(tflops / FP64_MFMA_PEAK_TFLOPS, 5), flop_per_stage=int(flop_stage)),
+                jacobian=dict(kernel="k_wide_eval<JAC>", instances=Bj, nnz_per_sec=Bj * nj / (jms * 1e-3), avg_launch_ms=round(jms, 4),
+                              achieved_GBps=round(jbytes / (jms * 1e-3) / 1e9, 1),
+                              frac_of_hbm_peak=round(jbytes / (jms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-blocks", action="store_true", help="skip the configs[4] (dense 129x129 blocks) side measurement")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +240,13 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
             cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
 
+    dense = None
+    if rank == 0 and world == 1 and not a.no_dense_blocks:
+        try:
+            dense = dense_block_measurement(dev)
+        except Exception as e:  # a side measurement of another config, never part of `value`
+            dense = dict(error=str(e))
+
     if rank == 0:
         out = dict(
             metric="SQP iterations/sec + Jacobian nnz/sec, acrobot T=1000, 1->8 GPU",
@@ -212,7 +260,7 @@ def main():
             jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=s.partitions(),
             gathered_trajectories=int(gathered.shape[0]),
-            roofline=roofline, cpu_baseline=cpu,
+            roofline=roofline, cpu_baseline=cpu, dense_blocks=dense,
         )
         print(json.dumps(out), flush=True)
     if dist is not None:
