@@ -1,0 +1,91 @@
+"""CPU-side checks of the wide-stage (configs[4], n = 64) model: symbolic model vs the oracle restatement, the
+constant-table / variable-entry / nonlinear-remainder split the plugin generator relies on, layout totals."""
+import numpy as np
+import pytest
+
+from _dag_eval import evaluate
+
+import dto_amd
+from dto_amd import problems as P
+from dto_amd.plugin import Structure, generate_source
+from dto_amd.symbolic import expr as E
+
+
+@pytest.fixture(scope="module")
+def padded():
+    return P.build_acrobot_padded(T=3)
+
+
+def _env(rng):
+    x, u, y, lam = rng.random(64), rng.random(1), rng.random(64), rng.random(64)
+    env = {}
+    for nm, v in (("x", x), ("u", u), ("y", y), ("lam", lam)):
+        for i, val in enumerate(v):
+            env[(nm, i)] = float(val)
+    return env, x, u, y, lam
+
+
+def test_symbolic_model_matches_oracle_restatement(padded):
+    from oracle.padded_model import PaddedAcrobot
+    d, c = padded["dynamics"][0], padded["objective"][0]
+    om = PaddedAcrobot(64)
+    env, x, u, y, lam = _env(np.random.default_rng(0))
+    assert (d.num_jacobian, d.num_hessian) == (64 * 129, 52)
+    assert np.max(np.abs(np.array(evaluate(d.evaluate_expr, env)) - om.residual(x, u, y))) < 1e-13
+    J = np.zeros((64, 129))
+    J[np.array(d.jacobian_sparsity[0]) - 1, np.array(d.jacobian_sparsity[1]) - 1] = evaluate(d.jacobian_expr, env)
+    assert np.max(np.abs(J - om.jacobian(x, u, y))) < 1e-13
+    H = np.zeros((129, 129))
+    H[np.array(d.hessian_sparsity[0]) - 1, np.array(d.hessian_sparsity[1]) - 1] = evaluate(d.hessian_expr, env)
+    assert np.max(np.abs(H - om.hessian(x, u, y, lam))) < 1e-13
+    g, _ = om.cost_grad_hess(x, u)
+    assert np.max(np.abs(np.array(evaluate(c.gradient_expr, env)) - g)) < 1e-15
+
+
+def test_constant_part_plus_remainder_reproduces_residual(padded):
+    """What csrc/dto_wide_kernels.hpp computes: d = FE_const [x;u;y] + remainder, remainder by symbolic substitution."""
+    d = padded["dynamics"][0]
+    x, u, y = E.variables("x", 64), E.variables("u", 1), E.variables("y", 64)
+    wrt = list(x) + list(u) + list(y)
+    fe = np.zeros((64, 129))
+    const_cols = {r: [] for r in range(64)}
+    nvar = 0
+    for r1, c1, e in zip(d.jacobian_sparsity[0], d.jacobian_sparsity[1], d.jacobian_expr):
+        if e.is_const:
+            fe[r1 - 1, c1 - 1] = float(e.value)
+            const_cols[r1 - 1].append(c1 - 1)
+        else:
+            nvar += 1
+    assert nvar == 18
+    rem = [E.substitute([d.evaluate_expr[r]], {wrt[c]: E.const(0.0) for c in const_cols[r]})[0] for r in range(64)]
+    assert [r for r in range(64) if not rem[r].is_zero()] == [2, 3]  # the two velocity rows of the acrobot are linear
+    env, xv, uv, yv, _ = _env(np.random.default_rng(3))
+    want = np.array(evaluate(d.evaluate_expr, env))
+    got = fe @ np.concatenate([xv, uv, yv]) + np.array(evaluate(rem, env))
+    assert np.max(np.abs(got - want)) < 1e-13
+
+
+def test_wide_plugin_source_and_structure_rules(padded):
+    st = Structure(padded["dynamics"], padded["objective"], padded["constraints"], None, True)
+    assert st.wide and len(st.kinds) == 3
+    src = generate_source(st, "acrobot_padded")
+    assert '#include "dto_wide_kernels.hpp"' in src and "dto_kkt_kernels.hpp" not in src
+    assert "NJV = 18" in src and "NNL = 2" in src and "WIDE_N = 64" in src
+    # the tile kernels are built for 64 states / one action / exact Hessians: anything else in the wide range is refused
+    bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 1, evaluate_hessian=True)
+    cost = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 1, evaluate_hessian=True)
+    costT = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 0, evaluate_hessian=True)
+    with pytest.raises(ValueError):
+        Structure([bad], [cost, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+
+
+def test_full_horizon_layout_totals():
+    """configs[4]: T = 2000 -> N_z, N_c, nnz_J as derived in SURVEY.md Appendix C terms (n=64, m=1, dense stage Jacobian)."""
+    p = P.build_acrobot_padded(T=2000)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    T, n, m = 2000, 64, 1
+    assert s.nlp.num_variables == (T - 1) * (n + m) + n
+    assert s.nlp.num_constraint == (T - 1) * n
+    assert s.nlp.num_jacobian == (T - 1) * n * (2 * n + m)
+    lo, hi = s.nlp.variable_bounds
+    assert np.all(lo[:n] == hi[:n]) and np.all(lo[-n:] == hi[-n:]) and hi[-n] == pytest.approx(np.pi)
