@@ -145,59 +145,73 @@ __device__ __forceinline__ void mm_row4(d4 (&c)[4], const double* A, int m0, con
   }
 }
 
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ---- unblocked LDL^T of the 16x16 diagonal tile at (o, o) by one wavefront: lane i (< 16) holds row i of the
-//      symmetric tile in registers and the pivot row travels by ds_bpermute (no LDS read-modify-write inside the
-//      16-step dependency chain).  Then the inverse of the unit-lower factor, lane c = column c, from broadcast reads
-//      of L (independent loads).  d/dinv get the pivots; cnt[0] += negative pivots, cnt[1] |= tiny pivot seen.
+//      symmetric tile in registers; values travel between lanes by v_readlane (lane indices are literals after
+//      unrolling), each broadcast value is consumed by the next instruction.  Step j, critical path: reciprocal of the
+//      lane's own diagonal -> scaled pivot row s_c = a_jc / d_j (which is also L[c][j]) -> broadcast -> one FMA.
+//      The inverse X of the unit-lower factor (lane c = column c) is built row by row inside the same loop: row j+1
+//      of L is final after step j, and its work fills the latency gaps of the factorisation chain.
+//      d/dinv get the pivots; cnt[0] += negative pivots, cnt[1] |= tiny pivot seen.
 __device__ __forceinline__ void diag_tile(double* Mx, int ld, int o, double* d, double* dinv, double* LIk, int li_ld,
-                                          double piv_tol, int* cnt) {
+                                          double piv_tol, int* cnt, long long* prof = nullptr) {
   const int l = lane_id();
   const int i = l & 15;
+  long long tq_ = prof ? clock64() : 0;
   double a[TB];
 #pragma unroll
   for (int c = 0; c < TB; ++c) a[c] = (c <= i) ? Mx[(o + i) * ld + o + c] : Mx[(o + c) * ld + o + i];
   const double diag0 = fabs(Mx[(o + i) * ld + o + i]);
+  if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[24] += t_ - tq_; tq_ = t_; }
   int nneg = 0, tiny = 0;
   double dj_mine = 0.0, idj_mine = 0.0;
+  double X[TB];
+  X[0] = (l == 0) ? 1.0 : 0.0;
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
-    double rj[TB];
+    const double pv = a[j];
+    double rc = __builtin_amdgcn_rcp(pv);
+    rc = fma(fma(-pv, rc, 1.0), rc, rc);
+    rc = fma(fma(-pv, rc, 1.0), rc, rc);
+    const double aij = a[j];
 #pragma unroll
-    for (int c = j; c < TB; ++c) rj[c] = __shfl(a[c], j);
-    const double d0 = __shfl(diag0, j);
-    const double dj = rj[j];
+    for (int c = j + 1; c < TB; ++c) {
+      const double sc = readlane_d(a[c] * rc, j);
+      if (i > j) a[c] -= aij * sc;
+    }
+    const double dj = readlane_d(pv, j);
+    const double d0 = readlane_d(diag0, j);
+    const double rcj = readlane_d(rc, j);
     if (!(fabs(dj) > piv_tol * fmax(1.0, d0))) tiny = 1;
     if (dj < 0.0) ++nneg;
-    const double idj = 1.0 / dj;
-    if (l == j) { dj_mine = dj; idj_mine = idj; }
-    const double lij = a[j] * idj;
-    if (i > j) {
+    if (l == j) { dj_mine = pv; idj_mine = rc; }
+    if (i > j) a[j] = aij * rcj;
+    // row j+1 of the inverse: X[j+1][c] = -sum_{k<=j} L[j+1][k] X[k][c]
+    if (j + 1 < TB) {
+      double sacc = 0.0;
 #pragma unroll
-      for (int c = j + 1; c < TB; ++c) a[c] -= lij * rj[c];
-      a[j] = lij;
+      for (int k = 0; k <= j; ++k) sacc += readlane_d(a[k], j + 1) * X[k];
+      X[j + 1] = (l == j + 1) ? 1.0 : (l < j + 1 ? -sacc : 0.0);
     }
   }
+  if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[25] += t_ - tq_; tq_ = t_; }
   if (l < TB) {
     d[o + l] = dj_mine;
     dinv[o + l] = idj_mine;
 #pragma unroll
     for (int k = 0; k < TB - 1; ++k)
       if (k < l) Mx[(o + l) * ld + o + k] = a[k];
-  }
-  if (l == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
-  // inverse of the unit-lower tile: X[r] = -sum_{k<r} L[r][k] X[k] below the unit diagonal, lane c = column c
-  if (l < TB) {
-    double X[TB];
-#pragma unroll
-    for (int r = 0; r < TB; ++r) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int k = 0; k < r; ++k) sacc += Mx[(o + r) * ld + o + k] * X[k];
-      X[r] = (r == l) ? 1.0 : (r > l ? -sacc : 0.0);
-    }
 #pragma unroll
     for (int r = 0; r < TB; ++r) LIk[r * li_ld + l] = X[r];
   }
+  if (l == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
+  if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[26] += t_ - tq_; tq_ = t_; }
 }
 
 // ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
@@ -212,7 +226,7 @@ __device__ __forceinline__ void ldl_blocked(double* Mx, double* d, double* dinv,
     double* LIk = LI + kb * TB * D::LI_LD;
     long long t0_ = 0;
     if (prof && threadIdx.x == 0) t0_ = clock64();
-    if (w == 0) diag_tile(Mx, LD, o, d, dinv, LIk, D::LI_LD, piv_tol, cnt);
+    if (w == 0) diag_tile(Mx, LD, o, d, dinv, LIk, D::LI_LD, piv_tol, cnt, prof);
     if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[20] += t1_ - t0_; t0_ = t1_; }
     __syncthreads();
     if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[21] += t1_ - t0_; t0_ = t1_; }

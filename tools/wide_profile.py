@@ -24,5 +24,5 @@ names = ["p0 load+const fill", "p1 model code", "p2 residual", "p3 scatter var/h
 c = prof.cpu().numpy()
 tot = c.sum()
 print("cycles per stage (clock64 @100MHz units if wall clock) total", tot / (T - 1))
-for i in list(range(17)) + [20, 21, 22, 23]:
+for i in list(range(17)) + [20, 21, 22, 23, 24, 25, 26, 27]:
     print(f"slot {i:2d} {c[i] / (T - 1):10.1f}  {100.0 * c[i] / tot:5.1f}%")
