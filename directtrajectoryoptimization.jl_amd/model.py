@@ -151,7 +151,9 @@ class Constraint:
         x = E.variables("x", num_state)
         u = E.variables("u", num_action)
         w = E.variables("w", num_parameter)
-        ev = _as_expr_list(f(x, u, w))
+        # `f` is the user closure, or (internal use: rows folded in from a stage-local GeneralConstraint) a ready list
+        # of expressions over the x / u / w symbols
+        ev = [E.as_expr(e) for e in f] if isinstance(f, (list, tuple)) else _as_expr_list(f(x, u, w))
         wrt = list(x) + list(u)
         self.evaluate_expr = ev
         self.num_constraint = len(ev)

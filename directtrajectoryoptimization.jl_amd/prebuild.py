@@ -30,6 +30,13 @@ def all_structures():
         p = builder(**kw)
         out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], p.get("general_constraint"),
                                     p["evaluate_hessian"])))
+        if p.get("general_constraint") is not None:
+            # the solver's internal form of a stage-local general constraint (solver.py:fold_general_constraint)
+            from .solver import fold_general_constraint
+            folded = fold_general_constraint(p["dynamics"], p["objective"], p["constraints"], p["general_constraint"],
+                                             p["evaluate_hessian"])
+            if folded is not None:
+                out.append((name + "_folded", Structure(p["dynamics"], p["objective"], folded[0], None, p["evaluate_hessian"])))
     return out
 
 

@@ -293,6 +293,19 @@ class Solver:
                            general_constraint=general_constraint, parameters=parameters, name=name)
         self._z0 = np.zeros(self.nlp.num_variables)
         self._solution = None
+        # The block-tridiagonal solver has no border for dense coupling rows.  A GeneralConstraint whose rows each
+        # touch the variables of ONE knot (the reference's own use, test/solve.jl:273: z[end-1:end] - xT) is folded
+        # into that knot's stage constraint for the solve; the evaluator callbacks keep the reference layout and the
+        # multipliers are mapped back to it ([dynamics; stage; general], src/data.jl:64-75).
+        self._solve_nlp = self.nlp
+        self._mu_to_reference = None
+        if general_constraint is not None and general_constraint.num_constraint > 0:
+            folded = fold_general_constraint(dynamics, objective, constraints, general_constraint, evaluate_hessian)
+            if folded is not None:
+                new_constraints, mu_map = folded
+                self._solve_nlp = NLPData(dynamics, objective, new_constraints, bounds, evaluate_hessian=evaluate_hessian,
+                                          general_constraint=None, parameters=parameters, name=name + "_folded")
+                self._mu_to_reference = mu_map
 
     @property
     def num_variables(self):
@@ -366,9 +379,58 @@ class Solver:
         capi.check(self.nlp._lib.dto_solver_end(self.nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo, stream or None))
 
 
+def fold_general_constraint(dynamics, objective, constraints, general, evaluate_hessian):
+    """Stage constraints equivalent to `constraints` + `general` when every general row depends on one knot only.
+
+    Returns (new_constraints, mu_map) with mu_map[i] = 0-based position in the reference multiplier vector of the
+    solver-internal constraint row i, or None if some row couples several knots or reads parameters."""
+    from .symbolic import expr as E
+    T = len(objective)
+    nxs = [c.num_state for c in objective]
+    nus = [c.num_action for c in objective]
+    zoff = np.concatenate([[0], np.cumsum([nxs[t] + nus[t] for t in range(T)])])
+    nz = int(zoff[-1])
+    if general.num_variables != nz or general.num_parameter != 0:
+        return None
+    stage_of = np.zeros(nz, dtype=int)
+    for t in range(T):
+        stage_of[zoff[t]:zoff[t + 1]] = t
+    rows_of_stage = {t: [] for t in range(T)}
+    for r, e in enumerate(general.evaluate_expr):
+        stages = {int(stage_of[n.index]) for n in E.topo_order([e]) if n.op == E.VAR and n.name == "z"}
+        if any(n.op == E.VAR and n.name == "w" for n in E.topo_order([e])) or len(stages) > 1:
+            return None
+        rows_of_stage[stages.pop() if stages else T - 1].append(r)
+    z = E.variables("z", nz)
+    new_constraints, stage_rows = [], []   # stage_rows[t] = list of ("s", j) / ("g", r) in internal row order
+    for t in range(T):
+        con, gr = constraints[t], rows_of_stage[t]
+        if not gr:
+            new_constraints.append(con)
+            stage_rows.append([("s", j) for j in range(con.num_constraint)])
+            continue
+        x, u = E.variables("x", nxs[t]), E.variables("u", nus[t])
+        mapping = {z[zoff[t] + i]: x[i] for i in range(nxs[t])}
+        mapping.update({z[zoff[t] + nxs[t] + j]: u[j] for j in range(nus[t])})
+        exprs = list(con.evaluate_expr) + E.substitute([general.evaluate_expr[r] for r in gr], mapping)
+        ineq = list(con.indices_inequality) + [con.num_constraint + k + 1 for k, r in enumerate(gr)
+                                               if (r + 1) in general.indices_inequality]
+        new_constraints.append(Constraint(exprs, nxs[t], nus[t], num_parameter=con.num_parameter if con.num_constraint else
+                                          objective[t].num_parameter, indices_inequality=ineq, evaluate_hessian=evaluate_hessian))
+        stage_rows.append([("s", j) for j in range(con.num_constraint)] + [("g", r) for r in gr])
+    n_dyn = sum(d.num_next_state for d in dynamics)
+    n_stage = sum(c.num_constraint for c in constraints)
+    stage_base = np.concatenate([[0], np.cumsum([c.num_constraint for c in constraints])])
+    mu_map = list(range(n_dyn))
+    for t in range(T):
+        for kind, j in stage_rows[t]:
+            mu_map.append(n_dyn + int(stage_base[t]) + j if kind == "s" else n_dyn + n_stage + j)
+    return new_constraints, np.asarray(mu_map, dtype=np.int64)
+
+
 def solve(solver: Solver):
     """solve!(solver) -- src/solver.jl:45-47: run the GPU interior-point solve from the initial guess."""
-    n = solver.nlp
+    n = solver._solve_nlp
     x = np.zeros(n.num_variables)
     mu = np.zeros(max(1, n.num_constraint))
     status, iters = C.c_int32(0), C.c_int32(0)
@@ -377,6 +439,10 @@ def solve(solver: Solver):
                                 C.byref(status), C.byref(iters)))
     solver._solution = x
     solver._duals = mu[:n.num_constraint]
+    if solver._mu_to_reference is not None:
+        ref = np.zeros(solver.nlp.num_constraint)
+        ref[solver._mu_to_reference] = mu[:n.num_constraint]
+        solver._duals = ref
     solver.status, solver.iterations = int(status.value), int(iters.value)
     return solver.status
 

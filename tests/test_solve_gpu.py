@@ -143,3 +143,30 @@ def test_default_mode_without_exact_hessians():
         assert s.iterations <= cap, (model, s.iterations)
         x_sol, u_sol = dto_amd.get_trajectory(s)
         assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
+
+
+@pytest.mark.parametrize("user_jacobian", [False, True])
+def test_reference_general_constraint_solve(user_jacobian):
+    """test/solve.jl:140-296 -- double integrator, T = 11, initial state fixed by bounds, terminal state imposed through
+    GeneralConstraint((z, w) -> z[end-1:end] - xT); second variant with the user-provided dense dynamics Jacobian
+    (test/solve.jl:149-183).  Same asserts as the reference: |x_1 - x1| < 1e-3, |x_T - xT| < 1e-3."""
+    import dto_amd
+    s, p = product_solver("ref_general", 11, evaluate_hessian=not user_jacobian)
+    rng = np.random.Generator(np.random.PCG64(5))
+    dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
+    dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3
+    assert np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
+    # multipliers come back in the reference order [dynamics; stage; general]: stationarity with the reference-layout Jacobian
+    n = s.nlp
+    z = s._solution
+    g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    J = np.zeros((n.num_constraint, n.num_variables))
+    for (r, c), v in zip(n.jacobian_structure(), Jv):
+        J[r - 1, c - 1] = v
+    r = g + J.T @ s._duals
+    free = np.ones(n.num_variables, bool); free[:2] = False     # x_1 is fixed by bounds (its bound multipliers absorb the rest)
+    assert np.max(np.abs(r[free])) < 1e-5

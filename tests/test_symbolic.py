@@ -87,3 +87,29 @@ def test_user_jacobian_ctor_dense_column_major():
     assert list(zip(*d.jacobian_sparsity)) == [(i, j) for j in range(1, 6) for i in range(1, 3)]
     vals = evaluate(d.jacobian_expr, {})
     assert vals == [-1.0, 0.0, -1.0, -1.0, 0.0, -1.0, 1.0, 0.0, 0.0, 1.0]
+
+
+def test_general_constraint_folding_for_the_solver():
+    """solver.py:fold_general_constraint -- stage-local general rows become stage rows (test/solve.jl:273's use);
+    multipliers map back to the reference order [dynamics; stage; general]; coupling rows are refused."""
+    from dto_amd.solver import fold_general_constraint
+    p = P.build_ref_general(user_jacobian=False)
+    new_cons, mu_map = fold_general_constraint(p["dynamics"], p["objective"], p["constraints"], p["general_constraint"], True)
+    T, n = p["T"], p["n"]
+    assert [c.num_constraint for c in new_cons] == [0] * (T - 1) + [2]
+    n_dyn = (T - 1) * n
+    assert list(mu_map) == list(range(n_dyn)) + [n_dyn, n_dyn + 1]
+    env = {("x", 0): 0.3, ("x", 1): -0.2}
+    assert np.allclose(evaluate(new_cons[-1].evaluate_expr, env), [0.3 - 1.0, -0.2 - 0.0])
+    nz = n * T + (T - 1)
+    coupling = dto_amd.GeneralConstraint(lambda z, w: z[0:1] + z[nz - 1:nz], nz, 0, evaluate_hessian=True)
+    assert fold_general_constraint(p["dynamics"], p["objective"], p["constraints"], coupling, True) is None
+    # mixed with an existing stage constraint and an inequality row
+    con = dto_amd.Constraint(lambda x, u, w: x[0:1] - 2.0, n, 0, evaluate_hessian=True)
+    gen = dto_amd.GeneralConstraint(lambda z, w: np.array([z[nz - 1] * z[nz - 2], z[3] - 1.0], dtype=object), nz, 0,
+                                    indices_inequality=[1], evaluate_hessian=True)
+    cons = [dto_amd.Constraint() for _ in range(T - 1)] + [con]
+    new_cons, mu_map = fold_general_constraint(p["dynamics"], p["objective"], cons, gen, True)
+    assert new_cons[1].num_constraint == 1 and new_cons[-1].num_constraint == 2 and new_cons[-1].indices_inequality == [2]
+    # internal rows: dyn..., stage 2: general row 2, stage T: own row, general row 1
+    assert list(mu_map[n_dyn:]) == [n_dyn + 1 + 1, n_dyn + 0, n_dyn + 1 + 0]
