@@ -364,6 +364,21 @@ def build_ref_general(user_jacobian=False):
                 bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=eh)
 
 
+def build_ref_userjac():
+    """test/solve.jl:140-226: double integrator, T = 11, user-provided dense dynamics Jacobian, both endpoints fixed by
+    bounds, Solver(...) in its default mode (no exact Hessians)."""
+    T, n, m = 11, 2, 1
+    x1 = np.array([0.0, 0.0])
+    xT = np.array([1.0, 0.0])
+    dt = Dynamics(double_integrator, double_integrator_grad, n, n, m)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x, x) + 0.1 * dot(u, u), n, m)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x, x), n, 0)
+    bounds = ([Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2)
+              + [Bound(n, 0, state_lower=xT, state_upper=xT)])
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
+                bounds=bounds, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=False)
+
+
 def build_param_pendulum(T=8):
     """Per-stage parameters w_t (src/solver.jl:10 `parameters` kwarg): pendulum whose mass and goal angle are
     parameters; exercises num_parameter > 0 in Dynamics, Cost and Constraint."""

@@ -170,3 +170,17 @@ def test_reference_general_constraint_solve(user_jacobian):
     r = g + J.T @ s._duals
     free = np.ones(n.num_variables, bool); free[:2] = False     # x_1 is fixed by bounds (its bound multipliers absorb the rest)
     assert np.max(np.abs(r[free])) < 1e-5
+
+
+def test_reference_user_jacobian_solve():
+    """test/solve.jl:140-226 -- user-provided dynamics Jacobian, endpoints fixed by bounds, default Solver(...) mode."""
+    import dto_amd
+    s, p = product_solver("ref_userjac", 11, evaluate_hessian=False)
+    rng = np.random.Generator(np.random.PCG64(6))
+    dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
+    dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3
+    assert np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
+    assert len(x_sol) == 11 and len(u_sol) == 10
