@@ -47,7 +47,8 @@ class Cost:
         x = E.variables("x", num_state)
         u = E.variables("u", num_action)
         w = E.variables("w", num_parameter)
-        ev = _as_expr_list(f(x, u, w))
+        # `f`: the user closure, or (internal: solver-side clone with exact Hessians) ready expressions over x / u / w
+        ev = [E.as_expr(e) for e in f] if isinstance(f, (list, tuple)) else _as_expr_list(f(x, u, w))
         if len(ev) != 1:
             raise ValueError("Cost function must return a scalar")
         wrt = list(x) + list(u)
@@ -93,7 +94,7 @@ class Dynamics:
         x = E.variables("x", num_state)
         u = E.variables("u", num_action)
         w = E.variables("w", num_parameter)
-        ev = _as_expr_list(f(y, x, u, w))
+        ev = [E.as_expr(e) for e in f] if isinstance(f, (list, tuple)) else _as_expr_list(f(y, x, u, w))
         if len(ev) != num_next_state:
             raise ValueError("dynamics residual has wrong length")
         wrt = list(x) + list(u) + list(y)

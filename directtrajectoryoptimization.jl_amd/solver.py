@@ -48,6 +48,10 @@ class Options:
     print_frequency_iter: int = 1
     print_frequency_time: float = 0.0
     skip_finalize_solution_call: str = "no"
+    # not a reference field: what the GPU solver uses for the Hessian of the Lagrangian when the problem was built with
+    # evaluate_hessian=false (where the reference leaves Ipopt on its limited-memory Hessian).  "auto": exact second
+    # derivatives derived from the traced expressions (they cost nothing here); "sr1": per-stage SR1 blocks.
+    hessian_approximation: str = "auto"
 
 
 class Indices:
@@ -299,13 +303,23 @@ class Solver:
         # multipliers are mapped back to it ([dynamics; stage; general], src/data.jl:64-75).
         self._solve_nlp = self.nlp
         self._mu_to_reference = None
-        if general_constraint is not None and general_constraint.num_constraint > 0:
-            folded = fold_general_constraint(dynamics, objective, constraints, general_constraint, evaluate_hessian)
+        s_dyn, s_obj, s_con, s_eh, changed = list(dynamics), list(objective), list(constraints), bool(evaluate_hessian), False
+        if not s_eh and self.options.hessian_approximation != "sr1":
+            # Default mode: the expressions are there, so the solver differentiates them twice itself; the MOI surface of
+            # self.nlp still reports [:Grad, :Jac] exactly like the reference (src/moi.jl:122).
+            up = _with_exact_hessians(s_dyn, s_obj, s_con)
+            if up is not None:
+                s_dyn, s_obj, s_con = up
+                s_eh, changed = True, True
+        gen = general_constraint if (general_constraint is not None and general_constraint.num_constraint > 0) else None
+        if gen is not None:
+            folded = fold_general_constraint(s_dyn, s_obj, s_con, gen, s_eh)
             if folded is not None:
-                new_constraints, mu_map = folded
-                self._solve_nlp = NLPData(dynamics, objective, new_constraints, bounds, evaluate_hessian=evaluate_hessian,
-                                          general_constraint=None, parameters=parameters, name=name + "_folded")
-                self._mu_to_reference = mu_map
+                s_con, self._mu_to_reference = folded
+                gen, changed = None, True
+        if changed:
+            self._solve_nlp = NLPData(s_dyn, s_obj, s_con, bounds, evaluate_hessian=s_eh, general_constraint=gen,
+                                      parameters=parameters, name=name if gen is None and self._mu_to_reference is None else name + "_folded")
 
     @property
     def num_variables(self):
@@ -314,38 +328,38 @@ class Solver:
     # ---- batched device entry points (torch tensors / raw device pointers)
     def kkt_step_batch(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, dx_ptr, lddx, dmu_ptr, lddmu, stream=0):
         """One regularised Newton-KKT step (include/dto.h: dto_kkt_step_batch). Returns inertia_ok."""
-        b = self.nlp._batch(x_ptr, B, ldx, stream)
+        b = self._solve_nlp._batch(x_ptr, B, ldx, stream)
         ok = C.c_int(1)
-        capi.check(self.nlp._lib.dto_kkt_step_batch(self.nlp._h, C.byref(b), mu_ptr, ldmu, float(delta_w), float(delta_c),
+        capi.check(self._solve_nlp._lib.dto_kkt_step_batch(self._solve_nlp._h, C.byref(b), mu_ptr, ldmu, float(delta_w), float(delta_c),
                                                     dx_ptr, lddx, dmu_ptr, lddmu, C.byref(ok)))
         return bool(ok.value)
 
     def solve_batch(self, x0_ptr, B, ldx, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0, check_every=10):
         """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays."""
-        b = self.nlp._batch(x0_ptr, B, ldx, stream)
+        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream)
         co = _c_options(self.options, check_every)
         self._B = B
         status = np.zeros(B, dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
-        capi.check(self.nlp._lib.dto_solve_batch(self.nlp._h, C.byref(co), C.byref(b), x_out_ptr, ldxo,
+        capi.check(self._solve_nlp._lib.dto_solve_batch(self._solve_nlp._h, C.byref(co), C.byref(b), x_out_ptr, ldxo,
                                                  mu_out_ptr or None, ldmuo, status.ctypes.data_as(capi.c_int32_p),
                                                  iters.ctypes.data_as(capi.c_int32_p)))
         return status, iters
 
     def begin_batch(self, x0_ptr, B, ldx, stream=0):
-        b = self.nlp._batch(x0_ptr, B, ldx, stream)
+        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream)
         co = _c_options(self.options)
-        capi.check(self.nlp._lib.dto_solver_begin(self.nlp._h, C.byref(co), C.byref(b)))
+        capi.check(self._solve_nlp._lib.dto_solver_begin(self._solve_nlp._h, C.byref(co), C.byref(b)))
         self._B = B
 
     def iterate_batch(self, n, stream=0):
-        capi.check(self.nlp._lib.dto_solver_iterate(self.nlp._h, int(n), stream or None))
+        capi.check(self._solve_nlp._lib.dto_solver_iterate(self._solve_nlp._h, int(n), stream or None))
 
     def stats_batch(self):
         B = self._B
         st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
         arrs = [np.zeros(B) for _ in range(6)]
-        capi.check(self.nlp._lib.dto_solver_stats(self.nlp._h, st.ctypes.data_as(capi.c_int32_p), it.ctypes.data_as(capi.c_int32_p),
+        capi.check(self._solve_nlp._lib.dto_solver_stats(self._solve_nlp._h, st.ctypes.data_as(capi.c_int32_p), it.ctypes.data_as(capi.c_int32_p),
                                                   *[capi.dptr(a) for a in arrs]))
         names = ["objective", "constr_viol", "dual_inf", "mu", "delta_w", "alpha"]
         return dict(status=st, iterations=it, **dict(zip(names, arrs)))
@@ -355,28 +369,58 @@ class Solver:
 
     def set_partitions(self, partitions: int):
         """Chunks of the time-partitioned factorisation (0 = automatic, 1 = sequential)."""
-        capi.check(self.nlp._lib.dto_solver_set_partitions(self.nlp._h, int(partitions)))
+        capi.check(self._solve_nlp._lib.dto_solver_set_partitions(self._solve_nlp._h, int(partitions)))
 
     def partitions(self) -> int:
         v = C.c_int(0)
-        capi.check(self.nlp._lib.dto_solver_partitions(self.nlp._h, C.byref(v)))
+        capi.check(self._solve_nlp._lib.dto_solver_partitions(self._solve_nlp._h, C.byref(v)))
         return v.value
 
     def launch_op(self, name: str, stream=0):
-        capi.check(self.nlp._lib.dto_solver_launch_op(self.nlp._h, self.KKT_OPS[name], stream or None))
+        capi.check(self._solve_nlp._lib.dto_solver_launch_op(self._solve_nlp._h, self.KKT_OPS[name], stream or None))
 
     def footprint(self):
         r, f, n, k = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
-        capi.check(self.nlp._lib.dto_solver_footprint(self.nlp._h, C.byref(r), C.byref(f), C.byref(n), C.byref(k)))
+        capi.check(self._solve_nlp._lib.dto_solver_footprint(self._solve_nlp._h, C.byref(r), C.byref(f), C.byref(n), C.byref(k)))
         return dict(record_doubles=r.value, factor_doubles=f.value, num_slacks=n.value, factor_rounds=k.value)
 
     def scalar_batch(self, name: str):
         out = np.zeros(self._B)
-        capi.check(self.nlp._lib.dto_solver_scalar(self.nlp._h, capi.SCALARS.index(name), capi.dptr(out)))
+        capi.check(self._solve_nlp._lib.dto_solver_scalar(self._solve_nlp._h, capi.SCALARS.index(name), capi.dptr(out)))
         return out
 
     def end_batch(self, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0):
-        capi.check(self.nlp._lib.dto_solver_end(self.nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo, stream or None))
+        capi.check(self._solve_nlp._lib.dto_solver_end(self._solve_nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo, stream or None))
+
+
+def _with_exact_hessians(dynamics, objective, constraints):
+    """Clones of the stage objects with Hessians, built from their traced expressions (object sharing preserved).
+    None if some dynamics came with a user-provided Jacobian (src/dynamics.jl:59-101: no expression to differentiate twice
+    is promised there)."""
+    cache = {}
+
+    def clone(o):
+        if id(o) in cache:
+            return cache[id(o)]
+        if isinstance(o, Dynamics):
+            if o.user_jacobian:
+                return None
+            n = o if o.evaluate_hessian else Dynamics(list(o.evaluate_expr), o.num_next_state, o.num_state, o.num_action,
+                                                      num_parameter=o.num_parameter, evaluate_hessian=True)
+        elif isinstance(o, Cost):
+            n = o if o.evaluate_hessian else Cost(list(o.evaluate_expr), o.num_state, o.num_action,
+                                                  num_parameter=o.num_parameter, evaluate_hessian=True)
+        else:
+            n = o if (o.num_constraint == 0 or o.evaluate_hessian) else Constraint(
+                list(o.evaluate_expr), o.num_state, o.num_action, num_parameter=o.num_parameter,
+                indices_inequality=o.indices_inequality, evaluate_hessian=True)
+        cache[id(o)] = n
+        return n
+
+    out = [[clone(o) for o in lst] for lst in (dynamics, objective, constraints)]
+    if any(o is None for lst in out for o in lst):
+        return None
+    return out
 
 
 def fold_general_constraint(dynamics, objective, constraints, general, evaluate_hessian):

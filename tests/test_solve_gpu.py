@@ -124,25 +124,48 @@ def test_single_instance_host_solve_matches_batched():
     assert np.array_equal(z, Z[1]) and s.iterations == iters[1]
 
 
-def test_default_mode_without_exact_hessians():
-    """The reference default: Solver(...) without evaluate_hessian (src/solver.jl:7) -- Ipopt then uses a
-    limited-memory Hessian.  Here the solver keeps a partitioned SR1 approximation of each stage's element
-    Hessian (csrc/dto_kkt_kernels.hpp, k_stage_eval); the MOI Hessian callback stays unavailable exactly as in the
-    reference (features_available == [:Grad, :Jac]).  The quasi-Newton path must stay within a small factor of
-    the exact-Hessian iteration counts on these models (pendulum 11-13, car ~30)."""
-    import torch
+def _solve_from_seed(s, p, seed):
     import dto_amd
-    for model, T, cap in (("car", 51, 80), ("pendulum", 50, 40)):
-        s, p = product_solver(model, T, evaluate_hessian=False)
-        assert s.nlp.features_available() == ["Grad", "Jac"]
-        rng = np.random.Generator(np.random.PCG64(0))
-        xs, us = p["guess"](rng)
-        dto_amd.initialize_states(s, xs)
-        dto_amd.initialize_controls(s, us)
-        assert dto_amd.solve(s) == 1, (model, s.status, s.iterations)
-        assert s.iterations <= cap, (model, s.iterations)
-        x_sol, u_sol = dto_amd.get_trajectory(s)
-        assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(seed)))
+    dto_amd.initialize_states(s, xs)
+    dto_amd.initialize_controls(s, us)
+    st = dto_amd.solve(s)
+    x_sol, _ = dto_amd.get_trajectory(s)
+    return st, x_sol
+
+
+@pytest.mark.parametrize("model,T,cap", [("pendulum", 50, 20), ("car", 51, 60), ("cartpole", 101, 100), ("acrobot", 101, 400)])
+def test_default_mode_without_exact_hessians(model, T, cap):
+    """The reference default, and how its examples are written (examples/acrobot/acrobot.jl:94-123 T=101,
+    examples/car/car.jl:63 T=51, examples/cartpole/cartpole.jl:12-99 T=101): Solver(...) without evaluate_hessian
+    (src/solver.jl:7), where Ipopt falls back to a limited-memory Hessian.  The GPU solver differentiates the traced
+    expressions twice itself, so it iterates exactly as in exact-Hessian mode, while the MOI surface keeps reporting
+    [:Grad, :Jac] (src/moi.jl:122) and the Hessian callback stays unavailable."""
+    import dto_amd
+    s, p = product_solver(model, T, evaluate_hessian=False)
+    assert s.nlp.features_available() == ["Grad", "Jac"]
+    assert int(s.nlp.sizes.nnz_hess_key) == 0 and s.nlp.hessian_lagrangian_structure() == []
+    st, x_sol = _solve_from_seed(s, p, 0)
+    assert st == 1, (model, s.status, s.iterations)
+    assert s.iterations <= cap, (model, s.iterations)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
+
+
+@pytest.mark.parametrize("model,T,cap", [("car", 51, 80), ("pendulum", 50, 40)])
+def test_quasi_newton_mode(model, T, cap):
+    """Options(hessian_approximation="sr1"): per-stage SR1 approximations of the element Hessians (csrc/dto_kkt_kernels.hpp,
+    k_stage_eval) -- the mode that is also used when the dynamics come with a user-provided Jacobian.  It must stay within a
+    small factor of the exact-Hessian iteration counts on these models (pendulum 11-13, car ~30)."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=False)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False,
+                       options=dto_amd.Options(hessian_approximation="sr1"), name=model)
+    assert s._solve_nlp is s.nlp
+    st, x_sol = _solve_from_seed(s, p, 0)
+    assert st == 1, (model, s.status, s.iterations)
+    assert s.iterations <= cap, (model, s.iterations)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
 
 
 @pytest.mark.parametrize("user_jacobian", [False, True])
