@@ -12,6 +12,8 @@ max_iter = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
 p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=True)
 s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name=model)
 s.options.max_iter = max_iter
+if os.environ.get("DTO_PART"):
+    s.set_partitions(int(os.environ["DTO_PART"]))
 nz, nc = s.nlp.num_variables, s.nlp.num_constraint
 if model == "acrobot":
     Z = make_guesses(s, p, B, seed=1000)
