@@ -295,14 +295,25 @@ __global__ __launch_bounds__(JAC_WAVES * WAVE) void k_jac(dto_eval_args a) {
 // ------------------------------------------------------------------------------------------------
 // Hessian of the Lagrangian, reference key order (row-major sorted unique, both triangles)
 // ------------------------------------------------------------------------------------------------
+// How the key image of a stage is filled (measured on MI355X: 107 ds_add_f64 per lane made the kernel LDS-atomic bound,
+// 64 cycles per wave instruction; read-modify-write of every entry exposed ~120 cycles of latency each):
+//   1. zero fill, 2. the dynamics Hessian entries of the stage's own rows are PLAIN STORES (within one stage every such
+//   entry has its own slot), 3. the few cost / constraint entries and, after a barrier, the previous stage's y-row
+//   entries are added.  Fixed order per slot -> deterministic.
 constexpr int HOWN = WAVE - 1;  // stages owned by one wave; lane 0 is the halo (stage t0-1)
-constexpr int HESS_WAVES = 2;   // wavefronts per workgroup (the output image is ~21 KiB per wave)
+constexpr int HESS_WAVES = 2;   // wavefronts per workgroup
+constexpr int HHALF = 32;       // stages per output image: the wave streams its 63 stages out in two images, which halves
+                                // the LDS footprint (~10 KiB per wave) and doubles the wavefronts a CU can hold
 
 template <class M>
 __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
-  __shared__ __attribute__((aligned(16))) double s_img[HESS_WAVES][HOWN * M::MAX_KEY + 2];
+  // image + one trash slot per lane: entries that do not belong to the image (map value -1) are written there, which
+  // keeps the deposit loops free of branches, so the map loads of a lane are all in flight at once
+  constexpr int IMG = HHALF * M::MAX_KEY + 2;
+  __shared__ __attribute__((aligned(16))) double s_img[HESS_WAVES][IMG + WAVE];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* s_o = s_img[wv];
+  const int trash = IMG + lane;
   const int wpi = (a.T + HOWN - 1) / HOWN;
   const int bpi = (wpi + HESS_WAVES - 1) / HESS_WAVES;
   const int64_t b = blockIdx.x / bpi;
@@ -310,34 +321,28 @@ __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
   const int t0 = tile * HOWN;                    // first owned stage
   const bool live_wave = t0 < a.T;
   const int tend = live_wave ? min(t0 + HOWN, a.T) : 0;  // one past the last owned stage
-  const int h0 = live_wave ? a.hoff[t0] : 0;
-  const int hlen = live_wave ? a.hoff[tend] - h0 : 0;
-  for (int i = lane; i < hlen; i += WAVE) s_o[i] = 0.0;
-  __syncthreads();
   const int s = t0 - 1 + lane;                   // this lane's stage (lane 0 is the halo)
   const bool live = live_wave && (s >= 0) && (s < tend);
   const bool own = live && (s >= t0);
   const double* mu = a.mu + b * a.ldmu;
   const int kind = live ? a.kind[s] : -1;
-  // values of dyn(s) that land in the rows of stage s+1 are kept in registers across the barrier
+  // ---- evaluate: all Hessian nonzeros of this lane's stage stay in registers
   arr<M::MAX_DYN_NH> hv;
-  int nh_dyn = 0;
+  arr<M::MAX_COST_NH> cv;
+  arr<M::MAX_CON_NH> kv;
   if (live) {
     dispatch_kind<M>(kind, [&](auto kc) {
       using KD = typename M::template Kind<decltype(kc)::value>;
       const double* zs = a.z + b * a.ldz + a.zoff[s];  // direct reads: contiguous per lane, L1-served overlap
       const double* wp = a.w + b * a.ldw + a.woff[s];
-      const int base = a.hoff[s] - h0;
-      const int* mrow = nullptr;
       if constexpr (M::template Cost<KD::COST>::NH > 0) {
         using C = typename M::template Cost<KD::COST>;
         if (own) {
           arr<C::NX> x; arr<C::NU> u; arr<C::NW> w; arr<C::NH> o;
           gmem_load(x, zs); gmem_load(u, zs + C::NX); gmem_load(w, wp);
           C::hess(x.data(), u.data(), w.data(), o.data());
-          mrow = a.hmap_cost + decltype(kc)::value * a.hmap_stride;
 #pragma unroll
-          for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += a.sigma * o[i];
+          for (int i = 0; i < C::NH; ++i) cv[i] = a.sigma * o[i];
         }
       }
       if constexpr (KD::DYN >= 0) {
@@ -347,17 +352,8 @@ __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
           gmem_load(x, zs); gmem_load(u, zs + D::NX); gmem_load(y, zs + D::NX + D::NU);
           gmem_load(w, wp); gmem_load(lam, mu + a.cdoff[s]);
           D::hess(x.data(), u.data(), y.data(), w.data(), lam.data(), o.data());
-          nh_dyn = D::NH;
 #pragma unroll
           for (int i = 0; i < D::NH; ++i) hv[i] = o[i];
-          if (own) {
-            mrow = a.hmap_dyn_own + decltype(kc)::value * a.hmap_stride;
-#pragma unroll
-            for (int i = 0; i < D::NH; ++i) {
-              const int m = mrow[i];
-              if (m >= 0) s_o[base + m] += o[i];
-            }
-          }
         }
       }
       if constexpr (KD::CON >= 0) {
@@ -368,29 +364,80 @@ __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
             gmem_load(x, zs); gmem_load(u, zs + C::NX); gmem_load(w, wp);
             gmem_load(lam, mu + a.ccoff[s]);
             C::hess(x.data(), u.data(), w.data(), lam.data(), o.data());
-            mrow = a.hmap_con + decltype(kc)::value * a.hmap_stride;
 #pragma unroll
-            for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += o[i];
+            for (int i = 0; i < C::NH; ++i) kv[i] = o[i];
           }
         }
       }
     });
   }
-  __syncthreads();
-  // phase B: yy (and y-row) entries of dyn(s) go to the rows of stage s+1 (owned by lane+1)
-  if (live && nh_dyn > 0 && s + 1 < tend) {
-    const int base = a.hoff[s + 1] - h0;
-    const int* mrow = a.hmap_dyn_next + a.kind[s + 1] * a.hmap_stride;
+  // ---- deposit and stream out, HHALF stages at a time.  Per slot: dynamics (store), cost, constraint (own lane, program
+  //      order), then the previous stage's y-rows (after the barrier).
+  for (int half = 0; half < (HOWN + HHALF - 1) / HHALF; ++half) {
+    const int ta = t0 + half * HHALF;                        // stages [ta, tb) are in this image
+    const bool live_half = live_wave && ta < tend;
+    const int tb = live_half ? min(ta + HHALF, tend) : ta;
+    const int h0 = live_half ? a.hoff[ta] : 0;
+    const int hlen = live_half ? a.hoff[tb] - h0 : 0;
+    for (int i = lane; i < hlen; i += WAVE) s_o[i] = 0.0;
+    __syncthreads();
+    if (own && s >= ta && s < tb) {
+      dispatch_kind<M>(kind, [&](auto kc) {
+        using KD = typename M::template Kind<decltype(kc)::value>;
+        const int base = a.hoff[s] - h0;
+        if constexpr (KD::DYN >= 0) {
+          using D = typename M::template Dyn<KD::DYN>;
+          if constexpr (D::NH > 0) {
+            const int* mrow = a.hmap_dyn_own + decltype(kc)::value * a.hmap_stride;
+            int mo[D::NH];
 #pragma unroll
-    for (int i = 0; i < M::MAX_DYN_NH; ++i) {
-      if (i < nh_dyn) {
-        const int m = mrow[i];
-        if (m >= 0) s_o[base + m] += hv[i];
-      }
+            for (int i = 0; i < D::NH; ++i) mo[i] = mrow[i];
+#pragma unroll
+            for (int i = 0; i < D::NH; ++i) s_o[mo[i] >= 0 ? base + mo[i] : trash] = hv[i];
+          }
+        }
+        if constexpr (M::template Cost<KD::COST>::NH > 0) {
+          using C = typename M::template Cost<KD::COST>;
+          const int* mrow = a.hmap_cost + decltype(kc)::value * a.hmap_stride;
+#pragma unroll
+          for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += cv[i];
+        }
+        if constexpr (KD::CON >= 0) {
+          using C = typename M::template Con<KD::CON>;
+          if constexpr (C::NH > 0) {
+            const int* mrow = a.hmap_con + decltype(kc)::value * a.hmap_stride;
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i) s_o[base + mrow[i]] += kv[i];
+          }
+        }
+      });
     }
+    __syncthreads();
+    // yy (and y-row) entries of dyn(s) go to the rows of stage s+1 (owned by lane+1, possibly in the next image)
+    if (live && s + 1 >= ta && s + 1 < tb) {
+      dispatch_kind<M>(kind, [&](auto kc) {
+        using KD = typename M::template Kind<decltype(kc)::value>;
+        if constexpr (KD::DYN >= 0) {
+          using D = typename M::template Dyn<KD::DYN>;
+          if constexpr (D::NH > 0) {
+            const int base = a.hoff[s + 1] - h0;
+            const int* mrow = a.hmap_dyn_next + a.kind[s + 1] * a.hmap_stride;
+            int mo[D::NH];
+#pragma unroll
+            for (int i = 0; i < D::NH; ++i) mo[i] = mrow[i];
+            double cur[D::NH];
+#pragma unroll
+            for (int i = 0; i < D::NH; ++i) cur[i] = s_o[mo[i] >= 0 ? base + mo[i] : trash];
+#pragma unroll
+            for (int i = 0; i < D::NH; ++i) s_o[mo[i] >= 0 ? base + mo[i] : trash] = cur[i] + hv[i];
+          }
+        }
+      });
+    }
+    __syncthreads();
+    if (live_half) wave_store_image(a.out + b * a.ldout + h0, s_o, hlen, lane);
+    __syncthreads();
   }
-  __syncthreads();
-  if (live_wave) wave_store_image(a.out + b * a.ldout + h0, s_o, hlen, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
