@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=8192, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-blocks", action="store_true", help="skip the configs[4] (dense 129x129 blocks) side measurement")
