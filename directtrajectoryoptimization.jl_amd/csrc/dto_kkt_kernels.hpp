@@ -215,6 +215,27 @@ int kkt_info(dto_kkt_info* out) {
   return 0;
 }
 
+// Everything a stage needs to treat its variable bounds, requested in ONE batch of independent loads before any of it
+// is used.  Written the obvious way (load lo/hi, branch, then load the multipliers inside the branch) every variable
+// costs two dependent memory round trips, and with one wavefront per SIMD those waits were most of the sweep time
+// (SQ_WAIT_ANY 65 % of the wave cycles).  The bound multipliers are only touched when the problem has finite bounds.
+template <int NP>
+struct StageBounds {
+  double lo[NP > 0 ? NP : 1], hi[NP > 0 ? NP : 1], p[NP > 0 ? NP : 1], zl[NP > 0 ? NP : 1], zu[NP > 0 ? NP : 1];
+};
+template <int NP>
+__device__ __forceinline__ void load_stage_bounds(const dto_kkt_args& a, int64_t g, int z0, StageBounds<NP>& b) {
+  const bool duals = a.n_bnd > 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    b.lo[i] = a.lo[z0 + i];
+    b.hi[i] = a.hi[z0 + i];
+    b.p[i] = duals ? *soa(a.z, g, a.Nz, z0 + i) : 0.0;
+    b.zl[i] = duals ? *soa(a.zl, g, a.Nz, z0 + i) : 0.0;
+    b.zu[i] = duals ? *soa(a.zu, g, a.Nz, z0 + i) : 0.0;
+  }
+}
+
 // wave-uniform kind dispatch (all lanes of a tile are at the same stage)
 template <class M, int K = 0, class F>
 __device__ __forceinline__ void dispatch_uniform(int kind, F&& f) {
@@ -567,14 +588,16 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
 #pragma unroll
       for (int i = 0; i < NBQ; ++i) put(D::R_B + i, B[i]);
     }
+    StageBounds<D::NP> sb;
+    load_stage_bounds<D::NP>(a, g, z0, sb);
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
       put(D::R_RP + i, rp[i]);
-      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      const double lo = sb.lo[i], hi = sb.hi[i];
       if (o.newton_only) {
         dinf = fmax(dinf, fabs(rp[i]));
       } else if (lo != hi) {
-        const double zl = *soa(a.zl, g, a.Nz, z0 + i), zu = *soa(a.zu, g, a.Nz, z0 + i);
+        const double zl = sb.zl[i], zu = sb.zu[i];
         dinf = fmax(dinf, fabs(rp[i] - zl + zu));
         if (finite_lo(lo)) {
           compl0 = fmax(compl0, (p[i] - lo) * zl);
@@ -762,23 +785,43 @@ struct Spike {
 };
 
 // Build the stage block S_t (with the carry-in P_t, py and, in chunks p >= 1, the spike coupling Cx), factorise
+template <class M, int K = 0>
+constexpr int max_rec() {
+  if constexpr (K >= M::N_KIND) return 2;
+  else return KindDims<M, K>::REC > max_rec<M, K + 1>() ? KindDims<M, K>::REC : max_rec<M, K + 1>();
+}
+template <class M>
+constexpr int rec_lds_doubles() { return ((max_rec<M>() + 1) / 2) * 2 * 64; }
+
+// The sweeps run one wavefront per SIMD (they need > 256 registers), so nothing but the wave itself can hide HBM
+// latency.  The structural record of the NEXT stage is therefore copied global -> LDS by the DMA path
+// (global_load_lds_dwordx4: no destination registers) while the current stage is being factorised, and read from LDS
+// when its turn comes.  The record of a (tile, stage) is `rows` consecutive 512-byte rows, so the copy is linear:
+// one wave instruction moves two rows.  Rows are rounded up to an even count (the buffer is padded by one row).
+__device__ __forceinline__ void record_dma(const dto_kkt_args& a, int64_t g, int t, double* lds) {
+  const int rows = (int)(a.recoff[t + 1] - a.recoff[t]);
+  const double* src = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + 2 * threadIdx.x;
+  for (int k = 0; k < rows; k += 2)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((int64_t)k << 6)),
+                                     (__attribute__((address_space(3))) void*)(lds + (k << 6)), 16, 0, 0);
+}
+__device__ __forceinline__ void record_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // it and run the forward substitutions.  On return S holds L (strict lower), dinv = 1/D, X = L^-1 O, y = w,
 // Z = L^-1 C.  Used by BOTH sweeps: the backward sweep recomputes instead of reading stored factors.
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
                                              bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
                                              double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
-                                             bool& ok, int& nneg) {
+                                             bool& ok, int& nneg, double* s_rec, int t_prefetch, double* keep) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
-  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
-  // the whole structural record of the stage is requested up front (all loads in flight at once: with one
-  // wave per SIMD nothing else hides HBM latency), then consumed from registers
-  double rr[D::REC > 0 ? D::REC : 1];
-#pragma unroll
-  for (int i = 0; i < D::REC; ++i) rr[i] = rec[(int64_t)i << 6];
-  auto R = [&](int e) { return rr[e]; };
+  // the structural record of this stage is in LDS (record_dma); every read of it happens before the factorisation
+  // starts, where the copy of the next stage's record is launched into the same buffer
+  const double* recl = s_rec + threadIdx.x;
+  auto R = [&](int e) { return recl[e << 6]; };
   const int z0 = a.zoff[t];
 
   using KD = typename D::KD;
@@ -860,24 +903,26 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     for (int j = 0; j <= i; ++j) S[tri(i, j)] += cy.P[tri(i, j)];
   }
   bool fixed[NP > 0 ? NP : 1];
+  StageBounds<NP> sb;
+  if (!o.newton_only) load_stage_bounds<NP>(a, g, z0, sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double rp = R(D::R_RP + i);
     double sig = dw;
     fixed[i] = false;
     if (!o.newton_only) {
-      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo == hi) {
         fixed[i] = true;
       } else {
-        const double p = *soa(a.z, g, a.Nz, z0 + i);
+        const double p = sb.p[i];
         if (finite_lo(lo)) {
-          const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+          const double zl = sb.zl[i];
           sig += zl / (p - lo);
           rp -= mu / (p - lo);
         }
         if (finite_hi(hi)) {
-          const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+          const double zu = sb.zu[i];
           sig += zu / (hi - p);
           rp += mu / (hi - p);
         }
@@ -965,6 +1010,17 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
       }
     }
   }
+  // values of the record the backward sweep still needs after the factorisation: residuals r_p, c, d
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) keep[i] = R(D::R_RP + i);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) keep[NP + j] = R(D::R_C + j);
+#pragma unroll
+    for (int k = 0; k < NY; ++k) keep[NP + Q + k] = R(D::R_D + k);
+  }
+  lds_reads_done();
+  if (t_prefetch >= 0) record_dma(a, g, t_prefetch, s_rec);
   // --- factor
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
   // --- X = L^-1 O, w = L^-1 y, Z = L^-1 C
@@ -987,7 +1043,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
                                               double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
-                                              bool& ok, int& nneg) {
+                                              bool& ok, int& nneg, double* s_rec, int t_prefetch) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   double S[BD * (BD + 1) / 2];
@@ -1009,36 +1065,50 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       for (int i = 0; i < NX * NX; ++i) fac[(int64_t)(D::F_CX + i) << 6] = sp.Cx[i];
     }
   }
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg);
-  // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, s_rec, t_prefetch,
+                          nullptr);
+  // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w   (D^-1 X and D^-1 Z are formed once: the sweep is
+  //     bound by dependent f64 arithmetic, not by memory)
+  double XD[BD * (NY > 0 ? NY : 1)];
+#pragma unroll
+  for (int i = 0; i < BD; ++i) {
+#pragma unroll
+    for (int c = 0; c < NY; ++c) XD[i * NY + c] = X[i * NY + c] * dinv[i];
+  }
 #pragma unroll
   for (int c = 0; c < NY; ++c) {
 #pragma unroll
     for (int e = 0; e <= c; ++e) {
       double acc = YYl[tri(c, e)];
 #pragma unroll
-      for (int i = 0; i < BD; ++i) acc -= X[i * NY + c] * X[i * NY + e] * dinv[i];
+      for (int i = 0; i < BD; ++i) acc -= XD[i * NY + c] * X[i * NY + e];
       cy.P[tri(c, e)] = acc;
     }
     double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < BD; ++i) acc += X[i * NY + c] * dinv[i] * y[i];
+    for (int i = 0; i < BD; ++i) acc += XD[i * NY + c] * y[i];
     cy.py[c] = acc;
   }
   if constexpr (SPK) {
     // separator contributions and the coupling handed to the next stage's x rows
+    double ZD[BD * NX];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) ZD[i * NX + c] = Z[i * NX + c] * dinv[i];
+    }
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
 #pragma unroll
       for (int e = 0; e <= c; ++e) {
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < BD; ++i) acc += Z[i * NX + c] * Z[i * NX + e] * dinv[i];
+        for (int i = 0; i < BD; ++i) acc += ZD[i * NX + c] * Z[i * NX + e];
         sp.RLL[tri(c, e)] -= acc;
       }
       double acc = 0.0;
 #pragma unroll
-      for (int i = 0; i < BD; ++i) acc += Z[i * NX + c] * dinv[i] * y[i];
+      for (int i = 0; i < BD; ++i) acc += ZD[i * NX + c] * y[i];
       sp.rL[c] -= acc;
     }
 #pragma unroll
@@ -1047,7 +1117,7 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       for (int c = 0; c < NX; ++c) {
         double acc = cx_direct[aa * NX + c];
 #pragma unroll
-        for (int i = 0; i < BD; ++i) acc -= X[i * NY + aa] * dinv[i] * Z[i * NX + c];
+        for (int i = 0; i < BD; ++i) acc -= XD[i * NY + aa] * Z[i * NX + c];
         sp.Cx[aa * NX + c] = acc;
       }
     }
@@ -1074,18 +1144,22 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
   for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
   bool ok = true;
   int nneg = 0;
-  if (p == 0) {
-    for (int t = t0; t < t1; ++t)
+  __shared__ __attribute__((aligned(16))) double s_rec[rec_lds_doubles<M>()];
+  record_dma(a, g, t0, s_rec);
+  for (int t = t0; t < t1; ++t) {
+    const int tp = (t + 1 < t1) ? t + 1 : -1;
+    record_wait();
+    if (p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg, s_rec, tp);
       });
-  } else {
-    for (int t = t0; t < t1; ++t)
+    } else {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
+          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg, s_rec, tp);
       });
+    }
   }
   if (!need) return;
   using CS = ChunkSum<M>;
@@ -1290,13 +1364,14 @@ struct StepAcc {
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
                                                double dw, double gam, bool first, const double* xL, double* xn,
-                                               StepAcc& acc) {
+                                               StepAcc& acc, double* s_rec, int t_prefetch) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
-  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
   const double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
-  auto R = [&](int e) { return rec[(int64_t)e << 6]; };
+  // residuals of the record, copied to registers by stage_factor before the LDS buffer is handed to the next stage
+  double keep[BD];
+  auto R = [&](int e) { return e >= D::R_C ? keep[NP + (e - D::R_C)] : (e >= D::R_D ? keep[NP + Q + (e - D::R_D)] : keep[e - D::R_RP]); };
   // --- rebuild this stage's factorisation from its record and the stored carry-in
   Carry<M> cy;
   Spike<M> sp;
@@ -1317,7 +1392,8 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   double dinv[BD];
   bool ok_unused = true;
   int nneg_unused = 0;
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused);
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, s_rec,
+                          t_prefetch, keep);
   double v[BD];
 #pragma unroll
   for (int i = 0; i < BD; ++i) {
@@ -1343,17 +1419,19 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   }
   const int z0 = a.zoff[t];
   // primal step, fraction to the boundary, barrier directional derivative
+  StageBounds<NP> sb;
+  if (!o.newton_only) load_stage_bounds<NP>(a, g, z0, sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const double dp = v[i];
     *soa(a.dz, g, a.Nz, z0 + i) = dp;
     acc.gphid += R(D::R_RP + i) * dp;
     if (!o.newton_only) {
-      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo != hi) {
-        const double p = *soa(a.z, g, a.Nz, z0 + i);
+        const double p = sb.p[i];
         if (finite_lo(lo)) {
-          const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+          const double zl = sb.zl[i];
           const double gap = p - lo;
           const double dzl = mu / gap - zl - (zl / gap) * dp;
           if (dp < 0.0) acc.apmax = fmin(acc.apmax, -tau * gap / dp);
@@ -1361,7 +1439,7 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
           acc.gphid -= mu / gap * dp;
         }
         if (finite_hi(hi)) {
-          const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+          const double zu = sb.zu[i];
           const double gap = hi - p;
           const double dzu = mu / gap - zu + (zu / gap) * dp;
           if (dp > 0.0) acc.apmax = fmin(acc.apmax, tau * gap / dp);
@@ -1425,17 +1503,21 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
     xn[i] = (p < a.P - 1) ? a.xsep[(((g * a.P + p + 1) * N + i) << 6) + threadIdx.x] : 0.0;
   }
   StepAcc acc{1.0, 1.0, 0.0, 0.0};
-  if (p == 0) {
-    for (int t = t1 - 1; t >= t0; --t)
+  __shared__ __attribute__((aligned(16))) double s_rec[rec_lds_doubles<M>()];
+  record_dma(a, g, t1 - 1, s_rec);
+  for (int t = t1 - 1; t >= t0; --t) {
+    const int tp = (t - 1 >= t0) ? t - 1 : -1;
+    record_wait();
+    if (p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
+        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc, s_rec, tp);
       });
-  } else {
-    for (int t = t1 - 1; t >= t0; --t)
+    } else {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc);
+          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc, s_rec, tp);
       });
+    }
   }
   double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
   ca[0 << 6] = acc.apmax;
@@ -1494,6 +1576,9 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
     arr<CO::NW> w;
     gmem_load(w, a.params + a.woff[t]);
     double* out = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
+    double blo[D::NP > 0 ? D::NP : 1], bhi[D::NP > 0 ? D::NP : 1];  // bounds: loaded once, not once per trial
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) { blo[i] = a.lo[z0 + i]; bhi[i] = a.hi[z0 + i]; }
     double alpha = amax;
 #pragma unroll 1
     for (int k = 0; k < DTO_LS_TRIALS; ++k) {
@@ -1509,7 +1594,7 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
       if (!o.newton_only) {
 #pragma unroll
         for (int i = 0; i < D::NP; ++i) {
-          const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+          const double lo = blo[i], hi = bhi[i];
           if (lo != hi) {
             if (finite_lo(lo)) phi -= mu * log(pk[i] - lo);
             if (finite_hi(hi)) phi -= mu * log(hi - pk[i]);
@@ -1648,16 +1733,24 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
     using D = KindDims<M, K>;
     if (!running) return;
     const int z0 = a.zoff[t];
+    StageBounds<D::NP> sb;
+    load_stage_bounds<D::NP>(a, g, z0, sb);
+    double dpv[D::NP > 0 ? D::NP : 1], pv[D::NP > 0 ? D::NP : 1];
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
-      const double p = *soa(a.z, g, a.Nz, z0 + i);
-      const double dp = *soa(a.dz, g, a.Nz, z0 + i);
+      pv[i] = *soa(a.z, g, a.Nz, z0 + i);
+      dpv[i] = *soa(a.dz, g, a.Nz, z0 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      const double p = pv[i];
+      const double dp = dpv[i];
       const double pn = p + al * dp;
       if (!o.newton_only) {
-        const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+        const double lo = sb.lo[i], hi = sb.hi[i];
         if (lo != hi) {
           if (finite_lo(lo)) {
-            const double zl = *soa(a.zl, g, a.Nz, z0 + i);
+            const double zl = sb.zl[i];
             const double gap = p - lo;
             const double dzl = mu / gap - zl - (zl / gap) * dp;
             double zn = zl + ad * dzl;
@@ -1666,7 +1759,7 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
             *soa(a.zl, g, a.Nz, z0 + i) = zn;
           }
           if (finite_hi(hi)) {
-            const double zu = *soa(a.zu, g, a.Nz, z0 + i);
+            const double zu = sb.zu[i];
             const double gap = hi - p;
             const double dzu = mu / gap - zu + (zu / gap) * dp;
             double zn = zu + ad * dzu;
