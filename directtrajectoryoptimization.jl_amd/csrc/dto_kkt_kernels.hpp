@@ -105,6 +105,7 @@ struct dto_kkt_args {
   int P;               // chunks of the time-partitioned factorisation
   const int* cstart;   // [P+1] first stage of every chunk
   double* csum; double* sfac; double* xsep; double* cacc;  // chunk summaries, separator factors/solutions, step partials
+  long long* prof;  // debug: cycle stamps of workgroup 0 (tools/kkt_profile.py), NULL otherwise
   double* cpart;       // [G][P][16][64] chunk-level partial reductions (k_part_reduce)
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
@@ -822,6 +823,8 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   // starts, where the copy of the next stage's record is launched into the same buffer
   const double* recl = s_rec + threadIdx.x;
   auto R = [&](int e) { return recl[e << 6]; };
+  long long tq_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
+#define DTO_KKT_TICK(slot) do { if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { const long long n_ = clock64(); a.prof[slot] += n_ - tq_; tq_ = n_; } } while (0)
   const int z0 = a.zoff[t];
 
   using KD = typename D::KD;
@@ -1019,10 +1022,14 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 #pragma unroll
     for (int k = 0; k < NY; ++k) keep[NP + Q + k] = R(D::R_D + k);
   }
+  DTO_KKT_TICK(1);
   lds_reads_done();
+  DTO_KKT_TICK(2);
   if (t_prefetch >= 0) record_dma(a, g, t_prefetch, s_rec);
+  DTO_KKT_TICK(3);
   // --- factor
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
+  DTO_KKT_TICK(4);
   // --- X = L^-1 O, w = L^-1 y, Z = L^-1 C
 #pragma unroll
   for (int i = 1; i < BD; ++i) {
@@ -1038,6 +1045,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
       }
     }
   }
+  DTO_KKT_TICK(5);
 }
 
 template <class M, int K, bool SPK>
@@ -1148,7 +1156,9 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
   record_dma(a, g, t0, s_rec);
   for (int t = t0; t < t1; ++t) {
     const int tp = (t + 1 < t1) ? t + 1 : -1;
+    long long tw_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
     record_wait();
+    if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { a.prof[0] += clock64() - tw_; a.prof[7] += 1; }
     if (p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg, s_rec, tp);
