@@ -242,6 +242,30 @@ def test_full_size_properties(model, T):
     assert np.max(np.abs(H - (1.3 * H10 + H0m))) <= 1e-10 * max(1.0, np.max(np.abs(H)))
 
 
+@pytest.mark.parametrize("model,T", [("acrobot", 1000), ("cartpole", 200), ("car", 500)])
+def test_full_size_sampled_stages_against_oracle(model, T):
+    """BASELINE sizes: the dynamics rows and Jacobian slots of sampled stages (first, last, and the stages around the 64-knot
+    wavefront tiles and the 63-stage Hessian tiles) equal the oracle's per-stage functions evaluated at that stage's
+    (x_t, u_t, x_{t+1}) -- ties the full-size outputs to the oracle without evaluating the whole oracle problem."""
+    from oracle import sympy_models as S
+    s, _ = product_solver(model, T)
+    n = s.nlp
+    op = S.build(model, 3, evaluate_hessian=True)
+    od = op["dynamics"][0]
+    rng = np.random.default_rng(17)
+    z, mu = rng.random(n.num_variables), rng.random(n.num_constraint)
+    c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
+    J = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(J, z)
+    idx = n.indices
+    stages = sorted({0, 1, 62, 63, 64, 65, 125, 126, 127, 128, T // 2, T - 3, T - 2} & set(range(T - 1)))
+    for t in stages:
+        x = z[np.array(idx.states[t]) - 1]
+        u = z[np.array(idx.actions[t]) - 1]
+        y = z[np.array(idx.states[t + 1]) - 1]
+        close(c[np.array(idx.dynamics_constraints[t]) - 1], od.evaluate(list(y), list(x), list(u), []))
+        close(J[np.array(idx.dynamics_jacobians[t]) - 1], od.jacobian(list(y), list(x), list(u), []))
+
+
 def test_ragged_and_tiny_horizons():
     """T not a multiple of the wave width, T smaller than a wave, T = 2; plus the 63-stage Hessian tiling edge."""
     from oracle import dto_oracle as O, sympy_models as S
