@@ -97,6 +97,8 @@ struct dto_kkt_args {
   int64_t rec_total, fac_total;
   const double* lo; const double* hi;  // [Nz] shared variable bounds
   const double* params;                // shared parameters
+  const double* wtile;                 // per-instance parameters as SoA tiles [G][Nw][64], or NULL (then `params` is used)
+  int64_t Nw;
   // SoA state, doubles
   double* z; double* lam; double* zl; double* zu; double* s; double* zs;
   double* dz; double* dlam; double* ds;
@@ -216,6 +218,19 @@ int kkt_info(dto_kkt_info* out) {
   return 0;
 }
 
+// parameters w_t of stage t: shared by all instances (the reference's one `parameters` vector, src/solver.jl:10), or one
+// set per instance (dto_batch.params: MPC rollouts that differ in initial state / target)
+template <int N>
+__device__ __forceinline__ void load_params(arr<N>& w, const dto_kkt_args& a, int64_t g, int t) {
+  if (a.wtile) {
+    const double* src = a.wtile + ((g * a.Nw + a.woff[t]) << 6) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = src[(int64_t)i << 6];
+  } else {
+    gmem_load(w, a.params + a.woff[t]);
+  }
+}
+
 // Everything a stage needs to treat its variable bounds, requested in ONE batch of independent loads before any of it
 // is used.  Written the obvious way (load lo/hi, branch, then load the multipliers inside the branch) every variable
 // costs two dependent memory round trips, and with one wavefront per SIMD those waits were most of the sweep time
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
       if (!o.newton_only) {
       using C = typename M::template Con<KD::CON>;
       arr<C::NW> w; arr<C::NC> c;
-      gmem_load(w, a.params + a.woff[t]);
+      load_params(w, a, g, t);
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) p[i] = *soa(a.z, g, a.Nz, z0 + i);
     arr<CO::NW> wc;
-    gmem_load(wc, a.params + a.woff[t]);
+    load_params(wc, a, g, t);
 
     // quasi-Newton mode: last iteration's Jacobian nonzeros (still in the record) for the secant pair
     double qn_old_dj[D::QN && D::N_DJ > 0 ? D::N_DJ : 1], qn_old_kj[D::QN && D::N_KJ > 0 ? D::N_KJ : 1];
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       using DY = typename M::template Dyn<KD::DYN>;
       arr<DY::NY> y, lam, d;
       arr<DY::NW> w;
-      gmem_load(w, a.params + a.woff[t]);
+      load_params(w, a, g, t);
 #pragma unroll
       for (int i = 0; i < DY::NY; ++i) {
         y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     if constexpr (KD::CON >= 0) {
       using C = typename M::template Con<KD::CON>;
       arr<C::NW> w; arr<C::NC> c, nu; arr<C::NJ> jv;
-      gmem_load(w, a.params + a.woff[t]);
+      load_params(w, a, g, t);
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     if constexpr (KD::PREV >= 0) {
       using DP = typename M::template Dyn<KD::PREV>;
       arr<DP::NX + DP::NU> pp; arr<DP::NY> lamp; arr<DP::NW> w; arr<DP::NJ> jv;
-      gmem_load(w, a.params + a.woff[t - 1]);
+      load_params(w, a, g, t - 1);
 #pragma unroll
       for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = *soa(a.z, g, a.Nz, a.zoff[t - 1] + i);
 #pragma unroll
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       if constexpr (KD::DYN >= 0) {
         using DY = typename M::template Dyn<KD::DYN>;
         arr<DY::NY> y, lam; arr<DY::NW> w; arr<DY::NJ> jn, jo;
-        gmem_load(w, a.params + a.woff[t]);
+        load_params(w, a, g, t);
 #pragma unroll
         for (int i = 0; i < DY::NY; ++i) {
           y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       if constexpr (KD::CON >= 0) {
         using C = typename M::template Con<KD::CON>;
         arr<C::NW> w; arr<C::NC> nu; arr<C::NJ> jn, jo;
-        gmem_load(w, a.params + a.woff[t]);
+        load_params(w, a, g, t);
 #pragma unroll
         for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
         C::jac(p.data(), p.data() + C::NX, w.data(), jn.data());
@@ -822,7 +837,11 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   // the structural record of this stage is in LDS (record_dma); every read of it happens before the factorisation
   // starts, where the copy of the next stage's record is launched into the same buffer
   const double* recl = s_rec + threadIdx.x;
-  auto R = [&](int e) { return recl[e << 6]; };
+  // all rows at once (one LDS latency), then consumed from registers by the literal-index scatter code below
+  double rr[D::REC > 0 ? D::REC : 1];
+#pragma unroll
+  for (int i = 0; i < D::REC; ++i) rr[i] = recl[i << 6];
+  auto R = [&](int e) { return rr[e]; };
   long long tq_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
 #define DTO_KKT_TICK(slot) do { if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { const long long n_ = clock64(); a.prof[slot] += n_ - tq_; tq_ = n_; } } while (0)
   const int z0 = a.zoff[t];
@@ -1584,7 +1603,7 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
       dy[i] = *soa(a.dz, g, a.Nz, a.zoff[t + 1] + i);
     }
     arr<CO::NW> w;
-    gmem_load(w, a.params + a.woff[t]);
+    load_params(w, a, g, t);
     double* out = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
     double blo[D::NP > 0 ? D::NP : 1], bhi[D::NP > 0 ? D::NP : 1];  // bounds: loaded once, not once per trial
 #pragma unroll
@@ -1828,6 +1847,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
           case 1: n = a.Nc; buf = a.lam; break;
           case 2: n = a.Nz; buf = a.dz; break;
           case 3: n = a.Nc; buf = a.dlam; break;
+          case 4: n = a.Nw; buf = const_cast<double*>(a.wtile); break;
           default: return -1;
         }
         if (n == 0) break;

@@ -29,6 +29,8 @@ struct SolverState {
   int64_t B = 0;
   int G = 0;
   int64_t Ni = 0, rec_total = 0, fac_total = 0, n_bnd = 0;
+  double* wtile = nullptr;      // per-instance parameters (SoA tiles), allocated on first use
+  bool use_wtile = false;
   std::vector<int> ioff;
   std::vector<int64_t> recoff, facoff;
   int* d_ioff = nullptr;
@@ -53,11 +55,11 @@ struct SolverState {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
-                    (void*)cacc, (void*)cpart, (void*)d_cstart})
+                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr;
+    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; wtile = nullptr; use_wtile = false;
     B = 0; G = 0;
   }
 };
@@ -224,6 +226,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.ioff = S.d_ioff; a.recoff = S.d_recoff; a.facoff = S.d_facoff;
   a.rec_total = S.rec_total; a.fac_total = S.fac_total;
   a.lo = S.d_lo; a.hi = S.d_hi; a.params = p->d_params;
+  a.wtile = S.use_wtile ? S.wtile : nullptr; a.Nw = L.Nw;
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
@@ -246,6 +249,22 @@ static int pack(Problem* p, dto_kkt_args a, int which, const double* src, int64_
 static int unpack(Problem* p, dto_kkt_args a, int which, double* dst, int64_t ld, hipStream_t st) {
   a.aos_out = dst; a.ld_aos = ld; a.aos_which = which;
   return kkt_launch(p, DTO_KKT_UNPACK, a, st);
+}
+
+// per-instance parameters of a batch: packed into SoA tiles next to the iterates (NULL: the problem's shared parameters)
+static int set_batch_params(Problem* p, const dto_batch* b, hipStream_t st) {
+  SolverState& S = *p->solver;
+  S.use_wtile = false;
+  if (!b->params || p->L.Nw == 0) return DTO_OK;
+  if (b->ldp < p->L.Nw) return set_error(DTO_ERR_INVALID, "ldp < num_parameters");
+  if (!S.wtile) {
+    int rc = dev_alloc(&S.wtile, (size_t)S.G * 64 * (size_t)p->L.Nw);
+    if (rc) return rc;
+  }
+  S.use_wtile = true;
+  dto_kkt_args a;
+  fill_kkt_args(p, a);
+  return pack(p, a, 4, b->params, b->ldp, st);
 }
 
 static int fetch_scalars(Problem* p, hipStream_t st) {
@@ -279,12 +298,15 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
                        double delta_c, double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !b || !b->x || !mu || !dx || !dmu) return set_error(DTO_ERR_INVALID, "null argument");
-  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported on the KKT path yet");
   if (b->ldx < p->L.Nz || ldmu < p->L.Nc || lddx < p->L.Nz || lddmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
-  if (p->vt->launch_wide) return dto::wide_step(p, b, mu, ldmu, delta_w, delta_c, dx, lddx, dmu, lddmu, inertia_ok);
+  if (p->vt->launch_wide) {
+    if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
+    return dto::wide_step(p, b, mu, ldmu, delta_w, delta_c, dx, lddx, dmu, lddmu, inertia_ok);
+  }
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
+  if ((rc = dto::set_batch_params(p, b, (hipStream_t)b->stream))) return rc;
   dto_options u;
   dto_options_default(&u);
   u.delta_c = delta_c;
@@ -318,11 +340,11 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
 int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !b || !b->x) return set_error(DTO_ERR_INVALID, "null argument");
-  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported on the KKT path yet");
   if (b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
+  if ((rc = dto::set_batch_params(p, b, (hipStream_t)b->stream))) return rc;
   dto_options u;
   if (opt) u = *opt; else dto_options_default(&u);
   S.user = u;

@@ -25,6 +25,7 @@ def all_structures():
         ("ref_general", P.build_ref_general, dict(user_jacobian=True)),
         ("param_pendulum", P.build_param_pendulum, dict(T=8)),
         ("ref_userjac", P.build_ref_userjac, {}),
+        ("mpc_pendulum", P.build_mpc_pendulum, dict(T=5)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=3)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=2)),
     ]:

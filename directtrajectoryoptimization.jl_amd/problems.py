@@ -403,3 +403,20 @@ def build_param_pendulum(T=8):
     params = [np.array([1.0 + 0.5 * rng.random(), 3.0 * rng.random()]) for _ in range(T)]
     return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[con] * (T - 1) + [conT],
                 bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], parameters=params, T=T, n=n, m=m, evaluate_hessian=True)
+
+
+def build_mpc_pendulum(T=30, x1=(0.0, 0.0), goal=PI):
+    """MPC-style instance family (BASELINE north star: "independent trajectory instances (MPC rollouts ...)"): pendulum
+    swing-up whose initial state and goal angle are PARAMETERS w_t = [x1_0, x1_1, goal], so that instances of one batch can
+    differ through dto_batch.params while sharing one compiled structure."""
+    n, m, nw = 2, 1, 3
+    dt = Dynamics(lambda y, x, u, w: pendulum_midpoint(y, x, u, w), n, n, m, num_parameter=nw, evaluate_hessian=True)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x, x) + 0.1 * dot(u, u), n, m, num_parameter=nw, evaluate_hessian=True)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x, x), n, 0, num_parameter=nw, evaluate_hessian=True)
+    con1 = Constraint(lambda x, u, w: x - w[0:2], n, m, num_parameter=nw, evaluate_hessian=True)
+    conT = Constraint(lambda x, u, w: np.array([x[0] - w[2], x[1]], dtype=object), n, 0, num_parameter=nw, evaluate_hessian=True)
+    w = np.array([x1[0], x1[1], goal], dtype=float)
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT],
+                constraints=[con1] + [Constraint() for _ in range(T - 2)] + [conT],
+                bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)], parameters=[w.copy() for _ in range(T)],
+                T=T, n=n, m=m, nw=nw, evaluate_hessian=True)

@@ -326,17 +326,20 @@ class Solver:
         return self.nlp.num_variables
 
     # ---- batched device entry points (torch tensors / raw device pointers)
-    def kkt_step_batch(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, dx_ptr, lddx, dmu_ptr, lddmu, stream=0):
+    def kkt_step_batch(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, dx_ptr, lddx, dmu_ptr, lddmu, stream=0,
+                       params_ptr=0, ldp=0):
         """One regularised Newton-KKT step (include/dto.h: dto_kkt_step_batch). Returns inertia_ok."""
-        b = self._solve_nlp._batch(x_ptr, B, ldx, stream)
+        b = self._solve_nlp._batch(x_ptr, B, ldx, stream, params_ptr, ldp)
         ok = C.c_int(1)
         capi.check(self._solve_nlp._lib.dto_kkt_step_batch(self._solve_nlp._h, C.byref(b), mu_ptr, ldmu, float(delta_w), float(delta_c),
                                                     dx_ptr, lddx, dmu_ptr, lddmu, C.byref(ok)))
         return bool(ok.value)
 
-    def solve_batch(self, x0_ptr, B, ldx, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0, check_every=10):
-        """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays."""
-        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream)
+    def solve_batch(self, x0_ptr, B, ldx, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0, check_every=10,
+                    params_ptr=0, ldp=0):
+        """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays.
+        params_ptr: optional DEVICE [B][ldp] per-instance parameter vectors (flattened w_1..w_T) replacing the shared ones."""
+        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
         co = _c_options(self.options, check_every)
         self._B = B
         status = np.zeros(B, dtype=np.int32)
@@ -346,8 +349,8 @@ class Solver:
                                                  iters.ctypes.data_as(capi.c_int32_p)))
         return status, iters
 
-    def begin_batch(self, x0_ptr, B, ldx, stream=0):
-        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream)
+    def begin_batch(self, x0_ptr, B, ldx, stream=0, params_ptr=0, ldp=0):
+        b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
         co = _c_options(self.options)
         capi.check(self._solve_nlp._lib.dto_solver_begin(self._solve_nlp._h, C.byref(co), C.byref(b)))
         self._B = B

@@ -121,7 +121,8 @@ int dto_eval_h(dto_problem* p, const double* x, double sigma, const double* mu, 
 
 /* ---- batched forms: B independent instances, DEVICE pointers, asynchronous on `stream` -------
  * x: [B][ldx] (ldx >= num_variables); outputs instance-major with the given leading dimension.
- * params: NULL = the spec's parameters shared by all instances, else [B][ldp].
+ * params: NULL = the spec's parameters shared by all instances, else [B][ldp] (also honoured by the solver entry points
+ * dto_kkt_step_batch / dto_solve_batch / dto_solver_begin: one parameter set per instance, e.g. MPC rollouts).
  * These run the same kernels as above without the PCIe copies. `stream` is a hipStream_t. */
 typedef struct dto_batch {
   int64_t B;

@@ -207,3 +207,47 @@ def test_reference_user_jacobian_solve():
     assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3
     assert np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
     assert len(x_sol) == 11 and len(u_sol) == 10
+
+
+def test_per_instance_parameters_mpc_batch():
+    """dto_batch.params on the solver path: one compiled structure, every instance of the batch with its own parameters
+    (initial state and goal of an MPC rollout).  Each instance must reach ITS goal from ITS initial state, and give the
+    same solution as a solve of that instance alone with shared parameters (src/solver.jl:10 `parameters`)."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    T, B = 30, 5
+    rng = np.random.default_rng(11)
+    x1s = 0.3 * rng.standard_normal((B, 2))
+    goals = np.pi * (0.5 + 0.5 * rng.random(B))
+    p = P.build_mpc_pendulum(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=p["parameters"], name="mpc_pendulum")
+    nz, nw = s.nlp.num_variables, s.nlp.num_parameters
+    assert nw == 3 * T
+    W = np.zeros((B, nw))
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        W[b] = np.tile([x1s[b, 0], x1s[b, 1], goals[b]], T)
+        dto_amd.initialize_states(s, dto_amd.linear_interpolation(x1s[b], np.array([goals[b], 0.0]), T))
+        dto_amd.initialize_controls(s, [0.1 * rng.standard_normal(1) for _ in range(T - 1)])
+        Z[b] = s._z0
+    z0, w = torch.tensor(Z, device="cuda"), torch.tensor(W, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, params_ptr=w.data_ptr(), ldp=nw)
+    torch.cuda.synchronize()
+    zo = zo.cpu().numpy()
+    assert np.all(status == 1), (status, iters)
+    idx = s.nlp.indices
+    for b in range(B):
+        xa = zo[b][np.array(idx.states[0]) - 1]
+        xb = zo[b][np.array(idx.states[-1]) - 1]
+        assert np.linalg.norm(xa - x1s[b]) < 1e-3 and abs(xb[0] - goals[b]) < 1e-3 and abs(xb[1]) < 1e-3
+        # the same instance alone, parameters given the reference way
+        pb = P.build_mpc_pendulum(T=T, x1=x1s[b], goal=goals[b])
+        sb = dto_amd.Solver(pb["dynamics"], pb["objective"], pb["constraints"], pb["bounds"], evaluate_hessian=True,
+                            parameters=pb["parameters"], name="mpc_pendulum")
+        sb._z0[:] = Z[b]
+        assert dto_amd.solve(sb) == 1
+        assert sb.iterations == iters[b]
+        assert np.max(np.abs(sb._solution - zo[b])) <= 1e-9 * max(1.0, np.max(np.abs(zo[b])))
