@@ -49,7 +49,7 @@ class Batch(C.Structure):
 class COptions(C.Structure):
     _fields_ = [("tol", C.c_double), ("s_max", C.c_double), ("max_iter", C.c_int), ("dual_inf_tol", C.c_double),
                 ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double), ("mu_init", C.c_double),
-                ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int)]
+                ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int), ("max_cpu_time", C.c_double)]
 
 
 # enum dto_scal (csrc/dto_kkt_kernels.hpp)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -291,6 +292,7 @@ int dto_options_default(dto_options* o) {
   o->tol = 1e-6; o->s_max = 100.0; o->max_iter = 1000;
   o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-3; o->compl_inf_tol = 1e-3;
   o->mu_init = 0.1; o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->check_every = 10;
+  o->max_cpu_time = 300.0;
   return DTO_OK;
 }
 
@@ -473,6 +475,7 @@ int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, 
   hipStream_t st = (hipStream_t)b->stream;
   const int chunk = std::max(1, S.user.check_every);
   int done_iters = 0;
+  const auto t_start = std::chrono::steady_clock::now();
   // max_iter + 1 evaluations: the last one only classifies the final iterate
   while (done_iters <= S.user.max_iter) {
     const int n = std::min(chunk, S.user.max_iter + 1 - done_iters);
@@ -482,6 +485,10 @@ int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, 
     bool any = false;
     for (int64_t i = 0; i < S.B && !any; ++i) any = dto::hscal(S, i, SC_STATUS) == 0.0;
     if (!any) break;
+    // Options.max_cpu_time (src/options.jl:10): the instances still running are handed back as they are (status 0)
+    if (S.user.max_cpu_time > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time)
+      break;
   }
   if ((rc = dto_solver_end(h, x_out, ldxo, mu_out, ldmuo, (void*)st))) return rc;
   HIP_TRY(hipStreamSynchronize(st));

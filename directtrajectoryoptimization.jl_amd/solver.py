@@ -282,6 +282,7 @@ def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
     c.tol, c.s_max, c.max_iter = o.tol, o.s_max, int(o.max_iter)
     c.dual_inf_tol, c.constr_viol_tol, c.compl_inf_tol = o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol
     c.check_every = check_every
+    c.max_cpu_time = float(o.max_cpu_time)
     return c
 
 

@@ -155,6 +155,8 @@ typedef struct dto_options {
   double delta_c;           /* 1e-8  dual regularisation, examples/pendulum/pendulum.jl:195 uses 1e-5 */
   double delta_w_init;      /* 1e-4  first primal regularisation tried when the inertia is wrong */
   int check_every;          /* host polls the batch for completion every this many iterations */
+  double max_cpu_time;      /* 300   src/options.jl:10: wall-clock limit of one dto_solve[_batch] call in seconds; instances
+                               still running when it expires are returned as they are with status 0 ("cut off") */
 } dto_options;
 int dto_options_default(dto_options* o);
 

@@ -251,3 +251,21 @@ def test_per_instance_parameters_mpc_batch():
         assert dto_amd.solve(sb) == 1
         assert sb.iterations == iters[b]
         assert np.max(np.abs(sb._solution - zo[b])) <= 1e-9 * max(1.0, np.max(np.abs(zo[b])))
+
+
+def test_max_cpu_time_cuts_the_solve_off():
+    """Options.max_cpu_time (src/options.jl:10): a solve that cannot finish in time returns the running instances as they
+    are (status 0), with iterates that are still finite."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_acrobot(T=1000, evaluate_hessian=True)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       options=dto_amd.Options(max_cpu_time=0.05, max_iter=100000), name="acrobot")
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs)
+    dto_amd.initialize_controls(s, us)
+    import time
+    t0 = time.perf_counter()
+    st = dto_amd.solve(s)
+    assert st == 0 and 0 < s.iterations < 100000 and time.perf_counter() - t0 < 5.0
+    assert np.all(np.isfinite(s._solution))
