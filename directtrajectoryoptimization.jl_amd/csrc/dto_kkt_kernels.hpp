@@ -730,7 +730,10 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   } else {
     const double dlast = sc[SC_DELTA_LAST << 6];
     // Ipopt's Algorithm IC: always try the unmodified matrix first (unless the last line search failed)
-    sc[SC_TRY_DW << 6] = (sc[SC_LS_FAIL << 6] != 0.0) ? fmax(10.0 * dlast, o.delta_w_init) : 0.0;
+    // after a failed line search start from a larger regularisation -- but never beyond the exact-Hessian cap: without
+    // the cap an instance whose trials keep being rejected by the filter multiplies delta_w by 10 every iteration
+    // (1e163 was observed), its steps vanish and it can never leave that state
+    sc[SC_TRY_DW << 6] = (sc[SC_LS_FAIL << 6] != 0.0) ? fmin(o.delta_w_exact_cap, fmax(10.0 * dlast, o.delta_w_init)) : 0.0;
   }
 }
 

@@ -250,7 +250,7 @@ static void factor_solve(port_solver* S) {
   const port_problem* P = &S->P;
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
-  if (S->ls_fail) dw = fmax(10.0 * dlast, P->delta_w_init);
+  if (S->ls_fail) dw = fmin(P->delta_w_exact_cap, fmax(10.0 * dlast, P->delta_w_init));  /* capped: see k_conv */
   int ok = 0;
   for (int attempt = 0; attempt <= P->max_refactor; ++attempt) {
     ok = forward_sweep(S, dw, gam);
