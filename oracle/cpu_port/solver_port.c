@@ -55,7 +55,7 @@ typedef struct {
   int Nz, Nc;
   double *z, *lam /* dyn rows then pin rows (first, last) */, *dz, *dlam;
   stage_t* st;
-  int status, iter, nfact, filter_n, ls_fail;
+  int status, iter, nfact, filter_n, ls_fail, full_streak;
   double f, th1, thinf, dinf, delta_w, delta_last, gamma, alpha, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
 } port_solver;
@@ -90,7 +90,7 @@ void port_destroy(port_solver* S) {
 void port_begin(port_solver* S, const double* z0) {
   memcpy(S->z, z0, S->Nz * sizeof(double));
   memset(S->lam, 0, S->Nc * sizeof(double));
-  S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0;
+  S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0;
   S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
 }
 
@@ -251,6 +251,7 @@ static void factor_solve(port_solver* S) {
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
   if (S->ls_fail) dw = fmin(P->delta_w_exact_cap, fmax(10.0 * dlast, P->delta_w_init));  /* capped: see k_conv */
+  else if (dlast > 1.1 * P->delta_w_init && S->full_streak < 2) dw = fmax(P->delta_w_init, dlast / 3.0);  /* no delta_w = 0 probe: see k_conv */
   int ok = 0;
   for (int attempt = 0; attempt <= P->max_refactor; ++attempt) {
     ok = forward_sweep(S, dw, gam);
@@ -341,6 +342,7 @@ static void line_search(port_solver* S) {
     S->filter_n++;
   }
   S->alpha = chosen;
+  S->full_streak = (chosen >= 1.0) ? S->full_streak + 1 : 0;
 }
 
 /* one iteration: EVAL -> CONV -> FACTOR_SOLVE -> LINESEARCH -> UPDATE; returns 1 if an iteration was executed */
