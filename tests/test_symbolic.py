@@ -113,3 +113,109 @@ def test_general_constraint_folding_for_the_solver():
     assert new_cons[1].num_constraint == 1 and new_cons[-1].num_constraint == 2 and new_cons[-1].indices_inequality == [2]
     # internal rows: dyn..., stage 2: general row 2, stage T: own row, general row 1
     assert list(mu_map[n_dyn:]) == [n_dyn + 1 + 1, n_dyn + 0, n_dyn + 1 + 0]
+
+
+def _random_model(seed):
+    """A random smooth stage model as a recipe that both front ends can trace: returns (dims, make_dyn, make_cost, make_con)
+    where make_*(lib) builds the closure for `lib` in {"product", "oracle"}."""
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(2, 4)), int(rng.integers(1, 3))
+    nv = 2 * n + m
+
+    def pick(k):
+        return [int(i) for i in rng.choice(nv, size=k, replace=False)]
+
+    rows = []
+    for i in range(n):
+        terms = []
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 4))
+            coef = float(np.round(rng.uniform(-2, 2), 3))
+            vs = pick(2)
+            terms.append((kind, coef, vs))
+        rows.append(terms)
+    cost_terms = [(int(rng.integers(0, 3)), float(np.round(rng.uniform(0.1, 2), 3)), [int(rng.integers(0, n + m)), int(rng.integers(0, n + m))])
+                  for _ in range(3)]
+    con_terms = [(int(rng.integers(0, 3)), float(np.round(rng.uniform(-1, 1), 3)), [int(rng.integers(0, n + m)), int(rng.integers(0, n + m))])
+                 for _ in range(2)]
+
+    def funcs(lib):
+        if lib == "product":
+            return dto_amd.sin, dto_amd.cos
+        import sympy as sp
+        return sp.sin, sp.cos
+
+    def term(kind, coef, a, b, sin, cos):
+        if kind == 0:
+            return coef * a * b
+        if kind == 1:
+            return coef * sin(a) * b
+        if kind == 2:
+            return coef * cos(a + b)
+        return coef * a - coef * a + coef * b      # exact cancellation: must not leave a structural entry for `a`
+
+    def make_dyn(lib):
+        sin, cos = funcs(lib)
+
+        def f(y, x, u, w):
+            v = list(x) + list(u) + list(y)
+            out = []
+            for i, terms in enumerate(rows):
+                e = y[i] - x[i]
+                for kind, coef, (ia, ib) in terms:
+                    e = e - 0.05 * term(kind, coef, v[ia], v[ib], sin, cos)
+                out.append(e)
+            return np.array(out, dtype=object) if lib == "product" else out
+        return f
+
+    def make_cost(lib):
+        sin, cos = funcs(lib)
+
+        def f(x, u, w):
+            v = list(x) + list(u)
+            e = 0.0
+            for kind, coef, (ia, ib) in cost_terms:
+                e = e + term(kind, coef, v[ia], v[ib], sin, cos) + coef * v[ia] * v[ia]
+            return e
+        return f
+
+    def make_con(lib):
+        sin, cos = funcs(lib)
+
+        def f(x, u, w):
+            v = list(x) + list(u)
+            out = [term(kind, coef, v[ia], v[ib], sin, cos) + v[0] for kind, coef, (ia, ib) in con_terms]
+            return np.array(out, dtype=object) if lib == "product" else out
+        return f
+
+    return (n, m), make_dyn, make_cost, make_con
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_patterns_and_values_match_oracle(seed):
+    """Random smooth stage models (products, sin, cos of sums, exact cancellations): local Jacobian / Hessian patterns of
+    the product's front end equal the oracle's (sympy) bit for bit, and the nonzero values agree at a random point."""
+    from oracle import sympy_models as S
+    (n, m), mk_dyn, mk_cost, mk_con = _random_model(seed)
+    pd = dto_amd.Dynamics(mk_dyn("product"), n, n, m, evaluate_hessian=True)
+    od = S.Dynamics(mk_dyn("oracle"), n, n, m, evaluate_hessian=True)
+    pc = dto_amd.Cost(mk_cost("product"), n, m, evaluate_hessian=True)
+    oc = S.Cost(mk_cost("oracle"), n, m, evaluate_hessian=True)
+    pk = dto_amd.Constraint(mk_con("product"), n, m, evaluate_hessian=True)
+    ok = S.Constraint(mk_con("oracle"), n, m, evaluate_hessian=True)
+    assert pd.jacobian_sparsity == od.jacobian_sparsity and pd.hessian_sparsity == od.hessian_sparsity
+    assert pc.sparsity == oc.sparsity
+    assert pk.jacobian_sparsity == ok.jacobian_sparsity and pk.hessian_sparsity == ok.hessian_sparsity
+    rng = np.random.default_rng(100 + seed)
+    x, u, y, lam = rng.random(n), rng.random(m), rng.random(n), rng.random(n)
+    env = {}
+    for nm, vec in (("x", x), ("u", u), ("y", y), ("lam", lam)):
+        for i, val in enumerate(vec):
+            env[(nm, i)] = float(val)
+    assert np.allclose(evaluate(pd.jacobian_expr, env), od.jacobian(list(y), list(x), list(u), []), rtol=1e-12, atol=1e-14)
+    assert np.allclose(evaluate(pd.hessian_expr, env), od.hessian(list(y), list(x), list(u), [], list(lam)), rtol=1e-12, atol=1e-14)
+    assert np.allclose(evaluate(pc.hessian_expr, env), oc.hessian(list(x), list(u), []), rtol=1e-12, atol=1e-14)
+    lamc = rng.random(2)
+    for i, val in enumerate(lamc):
+        env[("lam", i)] = float(val)
+    assert np.allclose(evaluate(pk.hessian_expr, env), ok.hessian(list(x), list(u), [], list(lamc)), rtol=1e-12, atol=1e-14)
