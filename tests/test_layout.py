@@ -107,3 +107,46 @@ def test_invalid_specs_are_rejected():
     q = P.build_pendulum(T=4, evaluate_hessian=False)
     with pytest.raises(ValueError):
         dto_amd.Solver(q["dynamics"], q["objective"], q["constraints"], q["bounds"], evaluate_hessian=True)
+
+
+@pytest.mark.parametrize("seed", [3, 8])
+def test_random_heterogeneous_problem_layout_matches_oracle(seed):
+    """A random problem whose stages differ (stage constraints on some knots only, one with an inequality row, different
+    terminal objects): global Jacobian / Hessian structures, totals and index vectors of the product (C++ layout through
+    the C-ABI) equal the oracle's restatement of src/data.jl:61-220 bit for bit."""
+    import dto_amd
+    from oracle import dto_oracle as O, sympy_models as S
+    from test_symbolic import _random_model
+    (n, m), mk_dyn, mk_cost, mk_con = _random_model(seed)
+    T = 5
+
+    def build(lib):
+        mod = dto_amd if lib == "product" else S
+        d = mod.Dynamics(mk_dyn(lib), n, n, m, evaluate_hessian=True)
+        c = mod.Cost(mk_cost(lib), n, m, evaluate_hessian=True)
+        if lib == "product":
+            cT = mod.Cost(lambda x, u, w: dto_amd.dot(x, x), n, 0, evaluate_hessian=True)
+        else:
+            cT = mod.Cost(lambda x, u, w: S.dot(x, x), n, 0, evaluate_hessian=True)
+        k_eq = mod.Constraint(mk_con(lib), n, m, evaluate_hessian=True)
+        k_in = mod.Constraint(mk_con(lib), n, m, indices_inequality=[2], evaluate_hessian=True)
+        if lib == "product":
+            kT = mod.Constraint(lambda x, u, w: x[0:1] * x[1:2], n, 0, evaluate_hessian=True)
+        else:
+            kT = mod.Constraint(lambda x, u, w: [x[0] * x[1]], n, 0, evaluate_hessian=True)
+        cons = [k_eq, mod.Constraint(), k_in, mod.Constraint(), kT]
+        bnds = [mod.Bound(n, m, action_lower=[-1.0] * m, action_upper=[1.0] * m)] * (T - 1) + [mod.Bound(n, 0)]
+        return [d] * (T - 1), [c] * (T - 1) + [cT], cons, bnds
+
+    dyn, obj, cons, bnds = build("product")
+    s = dto_amd.Solver(dyn, obj, cons, bnds, evaluate_hessian=True, name=f"random{seed}")
+    odyn, oobj, ocons, obnds = build("oracle")
+    onlp = O.NLPData(odyn, oobj, ocons, obnds, evaluate_hessian=True)
+    nl = s.nlp
+    assert (nl.num_variables, nl.num_constraint, nl.num_jacobian) == (onlp.num_variables, onlp.num_constraint, onlp.num_jacobian)
+    assert nl.num_hessian_lagrangian == onlp.num_hessian_lagrangian
+    assert nl.jacobian_structure() == onlp.jacobian_structure()
+    assert nl.hessian_lagrangian_structure() == onlp.hessian_lagrangian_structure()
+    clo, chi = nl.constraint_bounds
+    oclo, ochi = onlp.constraint_bounds
+    assert np.array_equal(np.isneginf(clo), np.isneginf(np.asarray(oclo, float))) and np.all(chi == 0.0)
