@@ -266,6 +266,27 @@ def test_full_size_sampled_stages_against_oracle(model, T):
         close(J[np.array(idx.dynamics_jacobians[t]) - 1], od.jacobian(list(y), list(x), list(u), []))
 
 
+@pytest.mark.parametrize("seed", [3, 8])
+def test_random_heterogeneous_problem_callbacks_match_oracle(seed):
+    """Random stage models, stages of different kinds (constraints on some knots, an inequality row, different terminal
+    objects): the five callbacks through the HIP kernels equal the oracle at a random point."""
+    import dto_amd
+    from oracle import dto_oracle as O
+    from test_layout import random_heterogeneous_problem
+    dyn, obj, cons, bnds = random_heterogeneous_problem(seed, "product")
+    s = dto_amd.Solver(dyn, obj, cons, bnds, evaluate_hessian=True, name=f"random{seed}")
+    onlp = O.NLPData(*random_heterogeneous_problem(seed, "oracle"), evaluate_hessian=True)
+    n = s.nlp
+    rng = np.random.default_rng(1000 + seed)
+    z, mu = rng.random(n.num_variables), rng.random(n.num_constraint)
+    assert abs(n.eval_objective(z) - onlp.eval_objective(z)) <= RTOL * max(1.0, abs(onlp.eval_objective(z)))
+    g = np.full(n.num_variables, np.nan); n.eval_objective_gradient(g, z); close(g, onlp.eval_objective_gradient(z))
+    c = np.full(n.num_constraint, np.nan); n.eval_constraint(c, z); close(c, onlp.eval_constraint(z))
+    J = np.full(n.num_jacobian, np.nan); n.eval_constraint_jacobian(J, z); close(J, onlp.eval_constraint_jacobian(z))
+    H = np.full(int(n.sizes.nnz_hess_key), np.nan); n.eval_hessian_lagrangian(H, z, 0.7, mu)
+    close(H, onlp.eval_hessian_lagrangian(z, 0.7, mu))
+
+
 def test_ragged_and_tiny_horizons():
     """T not a multiple of the wave width, T smaller than a wave, T = 2; plus the 63-stage Hessian tiling edge."""
     from oracle import dto_oracle as O, sympy_models as S

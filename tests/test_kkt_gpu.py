@@ -122,3 +122,31 @@ def test_inertia_flag_matches_dense_inertia():
         assert ok == dense_ok, (scale, dw, inertia, ok)
         seen.add(dense_ok)
     assert seen == {True, False}
+
+
+@pytest.mark.parametrize("seed", [3, 8])
+def test_kkt_step_random_heterogeneous_problem(seed):
+    """Random stage models with different stage kinds (see test_layout.random_heterogeneous_problem): one regularised KKT
+    step against numpy's dense solve of the oracle's system."""
+    import torch
+    import dto_amd
+    from oracle import dto_oracle as O
+    from test_layout import random_heterogeneous_problem
+    s = dto_amd.Solver(*random_heterogeneous_problem(seed, "product"), evaluate_hessian=True, name=f"random{seed}")
+    onlp = O.NLPData(*random_heterogeneous_problem(seed, "oracle"), evaluate_hessian=True)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(seed)
+    B, dw, dc = 3, 40.0, 1e-5
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    dz, dmu = torch.tensor(Z, device="cuda"), torch.tensor(MU, device="cuda")
+    dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    ok = s.kkt_step_batch(dz.data_ptr(), B, nz, dmu.data_ptr(), nc, dw, dc, dx.data_ptr(), nz, dl.data_ptr(), nc)
+    torch.cuda.synchronize()
+    dx, dl = dx.cpu().numpy(), dl.cpu().numpy()
+    for b in range(B):
+        rx, rl, inertia, cond = dense_kkt_solve(onlp, Z[b], MU[b], dw, dc)
+        assert inertia == (nz, nc), "test point must be quasi-definite; raise dw"
+        scale = max(np.max(np.abs(rx)), np.max(np.abs(rl)))
+        assert np.max(np.abs(dx[b] - rx)) <= 1e-8 * scale and np.max(np.abs(dl[b] - rl)) <= 1e-8 * scale
+    assert ok

@@ -109,35 +109,37 @@ def test_invalid_specs_are_rejected():
         dto_amd.Solver(q["dynamics"], q["objective"], q["constraints"], q["bounds"], evaluate_hessian=True)
 
 
+def random_heterogeneous_problem(seed, lib):
+    """(dynamics, objective, constraints, bounds) of a random 5-knot problem for lib in {"product", "oracle"}."""
+    import dto_amd
+    from oracle import sympy_models as S
+    from test_symbolic import _random_model
+    (n, m), mk_dyn, mk_cost, mk_con = _random_model(seed)
+    T = 5
+    mod = dto_amd if lib == "product" else S
+    d = mod.Dynamics(mk_dyn(lib), n, n, m, evaluate_hessian=True)
+    c = mod.Cost(mk_cost(lib), n, m, evaluate_hessian=True)
+    if lib == "product":
+        cT = mod.Cost(lambda x, u, w: dto_amd.dot(x, x), n, 0, evaluate_hessian=True)
+        kT = mod.Constraint(lambda x, u, w: x[0:1] * x[1:2], n, 0, evaluate_hessian=True)
+    else:
+        cT = mod.Cost(lambda x, u, w: S.dot(x, x), n, 0, evaluate_hessian=True)
+        kT = mod.Constraint(lambda x, u, w: [x[0] * x[1]], n, 0, evaluate_hessian=True)
+    k_eq = mod.Constraint(mk_con(lib), n, m, evaluate_hessian=True)
+    k_in = mod.Constraint(mk_con(lib), n, m, indices_inequality=[2], evaluate_hessian=True)
+    cons = [k_eq, mod.Constraint(), k_in, mod.Constraint(), kT]
+    bnds = [mod.Bound(n, m, action_lower=[-1.0] * m, action_upper=[1.0] * m)] * (T - 1) + [mod.Bound(n, 0)]
+    return [d] * (T - 1), [c] * (T - 1) + [cT], cons, bnds
+
+
 @pytest.mark.parametrize("seed", [3, 8])
 def test_random_heterogeneous_problem_layout_matches_oracle(seed):
     """A random problem whose stages differ (stage constraints on some knots only, one with an inequality row, different
     terminal objects): global Jacobian / Hessian structures, totals and index vectors of the product (C++ layout through
     the C-ABI) equal the oracle's restatement of src/data.jl:61-220 bit for bit."""
     import dto_amd
-    from oracle import dto_oracle as O, sympy_models as S
-    from test_symbolic import _random_model
-    (n, m), mk_dyn, mk_cost, mk_con = _random_model(seed)
-    T = 5
-
-    def build(lib):
-        mod = dto_amd if lib == "product" else S
-        d = mod.Dynamics(mk_dyn(lib), n, n, m, evaluate_hessian=True)
-        c = mod.Cost(mk_cost(lib), n, m, evaluate_hessian=True)
-        if lib == "product":
-            cT = mod.Cost(lambda x, u, w: dto_amd.dot(x, x), n, 0, evaluate_hessian=True)
-        else:
-            cT = mod.Cost(lambda x, u, w: S.dot(x, x), n, 0, evaluate_hessian=True)
-        k_eq = mod.Constraint(mk_con(lib), n, m, evaluate_hessian=True)
-        k_in = mod.Constraint(mk_con(lib), n, m, indices_inequality=[2], evaluate_hessian=True)
-        if lib == "product":
-            kT = mod.Constraint(lambda x, u, w: x[0:1] * x[1:2], n, 0, evaluate_hessian=True)
-        else:
-            kT = mod.Constraint(lambda x, u, w: [x[0] * x[1]], n, 0, evaluate_hessian=True)
-        cons = [k_eq, mod.Constraint(), k_in, mod.Constraint(), kT]
-        bnds = [mod.Bound(n, m, action_lower=[-1.0] * m, action_upper=[1.0] * m)] * (T - 1) + [mod.Bound(n, 0)]
-        return [d] * (T - 1), [c] * (T - 1) + [cT], cons, bnds
-
+    from oracle import dto_oracle as O
+    build = lambda lib: random_heterogeneous_problem(seed, lib)
     dyn, obj, cons, bnds = build("product")
     s = dto_amd.Solver(dyn, obj, cons, bnds, evaluate_hessian=True, name=f"random{seed}")
     odyn, oobj, ocons, obnds = build("oracle")
