@@ -117,6 +117,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
   a.delta_w = delta_w; a.delta_c = delta_c; a.piv_tol = 1e-9;
   a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
   a.fac = p->wide_fac; a.flags = p->wide_flags; a.Nc = L.Nc;
+  a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.active = nullptr; a.stats = nullptr;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_WIDE_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   const int lrc = p->vt->launch_wide(DTO_WIDE_STEP, &a, (void*)st);

@@ -47,7 +47,13 @@ struct dto_wide_args {
   int* flags;    // [B]: 1 = inertia (n, m, 0) and no tiny pivot
   int64_t Nc;
   long long* prof;  // optional [32] cycle counters of workgroup 0 (tools/wide_profile.py), else NULL
+  // ---- solver use (dto_solve_batch on wide models); all NULL / 0 for the plain dto_kkt_step_batch
+  const double* fixed_lo; const double* fixed_hi;  // [Nz] variable bounds: components with lo == hi get identity rows
+  const double* dw_inst;   // [B] per-instance delta_w (overrides delta_w)
+  const int* active;       // [B] 0 = skip this instance
+  double* stats;           // [B][DTO_WIDE_NSTAT]: f, theta_1, theta_inf, dual infeasibility, grad f' dz
 };
+enum { DTO_WIDE_F = 0, DTO_WIDE_TH1, DTO_WIDE_THINF, DTO_WIDE_DINF, DTO_WIDE_GPHID, DTO_WIDE_NSTAT = 8 };
 
 namespace dto {
 namespace wide {
@@ -66,8 +72,8 @@ struct Dims {
   static constexpr int LI = NT * TB * LI_LD;   // inverses of the unit-lower diagonal tiles
   // factor record of one stage in HBM
   static constexpr int F_LA = 0, F_FT = MAT, F_VT = 2 * MAT, F_LM = 3 * MAT, F_ET = 4 * MAT, F_VEC = 5 * MAT;
-  static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = 5 * N, V_VU = 6 * N, V_SC = 7 * N;
-  static constexpr int FAC = F_VEC + 7 * N + 8;
+  static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = 5 * N, V_VU = 6 * N, V_GC = 7 * N, V_SC = 8 * N + 8;
+  static constexpr int FAC = F_VEC + 8 * N + 16;
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -418,7 +424,11 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   const double* z = a.z + b * a.ldz;
   const double* mu = a.mu + b * a.ldmu;
   double* facb = a.fac + b * (int64_t)a.T * D::FAC;
-  const double dw = a.delta_w, dc = a.delta_c;
+  if (a.active && !a.active[b]) return;
+  const double dw = a.dw_inst ? a.dw_inst[b] : a.delta_w, dc = a.delta_c;
+  double* stat = vec + 20 * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4;  // f, th1, thinf, dinf (LDS scalars)
+  double* fxm = stat + 8;   // [N] 1.0 where x_t is fixed by equal bounds
+  if (tid < 8) stat[tid] = 0.0;
 
   long long tick_ = clock64();
   for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           lamv[tid] = mu[a.cdoff[t] + tid];
           au[tid] = 0.0; vu[tid] = 0.0; nlf[tid] = 0.0;
           MA[tid * LD + tid] += dw;
+          fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
         }
         if (tid == 0) { sc[0] = z[a.zoff[t] + N]; sc[1] = 0.0; }
         {
@@ -471,6 +482,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         } else {
           CO::grad(xv, sc, wp, gc);
           if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
+          if (a.stats) {
+            CO::eval(xv, sc, wp, stat + 6);
+            if (l == 0) stat[0] += stat[6];
+          }
         }
         __syncthreads();
         DTO_WIDE_TICK(1);
@@ -482,6 +497,14 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         __syncthreads();
         DTO_WIDE_TICK(2);
         // ---- phase 3: variable Jacobian entries, Hessian blocks
+        if (a.stats && w == 3) {
+          const double v = fabs(bd[l]);
+          const double sm_ = wave_sum(v);
+          double mx_ = v;
+#pragma unroll
+          for (int sft = 32; sft >= 1; sft >>= 1) mx_ = fmax(mx_, __shfl_xor(mx_, sft));
+          if (l == 0) { stat[1] += sm_; stat[2] = fmax(stat[2], mx_); }
+        }
         if (tid < DY::NJV) {
           const int r = DY::jv_row(tid), c = DY::jv_col(tid);
           const double v = jvv[tid];
@@ -529,6 +552,25 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         __syncthreads();
         DTO_WIDE_TICK(4);
+        // ---- solver use: dual infeasibility of the free variables; variables fixed by equal bounds become identity rows
+        if (a.stats && w == 3) {
+          double v = (fxm[l] != 0.0) ? 0.0 : fabs(bx[l] - byc[l]);
+          if (l == 0) v = fmax(v, fabs(sc[2]));
+#pragma unroll
+          for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
+          if (l == 0) stat[3] = fmax(stat[3], v);
+        }
+        if (a.fixed_lo) {
+          __syncthreads();
+          for (int i = tid; i < N * N; i += WG) {
+            const int r = i >> 6, c = i & 63;
+            if (fxm[r] != 0.0 || fxm[c] != 0.0) MA[r * LD + c] = (r == c) ? 1.0 : 0.0;
+            if (fxm[c] != 0.0) MF[r * LD + c] = 0.0;
+            if (fxm[r] != 0.0) MV[r * LD + c] = 0.0;
+          }
+          if (tid < N && fxm[tid] != 0.0) { au[tid] = 0.0; bx[tid] = 0.0; }
+          __syncthreads();
+        }
         // ---- phase 5: eliminate u
         const double piv = sc[3], ip = 1.0 / piv, bu = sc[2];
         for (int i = tid; i < N * N; i += WG) {
@@ -627,7 +669,9 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           fv[D::V_AU + tid] = au[tid];
           fv[D::V_FU + tid] = fu[tid];
           fv[D::V_VU + tid] = vu[tid];
+          fv[D::V_GC + tid] = gc[tid];
         }
+        if (tid == 0) fac[D::F_VEC + D::V_GC + N] = gc[N];
         if (tid == 0) { fac[D::F_VEC + D::V_SC + 0] = ip; fac[D::F_VEC + D::V_SC + 1] = bu; }
         __syncthreads();
 #pragma unroll
@@ -662,11 +706,18 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       if constexpr (KD::DYN < 0) {
         using CO = typename M::template Cost<KD::COST>;
         const double* wp = a.params + a.woff[t];
-        if (tid < N) xv[tid] = z[a.zoff[t] + tid];
+        if (tid < N) {
+          xv[tid] = z[a.zoff[t] + tid];
+          fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
+        }
         __syncthreads();
         if (w == 0) {
           CO::grad(xv, sc, wp, gc);
           if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
+          if (a.stats) {
+            CO::eval(xv, sc, wp, stat + 6);
+            if (l == 0) stat[0] += stat[6];
+          }
         }
         __syncthreads();
         if constexpr (CO::SNH > 0) {
@@ -678,6 +729,20 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid];
         }
         __syncthreads();
+        if (a.stats && w == 3) {
+          double v = (fxm[l] != 0.0) ? 0.0 : fabs(gc[l] + gyp[l]);
+#pragma unroll
+          for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
+          if (l == 0) stat[3] = fmax(stat[3], v);
+        }
+        if (a.fixed_lo) {
+          for (int i = tid; i < N * N; i += WG) {
+            const int r = i >> 6, c = i & 63;
+            if (fxm[r] != 0.0 || fxm[c] != 0.0) MA[r * LD + c] = (r == c) ? 1.0 : 0.0;
+          }
+          if (tid < N && fxm[tid] != 0.0) bx[tid] = 0.0;
+          __syncthreads();
+        }
         ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
         if (w == 0) {
           trsv_lower<N>(MA, bx);
@@ -686,6 +751,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if (l < N) {
             yv[l] = bx[l];
             a.dz[b * a.lddz + a.zoff[t] + l] = bx[l];
+          }
+          if (a.stats) {
+            const double part = wave_sum(gc[l] * bx[l]);
+            if (l == 0) stat[4] += part;
           }
         }
         __syncthreads();
@@ -741,13 +810,19 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     if (w == 1) {
       // u = (bu - au'x - fu'lam - vu'y) / piv
       const double part = wave_sum(au[l] * xv[l] + fu[l] * lamv[l] + vu[l] * yv[l]);
-      if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
+      const double du = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
+      if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = du;
+      if (a.stats) {
+        const double gpart = wave_sum(fv[D::V_GC + l] * xv[l]);
+        if (l == 0) stat[4] += gpart + fv[D::V_GC + N] * du;
+      }
     }
     __syncthreads();
     if (tid < N) yv[tid] = xv[tid];
     __syncthreads();
     DTO_WIDE_TICK(16);
   }
+  if (a.stats && tid < 5) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
 }
 
 // one wavefront per instance: out[b] = sum_t rows[b][t] in a fixed order (lane-strided partials, then a tree)
@@ -939,7 +1014,7 @@ int wide_info(dto_wide_info* out) {
   out->n = M::WIDE_N;
   out->nu = M::WIDE_NU;
   out->fac_stage = D::FAC;
-  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4);
+  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 8 + M::WIDE_N);
   return 0;
 }
 
