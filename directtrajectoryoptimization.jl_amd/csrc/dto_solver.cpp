@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -117,7 +118,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
   a.delta_w = delta_w; a.delta_c = delta_c; a.piv_tol = 1e-9;
   a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
   a.fac = p->wide_fac; a.flags = p->wide_flags; a.Nc = L.Nc;
-  a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.active = nullptr; a.stats = nullptr;
+  a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.active = nullptr; a.stats = nullptr; a.merit = nullptr;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_WIDE_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   const int lrc = p->vt->launch_wide(DTO_WIDE_STEP, &a, (void*)st);
@@ -129,6 +130,233 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
     *inertia_ok = 1;
     for (int v : fl) if (!v) *inertia_ok = 0;
   }
+  return DTO_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Solver for wide-stage models (configs[4]): the same filter line-search SQP iteration as the register path, driven from
+// the host -- one iteration costs a dense block factorisation per instance (hundreds of milliseconds at T = 2000), so a
+// few stream synchronisations per iteration are free.  Scope: dynamics rows plus variables fixed by equal bounds (what
+// the model uses); no inequality rows / finite bounds (no barrier), no Gauss-Newton fallback.
+// ------------------------------------------------------------------------------------------------
+static __global__ void k_rows_axpy(double* y, const double* x, const double* alpha, int64_t n, int64_t ldy, int64_t ldx) {
+  const int64_t b = blockIdx.y;
+  const double al = alpha[b];
+  if (al == 0.0) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[b * ldy + i] += al * x[b * ldx + i];
+}
+
+static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                            double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  const Layout& L = p->L;
+  if (L.Nstage != 0 || L.Ngen != 0) return set_error(DTO_ERR_UNSUPPORTED, "wide-stage models: dynamics rows and bounds only");
+  for (int64_t i = 0; i < L.Nz; ++i)
+    if (L.var_lo[i] != L.var_hi[i] && (std::isfinite(L.var_lo[i]) || std::isfinite(L.var_hi[i])))
+      return set_error(DTO_ERR_UNSUPPORTED, "wide-stage solver: variables may be free or fixed (lo == hi), not bounded");
+  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
+  dto_options u;
+  if (opt) u = *opt; else dto_options_default(&u);
+  dto_solver_opts o;
+  default_opts(o, u);
+  dto_wide_info info;
+  p->vt->wide_info(&info);
+  const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc;
+  hipStream_t st = (hipStream_t)b->stream;
+  // device state
+  const size_t need_fac = (size_t)B * (size_t)L.T * (size_t)info.fac_stage;
+  if (p->wide_fac_len < need_fac) {
+    if (p->wide_fac) (void)hipFree(p->wide_fac);
+    p->wide_fac = nullptr; p->wide_fac_len = 0;
+    HIP_TRY(hipMalloc((void**)&p->wide_fac, need_fac * sizeof(double)));
+    p->wide_fac_len = need_fac;
+  }
+  double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_dw = nullptr,
+         *d_stats = nullptr, *d_merit = nullptr, *d_alpha = nullptr;
+  int *d_flags = nullptr, *d_active = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)z, (void*)lam, (void*)dz, (void*)dlam, (void*)d_lo, (void*)d_hi, (void*)d_dw, (void*)d_stats,
+                    (void*)d_merit, (void*)d_alpha, (void*)d_flags, (void*)d_active})
+      if (q) (void)hipFree(q);
+  };
+#define WTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
+  WTRY(hipMalloc((void**)&z, (size_t)B * Nz * sizeof(double)));
+  WTRY(hipMalloc((void**)&lam, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double)));
+  WTRY(hipMalloc((void**)&dz, (size_t)B * Nz * sizeof(double)));
+  WTRY(hipMalloc((void**)&dlam, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_lo, Nz * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_hi, Nz * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_dw, B * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_stats, (size_t)B * DTO_WIDE_NSTAT * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_merit, (size_t)B * 2 * DTO_WIDE_TRIALS * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_alpha, B * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_flags, B * sizeof(int)));
+  WTRY(hipMalloc((void**)&d_active, B * sizeof(int)));
+  WTRY(hipMemcpyAsync(d_lo, L.var_lo.data(), Nz * sizeof(double), hipMemcpyHostToDevice, st));
+  WTRY(hipMemcpyAsync(d_hi, L.var_hi.data(), Nz * sizeof(double), hipMemcpyHostToDevice, st));
+  WTRY(hipMemcpy2DAsync(z, Nz * sizeof(double), b->x, b->ldx * sizeof(double), Nz * sizeof(double), B, hipMemcpyDeviceToDevice, st));
+  WTRY(hipMemsetAsync(lam, 0, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double), st));
+  WTRY(hipMemsetAsync(dz, 0, (size_t)B * Nz * sizeof(double), st));
+  WTRY(hipMemsetAsync(dlam, 0, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double), st));
+
+  struct Inst {
+    int status = 0, iter = 0, ls_fail = 0, full_streak = 0, attempt = 0;
+    double dw = 0.0, dlast = 0.0, theta_max = -1.0, theta_min = -1.0, alpha = 0.0;
+    std::vector<double> filt;  // (theta, phi) pairs, ring of DTO_FILTER_CAP
+    int filter_n = 0;
+  };
+  std::vector<Inst> I((size_t)B);
+  std::vector<int> h_active((size_t)B), h_flags((size_t)B);
+  std::vector<double> h_dw((size_t)B), h_stats((size_t)B * DTO_WIDE_NSTAT), h_merit((size_t)B * 2 * DTO_WIDE_TRIALS), h_alpha((size_t)B);
+  dto_wide_args a;
+  a.T = L.T; a.B = B;
+  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.params = p->d_params;
+  a.z = z; a.ldz = Nz; a.mu = lam; a.ldmu = Nc;
+  a.delta_w = 0.0; a.delta_c = o.delta_c; a.piv_tol = o.piv_tol;
+  a.dz = dz; a.lddz = Nz; a.dmu = dlam; a.lddmu = Nc;
+  a.fac = p->wide_fac; a.flags = d_flags; a.Nc = Nc; a.prof = nullptr;
+  a.fixed_lo = d_lo; a.fixed_hi = d_hi; a.dw_inst = d_dw; a.active = d_active; a.stats = d_stats; a.merit = d_merit;
+  auto launch = [&](int op) -> int {
+    const int lrc = p->vt->launch_wide(op, &a, (void*)st);
+    return lrc;
+  };
+  const auto t_start = std::chrono::steady_clock::now();
+  constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
+  bool any_running = true;
+  while (any_running) {
+    // ---- A: first factorisation attempt of every running instance
+    for (int64_t i = 0; i < B; ++i) {
+      Inst& s = I[(size_t)i];
+      h_active[(size_t)i] = s.status == 0;
+      if (s.status != 0) continue;
+      s.attempt = 0;
+      if (s.ls_fail) s.dw = std::min(o.delta_w_exact_cap, std::max(10.0 * s.dlast, o.delta_w_init));
+      else if (s.dlast > 1.1 * o.delta_w_init && s.full_streak < 2) s.dw = std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
+      else s.dw = 0.0;
+      h_dw[(size_t)i] = s.dw;
+    }
+    bool first_pass = true;
+    for (;;) {
+      WTRY(hipMemcpyAsync(d_active, h_active.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+      WTRY(hipMemcpyAsync(d_dw, h_dw.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+      { const int lrc = launch(DTO_WIDE_STEP); if (lrc) { cleanup(); return hip_fail((hipError_t)lrc, "wide step"); } }
+      WTRY(hipMemcpyAsync(h_flags.data(), d_flags, B * sizeof(int), hipMemcpyDeviceToHost, st));
+      WTRY(hipMemcpyAsync(h_stats.data(), d_stats, h_stats.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      WTRY(hipStreamSynchronize(st));
+      bool again = false;
+      for (int64_t i = 0; i < B; ++i) {
+        if (!h_active[(size_t)i]) continue;
+        Inst& s = I[(size_t)i];
+        const double* sv = &h_stats[(size_t)i * DTO_WIDE_NSTAT];
+        if (first_pass) {
+          // ---- B: convergence test at the current iterate (Ipopt's scaled error, reference Options tolerances)
+          const double f = sv[DTO_WIDE_F], th1 = sv[DTO_WIDE_TH1], thinf = sv[DTO_WIDE_THINF], dinf = sv[DTO_WIDE_DINF];
+          const double sd = std::max(o.s_max, sv[DTO_WIDE_SUMLAM] / (double)std::max<int64_t>(1, Nc)) / o.s_max;
+          const double e0 = std::max(dinf / sd, thinf);
+          if (!(f == f) || !(th1 == th1) || !(dinf == dinf)) s.status = 3;
+          else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol) s.status = 1;
+          else if (s.iter >= o.max_iter) s.status = 2;
+          if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
+          if (s.status != 0) { h_active[(size_t)i] = 0; continue; }
+        }
+        // ---- C: inertia (Algorithm IC, ladder on the exact Hessian)
+        if (h_flags[(size_t)i] || s.attempt >= o.max_refactor) {
+          if (s.dw > 0.0) s.dlast = s.dw;
+          if (s.dw == 0.0) s.dlast = 0.0;
+          if (!h_flags[(size_t)i]) s.ls_fail = 1;
+          h_active[(size_t)i] = 0;   // factorisation accepted: no further attempt
+          h_flags[(size_t)i] = 2;    // marks "step available" for the line search below
+        } else {
+          if (s.dw == 0.0) s.dw = (s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
+          else s.dw *= (s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
+          s.dw = std::min(s.dw, o.delta_w_max);
+          s.attempt++;
+          h_dw[(size_t)i] = s.dw;
+          again = true;
+        }
+      }
+      first_pass = false;
+      if (!again) break;
+    }
+    // ---- D: filter line search over the trial steps 2^-k
+    for (int64_t i = 0; i < B; ++i) h_active[(size_t)i] = (I[(size_t)i].status == 0);
+    any_running = false;
+    for (int64_t i = 0; i < B; ++i) any_running = any_running || h_active[(size_t)i];
+    if (!any_running) break;
+    WTRY(hipMemcpyAsync(d_active, h_active.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    { const int lrc = launch(DTO_WIDE_MERIT); if (lrc) { cleanup(); return hip_fail((hipError_t)lrc, "wide merit"); } }
+    WTRY(hipMemcpyAsync(h_merit.data(), d_merit, h_merit.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    WTRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < B; ++i) {
+      h_alpha[(size_t)i] = 0.0;
+      if (!h_active[(size_t)i]) continue;
+      Inst& s = I[(size_t)i];
+      const double* sv = &h_stats[(size_t)i * DTO_WIDE_NSTAT];
+      const double* mv = &h_merit[(size_t)i * 2 * DTO_WIDE_TRIALS];
+      const double th0 = sv[DTO_WIDE_TH1], phi0 = sv[DTO_WIDE_F], dphi = sv[DTO_WIDE_GPHID];
+      const int nf = std::min(s.filter_n, DTO_FILTER_CAP);
+      double alpha = 1.0, chosen = -1.0;
+      bool ftype = false;
+      int best = 0;
+      for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
+        const double pk = mv[2 * k], tk = mv[2 * k + 1];
+        if (tk < mv[2 * best + 1] || !(mv[2 * best + 1] == mv[2 * best + 1])) best = k;
+        bool ok = (tk == tk) && (pk == pk) && tk <= s.theta_max;
+        const bool sw = dphi < 0.0 && alpha * std::pow(-dphi, S_PHI) > std::pow(th0, S_TH);
+        if (ok) {
+          if (sw && th0 <= s.theta_min) ok = pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0);
+          else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
+        }
+        if (ok)
+          for (int q = 0; q < nf; ++q) {
+            const double tf = s.filt[2 * q], pf = s.filt[2 * q + 1];
+            if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
+          }
+        if (ok) { chosen = alpha; ftype = sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0)); break; }
+        alpha *= 0.5;
+      }
+      bool augment;
+      if (chosen < 0.0) {
+        double ab = 1.0;
+        for (int k = 0; k < best; ++k) ab *= 0.5;
+        chosen = (mv[2 * best + 1] == mv[2 * best + 1] && mv[2 * best + 1] < th0) ? ab : alpha * 2.0;
+        s.ls_fail = 1; augment = true;
+      } else { s.ls_fail = 0; augment = !ftype; }
+      if (augment) {
+        if ((int)s.filt.size() < 2 * DTO_FILTER_CAP) s.filt.resize(2 * DTO_FILTER_CAP, 0.0);
+        const int slot = s.filter_n % DTO_FILTER_CAP;
+        s.filt[2 * slot] = (1.0 - G_TH) * th0;
+        s.filt[2 * slot + 1] = phi0 - G_PHI * th0;
+        s.filter_n++;
+      }
+      s.alpha = chosen;
+      s.full_streak = (chosen >= 1.0) ? s.full_streak + 1 : 0;
+      if (i == 0 && getenv("DTO_WIDE_VERBOSE"))
+        fprintf(stderr, "it %3d f %.6e th1 %.3e thinf %.3e dinf %.3e dphi %.3e dw %.2e att %d alpha %.4g lsfail %d | f(1) %.6e th(1) %.3e f(.5) %.6e th(.5) %.3e\n",
+                s.iter, phi0, th0, sv[DTO_WIDE_THINF], sv[DTO_WIDE_DINF], dphi, s.dw, s.attempt, chosen, s.ls_fail, mv[0], mv[1], mv[2], mv[3]);
+      s.iter++;
+      h_alpha[(size_t)i] = chosen;
+    }
+    // ---- E: take the steps
+    WTRY(hipMemcpyAsync(d_alpha, h_alpha.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rows_axpy, dim3(64, (unsigned)B), dim3(256), 0, st, z, (const double*)dz, (const double*)d_alpha, Nz, Nz, Nz);
+    if (Nc > 0)
+      hipLaunchKernelGGL(k_rows_axpy, dim3(64, (unsigned)B), dim3(256), 0, st, lam, (const double*)dlam, (const double*)d_alpha, Nc, Nc, Nc);
+    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
+  }
+  WTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), B, hipMemcpyDeviceToDevice, st));
+  if (mu_out && Nc > 0)
+    WTRY(hipMemcpy2DAsync(mu_out, ldmuo * sizeof(double), lam, Nc * sizeof(double), Nc * sizeof(double), B, hipMemcpyDeviceToDevice, st));
+  WTRY(hipStreamSynchronize(st));
+#undef WTRY
+  for (int64_t i = 0; i < B; ++i) {
+    if (status) status[i] = I[(size_t)i].status;
+    if (iterations) iterations[i] = I[(size_t)i].iter;
+  }
+  cleanup();
   return DTO_OK;
 }
 
@@ -470,6 +698,8 @@ int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
 int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                     double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && b && b->x && x_out && p->vt->launch_wide)
+    return dto::wide_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
   int rc = dto_solver_begin(h, opt, b);
   if (rc) return rc;
   SolverState& S = *p->solver;

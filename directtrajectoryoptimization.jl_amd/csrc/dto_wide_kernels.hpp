@@ -21,7 +21,7 @@
 
 #include "dto_model_plugin.h"
 
-enum dto_wide_op { DTO_WIDE_STEP = 0 };
+enum dto_wide_op { DTO_WIDE_STEP = 0, DTO_WIDE_MERIT = 1 };
 
 struct dto_wide_info {
   int supported;
@@ -51,9 +51,11 @@ struct dto_wide_args {
   const double* fixed_lo; const double* fixed_hi;  // [Nz] variable bounds: components with lo == hi get identity rows
   const double* dw_inst;   // [B] per-instance delta_w (overrides delta_w)
   const int* active;       // [B] 0 = skip this instance
-  double* stats;           // [B][DTO_WIDE_NSTAT]: f, theta_1, theta_inf, dual infeasibility, grad f' dz
+  double* stats;           // [B][DTO_WIDE_NSTAT]: f, theta_1, theta_inf, dual infeasibility, grad f' dz, sum |lam|
+  double* merit;           // [B][2 * DTO_WIDE_TRIALS]: (f, theta_1) at z + 2^-k dz, k = 0..TRIALS-1 (DTO_WIDE_MERIT)
 };
-enum { DTO_WIDE_F = 0, DTO_WIDE_TH1, DTO_WIDE_THINF, DTO_WIDE_DINF, DTO_WIDE_GPHID, DTO_WIDE_NSTAT = 8 };
+enum { DTO_WIDE_F = 0, DTO_WIDE_TH1, DTO_WIDE_THINF, DTO_WIDE_DINF, DTO_WIDE_GPHID, DTO_WIDE_SUMLAM, DTO_WIDE_NSTAT = 8 };
+#define DTO_WIDE_TRIALS 8
 
 namespace dto {
 namespace wide {
@@ -497,6 +499,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         __syncthreads();
         DTO_WIDE_TICK(2);
         // ---- phase 3: variable Jacobian entries, Hessian blocks
+        if (a.stats && w == 2) {
+          const double sl_ = wave_sum(fabs(lamv[l]));
+          if (l == 0) stat[5] += sl_;
+        }
         if (a.stats && w == 3) {
           const double v = fabs(bd[l]);
           const double sm_ = wave_sum(v);
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     __syncthreads();
     DTO_WIDE_TICK(16);
   }
-  if (a.stats && tid < 5) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
+  if (a.stats && tid < 6) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
 }
 
 // one wavefront per instance: out[b] = sum_t rows[b][t] in a fixed order (lane-strided partials, then a tree)
@@ -1007,6 +1013,87 @@ int launch_wide_eval(int op, const dto_eval_args* a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// line search support for the solver on wide models: objective and ||c||_1 at the trial points z + 2^-k dz.
+// One workgroup per instance, one wavefront per knot (strided); the residual is linear in alpha except for the few
+// nonlinear rows, so the constant-table products are formed once per knot.
+// ---------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
+  constexpr int N = M::WIDE_N, NU = M::WIDE_NU, NC = 2 * N + NU;
+  extern __shared__ double sm[];
+  double* fe_s = sm;                       // [N][NC]
+  double* per = sm + N * NC;               // per wave: p(N+NU+1) y(N) dp(N+NU+1) dy(N) pk(N+NU+1) yk(N) nl(8)
+  constexpr int PW = 3 * (N + NU + 1) + 3 * N + 16;
+  double* red = per + 4 * PW;              // [4][2*TRIALS]
+  const int w = wave_id(), l = lane_id();
+  const int64_t b = blockIdx.x;
+  if (a.active && !a.active[b]) return;
+  {
+    const double* fe = M::template Dyn<0>::fe_const();
+    for (int i = threadIdx.x; i < N * NC; i += WG) fe_s[i] = fe[i];
+  }
+  __syncthreads();
+  double* pv = per + w * PW; double* yv = pv + N + NU + 1; double* dp = yv + N; double* dy = dp + N + NU + 1;
+  double* pk = dy + N; double* yk = pk + N + NU + 1; double* nl = yk + N;
+  const double* z = a.z + b * a.ldz;
+  const double* dz = a.dz + b * a.lddz;
+  double facc[DTO_WIDE_TRIALS], tacc[DTO_WIDE_TRIALS];
+#pragma unroll
+  for (int k = 0; k < DTO_WIDE_TRIALS; ++k) facc[k] = tacc[k] = 0.0;
+  for (int t = w; t < a.T; t += 4) {
+    const int wk = M::wk_of_kind(a.kind[t]);
+    const double* wp = a.params + a.woff[t];
+    M::dispatch_wk(wk, [&](auto wkc) {
+      using KD = typename M::template WKind<decltype(wkc)::value>;
+      using CO = typename M::template Cost<KD::COST>;
+      constexpr bool HAS_DYN = KD::DYN >= 0;
+      constexpr int NUK = HAS_DYN ? NU : 0;
+      pv[l] = z[a.zoff[t] + l]; dp[l] = dz[a.zoff[t] + l];
+      if (l < NUK) { pv[N + l] = z[a.zoff[t] + N + l]; dp[N + l] = dz[a.zoff[t] + N + l]; }
+      double lin0 = 0.0, lind = 0.0;
+      if constexpr (HAS_DYN) {
+        yv[l] = z[a.zoff[t + 1] + l]; dy[l] = dz[a.zoff[t + 1] + l];
+        const double* row = fe_s + l * NC;
+        lin0 = dot_rr<N>(row, pv) + dot_rr<N>(row + N + NU, yv);
+        lind = dot_rr<N>(row, dp) + dot_rr<N>(row + N + NU, dy);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { lin0 += row[N + j] * pv[N + j]; lind += row[N + j] * dp[N + j]; }
+      }
+      double alpha = 1.0;
+#pragma unroll 1
+      for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
+        pk[l] = pv[l] + alpha * dp[l];
+        if (l < NUK) pk[N + l] = pv[N + l] + alpha * dp[N + l];
+        CO::eval(pk, pk + N, wp, nl + 8);
+        if (l == 0) facc[k] += nl[8];
+        if constexpr (HAS_DYN) {
+          using DY = typename M::template Dyn<KD::DYN>;
+          yk[l] = yv[l] + alpha * dy[l];
+          DY::eval_nl(pk, pk + N, yk, wp, nl);
+          double r = lin0 + alpha * lind;
+#pragma unroll
+          for (int q = 0; q < DY::NNL; ++q)
+            if (DY::nl_row(q) == l) r += nl[q];
+          const double sum = wave_sum(fabs(r));
+          if (l == 0) tacc[k] += sum;
+        }
+        alpha *= 0.5;
+      }
+    });
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < DTO_WIDE_TRIALS; ++k) { red[w * 2 * DTO_WIDE_TRIALS + 2 * k] = facc[k]; red[w * 2 * DTO_WIDE_TRIALS + 2 * k + 1] = tacc[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * DTO_WIDE_TRIALS) {
+    double v = 0.0;
+    for (int ww = 0; ww < 4; ++ww) v += red[ww * 2 * DTO_WIDE_TRIALS + threadIdx.x];
+    a.merit[b * 2 * DTO_WIDE_TRIALS + threadIdx.x] = v;
+  }
+}
+
 template <class M>
 int wide_info(dto_wide_info* out) {
   using D = Dims<M::WIDE_N>;
@@ -1020,6 +1107,14 @@ int wide_info(dto_wide_info* out) {
 
 template <class M>
 int launch_wide(int op, const dto_wide_args* a, void* stream) {
+  if (op == DTO_WIDE_MERIT) {
+    constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+    const int lds = (int)sizeof(double) * (N * (2 * N + NU) + 4 * (3 * (N + NU + 1) + 3 * N + 16) + 4 * 2 * DTO_WIDE_TRIALS);
+    hipError_t em = hipFuncSetAttribute((const void*)k_wide_merit<M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (em != hipSuccess) return (int)em;
+    hipLaunchKernelGGL(k_wide_merit<M>, dim3((unsigned)a->B), dim3(WG), lds, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+  }
   if (op != DTO_WIDE_STEP) return (int)hipErrorInvalidValue;
   dto_wide_info info;
   wide_info<M>(&info);

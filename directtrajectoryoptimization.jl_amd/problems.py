@@ -238,19 +238,26 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
     )
 
 
-def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True):
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full"):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
-    blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does)."""
+    blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
+    terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
+    64-dimensional terminal state is reachable only for horizons of more than 64 knots."""
     m = 1
     x1 = np.zeros(n)
     xT = np.zeros(n)
-    xT[0] = PI
+    xT[0] = target
     dt = Dynamics(acrobot_padded_midpoint(n), n, n, m, evaluate_hessian=evaluate_hessian)
     ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
     cT = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]), n, 0, evaluate_hessian=evaluate_hessian)
     b1 = Bound(n, m, state_lower=x1, state_upper=x1)
     bt = Bound(n, m)
-    bT = Bound(n, 0, state_lower=xT, state_upper=xT)
+    if terminal == "physical":
+        lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+        lo[:4] = hi[:4] = xT[:4]
+        bT = Bound(n, 0, state_lower=lo, state_upper=hi)
+    else:
+        bT = Bound(n, 0, state_lower=xT, state_upper=xT)
     return dict(
         dynamics=[dt] * (T - 1),
         objective=[ct] * (T - 1) + [cT],

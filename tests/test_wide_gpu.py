@@ -148,3 +148,48 @@ def test_wide_callbacks_match_oracle():
     out = np.full(nc, np.nan)
     n.eval_constraint(out, Z[0])
     assert np.max(np.abs(out - c[0])) == 0.0
+
+
+@pytest.mark.parametrize("T,target,terminal", [(40, 0.5, "physical"), (24, 0.3, "physical")])
+def test_wide_solve_converges_to_a_kkt_point(T, target, terminal):
+    """dto_solve_batch on the 64-state model (host-driven filter line-search SQP around k_wide_step): every instance ends
+    with its fixed components in place, the dynamics satisfied and the Lagrangian stationary in the free variables --
+    checked with the ORACLE's derivatives, tolerances of the reference Options (tol 1e-6 scaled, constr_viol_tol 1e-3).
+    The padding states of the last knot are left free here: steering all 64 terminal states with one action needs more
+    than 64 knots and is then extremely ill-conditioned (T=80 does not converge in 1000 iterations).)"""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives
+    B = 3
+    p = P.build_acrobot_padded(T=T, target=target, terminal=terminal)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, [0.1 * u for u in us])
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    zo, lo = zo.cpu().numpy(), lo.cpu().numpy()
+    assert np.all(status == 1) and np.all(iters < 200), (status, iters)
+    om = PaddedAcrobot(64)
+    vlo, vhi = s.nlp.variable_bounds
+    fixed = vlo == vhi
+    assert fixed[:64].all() and fixed[-64:-60].all() and fixed.sum() == (128 if terminal == "full" else 68)
+    for b in range(B):
+        f, g, c, J, _ = dense_derivatives(om, T, zo[b], lo[b], 1.0)
+        assert np.max(np.abs(zo[b][fixed] - vlo[fixed])) < 1e-12
+        assert np.max(np.abs(c)) <= 1e-6
+        r = g + J.T @ lo[b]
+        assert np.max(np.abs(r[~fixed])) <= 1e-5 * max(1.0, np.max(np.abs(lo[b])))
+    # the single-instance host entry (solve!) takes the same path
+    s._z0[:] = Z[0]
+    assert dto_amd.solve(s) == 1 and s.iterations == iters[0]
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1][:4] - p["xT"][:4]) < 1e-3
