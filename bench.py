@@ -81,6 +81,19 @@ def dense_block_measurement(dev, T=2000, B=256):
     b, npr = 129, 64
     flop_stage = b ** 3 / 3 + 2 * b * b * npr + 2 * b * npr * npr
     tflops = B * (T - 1) * flop_stage / (ms * 1e-3) / 1e12
+    # a few iterations of the full solve (KKT step(s) + merit evaluation + filter line search, host driven)
+    import time as _time
+    s.options.max_iter = 3
+    zo = torch.empty_like(Z)
+    xs0, us0 = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs0); dto_amd.initialize_controls(s, us0)
+    Z0 = torch.tensor(np.tile(s._z0, (B, 1)), device=dev)
+    torch.cuda.synchronize()
+    t0 = _time.perf_counter()
+    st_, it_ = s.solve_batch(Z0.data_ptr(), B, nz, zo.data_ptr(), nz, stream=st)
+    torch.cuda.synchronize()
+    sqp_dt = _time.perf_counter() - t0
+    sqp_its = int(np.sum(it_))
     Bj = 16
     J = torch.empty((Bj, nj), device=dev, dtype=torch.float64)
     jfn = lambda: s.nlp.eval_constraint_jacobian_batch(Z.data_ptr(), Bj, nz, J.data_ptr(), nj, st)
@@ -90,6 +103,7 @@ def dense_block_measurement(dev, T=2000, B=256):
     return dict(workload=f"acrobot embedded in 64 states, T={T}, {B} instances (BASELINE.json configs[4])",
                 kernel="k_wide_step", inertia_ok=bool(ok), avg_launch_ms=round(ms, 3), block=129, stages=B * (T - 1),
                 kkt_steps_per_sec=round(B / (ms * 1e-3), 1),
+                sqp_iterations_per_sec=round(sqp_its / sqp_dt, 1), sqp_sample=f"{sqp_its} iterations in {sqp_dt:.2f} s (first 3 iterations from the straight-line guess)",
                 roofline=dict(bound="mfma", achieved=round(tflops, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                               frac=round(tflops / FP64_MFMA_PEAK_TFLOPS, 5), flop_per_stage=int(flop_stage)),
                 jacobian=dict(kernel="k_wide_eval<JAC>", instances=Bj, nnz_per_sec=Bj * nj / (jms * 1e-3), avg_launch_ms=round(jms, 4),
