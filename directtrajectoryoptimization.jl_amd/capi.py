@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
         "dto_solver_stats": [vp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p],
         "dto_solver_end": [vp, vp, C.c_int64, vp, C.c_int64, vp],
         "dto_solver_scalar": [vp, C.c_int, c_double_p],
+        "dto_solver_peek": [vp, C.c_int, vp, C.c_int64, vp],
         "dto_solver_launch_op": [vp, C.c_int, vp],
         "dto_solver_footprint": [vp, c_int64_p, c_int64_p, c_int64_p, C.POINTER(C.c_int)],
         "dto_solver_set_partitions": [vp, C.c_int],

@@ -1862,6 +1862,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
           case 2: n = a.Nz; buf = a.dz; break;
           case 3: n = a.Nc; buf = a.dlam; break;
           case 4: n = a.Nw; buf = const_cast<double*>(a.wtile); break;
+          case 5: n = a.Nz; buf = a.zl; break;
+          case 6: n = a.Nz; buf = a.zu; break;
+          case 7: n = a.Ni; buf = a.s; break;
+          case 8: n = a.Ni; buf = a.zs; break;
+          case 9: n = a.Ni; buf = a.ds; break;
           default: return -1;
         }
         if (n == 0) break;

@@ -677,6 +677,18 @@ int dto_solver_scalar(dto_problem* h, int slot, double* out) {
   return DTO_OK;
 }
 
+int dto_solver_peek(dto_problem* h, int which, double* out, int64_t ld, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->z || !out) return set_error(DTO_ERR_INVALID, "no solver state");
+  if (which < 0 || which > 9 || which == 4) return set_error(DTO_ERR_INVALID, "unknown vector");
+  SolverState& S = *p->solver;
+  const int64_t n = (which == 0 || which == 2 || which == 5 || which == 6) ? p->L.Nz : (which == 1 || which == 3) ? p->L.Nc : S.Ni;
+  if (ld < n) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  return dto::unpack(p, a, which, out, ld, (hipStream_t)stream);
+}
+
 int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");

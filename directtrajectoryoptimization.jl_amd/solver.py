@@ -393,6 +393,19 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_solver_scalar(self._solve_nlp._h, capi.SCALARS.index(name), capi.dptr(out)))
         return out
 
+    PEEK = dict(z=0, multipliers=1, dz=2, dmultipliers=3, z_lower=5, z_upper=6, slack=7, slack_multipliers=8, dslack=9)
+
+    def peek_batch(self, name: str):
+        """One vector of the solver's device state as a numpy array [B, n] (include/dto.h: dto_solver_peek)."""
+        import torch
+        which = self.PEEK[name]
+        n = self._solve_nlp.num_variables if which in (0, 2, 5, 6) else (
+            self._solve_nlp.num_constraint if which in (1, 3) else self.footprint()["num_slacks"])
+        out = torch.zeros((self._B, max(1, n)), device="cuda", dtype=torch.float64)
+        capi.check(self._solve_nlp._lib.dto_solver_peek(self._solve_nlp._h, which, out.data_ptr(), max(1, n), None))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()[:, :n]
+
     def end_batch(self, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0):
         capi.check(self._solve_nlp._lib.dto_solver_end(self._solve_nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo, stream or None))
 

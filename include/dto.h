@@ -196,6 +196,10 @@ int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* facto
                          int* factor_rounds /* (k_kkt_fwd, k_kkt_sep) launch pairs per iteration */);
 /* diagnostic: one per-instance scalar slot of the device state (enum dto_scal in csrc/dto_kkt_kernels.hpp), HOST [B] */
 int dto_solver_scalar(dto_problem* p, int slot, double* out);
+/* diagnostic: one vector of the device state, instance-major into DEVICE out[B][ld].  which: 0 z, 1 multipliers, 2 dz,
+ * 3 d multipliers, 5 z_L, 6 z_U (bound multipliers, [num_variables]), 7 slacks, 8 slack multipliers, 9 d slacks (one per
+ * inequality row, in stage order).  Used by the tests that re-derive the interior-point step in numpy. */
+int dto_solver_peek(dto_problem* p, int which, double* out, int64_t ld, void* stream);
 int dto_solver_end(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream);
 
 /* single instance, HOST pointers: solve!(solver) (src/solver.jl:45-47) */
