@@ -84,11 +84,11 @@ class Structure:
         self.wide = max_nx >= WIDE_MIN_STATE
         if self.wide:
             ok = (all(d.num_state == WIDE_STATE and d.num_next_state == WIDE_STATE and d.num_action == 1 for d in self.dyn)
-                  and not self.con and self.general is None and self.evaluate_hessian
+                  and not self.con and self.general is None
                   and all(d.num_parameter == 0 for d in self.dyn))
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
-                                 f"{WIDE_STATE} states, one action, exact Hessians and bound-only stage constraints")
+                                 f"{WIDE_STATE} states, one action and bound-only stage constraints")
         if self.evaluate_hessian:
             # all objects must agree on the flag
             for o in list(self.dyn) + list(self.cost) + list(self.con):
@@ -289,7 +289,7 @@ def generate_wide_source(st: Structure, name: str) -> str:
         va = {"x": "x", "u": "u", "y": "y", "w": "w", "lam": "lam"}
         sig = "const double* x, const double* u, const double* y, const double* w, double* out"
         sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
-        nh = d.num_hessian
+        nh = d.num_hessian if st.evaluate_hessian else 0
         max_njv, max_nh = max(max_njv, len(var_idx)), max(max_nh, nh)
         cl = [f"template <> struct Model::Dyn<{i}> {{"]
         cl.append(f"  static constexpr int NX = {nx}, NU = {nu}, NY = {ny}, NW = {d.num_parameter}, NJ = {d.num_jacobian}, "
@@ -312,19 +312,20 @@ def generate_wide_source(st: Structure, name: str) -> str:
         dev_tables.append(_dev_int_array(f"dyn{i}_nlr", nl_rows))
         dev_tables.append(_dev_int_array(f"dyn{i}_jvr", [d.jacobian_sparsity[0][k] - 1 for k in var_idx]))
         dev_tables.append(_dev_int_array(f"dyn{i}_jvc", [d.jacobian_sparsity[1][k] - 1 for k in var_idx]))
-        dev_tables.append(_dev_int_array(f"dyn{i}_hr0", [r - 1 for r in d.hessian_sparsity[0]]))
-        dev_tables.append(_dev_int_array(f"dyn{i}_hc0", [c - 1 for c in d.hessian_sparsity[1]]))
+        dev_tables.append(_dev_int_array(f"dyn{i}_hr0", [r - 1 for r in d.hessian_sparsity[0]] if nh else []))
+        dev_tables.append(_dev_int_array(f"dyn{i}_hc0", [c - 1 for c in d.hessian_sparsity[1]] if nh else []))
         host_tables.append(_int_array(f"dyn{i}_jr", d.jacobian_sparsity[0]))
         host_tables.append(_int_array(f"dyn{i}_jc", d.jacobian_sparsity[1]))
-        host_tables.append(_int_array(f"dyn{i}_hr", d.hessian_sparsity[0]))
-        host_tables.append(_int_array(f"dyn{i}_hc", d.hessian_sparsity[1]))
+        host_tables.append(_int_array(f"dyn{i}_hr", d.hessian_sparsity[0] if nh else []))
+        host_tables.append(_int_array(f"dyn{i}_hc", d.hessian_sparsity[1] if nh else []))
     for i, c in enumerate(st.cost):
         va = {"x": "x", "u": "u", "w": "w"}
         sig = "const double* x, const double* u, const double* w, double* out"
         snh = len(c.solver_hessian_expr)
         max_snh = max(max_snh, snh)
         cl = [f"template <> struct Model::Cost<{i}> {{"]
-        cl.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, NH = {c.num_hessian}, SNH = {snh};")
+        cl.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, "
+                  f"NH = {c.num_hessian if st.evaluate_hessian else 0}, SNH = {snh};")
         cl.append(_fn("eval", sig, emit_body(c.evaluate_expr, "out", va)))
         cl.append(_fn("grad", sig, emit_body(c.gradient_expr, "out", va)))
         cl.append(_fn("shess", sig, emit_body(c.solver_hessian_expr, "out", va) if snh else "    (void)x;"))
@@ -333,14 +334,14 @@ def generate_wide_source(st: Structure, name: str) -> str:
         classes.append("\n".join(cl))
         dev_tables.append(_dev_int_array(f"cost{i}_sr0", [r - 1 for r in c.solver_sparsity[0]]))
         dev_tables.append(_dev_int_array(f"cost{i}_sc0", [q - 1 for q in c.solver_sparsity[1]]))
-        host_tables.append(_int_array(f"cost{i}_hr", c.sparsity[0]))
-        host_tables.append(_int_array(f"cost{i}_hc", c.sparsity[1]))
+        host_tables.append(_int_array(f"cost{i}_hr", c.sparsity[0] if st.evaluate_hessian else []))
+        host_tables.append(_int_array(f"cost{i}_hc", c.sparsity[1] if st.evaluate_hessian else []))
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     out.append("struct Model {")
     out.append(f"  static constexpr int WIDE_N = {WIDE_STATE}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
     max_key = max([1] + [st.key_slots(k) for k in st.kinds])
-    out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = 1, MAX_KEY = {max_key};")
+    out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = {1 if st.evaluate_hessian else 0}, MAX_KEY = {max_key};")
     out.append("  template <int K> struct WKind;")
     out.append("  template <int C> struct Dyn;")
     out.append("  template <int C> struct Cost;")
@@ -356,10 +357,11 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.extend(host_tables)
     rows = []
     for i, d in enumerate(st.dyn):
-        rows.append(f"  {{{d.num_next_state}, {d.num_state}, {d.num_action}, {d.num_parameter}, {d.num_jacobian}, {d.num_hessian}, "
-                    f"dyn{i}_jr, dyn{i}_jc, dyn{i}_hr, dyn{i}_hc}}")
+        rows.append(f"  {{{d.num_next_state}, {d.num_state}, {d.num_action}, {d.num_parameter}, {d.num_jacobian}, "
+                    f"{d.num_hessian if st.evaluate_hessian else 0}, dyn{i}_jr, dyn{i}_jc, dyn{i}_hr, dyn{i}_hc}}")
     out.append("static const dto_dyn_class k_dyn[] = {\n" + ",\n".join(rows) + "\n};")
-    rows = [f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_hessian}, cost{i}_hr, cost{i}_hc}}" for i, c in enumerate(st.cost)]
+    rows = [f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_hessian if st.evaluate_hessian else 0}, cost{i}_hr, cost{i}_hc}}"
+            for i, c in enumerate(st.cost)]
     out.append("static const dto_cost_class k_cost[] = {\n" + ",\n".join(rows) + "\n};")
     out.append("static const dto_con_class k_con[] = {\n  {0}\n};")
     rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
@@ -368,7 +370,7 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
-    out.append("  k_dyn, k_cost, k_con, k_kinds, nullptr, 1,")
+    out.append(f"  k_dyn, k_cost, k_con, k_kinds, nullptr, {1 if st.evaluate_hessian else 0},")
     out.append(f"  {max_key}, launch, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>")
     out.append("};")
     out.append("}  // namespace")

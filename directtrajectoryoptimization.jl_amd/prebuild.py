@@ -28,6 +28,7 @@ def all_structures():
         ("mpc_pendulum", P.build_mpc_pendulum, dict(T=5)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=3)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=2)),
+        ("acrobot_padded", P.build_acrobot_padded, dict(T=3, evaluate_hessian=False)),
     ]:
         p = builder(**kw)
         out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], p.get("general_constraint"),

@@ -193,3 +193,34 @@ def test_wide_solve_converges_to_a_kkt_point(T, target, terminal):
     assert dto_amd.solve(s) == 1 and s.iterations == iters[0]
     x_sol, u_sol = dto_amd.get_trajectory(s)
     assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1][:4] - p["xT"][:4]) < 1e-3
+
+
+def test_wide_default_mode_solve_and_callbacks():
+    """The 64-state model built the reference's default way (no evaluate_hessian): the MOI surface reports [:Grad, :Jac] and
+    an empty Hessian structure, the callbacks still match the oracle, and solve! uses exact second derivatives internally
+    (same iteration count as the evaluate_hessian=true problem)."""
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives
+    T = 24
+    p = P.build_acrobot_padded(T=T, target=0.3, terminal="physical", evaluate_hessian=False)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], name="acrobot_padded")
+    n = s.nlp
+    assert n.features_available() == ["Grad", "Jac"] and n.hessian_lagrangian_structure() == []
+    rng = np.random.default_rng(4)
+    z = rng.random(n.num_variables)
+    f, g, c, J, _ = dense_derivatives(PaddedAcrobot(64), T, z, np.zeros(n.num_constraint), 1.0)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    jr, jc = np.array(n.jacobian_structure()).T - 1
+    Jd = np.zeros_like(J); Jd[jr, jc] = Jv
+    assert np.max(np.abs(Jd - J)) <= 1e-8 * np.max(np.abs(J))
+    cv = np.zeros(n.num_constraint); n.eval_constraint(cv, z)
+    assert np.max(np.abs(cv - c)) <= 1e-8 * max(1.0, np.max(np.abs(c)))
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+    assert dto_amd.solve(s) == 1
+    its_default = s.iterations
+    pe = P.build_acrobot_padded(T=T, target=0.3, terminal="physical", evaluate_hessian=True)
+    se = dto_amd.Solver(pe["dynamics"], pe["objective"], pe["constraints"], pe["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    se._z0[:] = s._z0
+    assert dto_amd.solve(se) == 1 and se.iterations == its_default
