@@ -118,7 +118,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
   a.delta_w = delta_w; a.delta_c = delta_c; a.piv_tol = 1e-9;
   a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
   a.fac = p->wide_fac; a.flags = p->wide_flags; a.Nc = L.Nc;
-  a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.active = nullptr; a.stats = nullptr; a.merit = nullptr;
+  a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.gam_inst = nullptr; a.active = nullptr; a.stats = nullptr; a.merit = nullptr;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_WIDE_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   const int lrc = p->vt->launch_wide(DTO_WIDE_STEP, &a, (void*)st);
@@ -138,7 +138,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
 // Solver for wide-stage models (configs[4]): the same filter line-search SQP iteration as the register path, driven from
 // the host -- one iteration costs a dense block factorisation per instance (hundreds of milliseconds at T = 2000), so a
 // few stream synchronisations per iteration are free.  Scope: dynamics rows plus variables fixed by equal bounds (what
-// the model uses); no inequality rows / finite bounds (no barrier), no Gauss-Newton fallback.
+// the model uses); no inequality rows / finite bounds (no barrier).
 // ------------------------------------------------------------------------------------------------
 static __global__ void k_rows_axpy(double* y, const double* x, const double* alpha, int64_t n, int64_t ldy, int64_t ldx) {
   const int64_t b = blockIdx.y;
@@ -175,11 +175,11 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     p->wide_fac_len = need_fac;
   }
   double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_dw = nullptr,
-         *d_stats = nullptr, *d_merit = nullptr, *d_alpha = nullptr;
+         *d_stats = nullptr, *d_merit = nullptr, *d_alpha = nullptr, *d_gam = nullptr;
   int *d_flags = nullptr, *d_active = nullptr;
   auto cleanup = [&]() {
     for (void* q : {(void*)z, (void*)lam, (void*)dz, (void*)dlam, (void*)d_lo, (void*)d_hi, (void*)d_dw, (void*)d_stats,
-                    (void*)d_merit, (void*)d_alpha, (void*)d_flags, (void*)d_active})
+                    (void*)d_merit, (void*)d_alpha, (void*)d_gam, (void*)d_flags, (void*)d_active})
       if (q) (void)hipFree(q);
   };
 #define WTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
@@ -193,6 +193,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   WTRY(hipMalloc((void**)&d_stats, (size_t)B * DTO_WIDE_NSTAT * sizeof(double)));
   WTRY(hipMalloc((void**)&d_merit, (size_t)B * 2 * DTO_WIDE_TRIALS * sizeof(double)));
   WTRY(hipMalloc((void**)&d_alpha, B * sizeof(double)));
+  WTRY(hipMalloc((void**)&d_gam, B * sizeof(double)));
   WTRY(hipMalloc((void**)&d_flags, B * sizeof(int)));
   WTRY(hipMalloc((void**)&d_active, B * sizeof(int)));
   WTRY(hipMemcpyAsync(d_lo, L.var_lo.data(), Nz * sizeof(double), hipMemcpyHostToDevice, st));
@@ -204,12 +205,13 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
 
   struct Inst {
     int status = 0, iter = 0, ls_fail = 0, full_streak = 0, attempt = 0;
-    double dw = 0.0, dlast = 0.0, theta_max = -1.0, theta_min = -1.0, alpha = 0.0;
+    double dw = 0.0, dlast = 0.0, theta_max = -1.0, theta_min = -1.0, alpha = 0.0, gam = 1.0, gamma_acc = 1.0;
     std::vector<double> filt;  // (theta, phi) pairs, ring of DTO_FILTER_CAP
     int filter_n = 0;
   };
   std::vector<Inst> I((size_t)B);
   std::vector<int> h_active((size_t)B), h_flags((size_t)B);
+  std::vector<double> h_gam((size_t)B, 1.0);
   std::vector<double> h_dw((size_t)B), h_stats((size_t)B * DTO_WIDE_NSTAT), h_merit((size_t)B * 2 * DTO_WIDE_TRIALS), h_alpha((size_t)B);
   dto_wide_args a;
   a.T = L.T; a.B = B;
@@ -218,7 +220,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   a.delta_w = 0.0; a.delta_c = o.delta_c; a.piv_tol = o.piv_tol;
   a.dz = dz; a.lddz = Nz; a.dmu = dlam; a.lddmu = Nc;
   a.fac = p->wide_fac; a.flags = d_flags; a.Nc = Nc; a.prof = nullptr;
-  a.fixed_lo = d_lo; a.fixed_hi = d_hi; a.dw_inst = d_dw; a.active = d_active; a.stats = d_stats; a.merit = d_merit;
+  a.fixed_lo = d_lo; a.fixed_hi = d_hi; a.dw_inst = d_dw; a.gam_inst = d_gam; a.active = d_active; a.stats = d_stats; a.merit = d_merit;
   auto launch = [&](int op) -> int {
     const int lrc = p->vt->launch_wide(op, &a, (void*)st);
     return lrc;
@@ -236,12 +238,15 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       if (s.ls_fail) s.dw = std::min(o.delta_w_exact_cap, std::max(10.0 * s.dlast, o.delta_w_init));
       else if (s.dlast > 1.1 * o.delta_w_init && s.full_streak < 2) s.dw = std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
       else s.dw = 0.0;
+      s.gam = 1.0;  // the exact Hessian of the Lagrangian first
       h_dw[(size_t)i] = s.dw;
+      h_gam[(size_t)i] = 1.0;
     }
     bool first_pass = true;
     for (;;) {
       WTRY(hipMemcpyAsync(d_active, h_active.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
       WTRY(hipMemcpyAsync(d_dw, h_dw.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+      WTRY(hipMemcpyAsync(d_gam, h_gam.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
       { const int lrc = launch(DTO_WIDE_STEP); if (lrc) { cleanup(); return hip_fail((hipError_t)lrc, "wide step"); } }
       WTRY(hipMemcpyAsync(h_flags.data(), d_flags, B * sizeof(int), hipMemcpyDeviceToHost, st));
       WTRY(hipMemcpyAsync(h_stats.data(), d_stats, h_stats.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -264,17 +269,26 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
         }
         // ---- C: inertia (Algorithm IC, ladder on the exact Hessian)
         if (h_flags[(size_t)i] || s.attempt >= o.max_refactor) {
-          if (s.dw > 0.0) s.dlast = s.dw;
+          if (s.dw > 0.0 && s.gam != 0.0) s.dlast = s.dw;
           if (s.dw == 0.0) s.dlast = 0.0;
+          s.gamma_acc = s.gam;
           if (!h_flags[(size_t)i]) s.ls_fail = 1;
           h_active[(size_t)i] = 0;   // factorisation accepted: no further attempt
           h_flags[(size_t)i] = 2;    // marks "step available" for the line search below
         } else {
-          if (s.dw == 0.0) s.dw = (s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
-          else s.dw *= (s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
-          s.dw = std::min(s.dw, o.delta_w_max);
+          // same ladder as k_kkt_sep: exact Hessian up to delta_w_exact_cap, then the constraint curvature is dropped
+          // (Gauss-Newton) instead of inflating delta_w further -- large delta_w only inflates the multipliers it fights
+          if (s.gam != 0.0) {
+            const bool skip_ladder = (s.gamma_acc == 0.0) && (s.iter % 4 != 0);
+            if (s.dw == 0.0 && !skip_ladder) s.dw = (s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
+            else if (!skip_ladder) s.dw *= (s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
+            if (skip_ladder || s.dw > o.delta_w_exact_cap) { s.gam = 0.0; s.dw = o.delta_w_init; }
+          } else {
+            s.dw = std::min(s.dw * o.kappa_w_plus, o.delta_w_max);
+          }
           s.attempt++;
           h_dw[(size_t)i] = s.dw;
+          h_gam[(size_t)i] = s.gam;
           again = true;
         }
       }

@@ -50,6 +50,7 @@ struct dto_wide_args {
   // ---- solver use (dto_solve_batch on wide models); all NULL / 0 for the plain dto_kkt_step_batch
   const double* fixed_lo; const double* fixed_hi;  // [Nz] variable bounds: components with lo == hi get identity rows
   const double* dw_inst;   // [B] per-instance delta_w (overrides delta_w)
+  const double* gam_inst;  // [B] 1: exact Hessian of the Lagrangian, 0: Gauss-Newton (constraint curvature lam' d'' dropped)
   const int* active;       // [B] 0 = skip this instance
   double* stats;           // [B][DTO_WIDE_NSTAT]: f, theta_1, theta_inf, dual infeasibility, grad f' dz, sum |lam|
   double* merit;           // [B][2 * DTO_WIDE_TRIALS]: (f, theta_1) at z + 2^-k dz, k = 0..TRIALS-1 (DTO_WIDE_MERIT)
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   double* facb = a.fac + b * (int64_t)a.T * D::FAC;
   if (a.active && !a.active[b]) return;
   const double dw = a.dw_inst ? a.dw_inst[b] : a.delta_w, dc = a.delta_c;
+  const double gam = a.gam_inst ? a.gam_inst[b] : 1.0;
   double* stat = vec + 20 * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4;  // f, th1, thinf, dinf (LDS scalars)
   double* fxm = stat + 8;   // [N] 1.0 where x_t is fixed by equal bounds
   if (tid < 8) stat[tid] = 0.0;
@@ -480,7 +482,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         } else if (w == 1) {
           DY::jac_var(xv, sc, yv, wp, jvv);
         } else if (w == 2) {
-          if constexpr (DY::NH > 0) DY::hess(xv, sc, yv, wp, lamv, hv);
+          if constexpr (DY::NH > 0) {
+            DY::hess(xv, sc, yv, wp, lamv, hv);
+            if (gam != 1.0 && l < DY::NH) hv[l] *= gam;
+          }
         } else {
           CO::grad(xv, sc, wp, gc);
           if constexpr (CO::SNH > 0) CO::shess(xv, sc, wp, chv);
