@@ -320,6 +320,16 @@ __device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
   if (l < N) v[l] = mine;
 }
 
+// whole-matrix copies between LDS and the factor record in HBM, 16 bytes per lane (MAT is even and every matrix starts
+// on a 16-byte boundary: MAT * 8 = 33 280 bytes)
+template <int MAT>
+__device__ __forceinline__ void copy_mat(double* dst, const double* src) {
+  static_assert(MAT % 2 == 0, "matrix size must be even for 16-byte copies");
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  for (int i = threadIdx.x; i < MAT / 2; i += WG) d2[i] = s2[i];
+}
+
 // dot products over N terms, fully unrolled with four independent accumulators (LDS loads all in flight)
 template <int N>
 __device__ __forceinline__ double dot_rr(const double* a, const double* v) {
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         if (tid < N) {
           tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
         }
-        for (int i = tid; i < MAT; i += WG) fac[D::F_LA + i] = MA[i];
+        copy_mat<MAT>(fac + D::F_LA, MA);
         __syncthreads();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
@@ -665,12 +675,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         if (tid < N) {
           tmp[tid] = byn[tid] - dot_crs<N>(MV + tid, LD, bx, dAi) + dot_crs<N>(ME + tid, LD, bd, dMi);
         }
-        for (int i = tid; i < MAT; i += WG) {
-          fac[D::F_LM + i] = MA[i];
-          fac[D::F_FT + i] = MF[i];
-          fac[D::F_VT + i] = MV[i];
-          fac[D::F_ET + i] = ME[i];
-        }
+        copy_mat<MAT>(fac + D::F_LM, MA);
+        copy_mat<MAT>(fac + D::F_FT, MF);
+        copy_mat<MAT>(fac + D::F_VT, MV);
+        copy_mat<MAT>(fac + D::F_ET, ME);
         if (tid < N) {
           double* fv = fac + D::F_VEC;
           fv[D::V_DA + tid] = dAi[tid];
@@ -780,12 +788,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   for (int t = a.T - 2; t >= 0; --t) {
     const double* fac = facb + (int64_t)t * D::FAC;
     const double* fv = fac + D::F_VEC;
-    for (int i = tid; i < MAT; i += WG) {
-      ME[i] = fac[D::F_ET + i];
-      MA[i] = fac[D::F_LM + i];
-      MF[i] = fac[D::F_FT + i];
-      MV[i] = fac[D::F_VT + i];
-    }
+    copy_mat<MAT>(ME, fac + D::F_ET);
+    copy_mat<MAT>(MA, fac + D::F_LM);
+    copy_mat<MAT>(MF, fac + D::F_FT);
+    copy_mat<MAT>(MV, fac + D::F_VT);
     if (tid < N) {
       dAi[tid] = fv[D::V_DA + tid];
       dMi[tid] = fv[D::V_DM + tid];
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       xv[tid] = (bx[tid] - dot_cr<N>(MF + tid, LD, lamv) - dot_rr<N>(MV + tid * LD, yv)) * dAi[tid];
     }
     __syncthreads();
-    for (int i = tid; i < MAT; i += WG) MA[i] = fac[D::F_LA + i];
+    copy_mat<MAT>(MA, fac + D::F_LA);
     __syncthreads();
     if (w == 0) trsv_lower_t<N>(MA, xv);
     __syncthreads();
