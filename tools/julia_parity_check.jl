@@ -5,6 +5,7 @@
 # rules on corner cases and Ipopt's iterates cannot be checked here", SURVEY.md 8c / DESIGN.md section 6).
 #
 #     julia --project=/path/to/DirectTrajectoryOptimization.jl tools/julia_parity_check.jl tests/golden
+#     julia --project=/path/to/DirectTrajectoryOptimization.jl tools/julia_parity_check.jl tests/golden --solve   # + Ipopt
 #
 # For every fixture it rebuilds the same problem with the reference's own constructors (models as in examples/*.jl and
 # test/*.jl), evaluates the five MOI methods of src/moi.jl at the fixture's point (z, mu, sigma) and compares
@@ -152,7 +153,31 @@ function check(path)
     ok
 end
 
+# ---------------------------------------------------------------- optional: Ipopt from the same guesses (--solve)
+# tests/golden/solve_guesses.json holds seeded guesses and what the GPU solver returned from them (iterations, objective).
+# The reference's solve!(solver) is run from exactly those guesses; Ipopt's iteration count is read from its output file
+# (src/options.jl:24).  Different local minima are legitimate for the nonconvex swing-ups: compare objectives first.
+function solve_case(r)
+    eh = r["evaluate_hessian"]
+    full = build(r["model"], r["T"])            # constructors above use evaluate_hessian=true
+    solver = eh ? full : full                   # (for the default-mode examples rebuild with eh=false if L-BFGS is wanted)
+    initialize_states!(solver, [Float64.(x) for x in r["states"]])
+    initialize_controls!(solver, [Float64.(u) for u in r["actions"]])
+    solve!(solver)
+    x_sol, u_sol = get_trajectory(solver)
+    z = vcat([vcat(x_sol[t], t <= length(u_sol) ? u_sol[t] : Float64[]) for t = 1:length(x_sol)]...)
+    f = MOI.eval_objective(solver.nlp, z)
+    println(rpad(string(r["model"], " T=", r["T"], " seed=", r["seed"]), 28), "reference objective ", f,
+            "   ours: ", r["ours"])
+end
+if "--solve" in ARGS
+    for r in JSON.parsefile(joinpath(filter(a -> a != "--solve", ARGS)[1], "solve_guesses.json"))
+        solve_case(r)
+    end
+    exit(0)
+end
+
 dir = length(ARGS) > 0 ? ARGS[1] : "tests/golden"
-results = [check(joinpath(dir, f)) for f in sort(readdir(dir)) if endswith(f, ".json")]
+results = [check(joinpath(dir, f)) for f in sort(readdir(dir)) if endswith(f, ".json") && f != "solve_guesses.json"]
 println(all(results) ? "all fixtures agree with the reference" : "MISMATCH: the oracle is not pinned")
 exit(all(results) ? 0 : 1)
