@@ -133,7 +133,7 @@ relerr(a, b) = maximum(abs.(a .- b) ./ max.(abs.(b), 1.0e-3 * maximum(abs.(b)) +
 
 function check(path)
     g = JSON.parsefile(path)
-    haskey(g, "model") || return true           # (the full-size structure file has another layout)
+    (g isa AbstractDict && haskey(g, "model")) || return true   # (the full-size structure file has another layout)
     solver = build(g["model"], g["T"])
     nlp = solver.nlp
     z, mu, sigma = Float64.(g["z"]), Float64.(g["mu"]), g["sigma"]
