@@ -57,6 +57,30 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def full_solve_measurement(dev, T=101, B=1024):
+    """Time to solution on a workload where every instance converges: the reference example's own horizon
+    (examples/acrobot/acrobot.jl:12, T = 101), 1024 seeded guesses solved to the reference Options tolerances in one batch.
+    (The headline workload, T = 1000, has non-isolated minimisers and is measured as iteration throughput: DESIGN.md 5.)"""
+    import time as _time
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_acrobot(T=T, evaluate_hessian=True)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
+    nz = s.nlp.num_variables
+    z0 = torch.tensor(make_guesses(s, p, B, seed=1000), device=dev)
+    zo = torch.empty_like(z0)
+    st = torch.cuda.current_stream().cuda_stream
+    s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, stream=st)      # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = _time.perf_counter()
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, stream=st)
+    torch.cuda.synchronize()
+    dt = _time.perf_counter() - t0
+    return dict(workload=f"acrobot swing-up T={T} (the reference example's horizon), {B} seeded guesses, solved to tol=1e-6",
+                converged=int(np.sum(status == 1)), instances=B, seconds=round(dt, 4), solves_per_sec=round(B / dt, 1),
+                iterations_median=float(np.median(iters)), sqp_iterations_per_sec=round(float(np.sum(iters)) / dt, 1))
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense FP64 matrix (no local guide figure; SURVEY.md 8(d))
 
 
@@ -254,6 +278,13 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
             cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
 
+    full = None
+    if rank == 0 and world == 1:
+        try:
+            full = full_solve_measurement(dev)
+        except Exception as e:  # side measurement, never part of `value`
+            full = dict(error=str(e))
+
     dense = None
     if rank == 0 and world == 1 and not a.no_dense_blocks:
         try:
@@ -274,7 +305,7 @@ def main():
             jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=s.partitions(),
             gathered_trajectories=int(gathered.shape[0]),
-            roofline=roofline, cpu_baseline=cpu, dense_blocks=dense,
+            roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,
         )
         print(json.dumps(out), flush=True)
     if dist is not None:
