@@ -505,6 +505,14 @@ def solve(solver: Solver):
         ref[solver._mu_to_reference] = mu[:n.num_constraint]
         solver._duals = ref
     solver.status, solver.iterations = int(status.value), int(iters.value)
+    if solver.options.print_level >= 5:
+        # the reference prints Ipopt's iteration log at this level (src/options.jl:23); here: one summary line
+        names = {0: "cut off (max_cpu_time)", 1: "converged", 2: "maximum iterations reached", 3: "failed (non-finite iterate)"}
+        try:
+            f = solver.nlp.eval_objective(x)
+        except Exception:
+            f = float("nan")
+        print(f"dto_amd: {names.get(solver.status, solver.status)} after {solver.iterations} iterations, objective {f:.10e}")
     return solver.status
 
 
