@@ -269,3 +269,44 @@ def test_max_cpu_time_cuts_the_solve_off():
     st = dto_amd.solve(s)
     assert st == 0 and 0 < s.iterations < 100000 and time.perf_counter() - t0 < 5.0
     assert np.all(np.isfinite(s._solution))
+
+
+def test_initial_point_is_pushed_into_the_bounds():
+    """Ipopt's initialisation (Waechter & Biegler 2006, section 3.6, kappa_1 = kappa_2 = 1e-2 = the reference's
+    bound_push / bound_frac defaults): a guess on or outside a two-sided bound is projected to
+    [lo + p_L, hi - p_U], p_L = min(k1 max(1, |lo|), k2 (hi - lo)); fixed variables (lo == hi) take their value; slacks of
+    inequality rows start at max(-c, k1 max(1, |c|)); bound and slack multipliers start on the central path,
+    z_L = mu_init / (z - lo) (Ipopt's bound_mult_init_method = "mu-based"; k_init, dto_kkt_kernels.hpp)."""
+    import torch
+    import dto_amd
+    s, p = product_solver("car", 6)
+    n = s.nlp
+    nz = n.num_variables
+    lo, hi = n.variable_bounds
+    rng = np.random.default_rng(0)
+    z0 = rng.standard_normal(nz)                      # states anywhere (also the fixed ones), actions far outside +-0.5
+    ia = np.concatenate([np.array(i) - 1 for i in n.indices.actions])
+    z0[ia] = np.array([0.5, -0.5, 3.0, -7.0, 0.0, 0.499, 0.2, -0.3, 0.5, 0.1])[:len(ia)]
+    zt = torch.tensor(z0[None, :], device="cuda")
+    s.begin_batch(zt.data_ptr(), 1, nz)
+    z = s.peek_batch("z")[0]
+    fixed = lo == hi
+    two = np.isfinite(lo) & np.isfinite(hi) & ~fixed
+    pl = np.minimum(1e-2 * np.maximum(1.0, np.abs(lo[two])), 1e-2 * (hi[two] - lo[two]))
+    pu = np.minimum(1e-2 * np.maximum(1.0, np.abs(hi[two])), 1e-2 * (hi[two] - lo[two]))
+    want = z0.copy()
+    want[two] = np.minimum(np.maximum(z0[two], lo[two] + pl), hi[two] - pu)
+    want[fixed] = lo[fixed]
+    assert np.max(np.abs(z - want)) < 1e-15
+    mu0 = 0.1                                         # dto_options.mu_init (include/dto.h), Ipopt default
+    assert np.max(np.abs(s.peek_batch("z_lower")[0][two] * (z[two] - lo[two]) - mu0)) < 1e-14
+    assert np.max(np.abs(s.peek_batch("z_upper")[0][two] * (hi[two] - z[two]) - mu0)) < 1e-14
+    from oracle import dto_oracle as O, sympy_models as S
+    op = S.build("car", 6, evaluate_hessian=True)
+    onlp = O.NLPData(op["dynamics"], op["objective"], op["constraints"], op["bounds"], evaluate_hessian=True)
+    c = onlp.eval_constraint(z)
+    clo, _ = n.constraint_bounds
+    ineq = np.isneginf(clo)
+    sl = s.peek_batch("slack")[0]
+    assert np.max(np.abs(sl - np.maximum(-c[ineq], 1e-2 * np.maximum(1.0, np.abs(c[ineq]))))) < 1e-12
+    assert np.max(np.abs(s.peek_batch("slack_multipliers")[0] * sl - mu0)) < 1e-14
