@@ -55,7 +55,7 @@ class COptions(C.Structure):
 # enum dto_scal (csrc/dto_kkt_kernels.hpp)
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
-           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak"]
+           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog"]
 
 
 class DtoError(RuntimeError):

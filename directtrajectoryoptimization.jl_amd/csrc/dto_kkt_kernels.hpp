@@ -54,7 +54,7 @@ enum dto_scal {
   SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed
   SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
-  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET, SC_FULL_STREAK,
+  SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET, SC_FULL_STREAK, SC_SHORT_STREAK, SC_WATCHDOG,
   SC_COUNT
 };
 
@@ -80,6 +80,7 @@ struct dto_solver_opts {
   double delta_w_exact_cap;  // largest delta_w tried with the exact Hessian before the Gauss-Newton fallback
   double eta_armijo, rho_penalty, piv_tol;
   int max_refactor;
+  int watchdog_trigger, watchdog_trials;  // Ipopt: watchdog_shortened_iter_trigger (10), watchdog_trial_iter_max (3); 0 = off
   int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (test entry dto_kkt_step)
   double fixed_delta_w;
 };
@@ -376,6 +377,8 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_LS_KIND) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_QN_RESET) = 1.0;  // quasi-Newton blocks start from the objective Hessian
     *soa(a.scal, g, SC_COUNT, SC_FULL_STREAK) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_SHORT_STREAK) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_WATCHDOG) = 0.0;
   }
 }
 
@@ -1703,6 +1706,13 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
   double chosen = -1.0;
   bool ftype = false;
   int best = 0;
+  // Watchdog (Ipopt: watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; Chamberlain et al. 1982): after
+  // `trigger` consecutive iterations whose step was cut by the filter, the next `trials` iterations take the
+  // fraction-to-the-boundary step without consulting the filter (only theta <= theta_max), then the filter decides again
+  // from wherever that led.  Ipopt keeps the watchdog iterate and returns to it if the trial iterations end outside the
+  // filter; here there is no rollback (no second copy of the iterate per instance).  Effect: DESIGN.md section 5.
+  const int wd_left = (int)sc[SC_WATCHDOG << 6];
+  const bool watchdog = wd_left > 0;
 #pragma unroll 1
   for (int k = 0; k < DTO_LS_TRIALS; ++k) {
     const double tk = th[k], pk = phi[k];
@@ -1718,7 +1728,8 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
         ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
       }
     }
-    if (ok) {
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= thmax;
+    if (ok && !watchdog) {
       for (int i = 0; i < nf; ++i) {
         const double tf = fl[(int64_t)(2 * i) << 6], pf = fl[(int64_t)(2 * i + 1) << 6];
         if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
@@ -1742,7 +1753,19 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     augment = true;
   } else {
     sc[SC_LS_FAIL << 6] = 0.0;
-    augment = !ftype;
+    augment = !ftype && !watchdog;
+  }
+  if (watchdog) {
+    sc[SC_WATCHDOG << 6] = (double)(wd_left - 1);
+    sc[SC_SHORT_STREAK << 6] = 0.0;
+  } else if (a.opt.watchdog_trigger > 0) {
+    const double streak = (chosen < sc[SC_ALPHA_PMAX << 6]) ? sc[SC_SHORT_STREAK << 6] + 1.0 : 0.0;
+    if (streak >= (double)a.opt.watchdog_trigger) {
+      sc[SC_WATCHDOG << 6] = (double)a.opt.watchdog_trials;
+      sc[SC_SHORT_STREAK << 6] = 0.0;
+    } else {
+      sc[SC_SHORT_STREAK << 6] = streak;
+    }
   }
   if (augment) {
     const int slot = nf_total % DTO_FILTER_CAP;
@@ -1750,7 +1773,7 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     fl[(int64_t)(2 * slot + 1) << 6] = phi0 - G_PHI * th0;
     sc[SC_FILTER_N << 6] = (double)(nf_total + 1);
   }
-  sc[SC_LS_KIND << 6] = chosen < 0.0 ? -1.0 : (ftype ? 1.0 : 2.0);
+  sc[SC_LS_KIND << 6] = chosen < 0.0 ? -1.0 : (watchdog ? 3.0 : (ftype ? 1.0 : 2.0));
   sc[SC_ALPHA << 6] = chosen;
   // consecutive full (fraction-to-the-boundary) steps: consulted by k_conv when it picks the first delta_w to try
   sc[SC_FULL_STREAK << 6] = (chosen >= sc[SC_ALPHA_PMAX << 6]) ? sc[SC_FULL_STREAK << 6] + 1.0 : 0.0;

@@ -82,8 +82,11 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.delta_c = u.delta_c; o.delta_w_init = u.delta_w_init; o.delta_w_min = 1e-20; o.delta_w_max = 1e20;
   o.kappa_w_minus = 1.0 / 3.0; o.kappa_w_plus = 8.0; o.kappa_w_plus_first = 100.0;
   o.delta_w_exact_cap = 1.0;
+  if (const char* e = getenv("DTO_EXACT_CAP")) o.delta_w_exact_cap = atof(e);  // experiment knob
   o.eta_armijo = 1e-4; o.rho_penalty = 0.1; o.piv_tol = 1e-9;
   o.max_refactor = 9;
+  o.watchdog_trigger = 10; o.watchdog_trials = 3;
+  if (const char* e = getenv("DTO_WATCHDOG")) sscanf(e, "%d,%d", &o.watchdog_trigger, &o.watchdog_trials);  // experiment knob
   o.newton_only = 0; o.fixed_delta_w = 0.0;
 }
 

@@ -16,6 +16,7 @@
  * independent implementation of the same algorithm, not against Ipopt's iterates.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,7 +41,7 @@ typedef struct {
   double x1[MAXN], xT[MAXN];
   /* options (mirrors csrc/dto_solver.cpp default_opts) */
   double tol, s_max, dual_inf_tol, constr_viol_tol, delta_c, delta_w_init, delta_w_max, delta_w_exact_cap, piv_tol;
-  int max_iter, max_refactor;
+  int max_iter, max_refactor, watchdog_trigger, watchdog_trials;
 } port_problem;
 
 typedef struct {
@@ -55,7 +56,7 @@ typedef struct {
   int Nz, Nc;
   double *z, *lam /* dyn rows then pin rows (first, last) */, *dz, *dlam;
   stage_t* st;
-  int status, iter, nfact, filter_n, ls_fail, full_streak;
+  int status, iter, nfact, filter_n, ls_fail, full_streak, short_streak, watchdog;
   double f, th1, thinf, dinf, delta_w, delta_last, gamma, alpha, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
 } port_solver;
@@ -90,7 +91,7 @@ void port_destroy(port_solver* S) {
 void port_begin(port_solver* S, const double* z0) {
   memcpy(S->z, z0, S->Nz * sizeof(double));
   memset(S->lam, 0, S->Nc * sizeof(double));
-  S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0;
+  S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0; S->short_streak = 0; S->watchdog = 0;
   S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
 }
 
@@ -310,6 +311,7 @@ static void line_search(port_solver* S) {
   const int nf = S->filter_n < FILTER_CAP ? S->filter_n : FILTER_CAP;
   double chosen = -1.0;
   int ftype = 0, best = 0;
+  const int wd_left = S->watchdog, watchdog = wd_left > 0;  /* rollback-free watchdog: see k_ls_reduce */
   alpha = 1.0;
   for (int k = 0; k < LS_TRIALS; ++k) {
     const double tk = th[k], pk = phi[k];
@@ -320,7 +322,8 @@ static void line_search(port_solver* S) {
       if (sw && th0 <= S->theta_min) ok = pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0);
       else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
     }
-    if (ok)
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
+    if (ok && !watchdog)
       for (int i = 0; i < nf; ++i) {
         const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
         if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = 0; break; }
@@ -334,7 +337,13 @@ static void line_search(port_solver* S) {
     for (int k = 0; k < best; ++k) ab *= 0.5;
     if (th[best] == th[best] && th[best] < th0) chosen = ab; else chosen = alpha * 2.0;
     S->ls_fail = 1; augment = 1;
-  } else { S->ls_fail = 0; augment = !ftype; }
+  } else { S->ls_fail = 0; augment = !ftype && !watchdog; }
+  if (watchdog) { S->watchdog = wd_left - 1; S->short_streak = 0; }
+  else if (S->P.watchdog_trigger > 0) {
+    const int streak = (chosen < 1.0) ? S->short_streak + 1 : 0;
+    if (streak >= S->P.watchdog_trigger) { S->watchdog = S->P.watchdog_trials; S->short_streak = 0; }
+    else S->short_streak = streak;
+  }
   if (augment) {
     const int slot = S->filter_n % FILTER_CAP;
     S->filt[2 * slot] = (1.0 - G_TH) * th0;
@@ -405,6 +414,7 @@ port_solver* port_create_named(const char* model, int T, const double* x1, const
   memcpy(P.xT, xT, P.n * sizeof(double));
   P.tol = 1e-6; P.s_max = 100.0; P.dual_inf_tol = 1.0; P.constr_viol_tol = 1e-3;
   P.delta_c = 1e-8; P.delta_w_init = 1e-4; P.delta_w_max = 1e20; P.delta_w_exact_cap = 1.0; P.piv_tol = 1e-9;
-  P.max_iter = max_iter; P.max_refactor = 12;
+  P.max_iter = max_iter; P.max_refactor = 12; P.watchdog_trigger = 10; P.watchdog_trials = 3;
+  if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &P.watchdog_trigger, &P.watchdog_trials);
   return port_create(&P);
 }

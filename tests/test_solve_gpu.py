@@ -310,3 +310,46 @@ def test_initial_point_is_pushed_into_the_bounds():
     sl = s.peek_batch("slack")[0]
     assert np.max(np.abs(sl - np.maximum(-c[ineq], 1e-2 * np.maximum(1.0, np.abs(c[ineq]))))) < 1e-12
     assert np.max(np.abs(s.peek_batch("slack_multipliers")[0] * sl - mu0)) < 1e-14
+
+
+def test_watchdog_state_machine():
+    """Ipopt's watchdog (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3), rollback-free form of
+    k_ls_reduce: after 10 consecutive iterations whose step the filter cut below the fraction-to-the-boundary step, the
+    next 3 iterations take that step unfiltered (ls_kind 3, alpha == alpha_pmax) and do not touch the filter; then the
+    count starts again.  Cartpole T=200 is the case that needs it."""
+    import torch
+    import dto_amd
+    s, p = product_solver("cartpole", 200)
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs)
+    dto_amd.initialize_controls(s, us)
+    nz = s.nlp.num_variables
+    z0 = torch.tensor(np.asarray(s._z0)[None, :].copy(), device="cuda")
+    old = s.options.max_iter
+    s.options.max_iter = 1000
+    try:
+        s.begin_batch(z0.data_ptr(), 1, nz)
+        streak, left, fired = 0, 0, 0
+        for it in range(150):
+            nf0 = float(s.scalar_batch("filter_n")[0])
+            mu0 = float(s.scalar_batch("mu")[0])
+            s.iterate_batch(1)
+            if float(s.scalar_batch("status")[0]) != 0:
+                break
+            al, ap, kind = (float(s.scalar_batch(k)[0]) for k in ("alpha", "alpha_pmax", "ls_kind"))
+            if left > 0:                                   # a watchdog iteration
+                assert kind == 3.0 and al == ap, (it, kind, al, ap)
+                if float(s.scalar_batch("mu")[0]) == mu0:  # (a barrier update resets the filter)
+                    assert float(s.scalar_batch("filter_n")[0]) == nf0
+                left -= 1
+                fired += 1
+                streak = 0
+            else:
+                assert kind != 3.0, (it, kind)
+                streak = streak + 1 if al < ap else 0
+                if streak >= 10:
+                    left, streak = 3, 0
+            assert float(s.scalar_batch("watchdog")[0]) == left and float(s.scalar_batch("short_streak")[0]) == streak
+        assert fired >= 3                                   # the mechanism was exercised
+    finally:
+        s.options.max_iter = old
