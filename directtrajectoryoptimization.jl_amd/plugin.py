@@ -551,13 +551,20 @@ def _kernel_headers_digest() -> str:
 
 def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> str:
     """Generate + compile (if not cached) and return the plugin path."""
-    src = generate_source(st, name)
-    digest = hashlib.sha256((src + _kernel_headers_digest() + GENERATOR_VERSION).encode()).hexdigest()[:16]
+    # cache key: the source with every expression body replaced by a structural (id-independent) fingerprint
+    from .symbolic import codegen as _cg
+    _cg.STRUCTURAL_KEYS = True
+    try:
+        key_src = generate_source(st, name)
+    finally:
+        _cg.STRUCTURAL_KEYS = False
+    digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION).encode()).hexdigest()[:16]
     os.makedirs(PLUGIN_DIR, exist_ok=True)
     base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")
     so = base + ".so"
     if os.path.exists(so):
         return so
+    src = generate_source(st, name)
     hip_src = base + ".hip"
     with open(hip_src, "w") as f:
         f.write(src)

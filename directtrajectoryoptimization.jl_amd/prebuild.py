@@ -5,9 +5,8 @@ from . import problems as P
 from .plugin import Structure, build_plugin
 
 
-def all_structures():
-    out = []
-    for name, builder, kw in [
+def _entries():
+    return [
         ("pendulum", P.build_pendulum, dict(T=6, evaluate_hessian=True)),
         ("pendulum", P.build_pendulum, dict(T=2, evaluate_hessian=True)),
         ("cartpole", P.build_cartpole, dict(T=5, evaluate_hessian=True)),
@@ -29,7 +28,13 @@ def all_structures():
         ("acrobot_padded", P.build_acrobot_padded, dict(T=3)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=2)),
         ("acrobot_padded", P.build_acrobot_padded, dict(T=3, evaluate_hessian=False)),
-    ]:
+        ("acrobot", P.build_acrobot, dict(T=5, evaluate_hessian=False)),
+    ]
+
+
+def all_structures():
+    out = []
+    for name, builder, kw in _entries():
         p = builder(**kw)
         out.append((name, Structure(p["dynamics"], p["objective"], p["constraints"], p.get("general_constraint"),
                                     p["evaluate_hessian"])))
@@ -47,4 +52,17 @@ def build_all(verbose: bool = False):
     paths = []
     for name, st in all_structures():
         paths.append(build_plugin(st, name, verbose=verbose))
+    # the solver-internal forms (exact-Hessian clones of evaluate_hessian=false models, solver.py:_with_exact_hessians):
+    # constructing the Solver builds whatever it will load; no device is needed for that
+    from .solver import Solver
+    for name, builder, kw in _entries():
+        p = builder(**kw)
+        if p["evaluate_hessian"]:
+            continue
+        try:
+            Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False,
+                   general_constraint=p.get("general_constraint"), parameters=p.get("parameters"), name=name)
+        except Exception as e:  # a model the solver does not take (callbacks only) still has its callback plugin above
+            if verbose:
+                print(f"prebuild: no solver form for {name}: {e}")
     return paths

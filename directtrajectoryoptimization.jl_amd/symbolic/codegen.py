@@ -43,12 +43,39 @@ _CFN = {"sin": "sin", "cos": "cos", "tan": "tan", "exp": "exp", "log": "log", "s
         "cosh": "cosh", "abs": "fabs"}
 
 
+# When set, emit_body returns a structural fingerprint of its outputs instead of C statements.  The statements name
+# temporaries after node ids and order commutative operands by id, and ids depend on everything traced earlier in the
+# process -- the same model would otherwise get a different source text (and plugin cache key) in every process.
+STRUCTURAL_KEYS = False
+
+
+def structural_hashes(outputs: Sequence[Expr]) -> List[str]:
+    """Merkle hash of every output: independent of node ids, commutative operands (ADD, MUL) sorted."""
+    import hashlib
+    memo: Dict[int, str] = {}
+    for n in E.topo_order(outputs):
+        if n.op == E.CONST:
+            key = ("c", repr(float(n.value)))
+        elif n.op == E.VAR:
+            key = ("v", n.name, int(n.index))
+        else:
+            kids = [memo[a.id] for a in n.args]
+            if n.op in (E.ADD, E.MUL):
+                kids.sort()
+            key = ("o", int(n.op), n.fn if n.op == E.FUNC else "", repr(n.value) if n.op == E.POWI else "", tuple(kids))
+        memo[n.id] = hashlib.blake2b(repr(key).encode(), digest_size=12).hexdigest()
+    return [memo[o.id] for o in outputs]
+
+
 def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str],
               tmp_prefix: str = "t", indent: str = "    ", scale: str | None = None) -> str:
     """C statements assigning `out_name[k] = outputs[k]` for all k.
 
     var_arrays maps a VAR family name ('x', 'u', 'y', 'w', 'lam', 'z') to the C array it is read from.
     """
+    if STRUCTURAL_KEYS:
+        va = ",".join(f"{k}={v}" for k, v in sorted(var_arrays.items()))
+        return f"{indent}// {out_name} {tmp_prefix} {scale} [{va}] " + " ".join(structural_hashes(outputs))
     order = E.topo_order(outputs)
     name: Dict[int, str] = {}
     lines: List[str] = []
