@@ -219,3 +219,26 @@ def test_random_models_patterns_and_values_match_oracle(seed):
     for i, val in enumerate(lamc):
         env[("lam", i)] = float(val)
     assert np.allclose(evaluate(pk.hessian_expr, env), ok.hessian(list(x), list(u), [], list(lamc)), rtol=1e-12, atol=1e-14)
+
+
+def test_plugin_cache_key_does_not_depend_on_tracing_history():
+    """The generated text names temporaries after DAG node ids, which depend on what the process traced before; the
+    cache key must not, or prebuilt plugins would miss in every process with another history (plugin.py:build_plugin).
+    Two fresh processes: one traces the acrobot first, the other a cartpole and a car before it."""
+    import subprocess, sys, json, os
+    prog = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+from dto_amd import problems as P
+from dto_amd.plugin import Structure, build_plugin, generate_source
+for b in sys.argv[1:]:
+    q = getattr(P, "build_" + b)(T=4, evaluate_hessian=True)
+    generate_source(Structure(q["dynamics"], q["objective"], q["constraints"], None, True), b)
+p = P.build_acrobot(T=5, evaluate_hessian=True)
+st = Structure(p["dynamics"], p["objective"], p["constraints"], None, True)
+print(json.dumps([build_plugin(st, "acrobot"), hashlib.sha256(generate_source(st, "acrobot").encode()).hexdigest()]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = [json.loads(subprocess.run([sys.executable, "-c", prog] + a, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+           for a in ([], ["cartpole", "car"])]
+    assert res[0][0] == res[1][0]                  # same plugin
+    assert res[0][1] != res[1][1]                  # although the text differs -- which is what the key must ignore
