@@ -10,7 +10,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 1
+DTO_ABI_VERSION = 2
 DTO_OK = 0
 STATUS_NAMES = {0: "DTO_OK", 1: "DTO_ERR_INVALID", 2: "DTO_ERR_PLUGIN", 3: "DTO_ERR_DEVICE",
                 4: "DTO_ERR_UNSUPPORTED", 5: "DTO_ERR_NOT_CONVERGED"}
@@ -29,6 +29,7 @@ class ProblemSpec(C.Structure):
         ("variable_lower", c_double_p),
         ("variable_upper", c_double_p),
         ("parameters", c_double_p),
+        ("num_parameters", C.c_int64),
         ("evaluate_hessian", C.c_int),
     ]
 
@@ -49,13 +50,17 @@ class Batch(C.Structure):
 class COptions(C.Structure):
     _fields_ = [("tol", C.c_double), ("s_max", C.c_double), ("max_iter", C.c_int), ("dual_inf_tol", C.c_double),
                 ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double), ("mu_init", C.c_double),
-                ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int), ("max_cpu_time", C.c_double)]
+                ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int), ("max_cpu_time", C.c_double),
+                ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int), ("acceptable_dual_inf_tol", C.c_double),
+                ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
+                ("acceptable_obj_change_tol", C.c_double), ("diverging_iterates_tol", C.c_double), ("mu_target", C.c_double)]
 
 
 # enum dto_scal (csrc/dto_kkt_kernels.hpp)
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
-           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog"]
+           "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog",
+           "acc_count", "f_last", "xmax"]
 
 
 class DtoError(RuntimeError):

@@ -156,7 +156,7 @@ int dto_problem_create(const dto_problem_spec* spec, dto_problem** out) {
   p->vt = get();
   if (!p->vt || p->vt->abi != DTO_PLUGIN_ABI) return set_error(DTO_ERR_PLUGIN, "plugin ABI version mismatch");
   if (!p->L.build(p->vt, spec->horizon, spec->stage_kind, spec->evaluate_hessian != 0, spec->variable_lower,
-                  spec->variable_upper, spec->parameters))
+                  spec->variable_upper, spec->parameters, spec->parameters ? spec->num_parameters : -1))
     return set_error(DTO_ERR_INVALID, p->L.error);
   *out = reinterpret_cast<dto_problem*>(p.release());
   return DTO_OK;

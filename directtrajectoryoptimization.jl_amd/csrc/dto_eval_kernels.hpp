@@ -10,15 +10,16 @@
 // Mapping (MI355X-first, not a translation of the loop):
 //   * one 64-lane wavefront = 64 consecutive knots of ONE instance; lane = knot t.  The model's
 //     expression DAG (generated, straight-line, all VGPR) is evaluated per lane.
-//   * inputs: the wave's slice of z is contiguous ([x_t;u_t] are laid end to end), so it is staged
-//     into LDS with coalesced 8-byte-per-lane loads; each lane then picks (x_t,u_t,x_{t+1}) from LDS.
+//   * inputs: a lane reads its (x_t, u_t, x_{t+1}) straight from global memory (contiguous per lane, overlapping the
+//     neighbour's; the vector L1 serves the stride).  Staging the inputs through LDS was measured and dropped: it
+//     costs a barrier and occupancy for nothing.
 //   * outputs: a knot's values (rows of c, nonzeros of J, key slots of H) are contiguous per stage
 //     and stages are contiguous per wave, so lanes deposit into an LDS image of the wave's output
 //     range and the wave streams that image to HBM fully coalesced (no scattered 8-byte stores).
 //   * the Hessian's `.+=` overlap (yy block of stage t-1 lands in the xx block of stage t,
 //     src/dynamics.jl:123) is resolved inside LDS in two phases instead of with f64 atomics; the wave
 //     owns 63 stages plus one halo lane that only contributes the overlap.
-//   * blocks are a single wave (64 threads): >= B*T/64 workgroups, LDS <= ~24 KiB per wave so 6+
+//   * blocks are 2-4 waves: >= B*T/256 workgroups, LDS <= ~24 KiB per wave so 6+
 //     waves share a CU; nothing is reused across workgroups, so the block->XCD mapping is left to
 //     the round-robin dispatcher (tables are < 64 KiB and live in every XCD's L2).
 #pragma once

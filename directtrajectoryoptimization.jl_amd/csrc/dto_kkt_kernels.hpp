@@ -51,14 +51,15 @@ enum dto_kkt_op {
 
 // per-instance scalar slots (SoA rows of `scal`)
 enum dto_scal {
-  SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed
+  SC_STATUS = 0,  // 0 running, 1 converged, 2 max_iter, 3 failed (non-finite), 4 acceptable level, 5 diverging iterates
   SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
   SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET, SC_FULL_STREAK, SC_SHORT_STREAK, SC_WATCHDOG,
+  SC_ACC_COUNT, SC_F_LAST, SC_XMAX,
   SC_COUNT
 };
 
-constexpr int DTO_NPART = 9;    // per-stage residual partials written by k_stage_eval
+constexpr int DTO_NPART = 10;   // per-stage residual partials written by k_stage_eval
 constexpr int DTO_LS_TRIALS = 8;
 constexpr int DTO_FILTER_CAP = 24;  // filter entries kept per instance (ring)
 
@@ -75,6 +76,9 @@ struct dto_kkt_info {
 struct dto_solver_opts {
   double tol, s_max, dual_inf_tol, constr_viol_tol, compl_inf_tol;
   int max_iter;
+  double acceptable_tol, acceptable_dual_inf_tol, acceptable_constr_viol_tol, acceptable_compl_inf_tol, acceptable_obj_change_tol;
+  int acceptable_iter;
+  double diverging_iterates_tol, mu_target;
   double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
   double delta_c, delta_w_init, delta_w_min, delta_w_max, kappa_w_minus, kappa_w_plus, kappa_w_plus_first;
   double delta_w_exact_cap;  // largest delta_w tried with the exact Hessian before the Gauss-Newton fallback
@@ -379,6 +383,9 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_FULL_STREAK) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_SHORT_STREAK) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_WATCHDOG) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_ACC_COUNT) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_F_LAST) = 1e300;
+    *soa(a.scal, g, SC_COUNT, SC_XMAX) = 0.0;
   }
 }
 
@@ -391,7 +398,6 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   const int t = blockIdx.x % a.T;
   const dto_solver_opts& o = a.opt;
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;  // finished instance: its record stays frozen
-  const double mu = *soa(a.scal, g, SC_COUNT, SC_MU);
   dispatch_uniform<M>(a.kind[t], [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -465,7 +471,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         sumlam += fabs(lam[i]);
       }
     }
-    double dinf = 0.0, compl0 = 0.0, complmu = 0.0, sumz = 0.0, logbar = 0.0;
+    // complementarity products s*z of this stage: largest and 1/smallest (k_conv measures max|s z - m| against any m:
+    // the current barrier parameter, mu_target, and the candidates of the fast monotone decrease)
+    double dinf = 0.0, szmax = 0.0, iszmax = 0.0, sumz = 0.0, logbar = 0.0, xmax = 0.0;
     if constexpr (KD::CON >= 0) {
       using C = typename M::template Con<KD::CON>;
       arr<C::NW> w; arr<C::NC> c, nu; arr<C::NJ> jv;
@@ -493,8 +501,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
           const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
           r = c[j] + sv;
           dinf = fmax(dinf, fabs(nu[j] - zv));
-          compl0 = fmax(compl0, sv * zv);
-          complmu = fmax(complmu, fabs(sv * zv - mu));
+          szmax = fmax(szmax, sv * zv);
+          iszmax = fmax(iszmax, 1.0 / (sv * zv));
           sumz += fabs(zv);
           logbar += log(sv);
         }
@@ -613,6 +621,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
       put(D::R_RP + i, rp[i]);
+      xmax = fmax(xmax, fabs(p[i]));
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (o.newton_only) {
         dinf = fmax(dinf, fabs(rp[i]));
@@ -620,14 +629,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         const double zl = sb.zl[i], zu = sb.zu[i];
         dinf = fmax(dinf, fabs(rp[i] - zl + zu));
         if (finite_lo(lo)) {
-          compl0 = fmax(compl0, (p[i] - lo) * zl);
-          complmu = fmax(complmu, fabs((p[i] - lo) * zl - mu));
+          szmax = fmax(szmax, (p[i] - lo) * zl);
+          iszmax = fmax(iszmax, 1.0 / ((p[i] - lo) * zl));
           sumz += fabs(zl);
           logbar += log(p[i] - lo);
         }
         if (finite_hi(hi)) {
-          compl0 = fmax(compl0, (hi - p[i]) * zu);
-          complmu = fmax(complmu, fabs((hi - p[i]) * zu - mu));
+          szmax = fmax(szmax, (hi - p[i]) * zu);
+          iszmax = fmax(iszmax, 1.0 / ((hi - p[i]) * zu));
           sumz += fabs(zu);
           logbar += log(hi - p[i]);
         }
@@ -638,11 +647,12 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     part[1 << 6] = th1;
     part[2 << 6] = thinf;
     part[3 << 6] = dinf;
-    part[4 << 6] = compl0;
-    part[5 << 6] = complmu;
+    part[4 << 6] = szmax;
+    part[5 << 6] = iszmax;
     part[6 << 6] = sumlam;
     part[7 << 6] = sumz;
     part[8 << 6] = logbar;
+    part[9 << 6] = xmax;
   });
 }
 
@@ -681,24 +691,29 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   const dto_solver_opts& o = a.opt;
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
-  double f = 0, th1 = 0, thinf = 0, dinf = 0, c0 = 0, cmu = 0, slam = 0, sz = 0, lb = 0;
+  double f = 0, th1 = 0, thinf = 0, dinf = 0, szmax = 0, iszmax = 0, slam = 0, sz = 0, lb = 0, xmax = 0;
   for (int c = 0; c < a.P; ++c) {
     const double* part = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
     f += part[0 << 6];
     th1 += part[1 << 6];
     thinf = fmax(thinf, part[2 << 6]);
     dinf = fmax(dinf, part[3 << 6]);
-    c0 = fmax(c0, part[4 << 6]);
-    cmu = fmax(cmu, part[5 << 6]);
+    szmax = fmax(szmax, part[4 << 6]);
+    iszmax = fmax(iszmax, part[5 << 6]);
     slam += part[6 << 6];
     sz += part[7 << 6];
     lb += part[8 << 6];
+    xmax = fmax(xmax, part[9 << 6]);
   }
   double mu = sc[SC_MU << 6];
   const double sd = fmax(o.s_max, (slam + sz) / (double)(n_mult + n_bnd > 0 ? n_mult + n_bnd : 1)) / o.s_max;
   const double scn = fmax(o.s_max, sz / (double)(n_bnd > 0 ? n_bnd : 1)) / o.s_max;
+  // max |s_i z_i - m| over all bound / slack pairs, for any m
+  const double szmin = iszmax > 0.0 ? 1.0 / iszmax : 1e300;
+  auto compl_at = [&](double m) { return n_bnd > 0 ? fmax(szmax - m, m - szmin) : 0.0; };
+  // Ipopt's mu_target: the termination tests measure complementarity against the target barrier parameter
+  const double c0 = compl_at(o.mu_target);
   const double e0 = fmax(fmax(dinf / sd, thinf), c0 / scn);
-  const double emu = fmax(fmax(dinf / sd, thinf), cmu / scn);
   sc[SC_F << 6] = f;
   sc[SC_THETA1 << 6] = th1;
   sc[SC_THETA_INF << 6] = thinf;
@@ -706,18 +721,42 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   sc[SC_COMPL << 6] = c0;
   sc[SC_E0 << 6] = e0;
   sc[SC_LOGBAR << 6] = lb;
+  sc[SC_XMAX << 6] = xmax;
   const double iter = sc[SC_ITER << 6];
   const bool nonfinite = !(f == f) || !(th1 == th1) || !(dinf == dinf) || fabs(f) > 1e300 || th1 > 1e300;
+  // Ipopt's acceptable level (OptimalityErrorConvergenceCheck::CurrentIsAcceptable), counted over consecutive iterations
+  const double f_last = sc[SC_F_LAST << 6];
+  const bool acceptable = o.acceptable_iter > 0 && e0 <= o.acceptable_tol && dinf <= o.acceptable_dual_inf_tol &&
+                          thinf <= o.acceptable_constr_viol_tol && c0 <= o.acceptable_compl_inf_tol &&
+                          fabs(f - f_last) / fmax(1.0, fabs(f)) <= o.acceptable_obj_change_tol;
+  const double acc_count = acceptable ? sc[SC_ACC_COUNT << 6] + 1.0 : 0.0;
+  sc[SC_ACC_COUNT << 6] = acc_count;
+  sc[SC_F_LAST << 6] = f;
   if (nonfinite) {
     sc[SC_STATUS << 6] = 3.0;
   } else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) {
     sc[SC_STATUS << 6] = 1.0;
+  } else if (o.acceptable_iter > 0 && acc_count >= (double)o.acceptable_iter) {
+    sc[SC_STATUS << 6] = 4.0;
+  } else if (!o.newton_only && xmax > o.diverging_iterates_tol) {
+    sc[SC_STATUS << 6] = 5.0;
   } else if (iter >= (double)o.max_iter) {
     sc[SC_STATUS << 6] = 2.0;
-  } else if (n_bnd > 0 && emu <= o.kappa_eps * mu) {
-    mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-    sc[SC_MU << 6] = mu;
-    sc[SC_FILTER_N << 6] = 0.0;  // new barrier problem: the filter is reset (Ipopt, step A-3)
+  } else if (n_bnd > 0) {
+    // monotone barrier update (Ipopt MonotoneMuUpdate, mu_allow_fast_monotone_decrease = yes): while the barrier problem is
+    // solved to kappa_eps * mu the parameter drops, but never below max(mu_target, min(tol, compl_inf_tol) / (kappa_eps + 1))
+    const double mu_floor = fmax(o.mu_target, fmin(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
+    bool changed = false;
+    for (int k = 0; k < 8; ++k) {
+      const double emu = fmax(fmax(dinf / sd, thinf), compl_at(mu) / scn);
+      if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
+      mu = fmax(mu_floor, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+      changed = true;
+    }
+    if (changed) {
+      sc[SC_MU << 6] = mu;
+      sc[SC_FILTER_N << 6] = 0.0;  // new barrier problem: the filter is reset (Ipopt, step A-3)
+    }
   }
   if (sc[SC_THETA_MAX << 6] < 0.0) {
     sc[SC_THETA_MAX << 6] = 1e4 * fmax(1.0, th1);
@@ -1901,9 +1940,9 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_CONV:
-        // slots 2..5 (theta_inf, dual inf, complementarity x2) are maxima, the others sums
+        // slots 2..5 and 9 (theta_inf, dual inf, max s*z, max 1/(s*z), max |x|) are maxima, the others sums
         hipLaunchKernelGGL(k_part_reduce<DTO_NPART>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
-                           (const double*)a.part, 0x3Cu);
+                           (const double*)a.part, 0x23Cu);
         hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd);
         break;
       case DTO_KKT_FACTOR_SOLVE: {

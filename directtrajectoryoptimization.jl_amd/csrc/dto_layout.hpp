@@ -48,7 +48,7 @@ struct Layout {
   std::string error;
 
   bool build(const dto_model_vtable* vtab, int horizon, const int32_t* stage_kind, bool want_hessian,
-             const double* lo, const double* hi, const double* par) {
+             const double* lo, const double* hi, const double* par, int64_t n_par = -1) {
     vt = vtab;
     T = horizon;
     hessian = want_hessian;
@@ -201,6 +201,9 @@ struct Layout {
     }
     if (g) for (int i = 0; i < g->num_inequality; ++i) con_lo[Ndyn + Nstage + g->indices_inequality[i] - 1] = -inf;
     params.assign(Nw, 0.0);
+    // the caller states how many doubles `par` holds: a short or long vector would silently shift every later stage's w_t
+    if (par && n_par != Nw) return fail("dto_problem_spec.num_parameters does not match the model (sum over the stages of the "
+                                        "largest num_parameter among the stage's dynamics, cost and constraint)");
     if (par && Nw) params.assign(par, par + Nw);
     return true;
   }

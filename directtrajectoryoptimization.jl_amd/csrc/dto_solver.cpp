@@ -77,6 +77,10 @@ void Problem::free_solver() {
 static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.tol = u.tol; o.s_max = u.s_max; o.dual_inf_tol = u.dual_inf_tol; o.constr_viol_tol = u.constr_viol_tol;
   o.compl_inf_tol = u.compl_inf_tol; o.max_iter = u.max_iter;
+  o.acceptable_tol = u.acceptable_tol; o.acceptable_iter = u.acceptable_iter; o.acceptable_dual_inf_tol = u.acceptable_dual_inf_tol;
+  o.acceptable_constr_viol_tol = u.acceptable_constr_viol_tol; o.acceptable_compl_inf_tol = u.acceptable_compl_inf_tol;
+  o.acceptable_obj_change_tol = u.acceptable_obj_change_tol;
+  o.diverging_iterates_tol = u.diverging_iterates_tol; o.mu_target = u.mu_target;
   o.mu_init = u.mu_init; o.kappa_eps = 10.0; o.kappa_mu = 0.2; o.theta_mu = 1.5; o.tau_min = 0.99;
   o.bound_push = 1e-2; o.bound_frac = 1e-2;
   o.delta_c = u.delta_c; o.delta_w_init = u.delta_w_init; o.delta_w_min = 1e-20; o.delta_w_max = 1e20;
@@ -143,11 +147,14 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
 // few stream synchronisations per iteration are free.  Scope: dynamics rows plus variables fixed by equal bounds (what
 // the model uses); no inequality rows / finite bounds (no barrier).
 // ------------------------------------------------------------------------------------------------
+constexpr int AXPY_BLOCKS_PER_ROW = 64;
 static __global__ void k_rows_axpy(double* y, const double* x, const double* alpha, int64_t n, int64_t ldy, int64_t ldx) {
-  const int64_t b = blockIdx.y;
+  // grid.x = B * AXPY_BLOCKS_PER_ROW (the instance index lives in grid.x: grid.y is limited to 65535)
+  const int64_t b = blockIdx.x / AXPY_BLOCKS_PER_ROW;
+  const int64_t blk = blockIdx.x % AXPY_BLOCKS_PER_ROW;
   const double al = alpha[b];
   if (al == 0.0) return;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = blk * blockDim.x + threadIdx.x; i < n; i += (int64_t)AXPY_BLOCKS_PER_ROW * blockDim.x)
     y[b * ldy + i] += al * x[b * ldx + i];
 }
 
@@ -207,7 +214,8 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   WTRY(hipMemsetAsync(dlam, 0, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double), st));
 
   struct Inst {
-    int status = 0, iter = 0, ls_fail = 0, full_streak = 0, attempt = 0;
+    int status = 0, iter = 0, ls_fail = 0, full_streak = 0, attempt = 0, acc_count = 0;
+    double f_last = 1e300;
     double dw = 0.0, dlast = 0.0, theta_max = -1.0, theta_min = -1.0, alpha = 0.0, gam = 1.0, gamma_acc = 1.0;
     std::vector<double> filt;  // (theta, phi) pairs, ring of DTO_FILTER_CAP
     int filter_n = 0;
@@ -264,8 +272,15 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
           const double f = sv[DTO_WIDE_F], th1 = sv[DTO_WIDE_TH1], thinf = sv[DTO_WIDE_THINF], dinf = sv[DTO_WIDE_DINF];
           const double sd = std::max(o.s_max, sv[DTO_WIDE_SUMLAM] / (double)std::max<int64_t>(1, Nc)) / o.s_max;
           const double e0 = std::max(dinf / sd, thinf);
+          // Ipopt's acceptable level over consecutive iterations (no bounds on this path: no complementarity term)
+          const bool acceptable = o.acceptable_iter > 0 && e0 <= o.acceptable_tol && dinf <= o.acceptable_dual_inf_tol &&
+                                  thinf <= o.acceptable_constr_viol_tol &&
+                                  std::fabs(f - s.f_last) / std::max(1.0, std::fabs(f)) <= o.acceptable_obj_change_tol;
+          s.acc_count = acceptable ? s.acc_count + 1 : 0;
+          s.f_last = f;
           if (!(f == f) || !(th1 == th1) || !(dinf == dinf)) s.status = 3;
           else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol) s.status = 1;
+          else if (o.acceptable_iter > 0 && s.acc_count >= o.acceptable_iter) s.status = 4;
           else if (s.iter >= o.max_iter) s.status = 2;
           if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
           if (s.status != 0) { h_active[(size_t)i] = 0; continue; }
@@ -359,9 +374,9 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     }
     // ---- E: take the steps
     WTRY(hipMemcpyAsync(d_alpha, h_alpha.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_rows_axpy, dim3(64, (unsigned)B), dim3(256), 0, st, z, (const double*)dz, (const double*)d_alpha, Nz, Nz, Nz);
+    hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, (const double*)dz, (const double*)d_alpha, Nz, Nz, Nz);
     if (Nc > 0)
-      hipLaunchKernelGGL(k_rows_axpy, dim3(64, (unsigned)B), dim3(256), 0, st, lam, (const double*)dlam, (const double*)d_alpha, Nc, Nc, Nc);
+      hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, lam, (const double*)dlam, (const double*)d_alpha, Nc, Nc, Nc);
     if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
   }
   WTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), B, hipMemcpyDeviceToDevice, st));
@@ -392,8 +407,14 @@ static int ensure_state(Problem* p, int64_t B) {
   SolverState& S = *p->solver;
   const Layout& L = p->L;
   const int G_new = (int)((B + 63) / 64);
-  // chunks: enough wavefronts to put one on every SIMD (256 CUs x 4), at least 8 stages per chunk
-  int P_new = S.forced_P > 0 ? S.forced_P : (1024 + G_new - 1) / G_new;
+  // chunks: enough wavefronts to put one on every SIMD (4 per CU: 1024 on an MI355X), at least 8 stages per chunk
+  int n_simd = 1024;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      n_simd = 4 * cus;
+  }
+  int P_new = S.forced_P > 0 ? S.forced_P : (n_simd + G_new - 1) / G_new;
   P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / 8))));
   if (S.B == B && S.z && S.P == P_new) return DTO_OK;
   const int keep_forced = S.forced_P;
@@ -459,6 +480,9 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P * 4))) return rc;
   if ((rc = dev_alloc(&S.cpart, lanes * (size_t)S.P * 16))) return rc;
   S.h_scal.assign(lanes * S.info.nscal, 0.0);
+  // the zero fills and table copies above ran on the null stream; the kernels run on the caller's stream, which may be a
+  // non-blocking one: order them once here (allocation time only)
+  HIP_TRY(hipDeviceSynchronize());
   return DTO_OK;
 }
 
@@ -539,6 +563,9 @@ int dto_options_default(dto_options* o) {
   o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-3; o->compl_inf_tol = 1e-3;
   o->mu_init = 0.1; o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->check_every = 10;
   o->max_cpu_time = 300.0;
+  o->acceptable_tol = 1e-6; o->acceptable_iter = 15; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
+  o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5;
+  o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
   return DTO_OK;
 }
 
@@ -768,18 +795,21 @@ int dto_solve(dto_problem* h, const dto_options* opt, const double* x0, double* 
   const dto::Layout& L = p->L;
   double* d_x = nullptr;
   double* d_mu = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_x, std::max<size_t>(1, L.Nz) * sizeof(double)));
-  HIP_TRY(hipMalloc((void**)&d_mu, std::max<size_t>(1, L.Nc) * sizeof(double)));
-  HIP_TRY(hipMemcpy(d_x, x0, L.Nz * sizeof(double), hipMemcpyHostToDevice));
-  dto_batch b;
-  b.B = 1; b.x = d_x; b.ldx = L.Nz; b.params = nullptr; b.ldp = 0; b.stream = (void*)p->stream;
-  rc = dto_solve_batch(h, opt, &b, d_x, L.Nz, d_mu, L.Nc, status, iterations);
-  if (rc == DTO_OK) {
+  auto run = [&]() -> int {
+    HIP_TRY(hipMalloc((void**)&d_x, std::max<size_t>(1, L.Nz) * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&d_mu, std::max<size_t>(1, L.Nc) * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_x, x0, L.Nz * sizeof(double), hipMemcpyHostToDevice));
+    dto_batch b;
+    b.B = 1; b.x = d_x; b.ldx = L.Nz; b.params = nullptr; b.ldp = 0; b.stream = (void*)p->stream;
+    const int r = dto_solve_batch(h, opt, &b, d_x, L.Nz, d_mu, L.Nc, status, iterations);
+    if (r != DTO_OK) return r;
     HIP_TRY(hipMemcpy(x, d_x, L.Nz * sizeof(double), hipMemcpyDeviceToHost));
     if (mu) HIP_TRY(hipMemcpy(mu, d_mu, L.Nc * sizeof(double), hipMemcpyDeviceToHost));
-  }
-  (void)hipFree(d_x);
-  (void)hipFree(d_mu);
+    return DTO_OK;
+  };
+  rc = run();  // the buffers are released on every path
+  if (d_x) (void)hipFree(d_x);
+  if (d_mu) (void)hipFree(d_mu);
   return rc;
 }
 

@@ -541,16 +541,25 @@ def generate_source(st: Structure, name: str) -> str:
 
 
 def _kernel_headers_digest() -> str:
+    """Everything besides the model that decides what a plugin contains: the hand-written kernel headers and the code
+    generator itself (the structural key replaces expression bodies by fingerprints, so a change in HOW an expression is
+    emitted would otherwise keep serving stale plugins)."""
     hsh = hashlib.sha256()
     for fn in sorted(os.listdir(CSRC)):
         if fn.endswith((".hpp", ".h")):
             with open(os.path.join(CSRC, fn), "rb") as f:
                 hsh.update(f.read())
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fn in ("plugin.py", os.path.join("symbolic", "codegen.py"), os.path.join("symbolic", "expr.py"),
+               os.path.join("symbolic", "diff.py")):
+        with open(os.path.join(here, fn), "rb") as f:
+            hsh.update(f.read())
     return hsh.hexdigest()
 
 
-def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> str:
-    """Generate + compile (if not cached) and return the plugin path."""
+def _prepare_plugin(st: Structure, name: str):
+    """(path of the plugin .so, compile command or None if it is already built).  Not thread-safe (the structural-key
+    switch of the code generator is a module global): call it serially, compile in parallel."""
     # cache key: the source with every expression body replaced by a structural (id-independent) fingerprint
     from .symbolic import codegen as _cg
     _cg.STRUCTURAL_KEYS = True
@@ -563,7 +572,7 @@ def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> s
     base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")
     so = base + ".so"
     if os.path.exists(so):
-        return so
+        return so, None
     src = generate_source(st, name)
     hip_src = base + ".hip"
     with open(hip_src, "w") as f:
@@ -572,10 +581,42 @@ def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> s
     tmp = so + f".tmp{os.getpid()}"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", CSRC,
            "-Wno-unused-value", "-o", tmp, hip_src]
+    return so, cmd
+
+
+COMPILED: List[str] = []   # plugins compiled by this process (tests/conftest.py reports it: a GPU box should compile none)
+
+
+def _compile_plugin(name: str, so: str, cmd, verbose: bool = False) -> str:
+    if cmd is None:
+        return so
+    COMPILED.append(os.path.basename(so))
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for plugin {name}:\n{res.stderr[-4000:]}")
-    os.replace(tmp, so)
+    os.replace(cmd[cmd.index("-o") + 1], so)
     return so
+
+
+def build_plugin(st: Structure, name: str = "model", verbose: bool = False) -> str:
+    """Generate + compile (if not cached) and return the plugin path."""
+    so, cmd = _prepare_plugin(st, name)
+    return _compile_plugin(name, so, cmd, verbose)
+
+
+def build_plugins(items, verbose: bool = False, jobs: int = 0):
+    """Build several plugins: sources are generated serially, hipcc runs `jobs` at a time (default: one per core, at
+    most 8 -- a plugin compile peaks at a few GB of host memory)."""
+    from concurrent.futures import ThreadPoolExecutor
+    prepared, seen = [], set()
+    for name, st in items:
+        so, cmd = _prepare_plugin(st, name)
+        if so in seen:
+            cmd = None
+        seen.add(so)
+        prepared.append((name, so, cmd))
+    jobs = jobs or max(1, min(8, os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        return list(ex.map(lambda a: _compile_plugin(a[0], a[1], a[2], verbose), prepared))

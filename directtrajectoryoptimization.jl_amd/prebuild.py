@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 from . import problems as P
-from .plugin import Structure, build_plugin
+from .plugin import Structure, build_plugin, build_plugins
 
 
 def _entries():
@@ -49,9 +49,17 @@ def all_structures():
 
 
 def build_all(verbose: bool = False):
-    paths = []
-    for name, st in all_structures():
-        paths.append(build_plugin(st, name, verbose=verbose))
+    items = list(all_structures())
+    # the solver-internal exact-Hessian clones of the evaluate_hessian=false models are compiled in the same parallel batch
+    from .solver import _with_exact_hessians, fold_general_constraint
+    for name, builder, kw in _entries():
+        p = builder(**kw)
+        if p["evaluate_hessian"] or p.get("general_constraint") is not None:
+            continue
+        up = _with_exact_hessians(list(p["dynamics"]), list(p["objective"]), list(p["constraints"]))
+        if up is not None:
+            items.append((name, Structure(up[0], up[1], up[2], None, True)))
+    paths = build_plugins(items, verbose=verbose)
     # the solver-internal forms (exact-Hessian clones of evaluate_hessian=false models, solver.py:_with_exact_hessians):
     # constructing the Solver builds whatever it will load; no device is needed for that
     from .solver import Solver

@@ -100,6 +100,8 @@ class NLPData:
             nxs.append(st.cost[c].num_state)
             nus.append(st.cost[c].num_action)
         nz = sum(nxs) + sum(nus)
+        if len(bounds) != self.T:
+            raise ValueError(f"bounds must hold one Bound per stage: got {len(bounds)}, horizon {self.T} (src/data.jl:123-133)")
         lo = np.full(nz, -np.inf)
         hi = np.full(nz, np.inf)
         off = 0
@@ -116,7 +118,30 @@ class NLPData:
             off += nx + nu
         par = None
         if parameters is not None:
-            flat = [np.asarray(p, dtype=float).ravel() for p in parameters]
+            # src/solver.jl:10: one vector per stage (the reference default appends an empty one for stage T).  Stage t reads
+            # w_t through its dynamics, cost and constraint; the flattened vector (src/data.jl:218) holds, per stage, as many
+            # entries as the largest of the three asks for.  A vector that is too short is an error; extra entries are never
+            # read by the closures and are dropped.
+            nws = []
+            for t in range(self.T):
+                d, pd, c, kc = st.kinds[st.stage_kind[t]]
+                nw = st.cost[c].num_parameter
+                if d >= 0:
+                    nw = max(nw, st.dyn[d].num_parameter)
+                if kc >= 0:
+                    nw = max(nw, st.con[kc].num_parameter)
+                nws.append(nw)
+            plist = list(parameters)
+            if len(plist) == self.T - 1:
+                plist.append(np.zeros(0))
+            if len(plist) != self.T:
+                raise ValueError(f"parameters must hold one vector per stage: got {len(parameters)}, horizon {self.T}")
+            flat = []
+            for t, w in enumerate(plist):
+                w = np.asarray(w, dtype=float).ravel()
+                if w.size < nws[t]:
+                    raise ValueError(f"parameters[{t}] has {w.size} entries, stage {t + 1} reads {nws[t]}")
+                flat.append(w[:nws[t]])
             par = np.concatenate(flat) if flat else np.zeros(0)
         kinds = np.asarray(st.stage_kind, dtype=np.int32)
         spec = capi.ProblemSpec()
@@ -127,6 +152,7 @@ class NLPData:
         spec.variable_lower = capi.dptr(lo)
         spec.variable_upper = capi.dptr(hi)
         spec.parameters = capi.dptr(par) if (par is not None and par.size) else None
+        spec.num_parameters = int(par.size) if (par is not None and par.size) else 0
         spec.evaluate_hessian = 1 if evaluate_hessian else 0
         h = C.c_void_p()
         capi.check(lib.dto_problem_create(C.byref(spec), C.byref(h)))
@@ -283,6 +309,10 @@ def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
     c.dual_inf_tol, c.constr_viol_tol, c.compl_inf_tol = o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol
     c.check_every = check_every
     c.max_cpu_time = float(o.max_cpu_time)
+    c.acceptable_tol, c.acceptable_iter = float(o.acceptable_tol), int(o.acceptable_iter)
+    c.acceptable_dual_inf_tol, c.acceptable_constr_viol_tol = float(o.acceptable_dual_inf_tol), float(o.acceptable_constr_viol_tol)
+    c.acceptable_compl_inf_tol, c.acceptable_obj_change_tol = float(o.acceptable_compl_inf_tol), float(o.acceptable_obj_change_tol)
+    c.diverging_iterates_tol, c.mu_target = float(o.diverging_iterates_tol), float(o.mu_target)
     return c
 
 

@@ -62,7 +62,7 @@ def structural_hashes(outputs: Sequence[Expr]) -> List[str]:
             kids = [memo[a.id] for a in n.args]
             if n.op in (E.ADD, E.MUL):
                 kids.sort()
-            key = ("o", int(n.op), n.fn if n.op == E.FUNC else "", repr(n.value) if n.op == E.POWI else "", tuple(kids))
+            key = ("o", int(n.op), n.fn if n.op in (E.FUNC, E.IFELSE) else "", repr(n.value) if n.op == E.POWI else "", tuple(kids))
         memo[n.id] = hashlib.blake2b(repr(key).encode(), digest_size=12).hexdigest()
     return [memo[o.id] for o in outputs]
 
@@ -117,6 +117,9 @@ def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str]
             rhs = _powi(ref(n.args[0]), n.value)
         elif op == E.POW:
             rhs = f"pow({ref(n.args[0])}, {ref(n.args[1])})"
+        elif op == E.IFELSE:
+            # a select, not a branch: both sides are straight-line temporaries already (v_cndmask on the GPU)
+            rhs = f"({ref(n.args[0])} {'<' if n.fn == 'lt' else '<='} {ref(n.args[1])}) ? {ref(n.args[2])} : {ref(n.args[3])}"
         else:
             aid = n.args[0].id
             if n.fn in ("sin", "cos") and aid in paired:
@@ -141,7 +144,7 @@ def op_count(outputs: Sequence[Expr]) -> Dict[str, int]:
     """Arithmetic census of the emitted body (for DESIGN.md roofline arithmetic)."""
     c = {"addsub": 0, "mul": 0, "div": 0, "trans": 0, "nodes": 0}
     for n in E.topo_order(outputs):
-        if n.op in (E.ADD, E.SUB):
+        if n.op in (E.ADD, E.SUB, E.IFELSE):
             c["addsub"] += 1
         elif n.op == E.MUL:
             c["mul"] += 1

@@ -54,7 +54,9 @@ def occurs(e: Expr) -> FrozenSet[VarKey]:
         elif len(n.args) == 1:
             s = _occ_cache[n.args[0].id]
         else:
-            s = _occ_cache[n.args[0].id] | _occ_cache[n.args[1].id]
+            s = _occ_cache[n.args[0].id]
+            for a in n.args[1:]:  # ifelse: the variables of the condition occur too (occurrence rule)
+                s = s | _occ_cache[a.id]
         _occ_cache[n.id] = s
     return _occ_cache[e.id]
 
@@ -105,6 +107,10 @@ def diff(e: Expr, v: Expr) -> Expr:
                 r = E.mul(E.mul(b, E.power(a, b.value - 1.0)), d(a))
             else:
                 r = E.mul(n, E.add(E.mul(d(b), E.func("log", a)), E.div(E.mul(b, d(a)), a)))
+        elif op == E.IFELSE:
+            # the branches are differentiated, the condition is kept (IfElse.ifelse under Symbolics.derivative)
+            l, rr, a, b = n.args
+            r = E.ifelse(E.Cond(n.fn, l, rr), d(a), d(b))
         else:  # FUNC
             a = n.args[0]
             fn = n.fn
@@ -255,6 +261,9 @@ def linearity_terms(e: Expr, col_of: Dict[VarKey, int]) -> FrozenSet[Term]:
             t = _tmul(a, a)  # degree caps at 2, so k >= 2 all look alike
         elif op == E.POW:
             t = _nonlinear(cache[n.args[0].id] | cache[n.args[1].id])
+        elif op == E.IFELSE:
+            # second derivatives come from the branches only: union of their terms, the condition contributes nothing
+            t = _prune(cache[n.args[2].id] | cache[n.args[3].id])
         else:
             t = _nonlinear(cache[n.args[0].id])
         cache[n.id] = t

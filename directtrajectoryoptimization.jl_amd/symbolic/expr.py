@@ -20,7 +20,7 @@ from typing import Dict, Iterable, List, Sequence, Tuple
 import numpy as np
 
 # op tags
-CONST, VAR, ADD, SUB, MUL, DIV, NEG, POWI, POW, FUNC = range(10)
+CONST, VAR, ADD, SUB, MUL, DIV, NEG, POWI, POW, FUNC, IFELSE = range(11)
 
 _FUNCS = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "atan", "asin", "acos", "sinh", "cosh", "abs")
 
@@ -41,6 +41,8 @@ class Expr:
             key = (FUNC, fn, args[0].id)
         elif op == POWI:
             key = (POWI, args[0].id, value)
+        elif op == IFELSE:
+            key = (IFELSE, fn) + tuple(a.id for a in args)
         else:
             key = (op,) + tuple(a.id for a in args)
         hit = cls._table.get(key)
@@ -168,6 +170,19 @@ class Expr:
     def __abs__(self):
         return func("abs", self)
 
+    # ---- comparisons build a condition for `ifelse` (IfElse.ifelse in the reference, src/DirectTrajectoryOptimization.jl:5)
+    def __lt__(self, o):
+        return Cond("lt", self, as_expr(o))
+
+    def __le__(self, o):
+        return Cond("le", self, as_expr(o))
+
+    def __gt__(self, o):
+        return Cond("lt", as_expr(o), self)
+
+    def __ge__(self, o):
+        return Cond("le", as_expr(o), self)
+
     def __repr__(self):
         return to_str(self)
 
@@ -175,6 +190,19 @@ class Expr:
         if self.op == CONST:
             return float(self.value)
         raise TypeError("symbolic expression has no float value")
+
+
+class Cond:
+    """`lhs < rhs` or `lhs <= rhs` between symbolic scalars; only meaningful as the first argument of `ifelse`."""
+
+    __slots__ = ("fn", "lhs", "rhs")
+
+    def __init__(self, fn, lhs, rhs):
+        self.fn, self.lhs, self.rhs = fn, lhs, rhs
+
+    def __bool__(self):
+        raise TypeError("a comparison of symbolic values has no truth value while the model is traced: write "
+                        "ifelse(a < b, x, y) / minimum(a, b) / maximum(a, b) instead of a Python `if`, min() or max()")
 
 
 def as_expr(v) -> Expr:
@@ -331,6 +359,52 @@ def func(fn: str, a: Expr) -> Expr:
     return Expr(FUNC, (a,), fn=fn)
 
 
+def ifelse(cond, a, b):
+    """IfElse.ifelse(cond, a, b): `a` where cond holds, else `b`.  cond is a comparison of symbolic scalars (or a bool).
+    Derivatives differentiate the branches and keep the condition (what Symbolics does for ifelse)."""
+    if isinstance(cond, (bool, np.bool_)):
+        return a if cond else b
+    if not isinstance(cond, Cond):
+        raise TypeError("ifelse: the condition must be a comparison such as x[0] < 0.0")
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        a2, b2 = np.broadcast_arrays(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
+        out = np.empty(a2.shape, dtype=object)
+        for i in np.ndindex(a2.shape):
+            out[i] = ifelse(cond, a2[i], b2[i])
+        return out
+    a, b = as_expr(a), as_expr(b)
+    l, r = cond.lhs, cond.rhs
+    if l.op == CONST and r.op == CONST:
+        return a if ((l.value < r.value) if cond.fn == "lt" else (l.value <= r.value)) else b
+    if a is b:
+        return a
+    return Expr(IFELSE, (l, r, a, b), fn=cond.fn)
+
+
+def minimum(a, b):
+    """min(a, b) on symbolic scalars (elementwise on arrays)."""
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        a2, b2 = np.broadcast_arrays(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
+        out = np.empty(a2.shape, dtype=object)
+        for i in np.ndindex(a2.shape):
+            out[i] = minimum(a2[i], b2[i])
+        return out
+    a, b = as_expr(a), as_expr(b)
+    return ifelse(Cond("lt", a, b), a, b)
+
+
+def maximum(a, b):
+    """max(a, b) on symbolic scalars (elementwise on arrays)."""
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        a2, b2 = np.broadcast_arrays(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
+        out = np.empty(a2.shape, dtype=object)
+        for i in np.ndindex(a2.shape):
+            out[i] = maximum(a2[i], b2[i])
+        return out
+    a, b = as_expr(a), as_expr(b)
+    return ifelse(Cond("lt", b, a), a, b)
+
+
 # convenience module-level functions (mirror of Base.sin etc. on symbolic scalars)
 def sin(a):
     return np.sin(a) if isinstance(a, np.ndarray) else (func("sin", a) if isinstance(a, Expr) else math.sin(a))
@@ -369,6 +443,10 @@ def to_str(e: Expr, depth: int = 0) -> str:
         return f"{e.fn}({to_str(e.args[0], depth + 1)})"
     if e.op == POWI:
         return f"{to_str(e.args[0], depth + 1)}^{e.value}"
+    if e.op == IFELSE:
+        sym = "<" if e.fn == "lt" else "<="
+        return (f"ifelse({to_str(e.args[0], depth + 1)} {sym} {to_str(e.args[1], depth + 1)}, "
+                f"{to_str(e.args[2], depth + 1)}, {to_str(e.args[3], depth + 1)})")
     sym = {ADD: "+", SUB: "-", MUL: "*", DIV: "/", POW: "^"}[e.op]
     return f"({to_str(e.args[0], depth + 1)} {sym} {to_str(e.args[1], depth + 1)})"
 
@@ -421,6 +499,8 @@ def substitute(roots: Sequence[Expr], mapping: Dict[Expr, Expr]) -> List[Expr]:
                 new = power(args[0], node.value)
             elif node.op == POW:
                 new = power(args[0], args[1])
+            elif node.op == IFELSE:
+                new = ifelse(Cond(node.fn, args[0], args[1]), args[2], args[3])
             else:
                 new = func(node.fn, args[0])
         memo[node.id] = new

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 1
+#define DTO_ABI_VERSION 2
 
 enum dto_status {
   DTO_OK = 0,
@@ -62,6 +62,8 @@ typedef struct dto_problem_spec {
   const double* variable_lower; /* [num_variables] or NULL = -Inf  (src/data.jl:123-133) */
   const double* variable_upper; /* [num_variables] or NULL = +Inf */
   const double* parameters;     /* [num_parameters] flattened w_1..w_T (src/data.jl:218) or NULL */
+  int64_t num_parameters;       /* length of `parameters`; must equal dto_sizes_t.num_parameters (sum over the stages of the
+                                   largest num_parameter among the stage's dynamics, cost and constraint) when it is given */
   int evaluate_hessian;         /* Solver(...; evaluate_hessian) (src/solver.jl:7) */
 } dto_problem_spec;
 
@@ -157,6 +159,19 @@ typedef struct dto_options {
   int check_every;          /* host polls the batch for completion every this many iterations */
   double max_cpu_time;      /* 300   src/options.jl:10: wall-clock limit of one dto_solve[_batch] call in seconds; instances
                                still running when it expires are returned as they are with status 0 ("cut off") */
+  /* Ipopt's "acceptable" termination (src/options.jl:15-20): an instance stops with status 4 after `acceptable_iter`
+   * consecutive iterations whose scaled error is <= acceptable_tol, whose unscaled residuals are within the three
+   * acceptable_*_tol values and whose objective changed by less than acceptable_obj_change_tol (relative). 0 = off. */
+  double acceptable_tol;             /* 1e-6  src/options.jl:15 */
+  int acceptable_iter;               /* 15    src/options.jl:16 */
+  double acceptable_dual_inf_tol;    /* 1e10  src/options.jl:17 */
+  double acceptable_constr_viol_tol; /* 1e-2  src/options.jl:18 */
+  double acceptable_compl_inf_tol;   /* 1e-2  src/options.jl:19 */
+  double acceptable_obj_change_tol;  /* 1e-5  src/options.jl:20 */
+  double diverging_iterates_tol;     /* 1e8   src/options.jl:21: status 5 once max|z_i| exceeds it */
+  double mu_target;                  /* 1e-4  src/options.jl:22: the barrier parameter is not driven below it and the
+                                        complementarity in every termination test is measured against it (Ipopt's
+                                        mu_target semantics); only matters for problems with bounds / inequality rows */
 } dto_options;
 int dto_options_default(dto_options* o);
 
@@ -174,7 +189,8 @@ int dto_kkt_step_batch(dto_problem* p, const dto_batch* b, const double* mu, int
  * x0: DEVICE [B][ldx] initial guesses (what initialize_states!/initialize_controls! set,
  * src/solver.jl:23-39); x_out/mu_out: DEVICE [B][ld*] final accepted iterates (get_trajectory,
  * src/solver.jl:41-43, returns the last *evaluated* point in the reference -- here it is the accepted one);
- * status/iterations: HOST [B] (0 running/cut off, 1 converged, 2 max_iter, 3 failed). */
+ * status/iterations: HOST [B] (0 running/cut off, 1 converged, 2 max_iter, 3 failed: non-finite iterate,
+ * 4 converged to the acceptable level, 5 diverging iterates). */
 int dto_solve_batch(dto_problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                     double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations);
 

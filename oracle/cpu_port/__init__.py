@@ -118,6 +118,13 @@ def acrobot_guesses(T, B, seed):
     return Z, x1, xT
 
 
+def guesses(model, T, B, seed):
+    """Seeded guesses of a port model (acrobot: the bench workload's)."""
+    if model == "acrobot":
+        return acrobot_guesses(T, B, seed)
+    raise ValueError(f"no guess generator for {model!r}")
+
+
 def cpu_baseline(T=1000, seed=1000, seconds=12.0, batch=4096, iters_per_instance=23):
     """SQP iterations/s of the C port on one host core for a bounded sample of the bench workload:
     the first instances of rank 0's batch, each run for the same number of iterations the GPU bench

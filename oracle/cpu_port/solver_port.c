@@ -70,6 +70,9 @@ static double* lam_pin(port_solver* S, int which) { return S->lam + (S->P.T - 1)
 static double* dlam_dyn(port_solver* S, int t) { return S->dlam + t * S->P.n; }
 static double* dlam_pin(port_solver* S, int which) { return S->dlam + (S->P.T - 1) * S->P.n + which * S->P.n; }
 
+static double g_rho = 0.0;
+static int g_nsoc = 0;
+int port_nsoc(void) { return g_nsoc; }
 port_solver* port_create(const port_problem* P) {
   port_solver* S = (port_solver*)calloc(1, sizeof(port_solver));
   S->P = *P;
@@ -93,6 +96,8 @@ void port_begin(port_solver* S, const double* z0) {
   memset(S->lam, 0, S->Nc * sizeof(double));
   S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0; S->short_streak = 0; S->watchdog = 0;
   S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
+  g_rho = 0.0;
+  if (getenv("PORT_DW0")) S->delta_last = 3.0 * atof(getenv("PORT_DW0"));
 }
 
 /* ---- derivative blocks of every stage + residual norms (k_stage_eval + k_conv on the GPU) ---- */
@@ -253,7 +258,28 @@ static void factor_solve(port_solver* S) {
   double dw = 0.0, gam = 1.0;
   if (S->ls_fail) dw = fmin(P->delta_w_exact_cap, fmax(10.0 * dlast, P->delta_w_init));  /* capped: see k_conv */
   else if (dlast > 1.1 * P->delta_w_init && S->full_streak < 2) dw = fmax(P->delta_w_init, dlast / 3.0);  /* no delta_w = 0 probe: see k_conv */
+  if (getenv("PORT_GN_THETA") && S->thinf > atof(getenv("PORT_GN_THETA"))) { gam = 0.0; if (dw == 0.0) dw = getenv("PORT_GN_DW") ? atof(getenv("PORT_GN_DW")) : P->delta_w_init; }
   int ok = 0;
+  const int TR = getenv("PORT_TR") ? atoi(getenv("PORT_TR")) : 0;
+  if (TR) {
+    /* experiment: delta_w as a Levenberg-Marquardt / trust-region parameter driven by the accepted step length */
+    const double up = getenv("PORT_TR_UP") ? atof(getenv("PORT_TR_UP")) : 4.0, down = getenv("PORT_TR_DOWN") ? atof(getenv("PORT_TR_DOWN")) : 1.0 / 3.0;
+    const double lo = getenv("PORT_TR_LO") ? atof(getenv("PORT_TR_LO")) : 0.25;
+    if (S->iter == 0) dw = getenv("PORT_TR_INIT") ? atof(getenv("PORT_TR_INIT")) : 0.0;
+    else if (S->alpha >= 1.0) dw = (dlast > 1.1 * P->delta_w_init || S->full_streak < 2) ? fmax(dlast * down, (dlast > 0 ? P->delta_w_init : 0.0)) : 0.0;
+    else if (S->alpha >= lo) dw = dlast;
+    else dw = fmax(dlast, P->delta_w_init) * up;
+    for (int attempt = 0; attempt <= 40; ++attempt) {
+      ok = forward_sweep(S, dw, 1.0);
+      S->nfact++;
+      if (ok) break;
+      dw = (dw == 0.0) ? fmax(P->delta_w_init, dlast * down) : dw * ((dlast == 0.0 && attempt == 1) ? 100.0 : 8.0);
+    }
+    backward_sweep(S);
+    S->delta_w = dw; S->delta_last = dw; S->gamma = 1.0;
+    if (!ok) S->ls_fail = 1;
+    return;
+  }
   for (int attempt = 0; attempt <= P->max_refactor; ++attempt) {
     ok = forward_sweep(S, dw, gam);
     S->nfact++;
@@ -276,10 +302,12 @@ static void factor_solve(port_solver* S) {
   if (!ok) S->ls_fail = 1;
 }
 
+static double g_lc, g_cc;  /* experiment: (lam + alpha dlam)'c and c'c at the last trial point */
 static void trial_point(port_solver* S, double alpha, double* phi, double* th) {
   const port_problem* P = &S->P;
   const int n = P->n, m = P->m, T = P->T;
   double f = 0, t1 = 0;
+  g_lc = 0; g_cc = 0;
   double xk[MAXP], yk[MAXN], d[MAXN], l;
   for (int t = 0; t < T; ++t) {
     const int np = np_of(P, t);
@@ -288,30 +316,197 @@ static void trial_point(port_solver* S, double alpha, double* phi, double* th) {
       for (int i = 0; i < n; ++i) yk[i] = S->z[zoff(P, t + 1) + i] + alpha * S->dz[zoff(P, t + 1) + i];
       P->costval(xk, xk + n, &l);
       P->dynres(xk, xk + n, yk, d);
-      for (int i = 0; i < n; ++i) t1 += fabs(d[i]);
+      for (int i = 0; i < n; ++i) {
+        t1 += fabs(d[i]);
+        g_lc += (lam_dyn(S, t)[i] + alpha * dlam_dyn(S, t)[i]) * d[i];
+        g_cc += d[i] * d[i];
+      }
     } else {
       P->costTval(xk, &l);
     }
     f += l;
     if (q_of(P, t)) {
       const double* target = t == 0 ? P->x1 : P->xT;
-      for (int i = 0; i < n; ++i) t1 += fabs(xk[i] - target[i]);
+      for (int i = 0; i < n; ++i) {
+        const double ci = xk[i] - target[i];
+        t1 += fabs(ci);
+        g_lc += (lam_pin(S, t == 0 ? 0 : 1)[i] + alpha * dlam_pin(S, t == 0 ? 0 : 1)[i]) * ci;
+        g_cc += ci * ci;
+      }
     }
   }
   (void)m;
   *phi = f; *th = t1;
 }
 
+static void line_search_al(port_solver* S) {
+  /* experiment: augmented-Lagrangian merit M = f + lam'c + rho/2 c'c, Armijo backtracking in (z, lam) jointly */
+  double phi, th;
+  trial_point(S, 0.0, &phi, &th);
+  const double f0 = phi, lc0 = g_lc, cc0 = g_cc;
+  /* M'(0) = rp'd + c'dlam - rho c'c ;  rp'd + lam'(Jd) part is S->gphid-like: recompute directly */
+  const port_problem* P = &S->P;
+  double rpd = 0, cdl = 0;
+  for (int t = 0; t < P->T; ++t) {
+    stage_t* s = &S->st[t];
+    const int np = np_of(P, t);
+    for (int i = 0; i < np; ++i) rpd += s->rp[i] * S->dz[zoff(P, t) + i];
+    if (t < P->T - 1) for (int i = 0; i < P->n; ++i) cdl += s->d[i] * dlam_dyn(S, t)[i];
+    if (q_of(P, t)) for (int i = 0; i < P->n; ++i) cdl += s->c[i] * dlam_pin(S, t == 0 ? 0 : 1)[i];
+  }
+  /* rp = grad f + J'lam, so d/dalpha [f + lam'c] = rp'd  (c terms: lam'Jd inside rp'd), plus dlam'c */
+  double slope0 = rpd + cdl;
+  double rho = g_rho;
+  const double want = -0.5 * fabs(rpd - cdl);  /* = -1/2 d'(H+dw)d when the KKT rows hold */
+  if (cc0 > 1e-300 && slope0 - rho * cc0 > want) rho = fmax(2.0 * rho, 2.0 * (slope0 - want) / cc0);
+  if (getenv("PORT_RHO_DECAY") && rho > 1.0) { const double need = cc0 > 1e-300 ? (slope0 - want) / cc0 : 0.0; if (need < 0.25 * rho) rho = fmax(need * 2.0, rho * atof(getenv("PORT_RHO_DECAY"))); }
+  g_rho = rho;
+  const double slope = slope0 - rho * cc0;
+  const double M0 = f0 + lc0 + 0.5 * rho * cc0;
+  double alpha = 1.0, chosen = -1.0;
+  const int ntr = getenv("PORT_AL_TRIALS") ? atoi(getenv("PORT_AL_TRIALS")) : 20;
+  for (int k = 0; k < ntr; ++k) {
+    trial_point(S, alpha, &phi, &th);
+    const double M = phi + g_lc + 0.5 * rho * g_cc;
+    if (M == M && M <= M0 + 1e-4 * alpha * slope + 1e-13 * fabs(M0)) { chosen = alpha; break; }
+    alpha *= 0.5;
+  }
+  if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6)
+    fprintf(stderr, "it %d f0 %.6e lc0 %.3e cc0 %.3e rho %.3e slope %.3e (rpd %.3e cdl %.3e) alpha %.4g\n", S->iter, f0, lc0, cc0, rho, slope, rpd, cdl, chosen);
+  if (chosen < 0.0) { chosen = alpha * 2.0; S->ls_fail = 1; } else S->ls_fail = 0;
+  S->alpha = chosen;
+  S->full_streak = (chosen >= 1.0) ? S->full_streak + 1 : 0;
+}
+
+/* constraint residuals at z + alpha dz, laid out like lam (dyn rows, first pin, last pin) */
+static void residuals_at(port_solver* S, double alpha, double* c) {
+  const port_problem* P = &S->P;
+  const int n = P->n, T = P->T;
+  double xk[MAXP], yk[MAXN];
+  for (int t = 0; t < T; ++t) {
+    const int np = np_of(P, t);
+    for (int i = 0; i < np; ++i) xk[i] = S->z[zoff(P, t) + i] + alpha * S->dz[zoff(P, t) + i];
+    if (t < T - 1) {
+      for (int i = 0; i < n; ++i) yk[i] = S->z[zoff(P, t + 1) + i] + alpha * S->dz[zoff(P, t + 1) + i];
+      P->dynres(xk, xk + n, yk, c + t * n);
+    }
+    if (q_of(P, t)) {
+      const double* target = t == 0 ? P->x1 : P->xT;
+      double* cp = c + (T - 1) * n + (t == 0 ? 0 : 1) * n;
+      for (int i = 0; i < n; ++i) cp[i] = xk[i] - target[i];
+    }
+  }
+}
+
+/* re-solve with the stored factors and the constraint right-hand side replaced by csoc (second-order correction) */
+static void soc_solve(port_solver* S, const double* csoc) {
+  const port_problem* P = &S->P;
+  const int n = P->n, T = P->T;
+  double py[MAXN];
+  memset(py, 0, sizeof(py));
+  for (int t = 0; t < T; ++t) {
+    stage_t* s = &S->st[t];
+    const int np = np_of(P, t), q = q_of(P, t), ny = ny_of(P, t), bd = np + q + ny;
+    double y[MAXBD];
+    for (int i = 0; i < np; ++i) y[i] = -s->rp[i] - (i < n ? py[i] : 0.0);
+    for (int j = 0; j < q; ++j) y[np + j] = -csoc[(T - 1) * n + (t == 0 ? 0 : 1) * n + j];
+    for (int k = 0; k < ny; ++k) y[np + q + k] = -csoc[t * n + k];
+    for (int i = 1; i < bd; ++i)
+      for (int k = 0; k < i; ++k) y[i] -= s->L[i * MAXBD + k] * y[k];
+    for (int c = 0; c < ny; ++c) {
+      double acc = 0;
+      for (int i = 0; i < bd; ++i) acc += s->X[i * MAXN + c] * s->dinv[i] * y[i];
+      py[c] = acc;
+    }
+    for (int i = 0; i < bd; ++i) s->w[i] = y[i];
+  }
+  const double keep = S->gphid;
+  backward_sweep(S);
+  S->gphid = keep;
+}
+
 static void line_search(port_solver* S) {
+  if (getenv("PORT_MERIT_AL")) { line_search_al(S); return; }
   const double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8, DELTA = 1.0;
   double phi[LS_TRIALS], th[LS_TRIALS];
   double alpha = 1.0;
   for (int k = 0; k < LS_TRIALS; ++k) { trial_point(S, alpha, &phi[k], &th[k]); alpha *= 0.5; }
   const double th0 = S->th1, phi0 = S->f, dphi = S->gphid;
   const int nf = S->filter_n < FILTER_CAP ? S->filter_n : FILTER_CAP;
+  if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6) {
+    double dn = 0; for (int i = 0; i < S->Nz; ++i) dn = fmax(dn, fabs(S->dz[i]));
+    fprintf(stderr, "it %d phi0 %.8e th0 %.3e dphi %.3e dw %.2e |dz|inf %.3e\n", S->iter, phi0, th0, dphi, S->delta_w, dn);
+    for (int k = 0; k < LS_TRIALS; ++k) fprintf(stderr, "   k %d phi-phi0 %+.3e th %.3e\n", k, phi[k] - phi0, th[k]);
+    for (int i = 0; i < nf; ++i) fprintf(stderr, "   filt %d th %.3e phi-phi0 %+.3e\n", i, S->filt[2*i], S->filt[2*i+1] - phi0);
+  }
   double chosen = -1.0;
   int ftype = 0, best = 0;
   const int wd_left = S->watchdog, watchdog = wd_left > 0;  /* rollback-free watchdog: see k_ls_reduce */
+  const int max_soc = getenv("PORT_SOC") ? atoi(getenv("PORT_SOC")) : 0;
+  if (max_soc > 0 && !watchdog) {
+    /* is the full step acceptable? */
+    int ok0;
+    {
+      const double tk = th[0], pk = phi[0];
+      ok0 = (tk == tk) && (pk == pk) && tk <= S->theta_max;
+      const int sw = dphi < 0.0 && pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
+      if (ok0) {
+        if (sw && th0 <= S->theta_min) ok0 = pk <= phi0 + ETA * dphi + 1e-13 * fabs(phi0);
+        else ok0 = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
+      }
+      if (ok0)
+        for (int i = 0; i < nf; ++i) {
+          const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
+          if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok0 = 0; break; }
+        }
+    }
+    if (!ok0 && th[0] >= th0) {
+      double* csoc = (double*)malloc(S->Nc * sizeof(double));
+      double* ctr = (double*)malloc(S->Nc * sizeof(double));
+      double* dz0 = (double*)malloc(S->Nz * sizeof(double));
+      double* dl0 = (double*)malloc(S->Nc * sizeof(double));
+      memcpy(dz0, S->dz, S->Nz * sizeof(double)); memcpy(dl0, S->dlam, S->Nc * sizeof(double));
+      residuals_at(S, 0.0, csoc);
+      residuals_at(S, 1.0, ctr);
+      for (int i = 0; i < S->Nc; ++i) csoc[i] += ctr[i];
+      double th_prev = th[0];
+      int accepted = 0;
+      for (int it = 0; it < max_soc; ++it) {
+        soc_solve(S, csoc);
+        double pk, tk;
+        trial_point(S, 1.0, &pk, &tk);
+        int ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
+        const int sw = dphi < 0.0 && pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
+        int ft = 0;
+        if (ok) {
+          if (sw && th0 <= S->theta_min) { ok = pk <= phi0 + ETA * dphi + 1e-13 * fabs(phi0); ft = ok; }
+          else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
+        }
+        if (ok)
+          for (int i = 0; i < nf; ++i) {
+            const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
+            if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = 0; break; }
+          }
+        if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6)
+          fprintf(stderr, "   soc %d: phi-phi0 %+.3e th %.3e ok %d\n", it, pk - phi0, tk, ok);
+        if (ok) {
+          accepted = 1;
+          S->alpha = 1.0; S->ls_fail = 0;
+          if (!ft) { const int slot = S->filter_n % FILTER_CAP; S->filt[2 * slot] = (1.0 - G_TH) * th0; S->filt[2 * slot + 1] = phi0 - G_PHI * th0; S->filter_n++; }
+          S->full_streak += 1; S->short_streak = 0;
+          g_nsoc++;
+          break;
+        }
+        if (!(tk < 0.99 * th_prev)) break;
+        th_prev = tk;
+        residuals_at(S, 1.0, ctr);
+        for (int i = 0; i < S->Nc; ++i) csoc[i] += ctr[i];
+      }
+      if (!accepted) { memcpy(S->dz, dz0, S->Nz * sizeof(double)); memcpy(S->dlam, dl0, S->Nc * sizeof(double)); }
+      free(csoc); free(ctr); free(dz0); free(dl0);
+      if (accepted) return;
+    }
+  }
   alpha = 1.0;
   for (int k = 0; k < LS_TRIALS; ++k) {
     const double tk = th[k], pk = phi[k];

@@ -34,6 +34,9 @@ def evaluate(roots: Sequence[Expr], env: Dict[Tuple[str, int], float]) -> List[f
             v = val[n.args[0].id] ** n.value
         elif n.op == POW:
             v = val[n.args[0].id] ** val[n.args[1].id]
+        elif n.op == E.IFELSE:
+            l, r = val[n.args[0].id], val[n.args[1].id]
+            v = val[n.args[2].id] if ((l < r) if n.fn == "lt" else (l <= r)) else val[n.args[3].id]
         else:
             v = _FOLD[n.fn](val[n.args[0].id])
         val[n.id] = v

@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """How many model plugins this session had to compile: 0 on a box that received the prebuilt ones
+    (python __graft_entry__.py builds them all; a nonzero count on the GPU box means prebuild.py misses a model)."""
+    try:
+        from dto_amd import plugin
+        terminalreporter.write_line(f"[dto] model plugins compiled in this session: {len(plugin.COMPILED)} {plugin.COMPILED}")
+    except Exception:
+        pass
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

@@ -242,3 +242,66 @@ print(json.dumps([build_plugin(st, "acrobot"), hashlib.sha256(generate_source(st
            for a in ([], ["cartpole", "car"])]
     assert res[0][0] == res[1][0]                  # same plugin
     assert res[0][1] != res[1][1]                  # although the text differs -- which is what the key must ignore
+
+
+def test_ifelse_min_max_abs_trace_differentiate_and_emit():
+    """The reference imports IfElse (src/DirectTrajectoryOptimization.jl:5): models may branch on symbolic values with
+    ifelse / min / max / abs.  Values and first derivatives against a plain numpy restatement (central differences),
+    patterns by the occurrence / linearity rules, and the emitted code is a select (no branch)."""
+    import dto_amd
+    from dto_amd.symbolic import codegen as CG, diff as D, expr as E
+    from _dag_eval import evaluate
+    x = E.variables("x", 3)
+    f = (dto_amd.ifelse(x[0] > 0.5, x[0] ** 2 * x[1], np.sin(x[2])) + dto_amd.maximum(x[1], 0.0) ** 2 + abs(x[2])
+         + dto_amd.minimum(x[0], x[1] * x[2]))
+
+    def num(p):
+        x0, x1, x2 = p
+        return (x0 ** 2 * x1 if x0 > 0.5 else np.sin(x2)) + max(x1, 0.0) ** 2 + abs(x2) + min(x0, x1 * x2)
+
+    for pt in ([0.7, 0.3, -0.2], [0.1, -0.4, 0.9], [0.9, 2.0, 1.5]):
+        env = {("x", i): pt[i] for i in range(3)}
+        assert abs(evaluate([f], env)[0] - num(pt)) < 1e-14
+        g = evaluate(D.gradient(f, list(x)), env)
+        for i in range(3):
+            e = np.zeros(3); e[i] = 1e-6
+            fd = (num(np.array(pt) + e) - num(np.array(pt) - e)) / 2e-6
+            assert abs(g[i] - fd) < 1e-8, (pt, i, g[i], fd)
+    assert D.jacobian_sparsity([f], list(x)) == [(0, 0), (0, 1), (0, 2)]
+    # x0^2 x1 | sin x2 | max(x1,0)^2 | |x2| | x1 x2: no (0,2) pair, the conditions contribute nothing
+    assert D.hessian_sparsity(f, list(x)) == [(0, 0), (1, 0), (0, 1), (1, 1), (2, 1), (1, 2), (2, 2)]
+    body = CG.emit_body(D.gradient(f, list(x)), "g", {"x": "x"})
+    assert " ? " in body and "if" not in body
+    # constant conditions fold at construction, identical branches collapse
+    assert dto_amd.ifelse(E.const(1.0) < E.const(2.0), x[0], x[1]) is x[0]
+    assert dto_amd.ifelse(x[0] < x[1], x[2], x[2]) is x[2]
+    with pytest.raises(TypeError):
+        bool(x[0] < x[1])
+    # a traced model closure using them builds (patterns by occurrence)
+    d = dto_amd.Dynamics(lambda y, xx, u, w: y - xx - 0.1 * dto_amd.maximum(u, -1.0) * dto_amd.ifelse(xx[0] < 0.0, 1.0, 0.5),
+                         1, 1, 1)
+    assert d.num_jacobian == 3
+
+
+def test_parameters_and_bounds_are_validated():
+    """a short / long / missing stage parameter vector used to shift every later stage's w_t (or read past the
+    end of the buffer) without an error; now the constructor checks it (src/solver.jl:10, src/data.jl:218)."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_param_pendulum(8)
+    pars = [np.asarray(w, dtype=float) for w in p["parameters"]]
+    with pytest.raises(ValueError, match="one vector per stage"):
+        dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=pars[:5], name="param_pendulum")
+    short = list(pars); short[3] = short[3][:-1]
+    with pytest.raises(ValueError, match=r"parameters\[3\]"):
+        dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=short, name="param_pendulum")
+    with pytest.raises(ValueError, match="one Bound per stage"):
+        dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"][:-1], evaluate_hessian=True,
+                       parameters=pars, name="param_pendulum")
+    # extra trailing entries of a stage vector are never read by the closures: dropped, not shifted into the next stage
+    longer = [np.concatenate([w, [123.0]]) for w in pars]
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=longer, name="param_pendulum")
+    assert s.nlp.num_parameters == sum(len(w) for w in pars)
