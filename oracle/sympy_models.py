@@ -231,6 +231,7 @@ class Cost:
 
     def __init__(self, f, num_state, num_action, num_parameter=0, evaluate_hessian=False):
         x, u, w = syms("x", num_state), syms("u", num_action), syms("w", num_parameter)
+        self.f = f   # kept for oracle/cpu_port/gen_model_c.py (C restatement of the same closures)
         ev = sp.sympify(f(x, u, w))
         wrt = x + u
         args = x + u + w
@@ -253,6 +254,7 @@ class Dynamics:
 
     def __init__(self, f, num_next_state, num_state, num_action, num_parameter=0, evaluate_hessian=False):
         y, x, u, w = syms("y", num_next_state), syms("x", num_state), syms("u", num_action), syms("w", num_parameter)
+        self.f = f
         ev = [sp.sympify(e) for e in f(y, x, u, w)]
         wrt = x + u + y
         args = y + x + u + w
@@ -280,6 +282,7 @@ class Constraint:
     def __init__(self, f=None, num_state=0, num_action=0, num_parameter=0, indices_inequality=(), evaluate_hessian=False):
         self.num_state, self.num_action, self.num_parameter = num_state, num_action, num_parameter
         self.indices_inequality = list(indices_inequality)
+        self.f = f
         if f is None:
             self.num_constraint = self.num_jacobian = self.num_hessian = 0
             self.jacobian_sparsity = [[], []]

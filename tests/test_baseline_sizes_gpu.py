@@ -169,4 +169,4 @@ def test_cfg2_cartpole_T200_converged_solve():
     assert all(-3.0 <= u[0] <= 3.0 for u in u_sol)
     rep = kkt_report(oracle_for("cartpole", 200), s._solution, s._duals)
     assert rep["violation"] <= 1e-6 and rep["bound_viol"] <= 1e-12, rep
-    assert rep["stationarity"] <= 1e-3, rep
+    assert rep["stationarity"] <= 1e-5 and rep["compl"] <= 1e-3, rep      # compl_inf_tol = 1e-3, mu_target = 1e-4

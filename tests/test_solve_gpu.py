@@ -19,8 +19,11 @@ def oracle_for(model, T):
 
 
 def kkt_report(onlp, z, lam):
-    """Unscaled KKT residuals of (z, lam) computed with the oracle; bound multipliers are eliminated by
-    projecting the stationarity residual onto the active bound directions."""
+    """Unscaled KKT residuals of (z, lam) computed with the oracle.  Bound multipliers are not handed over, so they are
+    eliminated: r = grad f + J'lam must be absorbed by z_L = max(r, 0) on a finite lower bound and z_U = max(-r, 0) on a
+    finite upper bound; what cannot be absorbed is `stationarity`, and the absorbed part must be complementary to the
+    bound distance: `bound_compl` = max (x - lo) z_L, (hi - x) z_U -- of the order of the final barrier parameter
+    (Options.mu_target = 1e-4, src/options.jl:22) and below compl_inf_tol = 1e-3."""
     g = onlp.eval_objective_gradient(z)
     c = onlp.eval_constraint(z)
     J = np.zeros((onlp.num_constraint, onlp.num_variables))
@@ -28,18 +31,18 @@ def kkt_report(onlp, z, lam):
         J[r - 1, cc - 1] = v
     r = g + J.T @ lam
     lo, hi = onlp.variable_bounds
-    tol = 1e-4   # an interior-point iterate sits ~mu/z_L inside an active bound
-    at_lo = np.isfinite(lo) & (z - lo <= tol * np.maximum(1, np.abs(lo)))
-    at_hi = np.isfinite(hi) & (hi - z <= tol * np.maximum(1, np.abs(hi)))
-    stat = r.copy()
-    stat[at_lo] = np.minimum(stat[at_lo], 0.0)   # z_L >= 0 absorbs positive residual
-    stat[at_hi] = np.maximum(stat[at_hi], 0.0)
-    stat[lo == hi] = 0.0
+    fixed = lo == hi
+    zl = np.where(np.isfinite(lo) & ~fixed, np.maximum(r, 0.0), 0.0)
+    zu = np.where(np.isfinite(hi) & ~fixed, np.maximum(-r, 0.0), 0.0)
+    stat = r - zl + zu
+    stat[fixed] = 0.0
+    with np.errstate(invalid="ignore"):
+        bc = np.maximum(np.where(zl > 0, (z - lo) * zl, 0.0), np.where(zu > 0, (hi - z) * zu, 0.0))
     clo, chi = onlp.constraint_bounds
     viol = np.where(np.isneginf(clo), np.maximum(c, 0.0), np.abs(c))
     ineq = np.isneginf(clo)
     compl = np.abs(lam[ineq] * c[ineq]) if np.any(ineq) else np.zeros(1)
-    return dict(stationarity=np.max(np.abs(stat)), violation=np.max(viol), compl=np.max(compl),
+    return dict(stationarity=np.max(np.abs(stat)), violation=np.max(viol), compl=max(np.max(compl), np.max(bc)),
                 bound_viol=max(np.max(lo - z), np.max(z - hi), 0.0), sign_ok=bool(np.all(lam[ineq] >= -1e-8)))
 
 
