@@ -1,199 +1,394 @@
 /*
  * ORACLE / CPU baseline (test infrastructure, never linked into the product): serial C port of the
- * interior-point / SQP iteration for equality-constrained stage problems with pinned end states
- * (BASELINE configs 1 and 3: pendulum, acrobot).  It restates, for ONE instance on ONE core:
- *   - the reference's stage loops: cost / gradient! / hessian!          src/costs.jl:49-73
- *                                  constraints! / jacobian! / hessian_lagrangian!  src/dynamics.jl:103-127
+ * interior-point iteration for the BASELINE stage problems (pendulum, acrobot, cartpole, car): equality and
+ * inequality stage constraints, variable bounds (finite, one-sided, or equal = fixed).  It restates, for ONE
+ * instance on ONE core:
+ *   - the reference's stage loops: cost / gradient! / hessian!                    src/costs.jl:49-73
+ *                                  constraints! / jacobian! / hessian_lagrangian!  src/dynamics.jl:103-127,
+ *                                                                                  src/constraints.jl:80-104
  *   - the KKT system the reference sketches at examples/pendulum/pendulum.jl:138-198
- *         [ H + dw I  J' ; J  -dc I ] [dz; dlam] = -[ grad L ; c ]
+ *         [ H + Sigma + dw I  J' ; J  -D ] [dz; dlam] = -[ grad L_mu ; c ]
  *     solved stage by stage (block-tridiagonal LDL^T),
- *   - the part the reference delegates to Ipopt (src/solver.jl:45-47): inertia correction,
- *     filter line search (Waechter & Biegler 2006), convergence test with the reference Options
- *     (tol 1e-6, constr_viol_tol 1e-3, dual_inf_tol 1, src/options.jl:7-14).
- * Variables follow the reference order z = [x_1;u_1;...;x_T] (src/dynamics.jl:188-195).
- * Used (a) as bench.py's cpu_baseline ("port", 1 core) and (b) by tests to cross-check the GPU
- * solver's iterates.  PARITY: Ipopt itself cannot run here, so this pins the GPU path against an
- * independent implementation of the same algorithm, not against Ipopt's iterates.
+ *   - the part the reference delegates to Ipopt (src/solver.jl:45-47, src/data.jl:229-255): barrier with monotone
+ *     update and mu_target, fraction to the boundary, inertia correction, filter line search (Waechter & Biegler 2006)
+ *     with second-order correction and watchdog, Ipopt's scaled termination test incl. the acceptable level, with the
+ *     reference Options (src/options.jl:6-36).
+ * Variables follow the reference order z = [x_1;u_1;...;x_T] (src/dynamics.jl:188-195); multipliers
+ * [dynamics t=1..T-1; stage constraints t=1..T] (src/data.jl:64-75).
+ * Used (a) as bench.py's cpu_baseline ("port") and (b) by tests to cross-check the GPU solver's iterates: it mirrors
+ * csrc/dto_kkt_kernels.hpp decision for decision, written independently (plain C over sympy-generated model code).
+ * PARITY: Ipopt itself cannot run here, so this pins the GPU path against an independent implementation of the same
+ * algorithm, not against Ipopt's iterates.
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include "port_model.h"
+
 #define MAXN 8
 #define MAXP 10
-#define MAXBD 26
+#define MAXQ PORT_MAXQ
+#define MAXBD (MAXP + MAXQ + MAXN)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 #define LS_TRIALS 8
 #define FILTER_CAP 24
 
-typedef void (*cost_fn)(const double*, const double*, double*, double*, double*);
-typedef void (*costT_fn)(const double*, double*, double*, double*);
-typedef void (*dyn_fn)(const double*, const double*, const double*, const double*, double*, double*, double*,
-                       double*, double*, double*);
-typedef void (*dynres_fn)(const double*, const double*, const double*, double*);
-typedef void (*costval_fn)(const double*, const double*, double*);
-typedef void (*costTval_fn)(const double*, double*);
+typedef struct {
+  /* mirrors dto_options (include/dto.h) + the interior-point constants of csrc/dto_solver.cpp:default_opts */
+  double tol, s_max, dual_inf_tol, constr_viol_tol, compl_inf_tol;
+  int max_iter;
+  double acceptable_tol, acceptable_dual_inf_tol, acceptable_constr_viol_tol, acceptable_compl_inf_tol, acceptable_obj_change_tol;
+  int acceptable_iter;
+  double diverging_iterates_tol, mu_target;
+  double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
+  double delta_c, delta_w_init, delta_w_max, delta_w_exact_cap, kappa_w_minus, kappa_w_plus, kappa_w_plus_first, piv_tol;
+  int max_refactor, watchdog_trigger, watchdog_trials, max_soc;
+} port_options;
 
 typedef struct {
-  int n, m, T;
-  cost_fn cost; costT_fn costT; dyn_fn dyn; dynres_fn dynres; costval_fn costval; costTval_fn costTval;
-  double x1[MAXN], xT[MAXN];
-  /* options (mirrors csrc/dto_solver.cpp default_opts) */
-  double tol, s_max, dual_inf_tol, constr_viol_tol, delta_c, delta_w_init, delta_w_max, delta_w_exact_cap, piv_tol;
-  int max_iter, max_refactor, watchdog_trigger, watchdog_trials;
-} port_problem;
-
-typedef struct {
-  double W[MAXP * (MAXP + 1) / 2], WD[MAXP * (MAXP + 1) / 2], V[MAXP * MAXN], YY[MAXN * (MAXN + 1) / 2];
-  double F[MAXN * MAXP], E[MAXN * MAXN], rp[MAXP], d[MAXN], c[MAXN];
+  double W[MAXP * (MAXP + 1) / 2], WD[MAXP * (MAXP + 1) / 2], WC[MAXP * (MAXP + 1) / 2], V[MAXP * MAXN], YY[MAXN * (MAXN + 1) / 2];
+  double F[MAXN * MAXP], E[MAXN * MAXN], G[MAXQ * MAXP], rp[MAXP], d[MAXN], c[MAXQ] /* residual incl. slack */;
   /* factors */
   double L[MAXBD * MAXBD], dinv[MAXBD], X[MAXBD * MAXN], w[MAXBD];
 } stage_t;
 
 typedef struct {
-  port_problem P;
-  int Nz, Nc;
-  double *z, *lam /* dyn rows then pin rows (first, last) */, *dz, *dlam;
+  const port_model* M;
+  port_options o;
+  int n, m, T, Nz, Nc, Ni, n_bnd;
+  int* con;      /* [T] constraint class of the stage or -1 */
+  int* ccoff;    /* [T+1] offsets of the stage rows inside lam */
+  int* ioff;     /* [T+1] slack offsets */
+  double *lo, *hi;
+  double *z, *lam, *zl, *zu, *s, *zs, *dz, *dlam, *ds;
+  double *soc_c, *soc_buf, *save_dz, *save_dlam, *save_ds;
   stage_t* st;
-  int status, iter, nfact, filter_n, ls_fail, full_streak, short_streak, watchdog;
-  double f, th1, thinf, dinf, delta_w, delta_last, gamma, alpha, gphid, theta_max, theta_min;
+  int status, iter, nfact, nsoc, filter_n, ls_fail, full_streak, short_streak, watchdog, acc_count, ls_kind;
+  double f, f_last, th1, thinf, dinf, compl, e0, logbar, xmax, mu, merit0;
+  double szmax, iszmax, sumlam, sumz;
+  double delta_w, delta_last, gamma, alpha, alpha_pmax, alpha_dmax, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
 } port_solver;
 
-static int np_of(const port_problem* P, int t) { return t < P->T - 1 ? P->n + P->m : P->n; }
-static int q_of(const port_problem* P, int t) { return (t == 0 || t == P->T - 1) ? P->n : 0; }
-static int ny_of(const port_problem* P, int t) { return t < P->T - 1 ? P->n : 0; }
-static int zoff(const port_problem* P, int t) { return t * (P->n + P->m); }
-static double* lam_dyn(port_solver* S, int t) { return S->lam + t * S->P.n; }
-static double* lam_pin(port_solver* S, int which) { return S->lam + (S->P.T - 1) * S->P.n + which * S->P.n; }
-static double* dlam_dyn(port_solver* S, int t) { return S->dlam + t * S->P.n; }
-static double* dlam_pin(port_solver* S, int which) { return S->dlam + (S->P.T - 1) * S->P.n + which * S->P.n; }
+static int np_of(const port_solver* S, int t) { return t < S->T - 1 ? S->n + S->m : S->n; }
+static int ny_of(const port_solver* S, int t) { return t < S->T - 1 ? S->n : 0; }
+static int q_of(const port_solver* S, int t) { return S->con[t] >= 0 ? S->M->cls[S->con[t]].nc : 0; }
+static int zoff(const port_solver* S, int t) { return t * (S->n + S->m); }
+static double* lam_dyn(port_solver* S, int t) { return S->lam + t * S->n; }
+static double* dlam_dyn(port_solver* S, int t) { return S->dlam + t * S->n; }
+static int finite_lo(double v) { return v > -1e300; }
+static int finite_hi(double v) { return v < 1e300; }
 
-static double g_rho = 0.0;
-static int g_nsoc = 0;
-int port_nsoc(void) { return g_nsoc; }
-port_solver* port_create(const port_problem* P) {
+void port_default_options(port_options* o) {
+  o->tol = 1e-6; o->s_max = 100.0; o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-3; o->compl_inf_tol = 1e-3; o->max_iter = 1000;
+  o->acceptable_tol = 1e-6; o->acceptable_iter = 15; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
+  o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5; o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
+  o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->bound_push = 1e-2; o->bound_frac = 1e-2;
+  o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_max = 1e20; o->delta_w_exact_cap = 1.0;
+  o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_first = 100.0; o->piv_tol = 1e-9;
+  o->max_refactor = 9; o->watchdog_trigger = 10; o->watchdog_trials = 3; o->max_soc = 0;
+  if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &o->watchdog_trigger, &o->watchdog_trials);
+  if (getenv("DTO_EXACT_CAP")) o->delta_w_exact_cap = atof(getenv("DTO_EXACT_CAP"));
+  if (getenv("DTO_MAX_SOC")) o->max_soc = atoi(getenv("DTO_MAX_SOC"));
+}
+
+port_solver* port_create(const char* model, int T, const int* con, const double* lo, const double* hi, int max_iter) {
+  const port_model* M = NULL;
+  for (int i = 0; i < PORT_NMODELS; ++i)
+    if (!strcmp(PORT_MODELS[i].name, model)) M = &PORT_MODELS[i];
+  if (!M || T < 2) return NULL;
   port_solver* S = (port_solver*)calloc(1, sizeof(port_solver));
-  S->P = *P;
-  S->Nz = P->T * (P->n + P->m) - P->m;
-  S->Nc = (P->T - 1) * P->n + 2 * P->n;
-  S->z = (double*)calloc(S->Nz, sizeof(double));
-  S->dz = (double*)calloc(S->Nz, sizeof(double));
-  S->lam = (double*)calloc(S->Nc, sizeof(double));
-  S->dlam = (double*)calloc(S->Nc, sizeof(double));
-  S->st = (stage_t*)calloc(P->T, sizeof(stage_t));
+  S->M = M; S->n = M->n; S->m = M->m; S->T = T;
+  port_default_options(&S->o);
+  S->o.max_iter = max_iter;
+  S->Nz = T * (M->n + M->m) - M->m;
+  S->con = (int*)calloc(T, sizeof(int));
+  S->ccoff = (int*)calloc(T + 1, sizeof(int));
+  S->ioff = (int*)calloc(T + 1, sizeof(int));
+  S->ccoff[0] = (T - 1) * M->n;
+  for (int t = 0; t < T; ++t) {
+    S->con[t] = con ? con[t] : -1;
+    if (S->con[t] >= M->n_class) { free(S->con); free(S->ccoff); free(S->ioff); free(S); return NULL; }
+    int q = 0, qi = 0;
+    if (S->con[t] >= 0) {
+      q = M->cls[S->con[t]].nc;
+      for (int j = 0; j < q; ++j) qi += M->cls[S->con[t]].ineq[j];
+    }
+    S->ccoff[t + 1] = S->ccoff[t] + q;
+    S->ioff[t + 1] = S->ioff[t] + qi;
+  }
+  S->Nc = S->ccoff[T]; S->Ni = S->ioff[T];
+  S->lo = (double*)malloc(S->Nz * sizeof(double)); S->hi = (double*)malloc(S->Nz * sizeof(double));
+  S->n_bnd = S->Ni;
+  for (int i = 0; i < S->Nz; ++i) {
+    S->lo[i] = lo ? lo[i] : -INFINITY; S->hi[i] = hi ? hi[i] : INFINITY;
+    if (S->lo[i] != S->hi[i]) { if (finite_lo(S->lo[i])) S->n_bnd++; if (finite_hi(S->hi[i])) S->n_bnd++; }
+  }
+#define ALLOC(p, n) S->p = (double*)calloc((n) > 0 ? (n) : 1, sizeof(double))
+  ALLOC(z, S->Nz); ALLOC(dz, S->Nz); ALLOC(zl, S->Nz); ALLOC(zu, S->Nz); ALLOC(save_dz, S->Nz);
+  ALLOC(lam, S->Nc); ALLOC(dlam, S->Nc); ALLOC(soc_c, S->Nc); ALLOC(soc_buf, S->Nc); ALLOC(save_dlam, S->Nc);
+  ALLOC(s, S->Ni); ALLOC(zs, S->Ni); ALLOC(ds, S->Ni); ALLOC(save_ds, S->Ni);
+#undef ALLOC
+  S->st = (stage_t*)calloc(T, sizeof(stage_t));
   return S;
 }
 
 void port_destroy(port_solver* S) {
   if (!S) return;
-  free(S->z); free(S->dz); free(S->lam); free(S->dlam); free(S->st); free(S);
+  free(S->con); free(S->ccoff); free(S->ioff); free(S->lo); free(S->hi);
+  free(S->z); free(S->dz); free(S->zl); free(S->zu); free(S->save_dz); free(S->lam); free(S->dlam); free(S->soc_c);
+  free(S->soc_buf); free(S->save_dlam); free(S->s); free(S->zs); free(S->ds); free(S->save_ds); free(S->st); free(S);
 }
 
+void port_set_int(port_solver* S, const char* name, int v) {
+  if (!strcmp(name, "max_soc")) S->o.max_soc = v;
+  else if (!strcmp(name, "max_iter")) S->o.max_iter = v;
+  else if (!strcmp(name, "watchdog_trigger")) S->o.watchdog_trigger = v;
+  else if (!strcmp(name, "watchdog_trials")) S->o.watchdog_trials = v;
+  else if (!strcmp(name, "acceptable_iter")) S->o.acceptable_iter = v;
+}
+void port_set_double(port_solver* S, const char* name, double v) {
+  if (!strcmp(name, "mu_target")) S->o.mu_target = v;
+  else if (!strcmp(name, "tol")) S->o.tol = v;
+  else if (!strcmp(name, "delta_w_exact_cap")) S->o.delta_w_exact_cap = v;
+}
+
+/* slack index of row j of stage t (-1: equality row) */
+static int slack_of(const port_solver* S, int t, int j) {
+  if (S->con[t] < 0 || !S->M->cls[S->con[t]].ineq[j]) return -1;
+  int k = 0;
+  for (int i = 0; i < j; ++i) k += S->M->cls[S->con[t]].ineq[i];
+  return S->ioff[t] + k;
+}
+
+/* ---- initialisation (k_init): push the guess into the bounds, slacks from the inequality values, multipliers on the
+ *      central path of mu_init (Waechter & Biegler 2006, section 3.6) ---- */
 void port_begin(port_solver* S, const double* z0) {
+  const port_options* o = &S->o;
   memcpy(S->z, z0, S->Nz * sizeof(double));
   memset(S->lam, 0, S->Nc * sizeof(double));
-  S->status = 0; S->iter = 0; S->nfact = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0; S->short_streak = 0; S->watchdog = 0;
+  for (int i = 0; i < S->Nz; ++i) {
+    double v = S->z[i];
+    const double lo = S->lo[i], hi = S->hi[i];
+    double zl = 0, zu = 0;
+    if (lo == hi) v = lo;
+    else {
+      const int fl = finite_lo(lo), fh = finite_hi(hi);
+      if (fl && fh) {
+        const double pl = fmin(o->bound_push * fmax(1.0, fabs(lo)), o->bound_frac * (hi - lo));
+        const double pu = fmin(o->bound_push * fmax(1.0, fabs(hi)), o->bound_frac * (hi - lo));
+        v = fmin(fmax(v, lo + pl), hi - pu);
+      } else if (fl) v = fmax(v, lo + o->bound_push * fmax(1.0, fabs(lo)));
+      else if (fh) v = fmin(v, hi - o->bound_push * fmax(1.0, fabs(hi)));
+      if (fl) zl = o->mu_init / (v - lo);
+      if (fh) zu = o->mu_init / (hi - v);
+    }
+    S->z[i] = v; S->zl[i] = zl; S->zu[i] = zu;
+  }
+  for (int t = 0; t < S->T; ++t) {
+    if (S->con[t] < 0) continue;
+    const port_con_class* C = &S->M->cls[S->con[t]];
+    double c[MAXQ];
+    const double* x = S->z + zoff(S, t);
+    C->val(x, x + S->n, c);
+    for (int j = 0; j < C->nc; ++j) {
+      const int k = slack_of(S, t, j);
+      if (k < 0) continue;
+      const double sv = fmax(-c[j], o->bound_push * fmax(1.0, fabs(c[j])));
+      S->s[k] = sv; S->zs[k] = o->mu_init / sv;
+      S->lam[S->ccoff[t] + j] = S->zs[k];
+    }
+  }
+  S->status = 0; S->iter = 0; S->nfact = 0; S->nsoc = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0; S->short_streak = 0;
+  S->watchdog = 0; S->acc_count = 0; S->ls_kind = 0;
+  S->mu = o->mu_init; S->f_last = 1e300;
   S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
-  g_rho = 0.0;
-  if (getenv("PORT_DW0")) S->delta_last = 3.0 * atof(getenv("PORT_DW0"));
 }
 
 /* ---- derivative blocks of every stage + residual norms (k_stage_eval + k_conv on the GPU) ---- */
 static void eval_all(port_solver* S) {
-  const port_problem* P = &S->P;
-  const int n = P->n, m = P->m, T = P->T;
-  double f = 0, th1 = 0, thinf = 0, dinf = 0;
+  const port_model* M = S->M;
+  const int n = S->n, T = S->T;
+  double f = 0, th1 = 0, thinf = 0, dinf = 0, szmax = 0, iszmax = 0, sumlam = 0, sumz = 0, logbar = 0, xmax = 0;
   for (int t = 0; t < T; ++t) {
     stage_t* s = &S->st[t];
-    const double* x = S->z + zoff(P, t);
-    const int np = np_of(P, t);
+    const double* x = S->z + zoff(S, t);
+    const int np = np_of(S, t);
     double l;
-    memset(s->WD, 0, sizeof(s->WD)); memset(s->V, 0, sizeof(s->V)); memset(s->YY, 0, sizeof(s->YY));
+    memset(s->WD, 0, sizeof(s->WD)); memset(s->WC, 0, sizeof(s->WC)); memset(s->V, 0, sizeof(s->V)); memset(s->YY, 0, sizeof(s->YY));
     if (t < T - 1) {
       const double* u = x + n;
-      const double* y = S->z + zoff(P, t + 1);
-      P->cost(x, u, &l, s->rp, s->W);
-      P->dyn(x, u, y, lam_dyn(S, t), s->d, s->F, s->E, s->WD, s->V, s->YY);
+      const double* y = S->z + zoff(S, t + 1);
+      M->cost(x, u, &l, s->rp, s->W);
+      M->dyn(x, u, y, lam_dyn(S, t), s->d, s->F, s->E, s->WD, s->V, s->YY);
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < np; ++j) s->rp[j] += s->F[i * np + j] * lam_dyn(S, t)[i];
-      for (int i = 0; i < n; ++i) { th1 += fabs(s->d[i]); thinf = fmax(thinf, fabs(s->d[i])); }
+      for (int i = 0; i < n; ++i) { th1 += fabs(s->d[i]); thinf = fmax(thinf, fabs(s->d[i])); sumlam += fabs(lam_dyn(S, t)[i]); }
     } else {
-      P->costT(x, &l, s->rp, s->W);
+      M->costT(x, &l, s->rp, s->W);
     }
     f += l;
+    if (S->con[t] >= 0) {
+      const port_con_class* C = &M->cls[S->con[t]];
+      const double* nu = S->lam + S->ccoff[t];
+      double c[MAXQ];
+      C->f(x, x + n, nu, c, s->G, s->WC);
+      for (int j = 0; j < C->nc; ++j) {
+        for (int i = 0; i < C->np; ++i) s->rp[i] += s->G[j * C->np + i] * nu[j];
+        double r = c[j];
+        const int k = slack_of(S, t, j);
+        if (k >= 0) {
+          const double sv = S->s[k], zv = S->zs[k];
+          r = c[j] + sv;
+          dinf = fmax(dinf, fabs(nu[j] - zv));
+          szmax = fmax(szmax, sv * zv); iszmax = fmax(iszmax, 1.0 / (sv * zv));
+          sumz += fabs(zv); logbar += log(sv);
+        }
+        s->c[j] = r;
+        th1 += fabs(r); thinf = fmax(thinf, fabs(r)); sumlam += fabs(nu[j]);
+      }
+    }
     if (t > 0) { /* E_{t-1}' lam_{t-1} lands in the x rows of stage t */
       const stage_t* sp = &S->st[t - 1];
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) s->rp[j] += sp->E[i * n + j] * lam_dyn(S, t - 1)[i];
     }
-    if (q_of(P, t)) {
-      const double* target = t == 0 ? P->x1 : P->xT;
-      const double* nu = lam_pin(S, t == 0 ? 0 : 1);
-      for (int i = 0; i < n; ++i) {
-        s->c[i] = x[i] - target[i];
-        s->rp[i] += nu[i];
-        th1 += fabs(s->c[i]); thinf = fmax(thinf, fabs(s->c[i]));
-      }
+    for (int i = 0; i < np; ++i) {
+      const int zi = zoff(S, t) + i;
+      const double lo = S->lo[zi], hi = S->hi[zi], p = S->z[zi];
+      xmax = fmax(xmax, fabs(p));
+      if (lo == hi) continue;
+      dinf = fmax(dinf, fabs(s->rp[i] - S->zl[zi] + S->zu[zi]));
+      if (finite_lo(lo)) { const double v = (p - lo) * S->zl[zi]; szmax = fmax(szmax, v); iszmax = fmax(iszmax, 1.0 / v); sumz += fabs(S->zl[zi]); logbar += log(p - lo); }
+      if (finite_hi(hi)) { const double v = (hi - p) * S->zu[zi]; szmax = fmax(szmax, v); iszmax = fmax(iszmax, 1.0 / v); sumz += fabs(S->zu[zi]); logbar += log(hi - p); }
     }
-    for (int i = 0; i < np; ++i) dinf = fmax(dinf, fabs(s->rp[i]));
   }
-  S->f = f; S->th1 = th1; S->thinf = thinf; S->dinf = dinf;
+  S->f = f; S->th1 = th1; S->thinf = thinf; S->dinf = dinf; S->logbar = logbar; S->xmax = xmax;
+  S->szmax = szmax; S->iszmax = iszmax; S->sumlam = sumlam; S->sumz = sumz;
 }
 
+static double compl_at(const port_solver* S, double m) {
+  const double szmin = S->iszmax > 0.0 ? 1.0 / S->iszmax : 1e300;
+  return S->n_bnd > 0 ? fmax(S->szmax - m, m - szmin) : 0.0;
+}
+
+/* k_conv: Ipopt's scaled termination test, acceptable level, monotone barrier update with mu_target */
 static void convergence(port_solver* S) {
-  const port_problem* P = &S->P;
-  double slam = 0;
-  for (int i = 0; i < S->Nc; ++i) slam += fabs(S->lam[i]);
-  const double sd = fmax(P->s_max, slam / (double)S->Nc) / P->s_max;
-  const double e0 = fmax(S->dinf / sd, S->thinf);
-  if (!(S->f == S->f) || !(S->th1 == S->th1) || !(S->dinf == S->dinf)) S->status = 3;
-  else if (e0 <= P->tol && S->dinf <= P->dual_inf_tol && S->thinf <= P->constr_viol_tol) S->status = 1;
-  else if (S->iter >= P->max_iter) S->status = 2;
+  const port_options* o = &S->o;
+  const int n_mult = S->Nc, n_bnd = S->n_bnd;
+  const double sd = fmax(o->s_max, (S->sumlam + S->sumz) / (double)(n_mult + n_bnd > 0 ? n_mult + n_bnd : 1)) / o->s_max;
+  const double scn = fmax(o->s_max, S->sumz / (double)(n_bnd > 0 ? n_bnd : 1)) / o->s_max;
+  const double c0 = compl_at(S, o->mu_target);
+  const double e0 = fmax(fmax(S->dinf / sd, S->thinf), c0 / scn);
+  S->compl = c0; S->e0 = e0;
+  const double f = S->f;
+  const int nonfinite = !(f == f) || !(S->th1 == S->th1) || !(S->dinf == S->dinf) || fabs(f) > 1e300 || S->th1 > 1e300;
+  const int acceptable = o->acceptable_iter > 0 && e0 <= o->acceptable_tol && S->dinf <= o->acceptable_dual_inf_tol &&
+                         S->thinf <= o->acceptable_constr_viol_tol && c0 <= o->acceptable_compl_inf_tol &&
+                         fabs(f - S->f_last) / fmax(1.0, fabs(f)) <= o->acceptable_obj_change_tol;
+  S->acc_count = acceptable ? S->acc_count + 1 : 0;
+  S->f_last = f;
+  if (nonfinite) S->status = 3;
+  else if (e0 <= o->tol && S->dinf <= o->dual_inf_tol && S->thinf <= o->constr_viol_tol && c0 <= o->compl_inf_tol) S->status = 1;
+  else if (o->acceptable_iter > 0 && S->acc_count >= o->acceptable_iter) S->status = 4;
+  else if (S->xmax > o->diverging_iterates_tol) S->status = 5;
+  else if (S->iter >= o->max_iter) S->status = 2;
+  else if (n_bnd > 0) {
+    const double mu_floor = fmax(o->mu_target, fmin(o->tol, o->compl_inf_tol) / (o->kappa_eps + 1.0));
+    int changed = 0;
+    double mu = S->mu;
+    for (int k = 0; k < 8; ++k) {
+      const double emu = fmax(fmax(S->dinf / sd, S->thinf), compl_at(S, mu) / scn);
+      if (!(emu <= o->kappa_eps * mu) || mu <= mu_floor) break;
+      mu = fmax(mu_floor, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
+      changed = 1;
+    }
+    if (changed) { S->mu = mu; S->filter_n = 0; }
+  }
   if (S->theta_max < 0) { S->theta_max = 1e4 * fmax(1.0, S->th1); S->theta_min = 1e-4 * fmax(1.0, S->th1); }
+  S->merit0 = f - S->mu * S->logbar;
 }
 
-/* ---- block-tridiagonal LDL^T, forward sweep; returns 1 if the inertia is (Nz, Nc, 0) and no pivot is tiny ---- */
-static int forward_sweep(port_solver* S, double dw, double gam) {
-  const port_problem* P = &S->P;
-  const int n = P->n, T = P->T;
+/* ---- block-tridiagonal LDL^T, forward sweep; returns 1 if the inertia is (Nz, Nc, 0) and no pivot is tiny.
+ *      rhs_c: NULL = the residuals of the current iterate, else replacement constraint residuals (second-order
+ *      correction: same matrix, other right-hand side) ---- */
+static int forward_sweep(port_solver* S, double dw, double gam, const double* rhs_c) {
+  const port_options* o = &S->o;
+  const int n = S->n, T = S->T;
+  const double mu = S->mu;
   double Pm[MAXN * MAXN], py[MAXN];
   memset(Pm, 0, sizeof(Pm)); memset(py, 0, sizeof(py));
   int ok = 1, nneg = 0;
   for (int t = 0; t < T; ++t) {
     stage_t* s = &S->st[t];
-    const int np = np_of(P, t), q = q_of(P, t), ny = ny_of(P, t), bd = np + q + ny;
+    const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), bd = np + q + ny, z0 = zoff(S, t);
     double A[MAXBD][MAXBD], y[MAXBD], X[MAXBD][MAXN];
-    memset(A, 0, sizeof(A));
-    for (int i = 0; i < np; ++i)
-      for (int j = 0; j <= i; ++j) A[i][j] = s->W[TRI(i, j)] + gam * s->WD[TRI(i, j)];
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j <= i; ++j) A[i][j] += Pm[i * n + j];
-    for (int i = 0; i < np; ++i) { A[i][i] += dw; y[i] = -s->rp[i] - (i < n ? py[i] : 0.0); }
-    for (int j = 0; j < q; ++j) { A[np + j][j] = 1.0; A[np + j][np + j] = -P->delta_c; y[np + j] = -s->c[j]; }
-    for (int k = 0; k < ny; ++k) {
-      for (int i = 0; i < np; ++i) A[np + q + k][i] = s->F[k * np + i];
-      A[np + q + k][np + q + k] = -P->delta_c;
-      y[np + q + k] = -s->d[k];
-    }
-    memset(X, 0, sizeof(X));
-    for (int i = 0; i < np; ++i) for (int c = 0; c < ny; ++c) X[i][c] = gam * s->V[i * ny + c];
-    for (int k = 0; k < ny; ++k) for (int c = 0; c < ny; ++c) X[np + q + k][c] = s->E[k * ny + c];
-    /* right-looking LDL^T, static order */
-    for (int j = 0; j < bd; ++j) {
-      double dj = A[j][j], cmax = 0;
-      for (int i = j + 1; i < bd; ++i) cmax = fmax(cmax, fabs(A[i][j]));
-      if (!(fabs(dj) > P->piv_tol * fmax(1.0, cmax))) { ok = 0; dj = (dj < 0 ? -1.0 : 1.0) * fmax(fabs(dj), P->piv_tol); }
-      if (dj < 0) ++nneg;
-      const double inv = 1.0 / dj;
-      s->dinv[j] = inv;
-      for (int i = j + 1; i < bd; ++i) {
-        const double lij = A[i][j] * inv;
-        for (int k = j + 1; k <= i; ++k) A[i][k] -= lij * A[k][j];
+    int fixed[MAXP];
+    int stage_ok = 1, stage_neg = 0;
+    {
+      memset(A, 0, sizeof(A));
+      memset(X, 0, sizeof(X));
+      for (int i = 0; i < np; ++i)
+        for (int j = 0; j <= i; ++j) A[i][j] = s->W[TRI(i, j)] + gam * (s->WD[TRI(i, j)] + s->WC[TRI(i, j)]);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) A[i][j] += Pm[i * n + j];
+      for (int i = 0; i < np; ++i) {
+        double rp = s->rp[i], sig = dw;
+        const double lo = S->lo[z0 + i], hi = S->hi[z0 + i], p = S->z[z0 + i];
+        fixed[i] = (lo == hi);
+        if (!fixed[i]) {
+          if (finite_lo(lo)) { sig += S->zl[z0 + i] / (p - lo); rp -= mu / (p - lo); }
+          if (finite_hi(hi)) { sig += S->zu[z0 + i] / (hi - p); rp += mu / (hi - p); }
+        }
+        A[i][i] += sig;
+        y[i] = -rp - (i < n ? py[i] : 0.0);
       }
-      for (int i = j + 1; i < bd; ++i) A[i][j] *= inv;
+      for (int j = 0; j < q; ++j) {
+        const port_con_class* C = &S->M->cls[S->con[t]];
+        for (int i = 0; i < C->np; ++i) A[np + j][i] = s->G[j * C->np + i];
+        double dc = o->delta_c;
+        double r = rhs_c ? rhs_c[S->ccoff[t] + j] : s->c[j];
+        const int k = slack_of(S, t, j);
+        if (k >= 0) {
+          const double sv = S->s[k], zv = S->zs[k], nu = S->lam[S->ccoff[t] + j];
+          dc += sv / zv;
+          r -= (sv / zv) * (nu - mu / sv);
+        }
+        A[np + j][np + j] = -dc;
+        y[np + j] = -r;
+      }
+      for (int k = 0; k < ny; ++k) {
+        for (int i = 0; i < np; ++i) A[np + q + k][i] = s->F[k * np + i];
+        A[np + q + k][np + q + k] = -o->delta_c;
+        y[np + q + k] = -(rhs_c ? rhs_c[t * n + k] : s->d[k]);
+      }
+      for (int i = 0; i < np; ++i) for (int c = 0; c < ny; ++c) X[i][c] = gam * s->V[i * ny + c];
+      for (int k = 0; k < ny; ++k) for (int c = 0; c < ny; ++c) X[np + q + k][c] = s->E[k * ny + c];
+      for (int i = 0; i < np; ++i) {
+        if (!fixed[i]) continue;
+        for (int r2 = 0; r2 < bd; ++r2) { if (r2 > i) A[r2][i] = 0.0; if (r2 < i) A[i][r2] = 0.0; }
+        A[i][i] = 1.0; y[i] = 0.0;
+        for (int c = 0; c < ny; ++c) X[i][c] = 0.0;
+      }
+      /* right-looking LDL^T, static order */
+      for (int j = 0; j < bd; ++j) {
+        double dj = A[j][j], cmax = 0;
+        for (int i = j + 1; i < bd; ++i) cmax = fmax(cmax, fabs(A[i][j]));
+        if (!(fabs(dj) > o->piv_tol * fmax(1.0, cmax))) { stage_ok = 0; dj = (dj < 0 ? -1.0 : 1.0) * fmax(fabs(dj), o->piv_tol); }
+        if (dj < 0) ++stage_neg;
+        const double inv = 1.0 / dj;
+        s->dinv[j] = inv;
+        for (int i = j + 1; i < bd; ++i) {
+          const double lij = A[i][j] * inv;
+          for (int k = j + 1; k <= i; ++k) A[i][k] -= lij * A[k][j];
+        }
+        for (int i = j + 1; i < bd; ++i) A[i][j] *= inv;
+      }
     }
+    if (!stage_ok) ok = 0;
+    nneg += stage_neg;
     for (int i = 1; i < bd; ++i)
       for (int k = 0; k < i; ++k) {
         const double l = A[i][k];
@@ -220,15 +415,19 @@ static int forward_sweep(port_solver* S, double dw, double gam) {
   return ok;
 }
 
+/* k_kkt_bwd: back substitution, step of the eliminated slack / bound multipliers, fraction to the boundary, directional
+ * derivative of the barrier objective.  res: the constraint residuals of the right-hand side that was solved (the
+ * iterate's own, or the second-order-correction ones) */
 static void backward_sweep(port_solver* S) {
-  const port_problem* P = &S->P;
-  const int n = P->n, T = P->T;
+  const port_options* o = &S->o;
+  const int n = S->n, T = S->T;
+  const double mu = S->mu, tau = fmax(o->tau_min, 1.0 - mu);
   double xn[MAXN];
   memset(xn, 0, sizeof(xn));
-  double gphid = 0;
+  double gphid = 0, apmax = 1.0, admax = 1.0;
   for (int t = T - 1; t >= 0; --t) {
     stage_t* s = &S->st[t];
-    const int np = np_of(P, t), q = q_of(P, t), ny = ny_of(P, t), bd = np + q + ny;
+    const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), bd = np + q + ny, z0 = zoff(S, t);
     double v[MAXBD];
     for (int i = 0; i < bd; ++i) {
       double r = s->w[i];
@@ -237,61 +436,70 @@ static void backward_sweep(port_solver* S) {
     }
     for (int i = bd - 1; i >= 1; --i)
       for (int k = 0; k < i; ++k) v[k] -= s->L[i * MAXBD + k] * v[i];
-    for (int i = 0; i < np; ++i) { S->dz[zoff(P, t) + i] = v[i]; gphid += s->rp[i] * v[i]; }
-    if (q) {
-      double* dnu = dlam_pin(S, t == 0 ? 0 : 1);
-      const double* nu = lam_pin(S, t == 0 ? 0 : 1);
-      for (int j = 0; j < q; ++j) { dnu[j] = v[np + j]; gphid += nu[j] * (s->c[j] - P->delta_c * dnu[j]); }
+    for (int i = 0; i < np; ++i) {
+      const double dp = v[i];
+      S->dz[z0 + i] = dp;
+      gphid += s->rp[i] * dp;
+      const double lo = S->lo[z0 + i], hi = S->hi[z0 + i], p = S->z[z0 + i];
+      if (lo == hi) continue;
+      if (finite_lo(lo)) {
+        const double zl = S->zl[z0 + i], gap = p - lo, dzl = mu / gap - zl - (zl / gap) * dp;
+        if (dp < 0.0) apmax = fmin(apmax, -tau * gap / dp);
+        if (dzl < 0.0) admax = fmin(admax, -tau * zl / dzl);
+        gphid -= mu / gap * dp;
+      }
+      if (finite_hi(hi)) {
+        const double zu = S->zu[z0 + i], gap = hi - p, dzu = mu / gap - zu + (zu / gap) * dp;
+        if (dp > 0.0) apmax = fmin(apmax, tau * gap / dp);
+        if (dzu < 0.0) admax = fmin(admax, -tau * zu / dzu);
+        gphid += mu / gap * dp;
+      }
+    }
+    for (int j = 0; j < q; ++j) {
+      const double dnu = v[np + j], nu = S->lam[S->ccoff[t] + j], r = s->c[j];
+      S->dlam[S->ccoff[t] + j] = dnu;
+      double dsv = 0.0;
+      const int k = slack_of(S, t, j);
+      if (k >= 0) {
+        const double sv = S->s[k], zv = S->zs[k];
+        dsv = -(sv / zv) * (nu - mu / sv + dnu);
+        const double dzs = mu / sv - zv - (zv / sv) * dsv;
+        S->ds[k] = dsv;
+        if (dsv < 0.0) apmax = fmin(apmax, -tau * sv / dsv);
+        if (dzs < 0.0) admax = fmin(admax, -tau * zv / dzs);
+        gphid -= mu / sv * dsv;
+      }
+      gphid += nu * (r - o->delta_c * dnu + dsv);
     }
     for (int k = 0; k < ny; ++k) {
       dlam_dyn(S, t)[k] = v[np + q + k];
-      gphid += lam_dyn(S, t)[k] * (s->d[k] - P->delta_c * v[np + q + k]);
+      gphid += lam_dyn(S, t)[k] * (s->d[k] - o->delta_c * v[np + q + k]);
     }
     for (int i = 0; i < n; ++i) xn[i] = v[i];
   }
-  S->gphid = gphid;
+  S->gphid = gphid; S->alpha_pmax = apmax; S->alpha_dmax = admax;
 }
 
+/* inertia correction: k_conv's choice of the first delta_w + k_kkt_sep's ladder */
 static void factor_solve(port_solver* S) {
-  const port_problem* P = &S->P;
+  const port_options* o = &S->o;
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
-  if (S->ls_fail) dw = fmin(P->delta_w_exact_cap, fmax(10.0 * dlast, P->delta_w_init));  /* capped: see k_conv */
-  else if (dlast > 1.1 * P->delta_w_init && S->full_streak < 2) dw = fmax(P->delta_w_init, dlast / 3.0);  /* no delta_w = 0 probe: see k_conv */
-  if (getenv("PORT_GN_THETA") && S->thinf > atof(getenv("PORT_GN_THETA"))) { gam = 0.0; if (dw == 0.0) dw = getenv("PORT_GN_DW") ? atof(getenv("PORT_GN_DW")) : P->delta_w_init; }
+  if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * dlast, o->delta_w_init));
+  else if (dlast > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * dlast);
   int ok = 0;
-  const int TR = getenv("PORT_TR") ? atoi(getenv("PORT_TR")) : 0;
-  if (TR) {
-    /* experiment: delta_w as a Levenberg-Marquardt / trust-region parameter driven by the accepted step length */
-    const double up = getenv("PORT_TR_UP") ? atof(getenv("PORT_TR_UP")) : 4.0, down = getenv("PORT_TR_DOWN") ? atof(getenv("PORT_TR_DOWN")) : 1.0 / 3.0;
-    const double lo = getenv("PORT_TR_LO") ? atof(getenv("PORT_TR_LO")) : 0.25;
-    if (S->iter == 0) dw = getenv("PORT_TR_INIT") ? atof(getenv("PORT_TR_INIT")) : 0.0;
-    else if (S->alpha >= 1.0) dw = (dlast > 1.1 * P->delta_w_init || S->full_streak < 2) ? fmax(dlast * down, (dlast > 0 ? P->delta_w_init : 0.0)) : 0.0;
-    else if (S->alpha >= lo) dw = dlast;
-    else dw = fmax(dlast, P->delta_w_init) * up;
-    for (int attempt = 0; attempt <= 40; ++attempt) {
-      ok = forward_sweep(S, dw, 1.0);
-      S->nfact++;
-      if (ok) break;
-      dw = (dw == 0.0) ? fmax(P->delta_w_init, dlast * down) : dw * ((dlast == 0.0 && attempt == 1) ? 100.0 : 8.0);
-    }
-    backward_sweep(S);
-    S->delta_w = dw; S->delta_last = dw; S->gamma = 1.0;
-    if (!ok) S->ls_fail = 1;
-    return;
-  }
-  for (int attempt = 0; attempt <= P->max_refactor; ++attempt) {
-    ok = forward_sweep(S, dw, gam);
+  for (int attempt = 0;; ++attempt) {
+    ok = forward_sweep(S, dw, gam, NULL);
     S->nfact++;
-    if (ok) break;
+    if (ok || attempt >= o->max_refactor) break;
     if (gam != 0.0) {
       const int skip_ladder = (S->gamma == 0.0) && (S->iter % 4 != 0);
-      if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? P->delta_w_init : fmax(P->delta_w_init, dlast / 3.0);
-      else if (!skip_ladder) dw *= (dlast == 0.0) ? 100.0 : 8.0;
-      if (skip_ladder || dw > P->delta_w_exact_cap) { gam = 0.0; dw = P->delta_w_init; }
+      if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o->delta_w_init : fmax(o->delta_w_init, o->kappa_w_minus * dlast);
+      else if (!skip_ladder) dw *= (dlast == 0.0) ? o->kappa_w_plus_first : o->kappa_w_plus;
+      if (skip_ladder || dw > o->delta_w_exact_cap) { gam = 0.0; dw = o->delta_w_init; }
     } else {
-      dw *= 8.0;
-      if (dw > P->delta_w_max) dw = P->delta_w_max;
+      dw *= o->kappa_w_plus;
+      if (dw > o->delta_w_max) dw = o->delta_w_max;
     }
   }
   backward_sweep(S);
@@ -299,254 +507,195 @@ static void factor_solve(port_solver* S) {
   if (dw > 0.0 && gam != 0.0) S->delta_last = dw;
   if (dw == 0.0) S->delta_last = 0.0;
   S->gamma = gam;
-  if (!ok) S->ls_fail = 1;
+  S->ls_fail = ok ? 0 : 1;
 }
 
-static double g_lc, g_cc;  /* experiment: (lam + alpha dlam)'c and c'c at the last trial point */
-static void trial_point(port_solver* S, double alpha, double* phi, double* th) {
-  const port_problem* P = &S->P;
-  const int n = P->n, m = P->m, T = P->T;
+/* barrier objective and l1 constraint violation at (z + alpha dz, s + alpha ds); res (may be NULL): the residuals, laid
+ * out like lam */
+static void trial_point(port_solver* S, double alpha, double* phi, double* th, double* res) {
+  const port_model* M = S->M;
+  const int n = S->n, T = S->T;
+  const double mu = S->mu;
   double f = 0, t1 = 0;
-  g_lc = 0; g_cc = 0;
-  double xk[MAXP], yk[MAXN], d[MAXN], l;
+  double xk[MAXP], yk[MAXN], d[MAXN], c[MAXQ], l;
   for (int t = 0; t < T; ++t) {
-    const int np = np_of(P, t);
-    for (int i = 0; i < np; ++i) xk[i] = S->z[zoff(P, t) + i] + alpha * S->dz[zoff(P, t) + i];
+    const int np = np_of(S, t), z0 = zoff(S, t);
+    for (int i = 0; i < np; ++i) xk[i] = S->z[z0 + i] + alpha * S->dz[z0 + i];
     if (t < T - 1) {
-      for (int i = 0; i < n; ++i) yk[i] = S->z[zoff(P, t + 1) + i] + alpha * S->dz[zoff(P, t + 1) + i];
-      P->costval(xk, xk + n, &l);
-      P->dynres(xk, xk + n, yk, d);
-      for (int i = 0; i < n; ++i) {
-        t1 += fabs(d[i]);
-        g_lc += (lam_dyn(S, t)[i] + alpha * dlam_dyn(S, t)[i]) * d[i];
-        g_cc += d[i] * d[i];
-      }
+      for (int i = 0; i < n; ++i) yk[i] = S->z[zoff(S, t + 1) + i] + alpha * S->dz[zoff(S, t + 1) + i];
+      M->costval(xk, xk + n, &l);
     } else {
-      P->costTval(xk, &l);
+      M->costTval(xk, &l);
     }
     f += l;
-    if (q_of(P, t)) {
-      const double* target = t == 0 ? P->x1 : P->xT;
-      for (int i = 0; i < n; ++i) {
-        const double ci = xk[i] - target[i];
-        t1 += fabs(ci);
-        g_lc += (lam_pin(S, t == 0 ? 0 : 1)[i] + alpha * dlam_pin(S, t == 0 ? 0 : 1)[i]) * ci;
-        g_cc += ci * ci;
+    for (int i = 0; i < np; ++i) {
+      const double lo = S->lo[z0 + i], hi = S->hi[z0 + i];
+      if (lo == hi) continue;
+      if (finite_lo(lo)) f -= mu * log(xk[i] - lo);
+      if (finite_hi(hi)) f -= mu * log(hi - xk[i]);
+    }
+    if (t < T - 1) {
+      M->dynres(xk, xk + n, yk, d);
+      for (int i = 0; i < n; ++i) { t1 += fabs(d[i]); if (res) res[t * n + i] = d[i]; }
+    }
+    if (S->con[t] >= 0) {
+      const port_con_class* C = &M->cls[S->con[t]];
+      C->val(xk, xk + n, c);
+      for (int j = 0; j < C->nc; ++j) {
+        double r = c[j];
+        const int k = slack_of(S, t, j);
+        if (k >= 0) { const double sk = S->s[k] + alpha * S->ds[k]; r += sk; f -= mu * log(sk); }
+        t1 += fabs(r);
+        if (res) res[S->ccoff[t] + j] = r;
       }
     }
   }
-  (void)m;
   *phi = f; *th = t1;
 }
 
-static void line_search_al(port_solver* S) {
-  /* experiment: augmented-Lagrangian merit M = f + lam'c + rho/2 c'c, Armijo backtracking in (z, lam) jointly */
-  double phi, th;
-  trial_point(S, 0.0, &phi, &th);
-  const double f0 = phi, lc0 = g_lc, cc0 = g_cc;
-  /* M'(0) = rp'd + c'dlam - rho c'c ;  rp'd + lam'(Jd) part is S->gphid-like: recompute directly */
-  const port_problem* P = &S->P;
-  double rpd = 0, cdl = 0;
-  for (int t = 0; t < P->T; ++t) {
-    stage_t* s = &S->st[t];
-    const int np = np_of(P, t);
-    for (int i = 0; i < np; ++i) rpd += s->rp[i] * S->dz[zoff(P, t) + i];
-    if (t < P->T - 1) for (int i = 0; i < P->n; ++i) cdl += s->d[i] * dlam_dyn(S, t)[i];
-    if (q_of(P, t)) for (int i = 0; i < P->n; ++i) cdl += s->c[i] * dlam_pin(S, t == 0 ? 0 : 1)[i];
-  }
-  /* rp = grad f + J'lam, so d/dalpha [f + lam'c] = rp'd  (c terms: lam'Jd inside rp'd), plus dlam'c */
-  double slope0 = rpd + cdl;
-  double rho = g_rho;
-  const double want = -0.5 * fabs(rpd - cdl);  /* = -1/2 d'(H+dw)d when the KKT rows hold */
-  if (cc0 > 1e-300 && slope0 - rho * cc0 > want) rho = fmax(2.0 * rho, 2.0 * (slope0 - want) / cc0);
-  if (getenv("PORT_RHO_DECAY") && rho > 1.0) { const double need = cc0 > 1e-300 ? (slope0 - want) / cc0 : 0.0; if (need < 0.25 * rho) rho = fmax(need * 2.0, rho * atof(getenv("PORT_RHO_DECAY"))); }
-  g_rho = rho;
-  const double slope = slope0 - rho * cc0;
-  const double M0 = f0 + lc0 + 0.5 * rho * cc0;
-  double alpha = 1.0, chosen = -1.0;
-  const int ntr = getenv("PORT_AL_TRIALS") ? atoi(getenv("PORT_AL_TRIALS")) : 20;
-  for (int k = 0; k < ntr; ++k) {
-    trial_point(S, alpha, &phi, &th);
-    const double M = phi + g_lc + 0.5 * rho * g_cc;
-    if (M == M && M <= M0 + 1e-4 * alpha * slope + 1e-13 * fabs(M0)) { chosen = alpha; break; }
-    alpha *= 0.5;
-  }
-  if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6)
-    fprintf(stderr, "it %d f0 %.6e lc0 %.3e cc0 %.3e rho %.3e slope %.3e (rpd %.3e cdl %.3e) alpha %.4g\n", S->iter, f0, lc0, cc0, rho, slope, rpd, cdl, chosen);
-  if (chosen < 0.0) { chosen = alpha * 2.0; S->ls_fail = 1; } else S->ls_fail = 0;
-  S->alpha = chosen;
-  S->full_streak = (chosen >= 1.0) ? S->full_streak + 1 : 0;
-}
-
-/* constraint residuals at z + alpha dz, laid out like lam (dyn rows, first pin, last pin) */
-static void residuals_at(port_solver* S, double alpha, double* c) {
-  const port_problem* P = &S->P;
-  const int n = P->n, T = P->T;
-  double xk[MAXP], yk[MAXN];
-  for (int t = 0; t < T; ++t) {
-    const int np = np_of(P, t);
-    for (int i = 0; i < np; ++i) xk[i] = S->z[zoff(P, t) + i] + alpha * S->dz[zoff(P, t) + i];
-    if (t < T - 1) {
-      for (int i = 0; i < n; ++i) yk[i] = S->z[zoff(P, t + 1) + i] + alpha * S->dz[zoff(P, t + 1) + i];
-      P->dynres(xk, xk + n, yk, c + t * n);
-    }
-    if (q_of(P, t)) {
-      const double* target = t == 0 ? P->x1 : P->xT;
-      double* cp = c + (T - 1) * n + (t == 0 ? 0 : 1) * n;
-      for (int i = 0; i < n; ++i) cp[i] = xk[i] - target[i];
-    }
-  }
-}
-
-/* re-solve with the stored factors and the constraint right-hand side replaced by csoc (second-order correction) */
-static void soc_solve(port_solver* S, const double* csoc) {
-  const port_problem* P = &S->P;
-  const int n = P->n, T = P->T;
-  double py[MAXN];
-  memset(py, 0, sizeof(py));
-  for (int t = 0; t < T; ++t) {
-    stage_t* s = &S->st[t];
-    const int np = np_of(P, t), q = q_of(P, t), ny = ny_of(P, t), bd = np + q + ny;
-    double y[MAXBD];
-    for (int i = 0; i < np; ++i) y[i] = -s->rp[i] - (i < n ? py[i] : 0.0);
-    for (int j = 0; j < q; ++j) y[np + j] = -csoc[(T - 1) * n + (t == 0 ? 0 : 1) * n + j];
-    for (int k = 0; k < ny; ++k) y[np + q + k] = -csoc[t * n + k];
-    for (int i = 1; i < bd; ++i)
-      for (int k = 0; k < i; ++k) y[i] -= s->L[i * MAXBD + k] * y[k];
-    for (int c = 0; c < ny; ++c) {
-      double acc = 0;
-      for (int i = 0; i < bd; ++i) acc += s->X[i * MAXN + c] * s->dinv[i] * y[i];
-      py[c] = acc;
-    }
-    for (int i = 0; i < bd; ++i) s->w[i] = y[i];
-  }
-  const double keep = S->gphid;
-  backward_sweep(S);
-  S->gphid = keep;
-}
-
-static void line_search(port_solver* S) {
-  if (getenv("PORT_MERIT_AL")) { line_search_al(S); return; }
-  const double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8, DELTA = 1.0;
-  double phi[LS_TRIALS], th[LS_TRIALS];
-  double alpha = 1.0;
-  for (int k = 0; k < LS_TRIALS; ++k) { trial_point(S, alpha, &phi[k], &th[k]); alpha *= 0.5; }
-  const double th0 = S->th1, phi0 = S->f, dphi = S->gphid;
+static int filter_ok(const port_solver* S, double tk, double pk) {
+  const double G_TH = 1e-5, G_PHI = 1e-8;
   const int nf = S->filter_n < FILTER_CAP ? S->filter_n : FILTER_CAP;
-  if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6) {
-    double dn = 0; for (int i = 0; i < S->Nz; ++i) dn = fmax(dn, fabs(S->dz[i]));
-    fprintf(stderr, "it %d phi0 %.8e th0 %.3e dphi %.3e dw %.2e |dz|inf %.3e\n", S->iter, phi0, th0, dphi, S->delta_w, dn);
-    for (int k = 0; k < LS_TRIALS; ++k) fprintf(stderr, "   k %d phi-phi0 %+.3e th %.3e\n", k, phi[k] - phi0, th[k]);
-    for (int i = 0; i < nf; ++i) fprintf(stderr, "   filt %d th %.3e phi-phi0 %+.3e\n", i, S->filt[2*i], S->filt[2*i+1] - phi0);
+  for (int i = 0; i < nf; ++i) {
+    const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
+    if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) return 0;
   }
+  return 1;
+}
+
+/* acceptance of one trial (theta, phi) at step size alpha against the current iterate (Waechter & Biegler, A-5.4) */
+static int trial_ok(const port_solver* S, double alpha, double tk, double pk, int* ftype) {
+  const double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8, DELTA = 1.0;
+  const double th0 = S->th1, phi0 = S->merit0, dphi = S->gphid;
+  int ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
+  const int sw = dphi < 0.0 && alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
+  const int armijo = pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0);
+  if (ok) {
+    if (sw && th0 <= S->theta_min) ok = armijo;
+    else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
+  }
+  *ftype = sw && armijo;
+  return ok;
+}
+
+static void filter_augment(port_solver* S) {
+  const double G_TH = 1e-5, G_PHI = 1e-8;
+  const int slot = S->filter_n % FILTER_CAP;
+  S->filt[2 * slot] = (1.0 - G_TH) * S->th1;
+  S->filt[2 * slot + 1] = S->merit0 - G_PHI * S->th1;
+  S->filter_n++;
+}
+
+/* second-order correction (Waechter & Biegler 2006, section 2.4; Ipopt max_soc = 4, kappa_soc = 0.99): the full
+ * fraction-to-the-boundary step was rejected and did not reduce the violation -> re-solve the same matrix with the
+ * constraint residual alpha c(x_k) + c(x_k + alpha d); accept the corrected step if the filter takes it */
+static int second_order_correction(port_solver* S, double th_first) {
+  const port_options* o = &S->o;
+  const double amax = S->alpha_pmax, admax0 = S->alpha_dmax, gph = S->gphid;
+  memcpy(S->save_dz, S->dz, S->Nz * sizeof(double)); memcpy(S->save_dlam, S->dlam, S->Nc * sizeof(double));
+  memcpy(S->save_ds, S->ds, S->Ni * sizeof(double));
+  double phi, th;
+  trial_point(S, amax, &phi, &th, S->soc_buf);           /* c(x_k + alpha d) */
+  trial_point(S, 0.0, &phi, &th, S->soc_c);              /* c(x_k) */
+  for (int i = 0; i < S->Nc; ++i) S->soc_c[i] = amax * S->soc_c[i] + S->soc_buf[i];
+  double th_prev = th_first;
+  for (int it = 0; it < o->max_soc; ++it) {
+    forward_sweep(S, S->delta_w, S->gamma, S->soc_c);
+    backward_sweep(S);                                    /* new dz, dlam, ds and their fraction-to-the-boundary limits */
+    const double alpha_soc = S->alpha_pmax;
+    S->gphid = gph;
+    double pk, tk;
+    trial_point(S, alpha_soc, &pk, &tk, S->soc_buf);
+    int ft = 0;
+    const int ok = trial_ok(S, alpha_soc, tk, pk, &ft) && filter_ok(S, tk, pk);
+    if (ok) {
+      S->alpha = alpha_soc; S->ls_fail = 0; S->ls_kind = 4;
+      if (!ft) filter_augment(S);
+      S->nsoc++;
+      return 1;
+    }
+    if (!(tk < 0.99 * th_prev)) break;
+    th_prev = tk;
+    for (int i = 0; i < S->Nc; ++i) S->soc_c[i] = alpha_soc * S->soc_c[i] + S->soc_buf[i];
+  }
+  memcpy(S->dz, S->save_dz, S->Nz * sizeof(double)); memcpy(S->dlam, S->save_dlam, S->Nc * sizeof(double));
+  memcpy(S->ds, S->save_ds, S->Ni * sizeof(double));
+  S->alpha_pmax = amax; S->alpha_dmax = admax0; S->gphid = gph;
+  return 0;
+}
+
+/* k_linesearch + k_ls_reduce */
+static void line_search(port_solver* S) {
+  double phi[LS_TRIALS], th[LS_TRIALS];
+  const double amax = S->alpha_pmax;
+  double alpha = amax;
+  for (int k = 0; k < LS_TRIALS; ++k) { trial_point(S, alpha, &phi[k], &th[k], NULL); alpha *= 0.5; }
+  const double th0 = S->th1;
   double chosen = -1.0;
   int ftype = 0, best = 0;
   const int wd_left = S->watchdog, watchdog = wd_left > 0;  /* rollback-free watchdog: see k_ls_reduce */
-  const int max_soc = getenv("PORT_SOC") ? atoi(getenv("PORT_SOC")) : 0;
-  if (max_soc > 0 && !watchdog) {
-    /* is the full step acceptable? */
-    int ok0;
-    {
-      const double tk = th[0], pk = phi[0];
-      ok0 = (tk == tk) && (pk == pk) && tk <= S->theta_max;
-      const int sw = dphi < 0.0 && pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
-      if (ok0) {
-        if (sw && th0 <= S->theta_min) ok0 = pk <= phi0 + ETA * dphi + 1e-13 * fabs(phi0);
-        else ok0 = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
-      }
-      if (ok0)
-        for (int i = 0; i < nf; ++i) {
-          const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
-          if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok0 = 0; break; }
-        }
-    }
-    if (!ok0 && th[0] >= th0) {
-      double* csoc = (double*)malloc(S->Nc * sizeof(double));
-      double* ctr = (double*)malloc(S->Nc * sizeof(double));
-      double* dz0 = (double*)malloc(S->Nz * sizeof(double));
-      double* dl0 = (double*)malloc(S->Nc * sizeof(double));
-      memcpy(dz0, S->dz, S->Nz * sizeof(double)); memcpy(dl0, S->dlam, S->Nc * sizeof(double));
-      residuals_at(S, 0.0, csoc);
-      residuals_at(S, 1.0, ctr);
-      for (int i = 0; i < S->Nc; ++i) csoc[i] += ctr[i];
-      double th_prev = th[0];
-      int accepted = 0;
-      for (int it = 0; it < max_soc; ++it) {
-        soc_solve(S, csoc);
-        double pk, tk;
-        trial_point(S, 1.0, &pk, &tk);
-        int ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
-        const int sw = dphi < 0.0 && pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
-        int ft = 0;
-        if (ok) {
-          if (sw && th0 <= S->theta_min) { ok = pk <= phi0 + ETA * dphi + 1e-13 * fabs(phi0); ft = ok; }
-          else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
-        }
-        if (ok)
-          for (int i = 0; i < nf; ++i) {
-            const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
-            if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = 0; break; }
-          }
-        if (getenv("PORT_DEBUG_IT") && S->iter >= atoi(getenv("PORT_DEBUG_IT")) && S->iter < atoi(getenv("PORT_DEBUG_IT")) + 6)
-          fprintf(stderr, "   soc %d: phi-phi0 %+.3e th %.3e ok %d\n", it, pk - phi0, tk, ok);
-        if (ok) {
-          accepted = 1;
-          S->alpha = 1.0; S->ls_fail = 0;
-          if (!ft) { const int slot = S->filter_n % FILTER_CAP; S->filt[2 * slot] = (1.0 - G_TH) * th0; S->filt[2 * slot + 1] = phi0 - G_PHI * th0; S->filter_n++; }
-          S->full_streak += 1; S->short_streak = 0;
-          g_nsoc++;
-          break;
-        }
-        if (!(tk < 0.99 * th_prev)) break;
-        th_prev = tk;
-        residuals_at(S, 1.0, ctr);
-        for (int i = 0; i < S->Nc; ++i) csoc[i] += ctr[i];
-      }
-      if (!accepted) { memcpy(S->dz, dz0, S->Nz * sizeof(double)); memcpy(S->dlam, dl0, S->Nc * sizeof(double)); }
-      free(csoc); free(ctr); free(dz0); free(dl0);
-      if (accepted) return;
+  if (S->o.max_soc > 0 && !watchdog) {
+    int ft;
+    const int ok0 = trial_ok(S, amax, th[0], phi[0], &ft) && filter_ok(S, th[0], phi[0]);
+    if (!ok0 && th[0] >= th0 && second_order_correction(S, th[0])) {
+      S->full_streak = S->full_streak + 1; S->short_streak = 0;
+      return;
     }
   }
-  alpha = 1.0;
+  alpha = amax;
   for (int k = 0; k < LS_TRIALS; ++k) {
     const double tk = th[k], pk = phi[k];
     if (th[k] < th[best] || !(th[best] == th[best])) best = k;
-    int ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
-    const int sw = dphi < 0.0 && alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_TH);
-    if (ok) {
-      if (sw && th0 <= S->theta_min) ok = pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0);
-      else ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
-    }
+    int ft;
+    int ok = trial_ok(S, alpha, tk, pk, &ft);
     if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
-    if (ok && !watchdog)
-      for (int i = 0; i < nf; ++i) {
-        const double tf = S->filt[2 * i], pf = S->filt[2 * i + 1];
-        if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = 0; break; }
-      }
-    if (ok) { chosen = alpha; ftype = sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * fabs(phi0)); break; }
+    if (ok && !watchdog) ok = filter_ok(S, tk, pk);
+    if (ok) { chosen = alpha; ftype = ft; break; }
     alpha *= 0.5;
   }
   int augment;
   if (chosen < 0.0) {
-    double ab = 1.0;
+    double ab = amax;
     for (int k = 0; k < best; ++k) ab *= 0.5;
     if (th[best] == th[best] && th[best] < th0) chosen = ab; else chosen = alpha * 2.0;
     S->ls_fail = 1; augment = 1;
   } else { S->ls_fail = 0; augment = !ftype && !watchdog; }
   if (watchdog) { S->watchdog = wd_left - 1; S->short_streak = 0; }
-  else if (S->P.watchdog_trigger > 0) {
-    const int streak = (chosen < 1.0) ? S->short_streak + 1 : 0;
-    if (streak >= S->P.watchdog_trigger) { S->watchdog = S->P.watchdog_trials; S->short_streak = 0; }
+  else if (S->o.watchdog_trigger > 0) {
+    const int streak = (chosen < amax) ? S->short_streak + 1 : 0;
+    if (streak >= S->o.watchdog_trigger) { S->watchdog = S->o.watchdog_trials; S->short_streak = 0; }
     else S->short_streak = streak;
   }
-  if (augment) {
-    const int slot = S->filter_n % FILTER_CAP;
-    S->filt[2 * slot] = (1.0 - G_TH) * th0;
-    S->filt[2 * slot + 1] = phi0 - G_PHI * th0;
-    S->filter_n++;
-  }
+  if (augment) filter_augment(S);
+  S->ls_kind = chosen < 0.0 ? -1 : (watchdog ? 3 : (ftype ? 1 : 2));
   S->alpha = chosen;
-  S->full_streak = (chosen >= 1.0) ? S->full_streak + 1 : 0;
+  S->full_streak = (chosen >= amax) ? S->full_streak + 1 : 0;
+}
+
+/* k_update */
+static void update(port_solver* S) {
+  const double mu = S->mu, al = S->alpha, ad = S->alpha_dmax, KSIG = 1e10;
+  for (int i = 0; i < S->Nz; ++i) {
+    const double p = S->z[i], dp = S->dz[i], pn = p + al * dp, lo = S->lo[i], hi = S->hi[i];
+    if (lo != hi) {
+      if (finite_lo(lo)) {
+        const double zl = S->zl[i], gap = p - lo, dzl = mu / gap - zl - (zl / gap) * dp, gn = pn - lo;
+        S->zl[i] = fmin(fmax(zl + ad * dzl, mu / (KSIG * gn)), KSIG * mu / gn);
+      }
+      if (finite_hi(hi)) {
+        const double zu = S->zu[i], gap = hi - p, dzu = mu / gap - zu + (zu / gap) * dp, gn = hi - pn;
+        S->zu[i] = fmin(fmax(zu + ad * dzu, mu / (KSIG * gn)), KSIG * mu / gn);
+      }
+    }
+    S->z[i] = pn;
+  }
+  for (int k = 0; k < S->Ni; ++k) {
+    const double sv = S->s[k], zv = S->zs[k], dsv = S->ds[k];
+    const double dzs = mu / sv - zv - (zv / sv) * dsv, sn = sv + al * dsv;
+    S->s[k] = sn;
+    S->zs[k] = fmin(fmax(zv + ad * dzs, mu / (KSIG * sn)), KSIG * mu / sn);
+  }
+  for (int i = 0; i < S->Nc; ++i) S->lam[i] += al * S->dlam[i];
 }
 
 /* one iteration: EVAL -> CONV -> FACTOR_SOLVE -> LINESEARCH -> UPDATE; returns 1 if an iteration was executed */
@@ -557,8 +706,7 @@ int port_iterate(port_solver* S) {
   if (S->status != 0) return 0;
   factor_solve(S);
   line_search(S);
-  for (int i = 0; i < S->Nz; ++i) S->z[i] += S->alpha * S->dz[i];
-  for (int i = 0; i < S->Nc; ++i) S->lam[i] += S->alpha * S->dlam[i];
+  update(S);
   S->iter++;
   return 1;
 }
@@ -567,49 +715,39 @@ int port_iterate(port_solver* S) {
 int port_status(const port_solver* S) { return S->status; }
 int port_iterations(const port_solver* S) { return S->iter; }
 int port_nfact(const port_solver* S) { return S->nfact; }
+int port_nsoc(const port_solver* S) { return S->nsoc; }
+int port_ls_kind(const port_solver* S) { return S->ls_kind; }
 int port_num_variables(const port_solver* S) { return S->Nz; }
 int port_num_constraint(const port_solver* S) { return S->Nc; }
+int port_num_slacks(const port_solver* S) { return S->Ni; }
 double port_objective(const port_solver* S) { return S->f; }
 double port_constr_viol(const port_solver* S) { return S->thinf; }
 double port_dual_inf(const port_solver* S) { return S->dinf; }
 double port_alpha(const port_solver* S) { return S->alpha; }
 double port_delta_w(const port_solver* S) { return S->delta_w; }
+double port_mu(const port_solver* S) { return S->mu; }
 const double* port_z(const port_solver* S) { return S->z; }
-/* multipliers in the reference order: dynamics rows, then stage rows (first pin, last pin) */
+/* multipliers in the reference order: dynamics rows, then stage rows t = 1..T */
 const double* port_lam(const port_solver* S) { return S->lam; }
 
-/* ---- model registry ---- */
-#define DECL(name)                                                                                             \
-  void name##_cost(const double*, const double*, double*, double*, double*);                                   \
-  void name##_costT(const double*, double*, double*, double*);                                                 \
-  void name##_dyn(const double*, const double*, const double*, const double*, double*, double*, double*, double*, \
-                  double*, double*);                                                                           \
-  void name##_dynres(const double*, const double*, const double*, double*);                                    \
-  void name##_costval(const double*, const double*, double*);                                                  \
-  void name##_costTval(const double*, double*);
-DECL(acrobot)
-DECL(pendulum)
-
-port_solver* port_create_named(const char* model, int T, const double* x1, const double* xT, int max_iter) {
-  port_problem P;
-  memset(&P, 0, sizeof(P));
-  if (!strcmp(model, "acrobot")) {
-    P.n = 4; P.m = 1;
-    P.cost = acrobot_cost; P.costT = acrobot_costT; P.dyn = acrobot_dyn; P.dynres = acrobot_dynres;
-    P.costval = acrobot_costval; P.costTval = acrobot_costTval;
-  } else if (!strcmp(model, "pendulum")) {
-    P.n = 2; P.m = 1;
-    P.cost = pendulum_cost; P.costT = pendulum_costT; P.dyn = pendulum_dyn; P.dynres = pendulum_dynres;
-    P.costval = pendulum_costval; P.costTval = pendulum_costTval;
-  } else {
-    return NULL;
+/* batched driver for the CPU baseline: solves (iters_per_instance <= 0) or runs a fixed number of iterations of B
+ * instances, OpenMP over instances when built with -fopenmp.  Z0: [B][Nz]; out_iters / out_status: [B]; returns the
+ * total number of iterations executed. */
+long port_run_batch(const char* model, int T, const int* con, const double* lo, const double* hi, int max_iter,
+                    int iters_per_instance, int B, const double* Z0, int* out_iters, int* out_status, long* out_nfact) {
+  long total = 0, nfact = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : total, nfact)
+  for (int b = 0; b < B; ++b) {
+    port_solver* S = port_create(model, T, con, lo, hi, max_iter);
+    if (!S) continue;
+    port_begin(S, Z0 + (size_t)b * S->Nz);
+    int k = 0;
+    while ((iters_per_instance <= 0 || k < iters_per_instance) && port_iterate(S)) ++k;
+    total += k; nfact += S->nfact;
+    if (out_iters) out_iters[b] = S->iter;
+    if (out_status) out_status[b] = S->status;
+    port_destroy(S);
   }
-  P.T = T;
-  memcpy(P.x1, x1, P.n * sizeof(double));
-  memcpy(P.xT, xT, P.n * sizeof(double));
-  P.tol = 1e-6; P.s_max = 100.0; P.dual_inf_tol = 1.0; P.constr_viol_tol = 1e-3;
-  P.delta_c = 1e-8; P.delta_w_init = 1e-4; P.delta_w_max = 1e20; P.delta_w_exact_cap = 1.0; P.piv_tol = 1e-9;
-  P.max_iter = max_iter; P.max_refactor = 12; P.watchdog_trigger = 10; P.watchdog_trials = 3;
-  if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &P.watchdog_trigger, &P.watchdog_trials);
-  return port_create(&P);
+  if (out_nfact) *out_nfact = nfact;
+  return total;
 }

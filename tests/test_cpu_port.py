@@ -1,9 +1,32 @@
-"""The oracle's serial C port (CPU baseline) on its own: it converges on the equality-constrained configs and
-its final point satisfies the KKT conditions computed with the numpy/sympy oracle evaluator."""
+"""The oracle's serial C port (CPU baseline) on its own: it converges on the BASELINE configs -- equality-constrained
+(acrobot), bounded (cartpole) and inequality-constrained (car) -- and its final point satisfies the KKT conditions computed
+with the numpy/sympy oracle evaluator."""
 import numpy as np
+import pytest
 
 from oracle import dto_oracle as O, sympy_models as S
-from oracle.cpu_port import PortSolver, acrobot_guesses
+from oracle.cpu_port import PortSolver, acrobot_guesses, guesses, run_batch
+
+
+def _kkt(onlp, z, lam):
+    c = onlp.eval_constraint(z)
+    J = np.zeros((onlp.num_constraint, onlp.num_variables))
+    for (r, cc), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
+        J[r - 1, cc - 1] = v
+    r = onlp.eval_objective_gradient(z) + J.T @ lam
+    lo, hi = onlp.variable_bounds
+    fixed = lo == hi
+    zl = np.where(np.isfinite(lo) & ~fixed, np.maximum(r, 0.0), 0.0)      # bound multipliers absorb what they can
+    zu = np.where(np.isfinite(hi) & ~fixed, np.maximum(-r, 0.0), 0.0)
+    stat = r - zl + zu
+    stat[fixed] = 0.0
+    with np.errstate(invalid="ignore"):
+        bc = np.maximum(np.where(zl > 0, (z - lo) * zl, 0.0), np.where(zu > 0, (hi - z) * zu, 0.0))
+    clo, _ = onlp.constraint_bounds
+    ineq = np.isneginf(clo)
+    viol = np.where(ineq, np.maximum(c, 0.0), np.abs(c))
+    compl = np.max(np.abs(lam[ineq] * c[ineq])) if np.any(ineq) else 0.0
+    return np.max(np.abs(stat)), np.max(viol), max(compl, np.max(bc))
 
 
 def test_port_converges_and_satisfies_kkt():
@@ -15,11 +38,40 @@ def test_port_converges_and_satisfies_kkt():
     for b in range(3):
         assert s.solve(Z[b]) == 1
         z, lam = s.z, s.lam
-        c = onlp.eval_constraint(z)
-        assert np.max(np.abs(c)) <= 1e-6
-        J = np.zeros((onlp.num_constraint, onlp.num_variables))
-        for (r, cc), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
-            J[r - 1, cc - 1] = v
-        g = onlp.eval_objective_gradient(z)
-        assert np.max(np.abs(g + J.T @ lam)) <= 1e-5          # multipliers are in the reference order
+        stat, viol, _ = _kkt(onlp, z, lam)
+        assert viol <= 1e-6 and stat <= 1e-5                     # multipliers are in the reference order
         assert np.linalg.norm(z[:4] - x1) < 1e-3 and np.linalg.norm(z[-4:] - xT) < 1e-3   # test/solve.jl:136-137
+
+
+@pytest.mark.parametrize("model,T", [("cartpole", 101), ("car", 51)])
+def test_port_barrier_path_converges_and_satisfies_kkt(model, T):
+    """Bounds (cartpole: u in [-3, 3]; car: u in [-0.5, 0.5]^2, end states fixed by equal bounds) and inequality rows (car:
+    obstacle at every knot): the interior-point path of the port, final barrier parameter = Options.mu_target."""
+    Z, x1, xT = guesses(model, T, 2, 0)
+    p = S.build(model, T, evaluate_hessian=False)
+    onlp = O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"])
+    s = PortSolver(model, T)
+    for b in range(2):
+        assert s.solve(Z[b]) == 1, (s.status, s.iterations)
+        z, lam = s.z, s.lam
+        stat, viol, compl = _kkt(onlp, z, lam)
+        assert viol <= 1e-5 and stat <= 1e-4 and compl <= 1e-3, (stat, viol, compl)
+        assert abs(s.stats()["mu"] - 1e-4) < 1e-12               # mu_target (src/options.jl:22)
+        n = p["n"]
+        assert np.linalg.norm(z[:n] - x1) < 1e-3 and np.linalg.norm(z[-n:] - xT) < 1e-3
+        lo, hi = onlp.variable_bounds
+        assert np.all(z >= lo - 1e-12) and np.all(z <= hi + 1e-12)
+
+
+def test_port_batch_driver_matches_single_solves():
+    """port_run_batch (OpenMP over instances, the all-cores CPU baseline) gives the same iteration counts as one solver
+    object driven instance by instance."""
+    T = 30
+    Z, x1, xT = guesses("pendulum", T, 6, 3)
+    total, dt, it, st, nf = run_batch("pendulum", T, Z, threads=2)
+    s = PortSolver("pendulum", T)
+    ref = []
+    for b in range(6):
+        assert s.solve(Z[b]) == 1
+        ref.append(s.iterations)
+    assert list(it) == ref and np.all(st == 1) and total == sum(ref)
