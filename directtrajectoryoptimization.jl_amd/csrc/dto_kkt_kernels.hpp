@@ -140,18 +140,23 @@ struct KindDims {
   static constexpr int QI = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NI; else return 0; }();
   static constexpr int NY = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NY; else return 0; }();
   static constexpr int BD = NP + Q + NY;
-  // record layout: STRUCTURAL nonzeros only (what the reference's nzval vectors hold), scattered into the
-  // dense stage blocks inside the factor kernel
-  static constexpr int N_CH = C::NHL;   // objective Hessian, lower triangle
-  static constexpr int N_DJ = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NJ; else return 0; }();
-  static constexpr int N_DH = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NHL; else return 0; }();
-  static constexpr int N_KJ = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NJ; else return 0; }();
-  static constexpr int N_KH = []() { if constexpr (KD::CON >= 0) return M::template Con<KD::CON>::NHL; else return 0; }();
+  // Stage record.  Exact-Hessian models (FUSED): only the RESIDUALS of the stage (r_p = grad_p L, d, c) -- the
+  // derivative values themselves are NOT stored: the sweeps re-evaluate the generated Jacobian / Hessian code from
+  // (z, lambda) in registers, which costs a few hundred flops per stage against 55 rows (28 KB per wavefront and stage)
+  // of HBM traffic, their LDS staging and the registers that held them (round 1 stored them: the sweeps were bound by
+  // exactly that handling, not by the factorisation).  Quasi-Newton models keep their per-stage SR1 block and the previous
+  // Jacobian values here (they cannot be recomputed).
+  static constexpr bool QN = (M::EVALUATE_HESSIAN == 0);
+  static constexpr bool FUSED = !QN;
+  static constexpr int N_CH = FUSED ? 0 : C::NHL;   // objective Hessian, lower triangle
+  static constexpr int N_DJ = []() { if constexpr (KD::DYN >= 0 && !FUSED) return M::template Dyn<KD::DYN>::NJ; else return 0; }();
+  static constexpr int N_DH = []() { if constexpr (KD::DYN >= 0 && !FUSED) return M::template Dyn<KD::DYN>::NHL; else return 0; }();
+  static constexpr int N_KJ = []() { if constexpr (KD::CON >= 0 && !FUSED) return M::template Con<KD::CON>::NJ; else return 0; }();
+  static constexpr int N_KH = []() { if constexpr (KD::CON >= 0 && !FUSED) return M::template Con<KD::CON>::NHL; else return 0; }();
   // quasi-Newton mode (problem built with evaluate_hessian=false, the reference default under which Ipopt uses a
-  // limited-memory BFGS Hessian): a partitioned, Powell-damped BFGS approximation B_t of the ELEMENT Hessian
+  // limited-memory BFGS Hessian): a partitioned SR1 approximation B_t of the ELEMENT Hessian
   // d^2/d(p_t,x_{t+1})^2 [ l_t + lam_t'd_t + nu_t'c_t ] is kept per stage (block structure preserved), together
   // with the previous objective gradient for the secant pair.
-  static constexpr bool QN = (M::EVALUATE_HESSIAN == 0);
   static constexpr int NE = NP + NY;
   static constexpr int N_B = QN ? NE * (NE + 1) / 2 : 0;
   static constexpr int N_GC = QN ? NP : 0;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       CO::eval(p.data(), p.data() + CO::NX, wc.data(), o1);
       cost_val = o1[0];
       CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
-      if constexpr (CO::SNH > 0) {
+      if constexpr (CO::SNH > 0 && !D::FUSED) {
         arr<CO::SNH> hv;
         arr<CO::NHL> hl;
         CO::shess(p.data(), p.data() + CO::NX, wc.data(), hv.data());
@@ -453,9 +458,11 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       arr<DY::NJ> jv;
       DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jv.data());
       DY::jtlam(jv.data(), lam.data(), rp.data());
+      if constexpr (!D::FUSED) {
 #pragma unroll
-      for (int i = 0; i < DY::NJ; ++i) put(D::R_DJ + i, jv[i]);
-      if constexpr (DY::NH > 0) {
+        for (int i = 0; i < DY::NJ; ++i) put(D::R_DJ + i, jv[i]);
+      }
+      if constexpr (DY::NH > 0 && !D::FUSED) {
         arr<DY::NH> hv;
         arr<DY::NHL> hl;
         DY::hess(p.data(), p.data() + DY::NX, y.data(), w.data(), lam.data(), hv.data());
@@ -483,9 +490,11 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
       C::jac(p.data(), p.data() + C::NX, w.data(), jv.data());
       C::jtlam(jv.data(), nu.data(), rp.data());
+      if constexpr (!D::FUSED) {
 #pragma unroll
-      for (int i = 0; i < C::NJ; ++i) put(D::R_KJ + i, jv[i]);
-      if constexpr (C::NH > 0) {
+        for (int i = 0; i < C::NJ; ++i) put(D::R_KJ + i, jv[i]);
+      }
+      if constexpr (C::NH > 0 && !D::FUSED) {
         arr<C::NH> hv;
         arr<C::NHL> hl;
         C::hess(p.data(), p.data() + C::NX, w.data(), nu.data(), hv.data());
@@ -855,53 +864,45 @@ struct Spike {
 };
 
 // Build the stage block S_t (with the carry-in P_t, py and, in chunks p >= 1, the spike coupling Cx), factorise
-template <class M, int K = 0>
-constexpr int max_rec() {
-  if constexpr (K >= M::N_KIND) return 2;
-  else return KindDims<M, K>::REC > max_rec<M, K + 1>() ? KindDims<M, K>::REC : max_rec<M, K + 1>();
-}
-template <class M>
-constexpr int rec_lds_doubles() { return ((max_rec<M>() + 1) / 2) * 2 * 64; }
-
-// The sweeps run one wavefront per SIMD (they need > 256 registers), so nothing but the wave itself can hide HBM
-// latency.  The structural record of the NEXT stage is therefore copied global -> LDS by the DMA path
-// (global_load_lds_dwordx4: no destination registers) while the current stage is being factorised, and read from LDS
-// when its turn comes.  The record of a (tile, stage) is `rows` consecutive 512-byte rows, so the copy is linear:
-// one wave instruction moves two rows.  Rows are rounded up to an even count (the buffer is padded by one row).
-__device__ __forceinline__ void record_dma(const dto_kkt_args& a, int64_t g, int t, double* lds) {
-  const int rows = (int)(a.recoff[t + 1] - a.recoff[t]);
-  const double* src = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + 2 * threadIdx.x;
-  for (int k = 0; k < rows; k += 2)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((int64_t)k << 6)),
-                                     (__attribute__((address_space(3))) void*)(lds + (k << 6)), 16, 0, 0);
-}
-__device__ __forceinline__ void record_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 // it and run the forward substitutions.  On return S holds L (strict lower), dinv = 1/D, X = L^-1 O, y = w,
 // Z = L^-1 C.  Used by BOTH sweeps: the backward sweep recomputes instead of reading stored factors.
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
                                              bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
                                              double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
-                                             bool& ok, int& nneg, double* s_rec, int t_prefetch, double* keep) {
+                                             bool& ok, int& nneg, double* keep) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
-  // the structural record of this stage is in LDS (record_dma); every read of it happens before the factorisation
-  // starts, where the copy of the next stage's record is launched into the same buffer
-  const double* recl = s_rec + threadIdx.x;
-  // all rows at once (one LDS latency), then consumed from registers by the literal-index scatter code below
-  double rr[D::REC > 0 ? D::REC : 1];
-#pragma unroll
-  for (int i = 0; i < D::REC; ++i) rr[i] = recl[i << 6];
-  auto R = [&](int e) { return rr[e]; };
-  long long tq_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
-#define DTO_KKT_TICK(slot) do { if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { const long long n_ = clock64(); a.prof[slot] += n_ - tq_; tq_ = n_; } } while (0)
-  const int z0 = a.zoff[t];
-
   using KD = typename D::KD;
   using CO = typename M::template Cost<KD::COST>;
+  const int z0 = a.zoff[t];
+  // the stage record (residuals; plus the quasi-Newton blocks of models without exact Hessians): every row is requested
+  // before any is used, together with the iterate the derivative code below needs -- one memory latency per stage
+  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+  double rr[D::REC > 0 ? D::REC : 1];
+#pragma unroll
+  for (int i = 0; i < D::REC; ++i) rr[i] = rec[(int64_t)i << 6];
+  auto R = [&](int e) { return rr[e]; };
+  arr<NP> pv;
+  arr<NY> yv, lamv;
+  arr<Q> nuv;
+  if constexpr (D::FUSED) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = *soa(a.z, g, a.Nz, z0 + i);
+    if constexpr (KD::DYN >= 0) {
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        yv[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
+        lamv[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) nuv[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+  }
+  long long tq_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
+#define DTO_KKT_TICK(slot) do { if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { const long long n_ = clock64(); a.prof[slot] += n_ - tq_; tq_ = n_; } } while (0)
+
 #pragma unroll
   for (int i = 0; i < BD * (BD + 1) / 2; ++i) S[i] = 0.0;
 #pragma unroll
@@ -911,8 +912,16 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   // --- scatter the structural nonzeros into the dense blocks (literal indices: registers only)
   if constexpr (CO::NHL > 0) {
     double hl[CO::NHL];
+    if constexpr (D::FUSED) {
+      arr<CO::NW> wc;
+      load_params(wc, a, g, t);
+      arr<CO::SNH> hv;
+      CO::shess(pv.data(), pv.data() + CO::NX, wc.data(), hv.data());
+      CO::pack_hess_lower(hv.data(), hl);
+    } else {
 #pragma unroll
-    for (int i = 0; i < CO::NHL; ++i) hl[i] = R(D::R_CH + i);
+      for (int i = 0; i < CO::NHL; ++i) hl[i] = R(D::R_CH + i);
+    }
     CO::scatter_hess_lower(hl, S);  // the pp block of S is packed exactly like W
   }
   if constexpr (D::QN) {
@@ -936,8 +945,14 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   if constexpr (KD::DYN >= 0) {
     using DY = typename M::template Dyn<KD::DYN>;
     double jv[DY::NJ], F[NY * NP];
+    arr<DY::NW> wd;
+    if constexpr (D::FUSED) {
+      load_params(wd, a, g, t);
+      DY::jac(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), jv);
+    } else {
 #pragma unroll
-    for (int i = 0; i < DY::NJ; ++i) jv[i] = R(D::R_DJ + i);
+      for (int i = 0; i < DY::NJ; ++i) jv[i] = R(D::R_DJ + i);
+    }
 #pragma unroll
     for (int i = 0; i < NY * NP; ++i) F[i] = 0.0;
     DY::scatter_jac(jv, F, X + (NP + Q) * NY);  // E rows of the coupling block
@@ -948,16 +963,28 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     }
     if constexpr (DY::NHL > 0) {
       double hl[DY::NHL];
+      if constexpr (D::FUSED) {
+        arr<DY::NH> hv;
+        DY::hess(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), lamv.data(), hv.data());
+        DY::pack_hess_lower(hv.data(), hl);
+      } else {
 #pragma unroll
-      for (int i = 0; i < DY::NHL; ++i) hl[i] = R(D::R_DH + i);
+        for (int i = 0; i < DY::NHL; ++i) hl[i] = R(D::R_DH + i);
+      }
       DY::scatter_hess_lower(hl, gam, S, X, YYl);  // W_D -> pp block, V -> p rows of the coupling block
     }
   }
   if constexpr (KD::CON >= 0) {
     using CN = typename M::template Con<KD::CON>;
     double jv[CN::NJ > 0 ? CN::NJ : 1], G[Q * NP > 0 ? Q * NP : 1];
+    arr<CN::NW> wk;
+    if constexpr (D::FUSED) {
+      load_params(wk, a, g, t);
+      CN::jac(pv.data(), pv.data() + CN::NX, wk.data(), jv);
+    } else {
 #pragma unroll
-    for (int i = 0; i < CN::NJ; ++i) jv[i] = R(D::R_KJ + i);
+      for (int i = 0; i < CN::NJ; ++i) jv[i] = R(D::R_KJ + i);
+    }
 #pragma unroll
     for (int i = 0; i < Q * NP; ++i) G[i] = 0.0;
     CN::scatter_jac(jv, G);
@@ -968,8 +995,14 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     }
     if constexpr (CN::NHL > 0) {
       double hl[CN::NHL];
+      if constexpr (D::FUSED) {
+        arr<CN::NH> hv;
+        CN::hess(pv.data(), pv.data() + CN::NX, wk.data(), nuv.data(), hv.data());
+        CN::pack_hess_lower(hv.data(), hl);
+      } else {
 #pragma unroll
-      for (int i = 0; i < CN::NHL; ++i) hl[i] = R(D::R_KH + i);
+        for (int i = 0; i < CN::NHL; ++i) hl[i] = R(D::R_KH + i);
+      }
       CN::scatter_hess_lower(hl, gam, S);
     }
   }
@@ -1096,10 +1129,6 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     for (int k = 0; k < NY; ++k) keep[NP + Q + k] = R(D::R_D + k);
   }
   DTO_KKT_TICK(1);
-  lds_reads_done();
-  DTO_KKT_TICK(2);
-  if (t_prefetch >= 0) record_dma(a, g, t_prefetch, s_rec);
-  DTO_KKT_TICK(3);
   // --- factor
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
   DTO_KKT_TICK(4);
@@ -1124,7 +1153,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
                                               double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
-                                              bool& ok, int& nneg, double* s_rec, int t_prefetch) {
+                                              bool& ok, int& nneg) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   double S[BD * (BD + 1) / 2];
@@ -1146,8 +1175,7 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       for (int i = 0; i < NX * NX; ++i) fac[(int64_t)(D::F_CX + i) << 6] = sp.Cx[i];
     }
   }
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, s_rec, t_prefetch,
-                          nullptr);
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, nullptr);
   // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w   (D^-1 X and D^-1 Z are formed once: the sweep is
   //     bound by dependent f64 arithmetic, not by memory)
   double XD[BD * (NY > 0 ? NY : 1)];
@@ -1205,8 +1233,10 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   }
 }
 
-template <class M>
-__global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
+// CHUNKED = false: the plain sequential sweep (P = 1) without any spike code -- a separate instantiation because the
+// spike blocks are what pushes the register count of the chunked form beyond one wavefront per SIMD
+template <class M, bool CHUNKED>
+__device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
   const int64_t g = blockIdx.x / a.P;
   const int p = blockIdx.x % a.P;
   const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
@@ -1225,22 +1255,17 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
   for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
   bool ok = true;
   int nneg = 0;
-  __shared__ __attribute__((aligned(16))) double s_rec[rec_lds_doubles<M>()];
-  record_dma(a, g, t0, s_rec);
   for (int t = t0; t < t1; ++t) {
-    const int tp = (t + 1 < t1) ? t + 1 : -1;
-    long long tw_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
-    record_wait();
-    if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { a.prof[0] += clock64() - tw_; a.prof[7] += 1; }
-    if (p == 0) {
+    if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
+    if (!CHUNKED || p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg, s_rec, tp);
+        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
       });
-    } else {
+    } else if constexpr (CHUNKED) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg, s_rec, tp);
+          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
       });
     }
   }
@@ -1262,6 +1287,13 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) {
   cs[(int64_t)CS::OK << 6] = ok ? 1.0 : 0.0;
   cs[(int64_t)CS::NNEG << 6] = (double)nneg;
 }
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) { kkt_fwd_body<M, true>(a); }
+// the plain sequential sweep is asked to fit two wavefronts per SIMD (256 VGPRs): nothing else hides its memory and
+// dependent-issue latencies
+template <class M>
+__global__ __launch_bounds__(WAVE, 2) void k_kkt_fwd_seq(dto_kkt_args a) { kkt_fwd_body<M, false>(a); }
 
 // reduced system over the separators + inertia + retry state machine.  grid = G waves.
 template <class M>
@@ -1447,7 +1479,7 @@ struct StepAcc {
 template <class M, int K, bool SPK>
 __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
                                                double dw, double gam, bool first, const double* xL, double* xn,
-                                               StepAcc& acc, double* s_rec, int t_prefetch) {
+                                               StepAcc& acc) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
@@ -1475,8 +1507,7 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   double dinv[BD];
   bool ok_unused = true;
   int nneg_unused = 0;
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, s_rec,
-                          t_prefetch, keep);
+  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, keep);
   double v[BD];
 #pragma unroll
   for (int i = 0; i < BD; ++i) {
@@ -1566,8 +1597,8 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   for (int i = 0; i < NX; ++i) xn[i] = v[i];
 }
 
-template <class M>
-__global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
+template <class M, bool CHUNKED>
+__device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   const int64_t g = blockIdx.x / a.P;
   const int p = blockIdx.x % a.P;
   const dto_solver_opts& o = a.opt;
@@ -1586,19 +1617,15 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
     xn[i] = (p < a.P - 1) ? a.xsep[(((g * a.P + p + 1) * N + i) << 6) + threadIdx.x] : 0.0;
   }
   StepAcc acc{1.0, 1.0, 0.0, 0.0};
-  __shared__ __attribute__((aligned(16))) double s_rec[rec_lds_doubles<M>()];
-  record_dma(a, g, t1 - 1, s_rec);
   for (int t = t1 - 1; t >= t0; --t) {
-    const int tp = (t - 1 >= t0) ? t - 1 : -1;
-    record_wait();
-    if (p == 0) {
+    if (!CHUNKED || p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc, s_rec, tp);
+        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
       });
-    } else {
+    } else if constexpr (CHUNKED) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc, s_rec, tp);
+          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc);
       });
     }
   }
@@ -1608,6 +1635,11 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) {
   ca[2 << 6] = acc.gphid;
   ca[3 << 6] = acc.rlam;
 }
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) { kkt_bwd_body<M, true>(a); }
+template <class M>
+__global__ __launch_bounds__(WAVE, 2) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
 
 static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) {
   const int64_t g = blockIdx.x;
@@ -1949,16 +1981,24 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         const unsigned gp = (unsigned)((int64_t)a.G * a.P);
         const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
         for (int r = 0; r < rounds; ++r) {
-          hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          if (a.P > 1) hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          else hipLaunchKernelGGL(k_kkt_fwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
           hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         }
-        hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+        if (a.P > 1) hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
         hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       }
-      case DTO_KKT_FWD: hipLaunchKernelGGL(k_kkt_fwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_FWD:
+        if (a.P > 1) hipLaunchKernelGGL(k_kkt_fwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL(k_kkt_fwd_seq<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        break;
       case DTO_KKT_SEP: hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_BWD: hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_BWD:
+        if (a.P > 1) hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        break;
       case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LS_REDUCE:

@@ -463,8 +463,7 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.dz, lanes * L.Nz))) return rc;
   if ((rc = dev_alloc(&S.dlam, lanes * L.Nc))) return rc;
   if ((rc = dev_alloc(&S.ds, lanes * S.Ni))) return rc;
-  // + one padding row: the sweeps copy records to LDS two 512-byte rows at a time (dto_kkt_kernels.hpp:record_dma)
-  if ((rc = dev_alloc(&S.rec, lanes * S.rec_total + 64))) return rc;
+  if ((rc = dev_alloc(&S.rec, lanes * S.rec_total))) return rc;
   if ((rc = dev_alloc(&S.fac, lanes * S.fac_total))) return rc;
   if ((rc = dev_alloc(&S.part, lanes * (size_t)L.T * S.info.npart))) return rc;
   if ((rc = dev_alloc(&S.lspart, lanes * (size_t)L.T * 2 * S.info.ls_trials))) return rc;
