@@ -12,9 +12,15 @@ guess = linear interpolation + u ~ N(0,1) from a seeded stream (rank-dependent).
 across ranks with no data-path collective (weak scaling); converged trajectories are all-gathered over
 RCCL after the timed region.  Inputs are resident in HBM when the timed region starts.
 
-value = (solver iterations actually executed by all instances of all ranks in the timed region) / time.
+Default run (no --steps): K = the reference's max_iter = 1000 (src/options.jl:9), W = 0 -- the timed region is the FULL
+SOLVE of every instance from its guess to the reference tolerances (or to the iteration limit), which is SURVEY.md 8(d)'s
+definition of the metric:  value = sum over instances of the iterations they executed / wall time.  Instances that
+terminate stop counting (and stop working).  With an explicit --steps K the same formula covers K iterations after
+W warm-up iterations.  `iteration_throughput` (extra key) is the same ratio over the first 25 timed iterations, where every
+instance is still running -- the round-1 headline figure.
 Extra keys: jacobian_nnz_per_sec (batched MOI Jacobian callback), roofline (dominant kernel of the step,
-HIP events on the launch stream), cpu_baseline (oracle C port on the host, rank 0, N = 1 only).
+HIP events on the launch stream), cpu_baseline (oracle C port on the host, rank 0, N = 1 only), solve (how the
+instances ended), full_solves (T = 101, the reference example's horizon), dense_blocks (configs[4]).
 """
 import argparse
 import json
@@ -138,9 +144,12 @@ def dense_block_measurement(dev, T=2000, B=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192, help="instances per GPU")
+    ap.add_argument("--steps", type=int, default=1000, help="timed solver iterations (default: the reference's max_iter = a full solve)")
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=131072,
+                    help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance; "
+                         ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD, DESIGN.md section 5)")
+    ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-blocks", action="store_true", help="skip the configs[4] (dense 129x129 blocks) side measurement")
@@ -173,9 +182,12 @@ def main():
     z0 = torch.tensor(Z, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
-    # ---- solver: W warmup iterations, then exactly K timed iterations
+    # ---- solver: W warmup iterations, then exactly K timed iterations (in slices of 25 so that the throughput profile of the
+    #      solve can be reported; a slice boundary is a stream synchronisation, nothing else)
+    s.options.max_iter = max(1000, a.steps + a.warmup)          # the reference default; never cut a longer requested run short
     s.begin_batch(z0.data_ptr(), B, nz, stream=st)
-    s.iterate_batch(a.warmup, stream=st)
+    if a.warmup:
+        s.iterate_batch(a.warmup, stream=st)
     torch.cuda.synchronize()
     it0 = s.scalar_batch("iter").copy()
     nf0 = s.scalar_batch("nfact").copy()
@@ -183,13 +195,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    s.iterate_batch(a.steps, stream=st)
+    done, profile = 0, []
+    while done < a.steps:
+        k = min(25, a.steps - done)
+        s.iterate_batch(k, stream=st)
+        done += k
+        if done < a.steps:
+            torch.cuda.synchronize()
+            profile.append((done, time.perf_counter() - t0))
+    # one more evaluation classifies the last iterate (converged / iteration limit); it is part of the solve
+    if a.steps + a.warmup >= s.options.max_iter:
+        s.launch_op("eval", stream=st)
+        s.launch_op("conv", stream=st)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    profile.append((done, dt))
     it1 = s.scalar_batch("iter")
     nf1 = s.scalar_batch("nfact")
+    status_end = s.scalar_batch("status").copy()
     iters_done = float(np.sum(it1 - it0))
     facts_done = float(np.sum(nf1 - nf0))
     tt = torch.tensor([dt, iters_done, facts_done], device=dev, dtype=torch.float64)
@@ -199,6 +224,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         iters_done, facts_done = float(tt[1]), float(tt[2])
+    # iteration throughput while every instance is still running: the first slice (this rank; aggregated below)
+    first_k, first_t = profile[0]
+    thr0 = torch.tensor([B * first_k / first_t], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(thr0, op=dist.ReduceOp.SUM)
+    solve_info = dict(converged=int(np.sum(status_end == 1)), acceptable=int(np.sum(status_end == 4)),
+                      iteration_limit=int(np.sum(status_end == 2)), failed=int(np.sum((status_end == 3) | (status_end == 5))),
+                      still_running=int(np.sum(status_end == 0)), instances=B,
+                      iterations_median=float(np.median(it1)), iterations_mean=float(np.mean(it1)),
+                      seconds_profile=[(int(k), round(t, 3)) for k, t in profile[:: max(1, len(profile) // 10)]] + [(int(profile[-1][0]), round(profile[-1][1], 3))],
+                      note="rank 0's shard; status per instance after the timed iterations")
+
+    # the per-kernel replay below needs running instances: restart the batch and advance it a few iterations
+    if np.sum(status_end == 0) < B // 2:
+        s.begin_batch(z0.data_ptr(), B, nz, stream=st)
+        s.iterate_batch(5, stream=st)
+        torch.cuda.synchronize()
 
     # ---- per-kernel durations (HIP events on the launch stream): the launch sequence of an iteration is
     #      replayed kernel by kernel for a few more iterations; averages are over ALL launches of a kernel,
@@ -206,7 +248,9 @@ def main():
     fp = s.footprint()
     rounds = fp["factor_rounds"]
     seq = (["eval", "conv"] + ["kkt_fwd", "kkt_sep"] * rounds + ["kkt_bwd", "kkt_post", "linesearch", "ls_reduce", "update"])
-    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd", kkt_sep="k_kkt_sep", kkt_bwd="k_kkt_bwd",
+    seq_sweep = s.partitions() == 1   # the plain sequential sweep has its own two-wavefront-per-SIMD instantiation
+    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd", kkt_sep="k_kkt_sep",
+                 kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd",
                  kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update")
     tot = {k: 0.0 for k in kname}
     cnt = {k: 0 for k in kname}
@@ -223,22 +267,26 @@ def main():
     per_iter_ms = {k: tot[k] / reps for k in kname}
     nfact_per_iter = facts_done / max(iters_done, 1.0)
     working = (nf_b - nf_a) / max(B * reps * rounds, 1)         # fraction of k_kkt_fwd launches x lanes that factorised
-    nnz_K = nj + (nh + nz) // 2 + nc                           # structural lower-triangular KKT entries
-    fac_d = fp["factor_doubles"]
-    rec_d = fp["record_doubles"]                               # structural stage records (Jacobian nnz + lower Hessian nnz + residuals)
+    # Algorithmic bytes per instance and launch.  The sweeps no longer read derivative values: they
+    # re-evaluate them from the iterate.  What a sweep MUST move per stage is therefore: the iterate (p_t, x_{t+1}, lambda_t,
+    # nu_t), the stage's right-hand side (record: r_p, d, c) and the carry that the backward sweep resumes from
+    # (P_t: n(n+1)/2, p_y: n; plus the n x n spike coupling when the horizon is cut into chunks).
+    nx_ = p["n"]
+    parts = s.partitions()
+    rec_d = fp["record_doubles"]
+    carry_d = (T - 1) * (nx_ * (nx_ + 1) // 2 + nx_ + (nx_ * nx_ if parts > 1 else 0))
+    sweep_read = 8 * (nz + (T - 1) * nx_ + nc + rec_d)
     alg_bytes = dict(                                          # per instance and per launch
-        eval=8 * (nz + nc + 1) + 8 * nnz_K,                    # fused KKT value scatter
-        # forward chunk sweep: read the KKT values once, write the per-stage carries (working launches only)
-        kkt_fwd=working * 8 * (nnz_K + (nz + nc) + fac_d),
-        # backward sweep: re-read the KKT values + carries (the factors are recomputed, not stored), write the step
-        kkt_bwd=8 * (nnz_K + (nz + nc) + fac_d) + 8 * (nz + nc),
-        linesearch=8 * (2 * nz) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 9 * T, ls_reduce=8 * 16 * T,
+        eval=8 * (2 * nz + 2 * nc) + 8 * rec_d + 8 * 10 * T,   # iterate (+ previous stage for E'lambda), record and partials out
+        kkt_fwd=working * (sweep_read + 8 * carry_d),          # working launches only (the others exit at once)
+        kkt_bwd=sweep_read + 8 * carry_d + 8 * (nz + nc),      # + the step written
+        linesearch=8 * (2 * nz + (T - 1) * 2 * nx_) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 10 * T, ls_reduce=8 * 16 * T,
         kkt_sep=8 * 64, kkt_post=8 * 4)
     dom = max(per_iter_ms, key=per_iter_ms.get)
     achieved = B * alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/, tools/pmc_summary.py)
-        with open(os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_acrobot_T{T}_B{B}.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_acrobot_T{T}_B{B}.json")) as f:
             traffic = json.load(f)["kernels"][kname[dom]]["hbm_bytes_per_launch_mean"]
     except Exception:
         traffic = None
@@ -274,12 +322,14 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             from oracle.cpu_port import cpu_baseline
-            cpu = cpu_baseline(T=T, seed=1000, seconds=12.0)
+            # the same workload on the host: full solves when the GPU run was one, else the same number of iterations
+            cpu = cpu_baseline(T=T, seed=1000, seconds=12.0,
+                               iters_per_instance=0 if a.steps + a.warmup >= 1000 else a.steps + a.warmup)
         except Exception as e:  # the baseline is a reported extra, never part of the measured path
             cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
 
     full = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_full_solves:
         try:
             full = full_solve_measurement(dev)
         except Exception as e:  # side measurement, never part of `value`
@@ -303,6 +353,9 @@ def main():
                         horizon=T, instances_per_gpu=B, instances_total=B * world, num_variables=nz, num_constraint=nc,
                         jacobian_nnz=nj, hessian_key=nh, parallelism=f"instance sharding x{world}, all-gather of trajectories"),
             jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
+            iteration_throughput=dict(value=float(thr0[0]), unit="SQP iterations/s",
+                                      note=f"first {first_k} timed iterations, every instance still running"),
+            solve=solve_info,
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=s.partitions(),
             gathered_trajectories=int(gathered.shape[0]),
             roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,

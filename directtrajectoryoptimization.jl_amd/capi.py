@@ -47,6 +47,11 @@ class Batch(C.Structure):
                 ("ldp", C.c_int64), ("stream", C.c_void_p)]
 
 
+class KktSystem(C.Structure):
+    _fields_ = [("mu", C.c_void_p), ("ldmu", C.c_int64), ("sigma_x", C.c_void_p), ("ldsx", C.c_int64),
+                ("sigma_c", C.c_void_p), ("ldsc", C.c_int64), ("delta_w", C.c_double), ("delta_c", C.c_double)]
+
+
 class COptions(C.Structure):
     _fields_ = [("tol", C.c_double), ("s_max", C.c_double), ("max_iter", C.c_int), ("dual_inf_tol", C.c_double),
                 ("constr_viol_tol", C.c_double), ("compl_inf_tol", C.c_double), ("mu_init", C.c_double),
@@ -60,7 +65,7 @@ class COptions(C.Structure):
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
            "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog",
-           "acc_count", "f_last", "xmax"]
+           "acc_count", "f_last", "xmax", "nneg"]
 
 
 class DtoError(RuntimeError):
@@ -108,6 +113,12 @@ def lib() -> C.CDLL:
                                C.POINTER(C.c_int)],
         "dto_solve_batch": [vp, C.POINTER(COptions), C.POINTER(Batch), vp, C.c_int64, vp, C.c_int64, c_int32_p, c_int32_p],
         "dto_solver_begin": [vp, C.POINTER(COptions), C.POINTER(Batch)],
+        "dto_solver_begin_warm": [vp, C.POINTER(COptions), C.POINTER(Batch), C.c_double],
+        "dto_solver_run": [vp, vp, C.c_int64, vp, C.c_int64, c_int32_p, c_int32_p, vp],
+        "dto_kkt_assemble": [vp, C.POINTER(Batch), C.POINTER(KktSystem)],
+        "dto_kkt_factor": [vp, c_int32_p, c_int32_p, vp],
+        "dto_kkt_solve": [vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp],
+        "dto_shard_range": [C.c_int64, C.c_int, C.c_int, c_int64_p, c_int64_p],
         "dto_solver_iterate": [vp, C.c_int, vp],
         "dto_solver_stats": [vp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p],
         "dto_solver_end": [vp, vp, C.c_int64, vp, C.c_int64, vp],

@@ -46,6 +46,8 @@ enum dto_kkt_op {
   DTO_KKT_LS_REDUCE = 7,   // pick the step size
   DTO_KKT_UPDATE = 8,      // take the step
   DTO_KKT_FWD = 9, DTO_KKT_SEP = 10, DTO_KKT_BWD = 11, DTO_KKT_POST = 12,  // the four kernels behind FACTOR_SOLVE
+  DTO_KKT_RHS = 13,        // linear-solver entry points: caller's right-hand side -> stage records
+  DTO_KKT_REARM = 14,      // linear-solver entry points: request one factorisation with the fixed delta_w
   DTO_KKT_OP_COUNT
 };
 
@@ -55,7 +57,7 @@ enum dto_scal {
   SC_ITER, SC_MU, SC_PENALTY, SC_DELTA_W, SC_F, SC_THETA1, SC_THETA_INF, SC_DINF, SC_COMPL, SC_E0,
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
   SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET, SC_FULL_STREAK, SC_SHORT_STREAK, SC_WATCHDOG,
-  SC_ACC_COUNT, SC_F_LAST, SC_XMAX,
+  SC_ACC_COUNT, SC_F_LAST, SC_XMAX, SC_NNEG,
   SC_COUNT
 };
 
@@ -85,8 +87,10 @@ struct dto_solver_opts {
   double eta_armijo, rho_penalty, piv_tol;
   int max_refactor;
   int watchdog_trigger, watchdog_trials;  // Ipopt: watchdog_shortened_iter_trigger (10), watchdog_trial_iter_max (3); 0 = off
-  int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (test entry dto_kkt_step)
+  int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (dto_kkt_step_batch, dto_kkt_factor/solve)
   double fixed_delta_w;
+  int warm;             // 1: dto_solver_begin_warm -- keep multipliers, bound multipliers, slacks (and mu unless mu_warm > 0)
+  double mu_warm;
 };
 
 struct dto_kkt_args {
@@ -114,6 +118,10 @@ struct dto_kkt_args {
   double* csum; double* sfac; double* xsep; double* cacc;  // chunk summaries, separator factors/solutions, step partials
   long long* prof;  // debug: cycle stamps of workgroup 0 (tools/kkt_profile.py), NULL otherwise
   double* cpart;       // [G][P][16][64] chunk-level partial reductions (k_part_reduce)
+  // linear-solver entry points (dto_kkt_assemble / factor / solve): optional extra diagonals as SoA tiles, and the caller's
+  // right-hand side (instance-major) that DTO_KKT_RHS writes into the stage records
+  const double* sigx; const double* sigc;
+  const double* rhs_x; int64_t ld_rhs_x; const double* rhs_c; int64_t ld_rhs_c;
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -307,7 +315,10 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
   const int64_t g = blockIdx.x / a.T;
   const int t = blockIdx.x % a.T;
   const dto_solver_opts& o = a.opt;
-  const double mu0 = o.mu_init;
+  // warm start (dto_solver_begin_warm): the multipliers, bound multipliers and slacks of the previous solve stay; the barrier
+  // parameter too unless the caller resets it.  Only entries that are unusable (non-positive) are re-initialised.
+  const double mu_prev = *soa(a.scal, g, SC_COUNT, SC_MU);
+  const double mu0 = !o.warm ? o.mu_init : (o.mu_warm > 0.0 ? o.mu_warm : (mu_prev > 0.0 ? mu_prev : o.mu_init));
   dispatch_uniform<M>(a.kind[t], [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -335,6 +346,11 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
           }
           if (fl) zl = mu0 / (v - lo);
           if (fh) zu = mu0 / (hi - v);
+          if (o.warm) {
+            const double pl = *soa(a.zl, g, a.Nz, z0 + i), pu = *soa(a.zu, g, a.Nz, z0 + i);
+            if (fl && pl > 0.0) zl = pl;
+            if (fh && pu > 0.0) zu = pu;
+          }
         }
       }
       p[i] = v;
@@ -343,9 +359,9 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
       *soa(a.zu, g, a.Nz, z0 + i) = zu;
     }
     // multipliers: lam = 0; inequality rows: slack from c(z), nu = zs = mu0 / s
-    // (newton_only keeps the caller's multipliers: dto_kkt_step evaluates at a given (z, lam))
+    // (newton_only keeps the caller's multipliers: dto_kkt_step evaluates at a given (z, lam); a warm start keeps them too)
     if constexpr (KD::DYN >= 0) {
-      if (!o.newton_only) {
+      if (!o.newton_only && !o.warm) {
 #pragma unroll
         for (int i = 0; i < D::NY; ++i) *soa(a.lam, g, a.Nc, a.cdoff[t] + i) = 0.0;
       }
@@ -358,12 +374,18 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
-        double nu = 0.0;
-        if (!o.newton_only && D::ineq(j)) {
-          const double sv = fmax(-c[j], o.bound_push * fmax(1.0, fabs(c[j])));
-          nu = mu0 / sv;
+        double nu = o.warm ? *soa(a.lam, g, a.Nc, a.ccoff[t] + j) : 0.0;
+        if (D::ineq(j)) {
+          double sv = fmax(-c[j], o.bound_push * fmax(1.0, fabs(c[j])));
+          double zv = mu0 / sv;
+          if (o.warm) {
+            const double ps = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)), pz = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+            if (ps > 0.0 && pz > 0.0) { sv = ps; zv = pz; } else nu = zv;
+          } else {
+            nu = zv;
+          }
           *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) = sv;
-          *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = nu;
+          *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = zv;
         }
         *soa(a.lam, g, a.Nc, a.ccoff[t] + j) = nu;
       }
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
   if (t == 0) {
     *soa(a.scal, g, SC_COUNT, SC_STATUS) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_ITER) = 0.0;
-    *soa(a.scal, g, SC_COUNT, SC_MU) = o.newton_only ? 0.0 : o.mu_init;
+    *soa(a.scal, g, SC_COUNT, SC_MU) = o.newton_only ? 0.0 : mu0;
     *soa(a.scal, g, SC_COUNT, SC_PENALTY) = 1.0;
     *soa(a.scal, g, SC_COUNT, SC_DELTA_W) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_DELTA_LAST) = 0.0;
@@ -391,7 +413,43 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_ACC_COUNT) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_F_LAST) = 1e300;
     *soa(a.scal, g, SC_COUNT, SC_XMAX) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_NNEG) = 0.0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// linear-solver entry points (dto_kkt_assemble / dto_kkt_factor / dto_kkt_solve): the caller's right-hand side
+// K v = (rhs_x, rhs_c) goes into the stage records (the sweeps solve K v = -(r_p, c, d)), and one factorisation with the
+// fixed delta_w is requested
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_rhs_record(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const int64_t inst = g * 64 + threadIdx.x;
+  const bool live = inst < a.B;
+  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+    const double* rx = a.rhs_x + inst * a.ld_rhs_x;
+    const double* rc = a.rhs_c + inst * a.ld_rhs_c;
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) rec[(int64_t)(D::R_RP + i) << 6] = live ? -rx[a.zoff[t] + i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < D::NY; ++k) rec[(int64_t)(D::R_D + k) << 6] = live ? -rc[a.cdoff[t] + k] : 0.0;
+#pragma unroll
+    for (int j = 0; j < D::Q; ++j) rec[(int64_t)(D::R_C + j) << 6] = live ? -rc[a.ccoff[t] + j] : 0.0;
+  });
+}
+
+static __global__ __launch_bounds__(WAVE) void k_rearm(dto_kkt_args a) {
+  double* sc = a.scal + (((int64_t)blockIdx.x * SC_COUNT) << 6) + threadIdx.x;
+  sc[SC_STATUS << 6] = 0.0;
+  sc[SC_NEED << 6] = 1.0;
+  sc[SC_ATTEMPT << 6] = 0.0;
+  sc[SC_TRY_DW << 6] = a.opt.fixed_delta_w;
+  sc[SC_TRY_GAM << 6] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1019,6 +1077,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     double rp = R(D::R_RP + i);
     double sig = dw;
     fixed[i] = false;
+    if (o.newton_only && a.sigx) sig += *soa(a.sigx, g, a.Nz, z0 + i);
     if (!o.newton_only) {
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo == hi) {
@@ -1045,6 +1104,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   for (int j = 0; j < Q; ++j) {
     double dc = o.delta_c;
     double r = R(D::R_C + j);
+    if (o.newton_only && a.sigc) dc += *soa(a.sigc, g, a.Nc, a.ccoff[t] + j);
     if (!o.newton_only && D::ineq(j)) {
       const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
       const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
@@ -1058,7 +1118,9 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   // --- dynamics rows
 #pragma unroll
   for (int k = 0; k < NY; ++k) {
-    S[tri(NP + Q + k, NP + Q + k)] = -o.delta_c;
+    double dc = o.delta_c;
+    if (o.newton_only && a.sigc) dc += *soa(a.sigc, g, a.Nc, a.cdoff[t] + k);
+    S[tri(NP + Q + k, NP + Q + k)] = -dc;
     y[NP + Q + k] = -R(D::R_D + k);
   }
   // --- fixed variables: identity rows/columns
@@ -1438,6 +1500,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
   // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
   if (nneg != (int)a.Nc) ok = false;
   sc[SC_NFACT << 6] += 1.0;
+  sc[SC_NNEG << 6] = (double)nneg;
   double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
   const double dlast = sc[SC_DELTA_LAST << 6];
   const int attempt = (int)sc[SC_ATTEMPT << 6];
@@ -1961,6 +2024,8 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
           case 7: n = a.Ni; buf = a.s; break;
           case 8: n = a.Ni; buf = a.zs; break;
           case 9: n = a.Ni; buf = a.ds; break;
+          case 10: n = a.Nz; buf = const_cast<double*>(a.sigx); break;
+          case 11: n = a.Nc; buf = const_cast<double*>(a.sigc); break;
           default: return -1;
         }
         if (n == 0) break;
@@ -2007,6 +2072,8 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_RHS: hipLaunchKernelGGL(k_rhs_record<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_REARM: hipLaunchKernelGGL(k_rearm, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       default: return -1;
     }
     return (int)hipGetLastError();

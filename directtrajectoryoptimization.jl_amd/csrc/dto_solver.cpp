@@ -33,6 +33,8 @@ struct SolverState {
   int64_t Ni = 0, rec_total = 0, fac_total = 0, n_bnd = 0;
   double* wtile = nullptr;      // per-instance parameters (SoA tiles), allocated on first use
   bool use_wtile = false;
+  double *sigx = nullptr, *sigc = nullptr;  // linear-solver entry points: extra diagonals (SoA tiles), allocated on first use
+  bool use_sigx = false, use_sigc = false, assembled = false;
   std::vector<int> ioff;
   std::vector<int64_t> recoff, facoff;
   int* d_ioff = nullptr;
@@ -57,11 +59,12 @@ struct SolverState {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
-                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile})
+                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile, (void*)sigx, (void*)sigc})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
     csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; wtile = nullptr; use_wtile = false;
+    sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
     B = 0; G = 0;
   }
 };
@@ -92,6 +95,7 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.watchdog_trigger = 10; o.watchdog_trials = 3;
   if (const char* e = getenv("DTO_WATCHDOG")) sscanf(e, "%d,%d", &o.watchdog_trigger, &o.watchdog_trials);  // experiment knob
   o.newton_only = 0; o.fixed_delta_w = 0.0;
+  o.warm = 0; o.mu_warm = 0.0;
 }
 
 // ---- wide-stage models (dto_wide_kernels.hpp): one workgroup per instance, AoS buffers used as they are
@@ -497,6 +501,8 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.rec_total = S.rec_total; a.fac_total = S.fac_total;
   a.lo = S.d_lo; a.hi = S.d_hi; a.params = p->d_params;
   a.wtile = S.use_wtile ? S.wtile : nullptr; a.Nw = L.Nw;
+  a.sigx = (S.opt.newton_only && S.use_sigx) ? S.sigx : nullptr;
+  a.sigc = (S.opt.newton_only && S.use_sigc) ? S.sigc : nullptr;
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
@@ -587,6 +593,7 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   dto::default_opts(S.opt, u);
   S.opt.newton_only = 1;
   S.opt.fixed_delta_w = delta_w;
+  S.use_sigx = S.use_sigc = S.assembled = false;
   hipStream_t st = (hipStream_t)b->stream;
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
@@ -750,15 +757,13 @@ int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
   return DTO_OK;
 }
 
-int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
-                    double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
+int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, int32_t* status,
+                   int32_t* iterations, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
-  if (p && b && b->x && x_out && p->vt->launch_wide)
-    return dto::wide_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
-  int rc = dto_solver_begin(h, opt, b);
-  if (rc) return rc;
+  if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin[_warm] has not been called");
   SolverState& S = *p->solver;
-  hipStream_t st = (hipStream_t)b->stream;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
   const int chunk = std::max(1, S.user.check_every);
   int done_iters = 0;
   const auto t_start = std::chrono::steady_clock::now();
@@ -782,6 +787,132 @@ int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, 
     if (status) status[i] = (int32_t)dto::hscal(S, i, SC_STATUS);
     if (iterations) iterations[i] = (int32_t)dto::hscal(S, i, SC_ITER);
   }
+  return DTO_OK;
+}
+
+int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                    double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && b && b->x && x_out && p->vt->launch_wide)
+    return dto::wide_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
+  int rc = dto_solver_begin(h, opt, b);
+  if (rc) return rc;
+  return dto_solver_run(h, x_out, ldxo, mu_out, ldmuo, status, iterations, b->stream);
+}
+
+int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batch* b, double mu0) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !b) return set_error(DTO_ERR_INVALID, "null argument");
+  if (p->vt->launch_wide) return set_error(DTO_ERR_UNSUPPORTED, "warm starts are not available for wide-stage models");
+  if (!p->solver || !p->solver->z || p->solver->B != b->B)
+    return set_error(DTO_ERR_INVALID, "dto_solver_begin_warm needs the device state of a previous solve of the same batch size");
+  if (b->x && b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
+  SolverState& S = *p->solver;
+  int rc;
+  if ((rc = dto::set_batch_params(p, b, (hipStream_t)b->stream))) return rc;
+  dto_options u;
+  if (opt) u = *opt; else dto_options_default(&u);
+  S.user = u;
+  dto::default_opts(S.opt, u);
+  S.opt.warm = 1;
+  S.opt.mu_warm = mu0;
+  S.use_sigx = S.use_sigc = S.assembled = false;
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  if (b->x && (rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
+  S.opt.warm = 0;   // the flag only concerns the initialisation kernel
+  S.begun = true;
+  return DTO_OK;
+}
+
+// ---- the linear solver alone ---------------------------------------------------------------------------------------
+int dto_kkt_assemble(dto_problem* h, const dto_batch* b, const dto_kkt_system* sys) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !b || !b->x || !sys || !sys->mu) return set_error(DTO_ERR_INVALID, "null argument");
+  if (p->vt->launch_wide) return set_error(DTO_ERR_UNSUPPORTED, "dto_kkt_assemble/factor/solve: use dto_kkt_step_batch for wide-stage models");
+  if (b->ldx < p->L.Nz || sys->ldmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  if ((sys->sigma_x && sys->ldsx < p->L.Nz) || (sys->sigma_c && sys->ldsc < p->L.Nc)) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  int rc = dto::ensure_state(p, b->B);
+  if (rc) return rc;
+  SolverState& S = *p->solver;
+  hipStream_t st = (hipStream_t)b->stream;
+  if ((rc = dto::set_batch_params(p, b, st))) return rc;
+  dto_options u;
+  dto_options_default(&u);
+  u.delta_c = sys->delta_c;
+  dto::default_opts(S.opt, u);
+  S.opt.newton_only = 1;
+  S.opt.fixed_delta_w = sys->delta_w;
+  const size_t lanes = (size_t)S.G * 64;
+  if (sys->sigma_x && !S.sigx && (rc = dto::dev_alloc(&S.sigx, lanes * (size_t)p->L.Nz))) return rc;
+  if (sys->sigma_c && !S.sigc && (rc = dto::dev_alloc(&S.sigc, lanes * (size_t)std::max<int64_t>(1, p->L.Nc)))) return rc;
+  S.use_sigx = sys->sigma_x != nullptr;
+  S.use_sigc = sys->sigma_c != nullptr;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  if ((rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
+  if ((rc = dto::pack(p, a, 1, sys->mu, sys->ldmu, st))) return rc;
+  if (sys->sigma_x && (rc = dto::pack(p, a, 10, sys->sigma_x, sys->ldsx, st))) return rc;
+  if (sys->sigma_c && (rc = dto::pack(p, a, 11, sys->sigma_c, sys->ldsc, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
+  // residuals of this point into the records (a right-hand side must be there for dto_kkt_factor; dto_kkt_solve replaces it)
+  if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
+  S.assembled = true;
+  S.begun = false;
+  return DTO_OK;
+}
+
+int dto_kkt_factor(dto_problem* h, int32_t* inertia_ok, int32_t* num_negative, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->assembled) return set_error(DTO_ERR_INVALID, "dto_kkt_assemble has not been called");
+  SolverState& S = *p->solver;
+  hipStream_t st = (hipStream_t)stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  int rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_REARM, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_FWD, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_SEP, a, st))) return rc;
+  if (inertia_ok || num_negative) {
+    if ((rc = dto::fetch_scalars(p, st))) return rc;
+    for (int64_t i = 0; i < S.B; ++i) {
+      if (inertia_ok) inertia_ok[i] = dto::hscal(S, i, SC_LS_FAIL) == 0.0 ? 1 : 0;
+      if (num_negative) num_negative[i] = (int32_t)dto::hscal(S, i, SC_NNEG);
+    }
+  }
+  return DTO_OK;
+}
+
+int dto_kkt_solve(dto_problem* h, const double* rhs_x, int64_t ldrx, const double* rhs_c, int64_t ldrc, double* sol_x,
+                  int64_t ldsx, double* sol_c, int64_t ldsc, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->assembled) return set_error(DTO_ERR_INVALID, "dto_kkt_assemble has not been called");
+  if (!rhs_x || !sol_x || (p->L.Nc > 0 && (!rhs_c || !sol_c))) return set_error(DTO_ERR_INVALID, "null argument");
+  if (ldrx < p->L.Nz || ldsx < p->L.Nz || ldrc < p->L.Nc || ldsc < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  dto_kkt_args a;
+  dto::fill_kkt_args(p, a);
+  a.rhs_x = rhs_x; a.ld_rhs_x = ldrx; a.rhs_c = rhs_c; a.ld_rhs_c = ldrc;
+  int rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_RHS, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_REARM, a, st))) return rc;
+  // the factors are not kept between calls (the sweeps recompute a stage's LDL^T instead of storing it):
+  // a solve is forward sweep + separator system + backward sweep with the new right-hand side
+  if ((rc = dto::kkt_launch(p, DTO_KKT_FWD, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_SEP, a, st))) return rc;
+  if ((rc = dto::kkt_launch(p, DTO_KKT_BWD, a, st))) return rc;
+  if ((rc = dto::unpack(p, a, 2, sol_x, ldsx, st))) return rc;
+  if (p->L.Nc > 0 && (rc = dto::unpack(p, a, 3, sol_c, ldsc, st))) return rc;
+  return DTO_OK;
+}
+
+int dto_shard_range(int64_t total, int rank, int world, int64_t* first, int64_t* count) {
+  if (total < 0 || world < 1 || rank < 0 || rank >= world || !first || !count) return set_error(DTO_ERR_INVALID, "bad shard arguments");
+  const int64_t lo = (total * rank) / world, hi = (total * (rank + 1)) / world;
+  *first = lo;
+  *count = hi - lo;
   return DTO_OK;
 }
 

@@ -14,9 +14,12 @@ import numpy as np
 
 def shard_range(num_instances: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of instances owned by `rank`: b in [r*B/R, (r+1)*B/R)."""
-    lo = (num_instances * rank) // world
-    hi = (num_instances * (rank + 1)) // world
-    return lo, hi
+    # the rule lives on the C-ABI (dto_shard_range) so that every host language shards identically
+    import ctypes as C
+    from . import capi
+    first, count = C.c_int64(), C.c_int64()
+    capi.check(capi.lib().dto_shard_range(int(num_instances), int(rank), int(world), C.byref(first), C.byref(count)))
+    return first.value, first.value + count.value
 
 
 def gather_trajectories(z_local, status_local, dist):

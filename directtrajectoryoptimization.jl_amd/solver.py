@@ -386,6 +386,46 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_solver_begin(self._solve_nlp._h, C.byref(co), C.byref(b)))
         self._B = B
 
+    def begin_warm_batch(self, B, x0_ptr=0, ldx=0, stream=0, params_ptr=0, ldp=0, mu0=0.0):
+        """dto_solver_begin_warm: re-solve from the device-resident state of the previous solve (receding-horizon MPC).
+        x0_ptr = 0 keeps the final iterate; mu0 <= 0 keeps the barrier parameter."""
+        b = self._solve_nlp._batch(x0_ptr, B, ldx or self._solve_nlp.num_variables, stream, params_ptr, ldp)
+        co = _c_options(self.options)
+        capi.check(self._solve_nlp._lib.dto_solver_begin_warm(self._solve_nlp._h, C.byref(co), C.byref(b), float(mu0)))
+        self._B = B
+
+    def run_batch(self, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0):
+        """dto_solver_run: iterate the begun batch to termination; returns (status[B], iterations[B])."""
+        B = self._B
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        capi.check(self._solve_nlp._lib.dto_solver_run(self._solve_nlp._h, x_out_ptr, ldxo, mu_out_ptr or None, ldmuo,
+                                                       status.ctypes.data_as(capi.c_int32_p), iters.ctypes.data_as(capi.c_int32_p),
+                                                       stream or None))
+        return status, iters
+
+    # ---- the linear solver alone (include/dto.h: dto_kkt_assemble / dto_kkt_factor / dto_kkt_solve)
+    def kkt_assemble(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, sigma_x_ptr=0, ldsx=0, sigma_c_ptr=0, ldsc=0, stream=0,
+                     params_ptr=0, ldp=0):
+        b = self._solve_nlp._batch(x_ptr, B, ldx, stream, params_ptr, ldp)
+        sysd = capi.KktSystem()
+        sysd.mu, sysd.ldmu = mu_ptr, ldmu
+        sysd.sigma_x, sysd.ldsx = sigma_x_ptr or None, ldsx
+        sysd.sigma_c, sysd.ldsc = sigma_c_ptr or None, ldsc
+        sysd.delta_w, sysd.delta_c = float(delta_w), float(delta_c)
+        capi.check(self._solve_nlp._lib.dto_kkt_assemble(self._solve_nlp._h, C.byref(b), C.byref(sysd)))
+        self._B = B
+
+    def kkt_factor(self, stream=0):
+        """Returns (inertia_ok[B], num_negative[B])."""
+        ok, neg = np.zeros(self._B, dtype=np.int32), np.zeros(self._B, dtype=np.int32)
+        capi.check(self._solve_nlp._lib.dto_kkt_factor(self._solve_nlp._h, ok.ctypes.data_as(capi.c_int32_p),
+                                                       neg.ctypes.data_as(capi.c_int32_p), stream or None))
+        return ok, neg
+
+    def kkt_solve(self, rhs_x_ptr, ldrx, rhs_c_ptr, ldrc, sol_x_ptr, ldsx, sol_c_ptr, ldsc, stream=0):
+        capi.check(self._solve_nlp._lib.dto_kkt_solve(self._solve_nlp._h, rhs_x_ptr, ldrx, rhs_c_ptr, ldrc, sol_x_ptr, ldsx,
+                                                      sol_c_ptr, ldsc, stream or None))
+
     def iterate_batch(self, n, stream=0):
         capi.check(self._solve_nlp._lib.dto_solver_iterate(self._solve_nlp._h, int(n), stream or None))
 

@@ -185,6 +185,27 @@ int dto_options_default(dto_options* o);
 int dto_kkt_step_batch(dto_problem* p, const dto_batch* b, const double* mu, int64_t ldmu, double delta_w,
                        double delta_c, double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok);
 
+/* ---- the linear solver alone: for a caller that keeps its own outer iteration (Ipopt's augmented system,
+ *      cf. the sketch at examples/pendulum/pendulum.jl:138-198 with delta_w / delta_c on the diagonals):
+ *     [ W(x, mu) + diag(sigma_x) + delta_w I            J(x)'               ] [ sol_x ]   [ rhs_x ]
+ *     [ J(x)                              -diag(sigma_c) - delta_c I  ] [ sol_c ] = [ rhs_c ]
+ *  W = hess f + sum_i mu_i hess c_i (exact Hessians), every constraint row treated as an equality, bounds ignored -- barrier
+ *  terms enter through sigma_x / sigma_c.  DEVICE pointers, instance-major.  dto_kkt_assemble packs the point and the
+ *  diagonals; dto_kkt_factor runs the block-tridiagonal LDL^T once and reports the inertia (HOST arrays [B], may be NULL:
+ *  inertia_ok[i] = the matrix has exactly num_constraint negative and no tiny pivots; num_negative[i] = negative pivots);
+ *  dto_kkt_solve solves for one right-hand side.  The factors are not stored between calls (the sweeps recompute each
+ *  stage's LDL^T -- cheaper than the HBM traffic on this hardware), so every dto_kkt_solve costs a forward + backward sweep. */
+typedef struct dto_kkt_system {
+  const double* mu;      int64_t ldmu;   /* [B][ldmu] multipliers inside W */
+  const double* sigma_x; int64_t ldsx;   /* [B][ldsx] >= 0, or NULL */
+  const double* sigma_c; int64_t ldsc;   /* [B][ldsc] >= 0, or NULL */
+  double delta_w, delta_c;
+} dto_kkt_system;
+int dto_kkt_assemble(dto_problem* p, const dto_batch* b, const dto_kkt_system* sys);
+int dto_kkt_factor(dto_problem* p, int32_t* inertia_ok, int32_t* num_negative, void* stream);
+int dto_kkt_solve(dto_problem* p, const double* rhs_x, int64_t ldrx, const double* rhs_c, int64_t ldrc, double* sol_x,
+                  int64_t ldsx, double* sol_c, int64_t ldsc, void* stream);
+
 /* Batched interior-point solve, one independent NLP per instance, same structure, different guesses.
  * x0: DEVICE [B][ldx] initial guesses (what initialize_states!/initialize_controls! set,
  * src/solver.jl:23-39); x_out/mu_out: DEVICE [B][ld*] final accepted iterates (get_trajectory,
@@ -196,6 +217,15 @@ int dto_solve_batch(dto_problem* p, const dto_options* opt, const dto_batch* b, 
 
 /* The same solve split in three so a caller (bench.py) can time exactly K iterations. */
 int dto_solver_begin(dto_problem* p, const dto_options* opt, const dto_batch* b);
+/* Warm start for receding-horizon (MPC) re-solves -- what repeated initialize_states!/initialize_controls! + solve! calls
+ * (src/solver.jl:23-47) amount to, without re-initialising the interior-point state: the multipliers, bound multipliers, slacks
+ * and the barrier parameter of the previous solve of this handle stay on the device.  b->x (DEVICE, may be NULL = keep the
+ * final iterate) replaces the primal iterate (e.g. the shifted trajectory), b->params the parameters (e.g. the newly
+ * measured state); b->B must equal the previous batch size.  mu0 > 0 resets the barrier parameter, mu0 <= 0 keeps it. */
+int dto_solver_begin_warm(dto_problem* p, const dto_options* opt, const dto_batch* b, double mu0);
+/* iterate the begun batch to termination (the polling loop of dto_solve_batch) and hand the results over */
+int dto_solver_run(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, int32_t* status,
+                   int32_t* iterations, void* stream);
 int dto_solver_iterate(dto_problem* p, int n_iterations, void* stream);
 /* per-instance scalars, HOST [B] each, any may be NULL */
 int dto_solver_stats(dto_problem* p, int32_t* status, int32_t* iterations, double* objective, double* constr_viol,
@@ -229,6 +259,8 @@ int dto_copy_to_device(void* dst, const void* src, int64_t bytes);
 int dto_copy_to_host(void* dst, const void* src, int64_t bytes);
 int dto_device_synchronize(void);
 int dto_device_count(int* n);
+/* instance sharding across ranks (one process per GPU): contiguous block [first, first + count) of `total` for `rank` */
+int dto_shard_range(int64_t total, int rank, int world, int64_t* first, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -486,13 +486,12 @@ static void factor_solve(port_solver* S) {
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
   if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * dlast, o->delta_w_init));
-  else if (dlast > (getenv("PORT_STICKY_FLOOR") ? 0.0 : 1.1 * o->delta_w_init) && S->full_streak < (getenv("PORT_STREAK") ? atoi(getenv("PORT_STREAK")) : 2)) dw = fmax(o->delta_w_init, (getenv("PORT_KMINUS") ? atof(getenv("PORT_KMINUS")) : o->kappa_w_minus) * dlast);
+  else if (dlast > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * dlast);
   int ok = 0;
   for (int attempt = 0;; ++attempt) {
     ok = forward_sweep(S, dw, gam, NULL);
     S->nfact++;
     if (ok || attempt >= o->max_refactor) break;
-    if (getenv("PORT_GN_AFTER") && gam != 0.0 && attempt + 1 >= atoi(getenv("PORT_GN_AFTER"))) { gam = 0.0; dw = fmax(o->delta_w_init, getenv("PORT_GN_DW") ? atof(getenv("PORT_GN_DW")) : 0.0); continue; }
     if (gam != 0.0) {
       const int skip_ladder = (S->gamma == 0.0) && (S->iter % 4 != 0);
       if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o->delta_w_init : fmax(o->delta_w_init, o->kappa_w_minus * dlast);

@@ -35,3 +35,43 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     with pytest.raises(capi.DtoError) as e:
         s.nlp.eval_objective(np.zeros(s.nlp.num_variables))
     assert e.value.code == 3  # DTO_ERR_DEVICE: there is no CPU fallback
+
+
+def test_header_compiles_as_c99_and_structs_match_the_ctypes_mirror():
+    """include/dto.h is plain C (no C++ needed by a host language); the ctypes structures have the C compiler's layout."""
+    import subprocess, tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "dto.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(dto_problem_spec), sizeof(dto_options), sizeof(dto_batch), sizeof(dto_kkt_system), sizeof(dto_sizes_t));
+  printf("%zu %zu %zu\n", offsetof(dto_problem_spec, evaluate_hessian), offsetof(dto_options, mu_target), offsetof(dto_kkt_system, delta_c));
+  return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    sizes = [int(v) for v in out]
+    assert sizes[:5] == [ctypes.sizeof(capi.ProblemSpec), ctypes.sizeof(capi.COptions), ctypes.sizeof(capi.Batch),
+                         ctypes.sizeof(capi.KktSystem), ctypes.sizeof(capi.Sizes)]
+    assert sizes[5:] == [capi.ProblemSpec.evaluate_hessian.offset, capi.COptions.mu_target.offset, capi.KktSystem.delta_c.offset]
+
+
+def test_shard_range_on_the_c_abi():
+    """dto_shard_range: contiguous blocks in rank order that cover every instance exactly once (SURVEY.md 8e)."""
+    from dto_amd.parallel import shard_range
+    import pytest
+    for total, world in ((512, 8), (10, 4), (3, 8), (0, 2), (131072, 7)):
+        seen = []
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            assert lo == (total * r) // world and hi == (total * (r + 1)) // world
+            seen += list(range(lo, hi))
+        assert seen == list(range(total))
+    with pytest.raises(capi.DtoError):
+        shard_range(8, 3, 2)

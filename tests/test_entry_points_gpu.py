@@ -1,0 +1,142 @@
+"""The C-ABI entry points added in round 2 (include/dto.h), through ctypes:
+
+* dto_kkt_assemble / dto_kkt_factor / dto_kkt_solve -- the block-tridiagonal LDL^T as a linear solver for a caller that
+  keeps its own outer iteration (Ipopt's augmented system with Sigma_x / Sigma_c / delta_w / delta_c on the diagonals),
+  against numpy dense solves of the ORACLE's matrices, several right-hand sides per factorisation, inertia against the
+  dense eigenvalue count;
+* dto_solver_begin_warm / dto_solver_run -- receding-horizon re-solves that keep the interior-point state on the device.
+"""
+import numpy as np
+import pytest
+
+from conftest import product_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_blocks(onlp, z, mu):
+    nz, nc = onlp.num_variables, onlp.num_constraint
+    H = np.zeros((nz, nz))
+    for (r, c), v in zip(onlp.hessian_lagrangian_structure(), onlp.eval_hessian_lagrangian(z, 1.0, mu)):
+        H[r - 1, c - 1] = v
+    J = np.zeros((nc, nz))
+    for (r, c), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
+        J[r - 1, c - 1] = v
+    return H, J
+
+
+@pytest.mark.parametrize("model,T,dw,partitions", [("pendulum", 6, 30.0, 0), ("acrobot", 70, 60.0, 0), ("acrobot", 70, 60.0, 7),
+                                                   ("car", 6, 10.0, 0), ("cartpole", 40, 400.0, 3)])
+def test_linear_solver_entry_points_match_dense_solves(model, T, dw, partitions):
+    import torch
+    from oracle import dto_oracle as O, sympy_models as S
+    s, _ = product_solver(model, T)
+    p = S.build(model, T, evaluate_hessian=True)
+    onlp = O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(17 * T + partitions)
+    B, dc = 3, 1e-6
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    SX, SC = rng.random((B, nz)) * 3.0, rng.random((B, nc)) * 0.5
+    SX[:, ::3] = 0.0                                           # some variables without a barrier term
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    dZ, dMU, dSX, dSC = dev(Z), dev(MU), dev(SX), dev(SC)
+    s.set_partitions(partitions)
+    try:
+        s.kkt_assemble(dZ.data_ptr(), B, nz, dMU.data_ptr(), nc, dw, dc, dSX.data_ptr(), nz, dSC.data_ptr(), nc)
+        ok, neg = s.kkt_factor()
+        Ks = []
+        for b in range(B):
+            H, J = dense_blocks(onlp, Z[b], MU[b])
+            K = np.block([[H + np.diag(SX[b]) + dw * np.eye(nz), J.T], [J, -np.diag(SC[b]) - dc * np.eye(nc)]])
+            Ks.append(K)
+            eig = np.linalg.eigvalsh(K)
+            assert int(np.sum(eig < 0)) == neg[b], (int(np.sum(eig < 0)), neg[b])      # Sylvester: pivots count the inertia
+            assert bool(ok[b]) == (int(np.sum(eig < 0)) == nc)
+        for _ in range(3):                                     # several right-hand sides on one assembled system
+            RX, RC = rng.standard_normal((B, nz)), rng.standard_normal((B, nc))
+            dRX, dRC = dev(RX), dev(RC)
+            oX = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+            oC = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+            s.kkt_solve(dRX.data_ptr(), nz, dRC.data_ptr(), nc, oX.data_ptr(), nz, oC.data_ptr(), nc)
+            torch.cuda.synchronize()
+            oX, oC = oX.cpu().numpy(), oC.cpu().numpy()
+            for b in range(B):
+                sol = np.linalg.solve(Ks[b], np.concatenate([RX[b], RC[b]]))
+                scale = np.max(np.abs(sol))
+                assert np.max(np.abs(oX[b] - sol[:nz])) <= 1e-8 * scale and np.max(np.abs(oC[b] - sol[nz:])) <= 1e-8 * scale
+    finally:
+        s.set_partitions(0)
+    # an indefinite case: no regularisation, large multipliers -> the factorisation reports the wrong inertia
+    MU2 = 300.0 * rng.standard_normal((B, nc))
+    dMU2 = dev(MU2)
+    s.kkt_assemble(dZ.data_ptr(), B, nz, dMU2.data_ptr(), nc, 0.0, dc)
+    ok2, neg2 = s.kkt_factor()
+    for b in range(B):
+        H, J = dense_blocks(onlp, Z[b], MU2[b])
+        K = np.block([[H, J.T], [J, -dc * np.eye(nc)]])
+        eig = np.linalg.eigvalsh(K)
+        if np.min(np.abs(eig)) > 1e-6:                         # away from singular matrices the counts agree exactly
+            assert int(np.sum(eig < 0)) == neg2[b]
+            assert bool(ok2[b]) == (int(np.sum(eig < 0)) == nc)
+
+
+def test_linear_solver_entry_points_reject_misuse():
+    import torch
+    import dto_amd
+    from dto_amd import capi
+    s, _ = product_solver("pendulum", 6)
+    s2 = dto_amd.Solver(*[product_solver("pendulum", 6)[1][k] for k in ("dynamics", "objective", "constraints", "bounds")],
+                        evaluate_hessian=True, name="pendulum")
+    with pytest.raises(capi.DtoError, match="dto_kkt_assemble has not been called"):
+        s2._B = 1
+        s2.kkt_factor()
+
+
+def test_warm_started_mpc_resolve_keeps_the_interior_point_state():
+    """Receding horizon: solve a batch of pendulum MPC problems, move every measured initial state a little, and re-solve
+    (a) cold from the previous solution as the guess and (b) warm with dto_solver_begin_warm.  Both reach the same solutions;
+    the warm start, which keeps multipliers, slack/bound multipliers and the barrier parameter, needs clearly fewer iterations."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    T, B = 30, 6
+    rng = np.random.default_rng(5)
+    p = P.build_mpc_pendulum(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=p["parameters"], name="mpc_pendulum")
+    nz, nc, nw = s.nlp.num_variables, s.nlp.num_constraint, s.nlp.num_parameters
+    x1s = 0.3 * rng.standard_normal((B, 2))
+    goals = np.pi * (0.5 + 0.5 * rng.random(B))
+    W = np.stack([np.tile([x1s[b, 0], x1s[b, 1], goals[b]], T) for b in range(B)])
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        dto_amd.initialize_states(s, dto_amd.linear_interpolation(x1s[b], np.array([goals[b], 0.0]), T))
+        dto_amd.initialize_controls(s, [0.1 * rng.standard_normal(1) for _ in range(T - 1)])
+        Z[b] = s._z0
+    z0, w = torch.tensor(Z, device="cuda"), torch.tensor(W, device="cuda")
+    z1 = torch.empty_like(z0)
+    st, it0 = s.solve_batch(z0.data_ptr(), B, nz, z1.data_ptr(), nz, params_ptr=w.data_ptr(), ldp=nw)
+    assert np.all(st == 1)
+    mu_end = s.scalar_batch("mu").copy()
+    # the plant moved: new measured states
+    W2 = W.copy()
+    for b in range(B):
+        W2[b].reshape(T, 3)[:, :2] += 0.02 * rng.standard_normal(2)
+    w2 = torch.tensor(W2, device="cuda")
+    # (b) warm: device state kept, only the parameters change
+    zw = torch.empty_like(z0)
+    s.begin_warm_batch(B, params_ptr=w2.data_ptr(), ldp=nw)
+    assert np.allclose(s.scalar_batch("mu"), mu_end)           # the barrier parameter was kept
+    st_w, it_w = s.run_batch(zw.data_ptr(), nz)
+    # (a) cold: same guess (the previous solution), fresh interior-point state
+    zc = torch.empty_like(z0)
+    st_c, it_c = s.solve_batch(z1.data_ptr(), B, nz, zc.data_ptr(), nz, params_ptr=w2.data_ptr(), ldp=nw)
+    torch.cuda.synchronize()
+    assert np.all(st_w == 1) and np.all(st_c == 1), (st_w, st_c)
+    assert np.max(np.abs(zw.cpu().numpy() - zc.cpu().numpy())) < 1e-5
+    assert it_w.sum() < it_c.sum(), (it_w, it_c)
+    # a batch of another size has no state to continue from
+    from dto_amd import capi
+    with pytest.raises(capi.DtoError, match="same batch size"):
+        s.begin_warm_batch(B + 1, params_ptr=w2.data_ptr(), ldp=nw)
