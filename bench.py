@@ -201,8 +201,9 @@ def main():
         s.iterate_batch(k, stream=st)
         done += k
         if done < a.steps:
+            running = s.repack_batch(stream=st)      # finished instances leave the tiles (part of the solve, hence timed)
             torch.cuda.synchronize()
-            profile.append((done, time.perf_counter() - t0))
+            profile.append((done, time.perf_counter() - t0, running))
     # one more evaluation classifies the last iterate (converged / iteration limit); it is part of the solve
     if a.steps + a.warmup >= s.options.max_iter:
         s.launch_op("eval", stream=st)
@@ -211,7 +212,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    profile.append((done, dt))
+    profile.append((done, dt, None))
     it1 = s.scalar_batch("iter")
     nf1 = s.scalar_batch("nfact")
     status_end = s.scalar_batch("status").copy()
@@ -225,7 +226,7 @@ def main():
         dt = float(tmax[0])
         iters_done, facts_done = float(tt[1]), float(tt[2])
     # iteration throughput while every instance is still running: the first slice (this rank; aggregated below)
-    first_k, first_t = profile[0]
+    first_k, first_t = profile[0][0], profile[0][1]
     thr0 = torch.tensor([B * first_k / first_t], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(thr0, op=dist.ReduceOp.SUM)
@@ -233,7 +234,8 @@ def main():
                       iteration_limit=int(np.sum(status_end == 2)), failed=int(np.sum((status_end == 3) | (status_end == 5))),
                       still_running=int(np.sum(status_end == 0)), instances=B,
                       iterations_median=float(np.median(it1)), iterations_mean=float(np.mean(it1)),
-                      seconds_profile=[(int(k), round(t, 3)) for k, t in profile[:: max(1, len(profile) // 10)]] + [(int(profile[-1][0]), round(profile[-1][1], 3))],
+                      profile=[dict(iterations=int(k), seconds=round(t, 3), running=r) for k, t, r in profile[:: max(1, len(profile) // 10)]]
+                      + [dict(iterations=int(profile[-1][0]), seconds=round(profile[-1][1], 3), running=int(np.sum(status_end == 0)))],
                       note="rank 0's shard; status per instance after the timed iterations")
 
     # the per-kernel replay below needs running instances: restart the batch and advance it a few iterations

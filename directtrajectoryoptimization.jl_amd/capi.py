@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         "dto_solve_batch": [vp, C.POINTER(COptions), C.POINTER(Batch), vp, C.c_int64, vp, C.c_int64, c_int32_p, c_int32_p],
         "dto_solver_begin": [vp, C.POINTER(COptions), C.POINTER(Batch)],
         "dto_solver_begin_warm": [vp, C.POINTER(COptions), C.POINTER(Batch), C.c_double],
+        "dto_solver_repack": [vp, C.POINTER(C.c_int), vp],
         "dto_solver_run": [vp, vp, C.c_int64, vp, C.c_int64, c_int32_p, c_int32_p, vp],
         "dto_kkt_assemble": [vp, C.POINTER(Batch), C.POINTER(KktSystem)],
         "dto_kkt_factor": [vp, c_int32_p, c_int32_p, vp],

@@ -73,6 +73,7 @@ struct dto_kkt_info {
   int n_ineq[16];     // inequality rows (slacks) by kind
   int npart, nscal, ls_trials, filter_cap;
   int chunk_sum_size, sep_fac_size, nx;  // per (tile, chunk) doubles of the partitioned factorisation
+  int quasi_newton;                      // 1: the stage records hold persistent quasi-Newton blocks
 };
 
 struct dto_solver_opts {
@@ -122,6 +123,8 @@ struct dto_kkt_args {
   // right-hand side (instance-major) that DTO_KKT_RHS writes into the stage records
   const double* sigx; const double* sigc;
   const double* rhs_x; int64_t ld_rhs_x; const double* rhs_c; int64_t ld_rhs_c;
+  // slot -> instance map after dto_solver_repack moved the running instances to the front (NULL: identity)
+  const int* inst_of_slot;
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -233,6 +236,7 @@ int kkt_info(dto_kkt_info* out) {
   out->chunk_sum_size = ChunkSum<M>::SIZE;
   out->sep_fac_size = SepFac<M>::SIZE;
   out->nx = M::MAX_NX;
+  out->quasi_newton = (M::EVALUATE_HESSIAN == 0) ? 1 : 0;
   return 0;
 }
 
@@ -290,7 +294,8 @@ static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, 
   const int64_t tile = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t inst = tile * 64 + lane;
+  const int64_t slot = tile * 64 + lane;
+  const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   if (i >= n) return;
   double v = 0.0;
   if (inst < a.B) v = a.aos_in[inst * a.ld_aos + i];
@@ -301,7 +306,8 @@ static __global__ __launch_bounds__(256) void k_unpack(dto_kkt_args a, int64_t n
   const int64_t tile = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t inst = tile * 64 + lane;
+  const int64_t slot = tile * 64 + lane;
+  const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   if (i >= n || inst >= a.B) return;
   a.aos_out[inst * a.ld_aos + i] = src[((tile * n + i) << 6) + lane];
 }
@@ -426,7 +432,8 @@ template <class M>
 __global__ __launch_bounds__(WAVE) void k_rhs_record(dto_kkt_args a) {
   const int64_t g = blockIdx.x / a.T;
   const int t = blockIdx.x % a.T;
-  const int64_t inst = g * 64 + threadIdx.x;
+  const int64_t slot = g * 64 + threadIdx.x;
+  const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   const bool live = inst < a.B;
   dispatch_uniform<M>(a.kind[t], [&](auto kc) {
     constexpr int K = decltype(kc)::value;

@@ -33,6 +33,13 @@ struct SolverState {
   int64_t Ni = 0, rec_total = 0, fac_total = 0, n_bnd = 0;
   double* wtile = nullptr;      // per-instance parameters (SoA tiles), allocated on first use
   bool use_wtile = false;
+  // dto_solver_repack: running instances are moved to the leading tiles; slot <-> instance maps (identity until then)
+  int G_active = 0;
+  std::vector<int> inst_of_slot, slot_of_inst;
+  int* d_inst_of_slot = nullptr;   // NULL while the map is the identity
+  int* d_src_slot = nullptr;
+  double* repack_tmp = nullptr;
+  size_t repack_tmp_len = 0;
   double *sigx = nullptr, *sigc = nullptr;  // linear-solver entry points: extra diagonals (SoA tiles), allocated on first use
   bool use_sigx = false, use_sigc = false, assembled = false;
   std::vector<int> ioff;
@@ -59,12 +66,15 @@ struct SolverState {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
-                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile, (void*)sigx, (void*)sigc})
+                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
+                    (void*)d_src_slot, (void*)repack_tmp})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
     csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
+    d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
+    inst_of_slot.clear(); slot_of_inst.clear();
     B = 0; G = 0;
   }
 };
@@ -506,6 +516,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
+  a.inst_of_slot = S.d_inst_of_slot;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
@@ -551,7 +562,85 @@ static int fetch_scalars(Problem* p, hipStream_t st) {
 }
 
 static inline double hscal(const SolverState& S, int64_t inst, int slot) {
-  return S.h_scal[((inst >> 6) * S.info.nscal + slot) * 64 + (inst & 63)];
+  const int64_t pos = S.slot_of_inst.empty() ? inst : S.slot_of_inst[(size_t)inst];
+  return S.h_scal[((pos >> 6) * S.info.nscal + slot) * 64 + (pos & 63)];
+}
+
+// identity slot <-> instance map (every entry point that loads a fresh batch)
+static void reset_slot_map(SolverState& S) {
+  if (S.d_inst_of_slot) { (void)hipFree(S.d_inst_of_slot); S.d_inst_of_slot = nullptr; }
+  S.inst_of_slot.clear(); S.slot_of_inst.clear();
+  S.G_active = S.G;
+}
+
+static __global__ void k_gather_rows(double* dst, const double* src, int64_t n, const int* src_slot) {
+  // grid (ceil(n / 4), G); block 256 = 4 rows x 64 lanes: dst[tile][i][lane] = src[tile'][i][lane'], (tile', lane') = src_slot
+  const int64_t tile = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int ss = src_slot[tile * 64 + lane];
+  dst[((tile * n + i) << 6) + lane] = src[((((int64_t)(ss >> 6)) * n + i) << 6) + (ss & 63)];
+}
+
+// Move the instances that are still running to the leading tiles (stable), the finished ones behind them, so that the
+// per-iteration kernels only cover tiles with work: without it a batch keeps paying for all its tiles until the last lane
+// of each has terminated.  Only the persistent per-instance state moves (iterates, multipliers, filter, scalars,
+// per-instance parameters); records, carries and partials are rebuilt by every iteration.  h_scal must be current.
+static int repack(Problem* p, hipStream_t st, int* n_running_out) {
+  SolverState& S = *p->solver;
+  const Layout& L = p->L;
+  const int lanes = S.G * 64;
+  if (S.info.quasi_newton) { if (n_running_out) *n_running_out = -1; return DTO_OK; }
+  if (S.inst_of_slot.empty()) {
+    S.inst_of_slot.resize(lanes); S.slot_of_inst.resize(lanes);
+    for (int i = 0; i < lanes; ++i) S.inst_of_slot[i] = S.slot_of_inst[i] = i;
+  }
+  std::vector<int> src(lanes);
+  int nrun = 0, k = 0;
+  auto running = [&](int slot) {
+    return S.inst_of_slot[slot] < S.B && S.h_scal[(((size_t)slot >> 6) * S.info.nscal + SC_STATUS) * 64 + (slot & 63)] == 0.0;
+  };
+  for (int sl = 0; sl < lanes; ++sl) if (running(sl)) src[k++] = sl;
+  nrun = k;
+  for (int sl = 0; sl < lanes; ++sl) if (!running(sl)) src[k++] = sl;
+  if (n_running_out) *n_running_out = nrun;
+  const int g_new = std::max(1, (nrun + 63) / 64);
+  if (g_new >= S.G_active) return DTO_OK;            // nothing to gain
+  if (!S.d_src_slot) HIP_TRY(hipMalloc((void**)&S.d_src_slot, lanes * sizeof(int)));
+  if (!S.d_inst_of_slot) HIP_TRY(hipMalloc((void**)&S.d_inst_of_slot, lanes * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(S.d_src_slot, src.data(), lanes * sizeof(int), hipMemcpyHostToDevice, st));
+  const size_t need = (size_t)lanes * (size_t)std::max<int64_t>(std::max<int64_t>(L.Nz, L.Nc), std::max<int64_t>(S.info.nscal, L.Nw));
+  if (S.repack_tmp_len < need) {
+    if (S.repack_tmp) (void)hipFree(S.repack_tmp);
+    S.repack_tmp = nullptr; S.repack_tmp_len = 0;
+    HIP_TRY(hipMalloc((void**)&S.repack_tmp, need * sizeof(double)));
+    S.repack_tmp_len = need;
+  }
+  auto move = [&](double* buf, int64_t n) -> int {
+    if (!buf || n <= 0) return DTO_OK;
+    dim3 grid((unsigned)((n + 3) / 4), (unsigned)S.G);
+    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, S.repack_tmp, (const double*)buf, n, (const int*)S.d_src_slot);
+    HIP_TRY(hipMemcpyAsync(buf, S.repack_tmp, (size_t)lanes * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return DTO_OK;
+  };
+  int rc;
+  if ((rc = move(S.z, L.Nz))) return rc;
+  if ((rc = move(S.lam, L.Nc))) return rc;
+  if (S.n_bnd > S.Ni) { if ((rc = move(S.zl, L.Nz))) return rc; if ((rc = move(S.zu, L.Nz))) return rc; }
+  if ((rc = move(S.s, S.Ni))) return rc;
+  if ((rc = move(S.zs, S.Ni))) return rc;
+  if ((rc = move(S.filt, 2 * S.info.filter_cap))) return rc;
+  if ((rc = move(S.scal, S.info.nscal))) return rc;
+  if (S.use_wtile && (rc = move(S.wtile, L.Nw))) return rc;
+  std::vector<int> inst_new(lanes);
+  for (int sl = 0; sl < lanes; ++sl) inst_new[sl] = S.inst_of_slot[src[sl]];
+  S.inst_of_slot.swap(inst_new);
+  for (int sl = 0; sl < lanes; ++sl) S.slot_of_inst[S.inst_of_slot[sl]] = sl;
+  HIP_TRY(hipMemcpyAsync(S.d_inst_of_slot, S.inst_of_slot.data(), lanes * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));   // src / inst_new are host temporaries of this call
+  S.G_active = g_new;
+  return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
 }
 
 }  // namespace dto
@@ -594,6 +683,7 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   S.opt.newton_only = 1;
   S.opt.fixed_delta_w = delta_w;
   S.use_sigx = S.use_sigc = S.assembled = false;
+  dto::reset_slot_map(S);
   hipStream_t st = (hipStream_t)b->stream;
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
@@ -625,6 +715,8 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
+  dto::reset_slot_map(S);
+  S.use_sigx = S.use_sigc = S.assembled = false;
   if ((rc = dto::set_batch_params(p, b, (hipStream_t)b->stream))) return rc;
   dto_options u;
   if (opt) u = *opt; else dto_options_default(&u);
@@ -647,6 +739,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
+  if (p->solver->G_active > 0) a.G = p->solver->G_active;   // tiles behind hold finished instances only (dto_solver_repack)
   int rc;
   for (int it = 0; it < n; ++it) {
     if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
@@ -773,9 +866,11 @@ int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
     if ((rc = dto_solver_iterate(h, n, (void*)st))) return rc;
     done_iters += n;
     if ((rc = dto::fetch_scalars(p, st))) return rc;
-    bool any = false;
-    for (int64_t i = 0; i < S.B && !any; ++i) any = dto::hscal(S, i, SC_STATUS) == 0.0;
-    if (!any) break;
+    int64_t n_run = 0;
+    for (int64_t i = 0; i < S.B; ++i) n_run += dto::hscal(S, i, SC_STATUS) == 0.0;
+    if (n_run == 0) break;
+    // tiles are only worth running while they hold work: close the gaps once a quarter of the active lanes has finished
+    if (S.G_active > 1 && n_run < (int64_t)48 * S.G_active && (rc = dto::repack(p, st, nullptr))) return rc;
     // Options.max_cpu_time (src/options.jl:10): the instances still running are handed back as they are (status 0)
     if (S.user.max_cpu_time > 0.0 &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time)
@@ -788,6 +883,14 @@ int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
     if (iterations) iterations[i] = (int32_t)dto::hscal(S, i, SC_ITER);
   }
   return DTO_OK;
+}
+
+int dto_solver_repack(dto_problem* h, int* num_running, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin[_warm] has not been called");
+  int rc = dto::fetch_scalars(p, (hipStream_t)stream);
+  if (rc) return rc;
+  return dto::repack(p, (hipStream_t)stream, num_running);
 }
 
 int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
@@ -816,6 +919,7 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   dto::default_opts(S.opt, u);
   S.opt.warm = 1;
   S.opt.mu_warm = mu0;
+  S.G_active = S.G;   // every instance runs again (the slot map of an earlier dto_solver_repack stays valid)
   S.use_sigx = S.use_sigc = S.assembled = false;
   hipStream_t st = (hipStream_t)b->stream;
   dto_kkt_args a;
@@ -837,6 +941,7 @@ int dto_kkt_assemble(dto_problem* h, const dto_batch* b, const dto_kkt_system* s
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
+  dto::reset_slot_map(S);
   hipStream_t st = (hipStream_t)b->stream;
   if ((rc = dto::set_batch_params(p, b, st))) return rc;
   dto_options u;

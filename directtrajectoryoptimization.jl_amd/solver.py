@@ -394,6 +394,12 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_solver_begin_warm(self._solve_nlp._h, C.byref(co), C.byref(b), float(mu0)))
         self._B = B
 
+    def repack_batch(self, stream=0) -> int:
+        """dto_solver_repack: close the gaps finished instances leave in the tiles; returns the number still running."""
+        n = C.c_int(0)
+        capi.check(self._solve_nlp._lib.dto_solver_repack(self._solve_nlp._h, C.byref(n), stream or None))
+        return n.value
+
     def run_batch(self, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0):
         """dto_solver_run: iterate the begun batch to termination; returns (status[B], iterations[B])."""
         B = self._B

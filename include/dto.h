@@ -223,6 +223,11 @@ int dto_solver_begin(dto_problem* p, const dto_options* opt, const dto_batch* b)
  * final iterate) replaces the primal iterate (e.g. the shifted trajectory), b->params the parameters (e.g. the newly
  * measured state); b->B must equal the previous batch size.  mu0 > 0 resets the barrier parameter, mu0 <= 0 keeps it. */
 int dto_solver_begin_warm(dto_problem* p, const dto_options* opt, const dto_batch* b, double mu0);
+/* Move the instances that are still running to the leading tiles of the batch so that the following iterations only cover
+ * tiles with work (a batch otherwise pays for every tile until its last lane has terminated); results keep coming back in
+ * the caller's instance order.  dto_solver_run / dto_solve_batch do this by themselves; a caller that drives
+ * dto_solver_iterate directly (bench.py) calls it between slices.  *num_running (may be NULL) = instances still iterating. */
+int dto_solver_repack(dto_problem* p, int* num_running, void* stream);
 /* iterate the begun batch to termination (the polling loop of dto_solve_batch) and hand the results over */
 int dto_solver_run(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, int32_t* status,
                    int32_t* iterations, void* stream);

@@ -140,3 +140,47 @@ def test_warm_started_mpc_resolve_keeps_the_interior_point_state():
     from dto_amd import capi
     with pytest.raises(capi.DtoError, match="same batch size"):
         s.begin_warm_batch(B + 1, params_ptr=w2.data_ptr(), ldp=nw)
+
+
+def test_repack_of_running_instances_changes_nothing_but_the_cost():
+    """dto_solver_repack moves the still-running instances to the leading tiles.  Per-instance arithmetic does not depend on
+    the slot an instance sits in, so a solve with repacking (dto_solve_batch does it by itself) returns bit for bit what a
+    plain iterate loop without it returns, in the caller's instance order -- including statuses and iteration counts."""
+    import torch
+    from bench import make_guesses
+    s, p = product_solver("acrobot", 101)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    B = 200                                                    # 4 tiles, the last one partially filled
+    Z = make_guesses(s, p, B, seed=77)
+    z0 = torch.tensor(Z, device="cuda")
+    # (a) no repacking: drive the iteration by hand
+    s.begin_batch(z0.data_ptr(), B, nz)
+    for _ in range(100):
+        s.iterate_batch(10)
+        if not np.any(s.scalar_batch("status") == 0):
+            break
+    za = torch.empty_like(z0); la = torch.empty((B, nc), device="cuda", dtype=torch.float64)
+    s.end_batch(za.data_ptr(), nz, la.data_ptr(), nc)
+    torch.cuda.synchronize()
+    st_a, it_a = s.scalar_batch("status").copy(), s.scalar_batch("iter").copy()
+    # (b) explicit repacking between slices
+    s.begin_batch(z0.data_ptr(), B, nz)
+    counts = []
+    for _ in range(100):
+        s.iterate_batch(10)
+        counts.append(s.repack_batch())
+        if counts[-1] == 0:
+            break
+    zb = torch.empty_like(z0); lb = torch.empty((B, nc), device="cuda", dtype=torch.float64)
+    s.end_batch(zb.data_ptr(), nz, lb.data_ptr(), nc)
+    torch.cuda.synchronize()
+    st_b, it_b = s.scalar_batch("status").copy(), s.scalar_batch("iter").copy()
+    assert counts[0] > counts[-1] and sorted(counts, reverse=True) == counts      # instances only ever leave
+    assert np.array_equal(st_a, st_b) and np.array_equal(it_a, it_b) and np.all(st_a == 1)
+    assert torch.equal(za, zb) and torch.equal(la, lb)
+    # (c) the one-call solve (repacks by itself)
+    zc = torch.empty_like(z0)
+    st_c, it_c = s.solve_batch(z0.data_ptr(), B, nz, zc.data_ptr(), nz)
+    torch.cuda.synchronize()
+    assert np.array_equal(st_c, st_a.astype(np.int32)) and np.array_equal(it_c, it_a.astype(np.int32)) and torch.equal(zc, za)
+    assert len(set(it_a.tolist())) > 10                         # the instances really finished at different times
