@@ -150,6 +150,9 @@ def main():
                     help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance; "
                          ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD, DESIGN.md section 5)")
     ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")
+    ap.add_argument("--loop-only", action="store_true",
+                    help="run only the headline loop (warm-up + timed iterations) and print value / ms_per_step: the command "
+                         "profiled under rocprofv3 so that the kernel statistics contain nothing but that loop")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-blocks", action="store_true", help="skip the configs[4] (dense 129x129 blocks) side measurement")
@@ -230,6 +233,14 @@ def main():
     thr0 = torch.tensor([B * first_k / first_t], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(thr0, op=dist.ReduceOp.SUM)
+    if a.loop_only:
+        if rank == 0:
+            print(json.dumps(dict(value=iters_done / dt, unit="SQP iterations/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=s.partitions(),
+                                  factorizations_per_iteration=round(facts_done / max(iters_done, 1.0), 3))), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     solve_info = dict(converged=int(np.sum(status_end == 1)), acceptable=int(np.sum(status_end == 4)),
                       iteration_limit=int(np.sum(status_end == 2)), failed=int(np.sum((status_end == 3) | (status_end == 5))),
                       still_running=int(np.sum(status_end == 0)), instances=B,
