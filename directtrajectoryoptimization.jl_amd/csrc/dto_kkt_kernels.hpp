@@ -931,11 +931,17 @@ struct Spike {
 // Build the stage block S_t (with the carry-in P_t, py and, in chunks p >= 1, the spike coupling Cx), factorise
 // it and run the forward substitutions.  On return S holds L (strict lower), dinv = 1/D, X = L^-1 O, y = w,
 // Z = L^-1 C.  Used by BOTH sweeps: the backward sweep recomputes instead of reading stored factors.
-template <class M, int K, bool SPK>
+// BWD (backward sweep): the step of the neighbouring blocks is already known (xn = dx_{t+1}, xL = the chunk's left
+// separator), so the couplings are folded into the right-hand side BEFORE the factorisation,
+//     v_t = L^-T D^-1 L^-1 (y - O xn - C xL),
+// and the panels X = L^-1 O, Z = L^-1 C are never formed: the backward sweep needs neither their registers (72 doubles for
+// the acrobot) nor their substitutions.
+template <class M, int K, bool SPK, bool BWD = false>
 __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
                                              bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
                                              double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
-                                             bool& ok, int& nneg, double* keep) {
+                                             bool& ok, int& nneg, double* keep, const double* xn = nullptr,
+                                             const double* xL = nullptr) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   const dto_solver_opts& o = a.opt;
@@ -1198,6 +1204,19 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     for (int k = 0; k < NY; ++k) keep[NP + Q + k] = R(D::R_D + k);
   }
   DTO_KKT_TICK(1);
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      double r = y[i];
+#pragma unroll
+      for (int c = 0; c < NY; ++c) r -= X[i * NY + c] * xn[c];
+      if constexpr (SPK) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) r -= Z[i * NX + c] * xL[c];
+      }
+      y[i] = r;
+    }
+  }
   // --- factor
   ldl_inplace<BD>(S, dinv, o.piv_tol, ok, nneg);
   DTO_KKT_TICK(4);
@@ -1207,10 +1226,12 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 #pragma unroll
     for (int k = 0; k < i; ++k) {
       const double l = S[tri(i, k)];
+      if constexpr (!BWD) {
 #pragma unroll
-      for (int c = 0; c < NY; ++c) X[i * NY + c] -= l * X[k * NY + c];
+        for (int c = 0; c < NY; ++c) X[i * NY + c] -= l * X[k * NY + c];
+      }
       y[i] -= l * y[k];
-      if constexpr (SPK) {
+      if constexpr (SPK && !BWD) {
 #pragma unroll
         for (int c = 0; c < NX; ++c) Z[i * NX + c] -= l * Z[k * NX + c];
       }
@@ -1302,6 +1323,25 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   }
 }
 
+// Stage kinds whose dense blocks are much larger than the rest (e.g. the end stages that carry the pin constraints: 13 x 13
+// instead of 9 x 9 for the acrobot) would dictate the register allocation of the whole sweep although they run once per
+// horizon: they are called out of line on copies of the loop-carried state, so that the common stages keep theirs in
+// registers and the two-wavefront-per-SIMD form of the sweep does not spill in its hot loop.
+template <class M, int K>
+constexpr bool heavy_kind() {
+  using D = KindDims<M, K>;
+  return D::BD * (D::BD + 1) / 2 + D::BD * D::NY > 100;
+}
+template <class M, int K, bool SPK>
+__device__ __attribute__((noinline)) void stage_forward_cold(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
+                                                            bool first, bool need, Carry<M>* cy, Spike<M>* sp, int* okneg) {
+  bool ok = okneg[0] != 0;
+  int nneg = okneg[1];
+  stage_forward<M, K, SPK>(a, g, t, mu, dw, gam, first, need, *cy, *sp, ok, nneg);
+  okneg[0] = ok ? 1 : 0;
+  okneg[1] = nneg;
+}
+
 // CHUNKED = false: the plain sequential sweep (P = 1) without any spike code -- a separate instantiation because the
 // spike blocks are what pushes the register count of the chunked form beyond one wavefront per SIMD
 template <class M, bool CHUNKED>
@@ -1328,7 +1368,18 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
     if (!CHUNKED || p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_forward<M, decltype(kc)::value, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+        constexpr int K = decltype(kc)::value;
+        if constexpr (!CHUNKED && heavy_kind<M, K>()) {
+          Carry<M> cyc = cy;
+          Spike<M> spc = sp;
+          int okneg[2] = {ok ? 1 : 0, nneg};
+          stage_forward_cold<M, K, false>(a, g, t, mu, dw, gam, false, need, &cyc, &spc, okneg);
+          cy = cyc;
+          ok = okneg[0] != 0;
+          nneg = okneg[1];
+        } else {
+          stage_forward<M, K, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+        }
       });
     } else if constexpr (CHUNKED) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
@@ -1577,19 +1628,11 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   double dinv[BD];
   bool ok_unused = true;
   int nneg_unused = 0;
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, keep);
+  stage_factor<M, K, SPK, true>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, keep,
+                                xn, xL);
   double v[BD];
 #pragma unroll
-  for (int i = 0; i < BD; ++i) {
-    double r = w[i];
-#pragma unroll
-    for (int c = 0; c < NY; ++c) r -= X[i * NY + c] * xn[c];
-    if constexpr (SPK) {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) r -= Z[i * NX + c] * xL[c];
-    }
-    v[i] = r * dinv[i];
-  }
+  for (int i = 0; i < BD; ++i) v[i] = w[i] * dinv[i];
 #pragma unroll
   for (int i = BD - 1; i >= 1; --i) {
 #pragma unroll
@@ -1690,7 +1733,10 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   for (int t = t1 - 1; t >= t0; --t) {
     if (!CHUNKED || p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        stage_backward<M, decltype(kc)::value, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
+        constexpr int K = decltype(kc)::value;
+        {
+          stage_backward<M, K, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
+        }
       });
     } else if constexpr (CHUNKED) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
