@@ -61,7 +61,8 @@ enum dto_scal {
   SC_COUNT
 };
 
-constexpr int DTO_NPART = 10;   // per-stage residual partials written by k_stage_eval
+constexpr int DTO_NPART = 10;   // residual partials written by k_stage_eval
+constexpr int DTO_SB = 8;       // consecutive stages one wavefront of the stage-parallel kernels walks (partials summed in registers)
 constexpr int DTO_LS_TRIALS = 8;
 constexpr int DTO_FILTER_CAP = 24;  // filter entries kept per instance (ring)
 
@@ -464,10 +465,20 @@ static __global__ __launch_bounds__(WAVE) void k_rearm(dto_kkt_args a) {
 // ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
-  const int64_t g = blockIdx.x / a.T;
-  const int t = blockIdx.x % a.T;
+  // a wavefront walks DTO_SB consecutive stages: the residual partials are summed in registers in stage order (one row set
+  // per block instead of one per stage goes to memory), and E_t' lambda_t is handed to the next stage instead of
+  // re-evaluating the previous stage's Jacobian there
+  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
+  const int64_t g = blockIdx.x / nblk;
+  const int blk = blockIdx.x % nblk;
   const dto_solver_opts& o = a.opt;
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;  // finished instance: its record stays frozen
+  double A_f = 0.0, A_th1 = 0.0, A_thinf = 0.0, A_dinf = 0.0, A_szmax = 0.0, A_isz = 0.0, A_sumlam = 0.0, A_sumz = 0.0,
+         A_logbar = 0.0, A_xmax = 0.0;
+  double ecarry[M::MAX_NX], enext[M::MAX_NX];   // E_{t-1}' lambda_{t-1} from the previous stage / E_t' lambda_t for the next
+  bool have_carry = false;
+  const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
+  for (int t = blk * DTO_SB; t < t_end; ++t) {
   dispatch_uniform<M>(a.kind[t], [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -523,6 +534,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       arr<DY::NJ> jv;
       DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jv.data());
       DY::jtlam(jv.data(), lam.data(), rp.data());
+#pragma unroll
+      for (int i = 0; i < M::MAX_NX; ++i) enext[i] = 0.0;
+      DY::etlam(jv.data(), lam.data(), enext);
       if constexpr (!D::FUSED) {
 #pragma unroll
         for (int i = 0; i < DY::NJ; ++i) put(D::R_DJ + i, jv[i]);
@@ -586,9 +600,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         sumlam += fabs(nu[j]);
       }
     }
-    // E_{t-1}' lam_{t-1}: re-evaluate the previous stage's Jacobian (cheaper than a carry pass)
+    // E_{t-1}' lam_{t-1}: handed over by the previous stage of this block; the first stage of a block re-evaluates the
+    // previous stage's Jacobian (cheaper than a carry pass through memory)
     if constexpr (KD::PREV >= 0) {
       using DP = typename M::template Dyn<KD::PREV>;
+      if (have_carry) {
+#pragma unroll
+        for (int i = 0; i < DP::NY; ++i) rp[i] += ecarry[i];
+      } else {
       arr<DP::NX + DP::NU> pp; arr<DP::NY> lamp; arr<DP::NW> w; arr<DP::NJ> jv;
       load_params(w, a, g, t - 1);
 #pragma unroll
@@ -597,6 +616,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, a.cdoff[t - 1] + i);
       DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
       DP::etlam(jv.data(), lamp.data(), rp.data());
+      }
     }
     if constexpr (D::QN) {
       // ---- partitioned SR1 on the element Hessian of this stage
@@ -716,18 +736,32 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         }
       }
     }
-    double* part = a.part + (((g * a.T + t) * DTO_NPART) << 6) + threadIdx.x;
-    part[0 << 6] = cost_val;
-    part[1 << 6] = th1;
-    part[2 << 6] = thinf;
-    part[3 << 6] = dinf;
-    part[4 << 6] = szmax;
-    part[5 << 6] = iszmax;
-    part[6 << 6] = sumlam;
-    part[7 << 6] = sumz;
-    part[8 << 6] = logbar;
-    part[9 << 6] = xmax;
+    A_f += cost_val;
+    A_th1 += th1;
+    A_thinf = fmax(A_thinf, thinf);
+    A_dinf = fmax(A_dinf, dinf);
+    A_szmax = fmax(A_szmax, szmax);
+    A_isz = fmax(A_isz, iszmax);
+    A_sumlam += sumlam;
+    A_sumz += sumz;
+    A_logbar += logbar;
+    A_xmax = fmax(A_xmax, xmax);
+    have_carry = (KD::DYN >= 0);
+#pragma unroll
+    for (int i = 0; i < M::MAX_NX; ++i) ecarry[i] = enext[i];
   });
+  }
+  double* part = a.part + (((g * nblk + blk) * DTO_NPART) << 6) + threadIdx.x;
+  part[0 << 6] = A_f;
+  part[1 << 6] = A_th1;
+  part[2 << 6] = A_thinf;
+  part[3 << 6] = A_dinf;
+  part[4 << 6] = A_szmax;
+  part[5 << 6] = A_isz;
+  part[6 << 6] = A_sumlam;
+  part[7 << 6] = A_sumz;
+  part[8 << 6] = A_logbar;
+  part[9 << 6] = A_xmax;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -743,8 +777,11 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
   double acc[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-  for (int t = a.cstart[p]; t < a.cstart[p + 1]; ++t) {
-    const double* row = in + (((g * a.T + t) * NV) << 6) + threadIdx.x;
+  // a block of DTO_SB stages belongs to the chunk that holds its first stage (every block is counted exactly once)
+  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
+  const int b0 = (a.cstart[p] + DTO_SB - 1) / DTO_SB, b1 = (a.cstart[p + 1] + DTO_SB - 1) / DTO_SB;
+  for (int t = b0; t < b1; ++t) {
+    const double* row = in + (((g * nblk + t) * NV) << 6) + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const double v = row[(int64_t)k << 6];
@@ -1779,13 +1816,23 @@ static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) {
 // ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
-  const int64_t g = blockIdx.x / a.T;
-  const int t = blockIdx.x % a.T;
+  // a wavefront walks DTO_SB consecutive stages and sums the merit partials of the eight trial step sizes in registers
+  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
+  const int64_t g = blockIdx.x / nblk;
+  const int blk = blockIdx.x % nblk;
   const dto_solver_opts& o = a.opt;
   const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const double mu = sc[SC_MU << 6];
   const double amax = sc[SC_ALPHA_PMAX << 6];
+  // the trial loop stays rolled (one copy of the model code, few registers: three wavefronts per SIMD); its sixteen
+  // running sums are indexed by the trial number, so they live in LDS (8 KiB per wavefront, lane-private columns)
+  __shared__ double s_acc[2 * DTO_LS_TRIALS * WAVE];
+  double* acc = s_acc + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2 * DTO_LS_TRIALS; ++k) acc[k * WAVE] = 0.0;
+  const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
+  for (int t = blk * DTO_SB; t < t_end; ++t) {
   dispatch_uniform<M>(a.kind[t], [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -1806,10 +1853,17 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
     }
     arr<CO::NW> w;
     load_params(w, a, g, t);
-    double* out = a.lspart + (((g * a.T + t) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
     double blo[D::NP > 0 ? D::NP : 1], bhi[D::NP > 0 ? D::NP : 1];  // bounds: loaded once, not once per trial
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) { blo[i] = a.lo[z0 + i]; bhi[i] = a.hi[z0 + i]; }
+    double sl[D::QI > 0 ? D::QI : 1], dsl[D::QI > 0 ? D::QI : 1];
+    if (!o.newton_only) {
+#pragma unroll
+      for (int j = 0; j < D::QI; ++j) {
+        sl[j] = *soa(a.s, g, a.Ni, a.ioff[t] + j);
+        dsl[j] = *soa(a.ds, g, a.Ni, a.ioff[t] + j);
+      }
+    }
     double alpha = amax;
 #pragma unroll 1
     for (int k = 0; k < DTO_LS_TRIALS; ++k) {
@@ -1849,18 +1903,22 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
         for (int j = 0; j < C::NC; ++j) {
           double r = c[j];
           if (!o.newton_only && D::ineq(j)) {
-            const double sk = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) + alpha * *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j));
+            const double sk = sl[D::slack(j)] + alpha * dsl[D::slack(j)];
             r += sk;
             phi -= mu * log(sk);
           }
           th += fabs(r);
         }
       }
-      out[(int64_t)(2 * k) << 6] = phi;
-      out[(int64_t)(2 * k + 1) << 6] = th;
+      acc[(2 * k) * WAVE] += phi;
+      acc[(2 * k + 1) * WAVE] += th;
       alpha *= 0.5;
     }
   });
+  }
+  double* out = a.lspart + (((g * nblk + blk) * (2 * DTO_LS_TRIALS)) << 6) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2 * DTO_LS_TRIALS; ++k) out[(int64_t)k << 6] = acc[k * WAVE];
 }
 
 static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
@@ -2058,6 +2116,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   const dto_kkt_args& a = *args;
   const unsigned gt = (unsigned)((int64_t)a.G * a.T);
+  const unsigned gb = (unsigned)((int64_t)a.G * ((a.T + DTO_SB - 1) / DTO_SB));  // blocks of DTO_SB stages
   if constexpr (M::HAS_GENERAL) {
     return (int)hipErrorNotSupported;
   } else {
@@ -2088,7 +2147,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         break;
       }
       case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gb), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_CONV:
         // slots 2..5 and 9 (theta_inf, dual inf, max s*z, max 1/(s*z), max |x|) are maxima, the others sums
         hipLaunchKernelGGL(k_part_reduce<DTO_NPART>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
@@ -2118,7 +2177,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gb), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LS_REDUCE:
         hipLaunchKernelGGL(k_part_reduce<2 * DTO_LS_TRIALS>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
                            (const double*)a.lspart, 0u);
