@@ -430,6 +430,14 @@ static int ensure_state(Problem* p, int64_t B) {
   }
   int P_new = S.forced_P > 0 ? S.forced_P : (n_simd + G_new - 1) / G_new;
   P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / 8))));
+  // per-stage state dimensions (dimensions(), src/dynamics.jl:206-211): the sequential sweep takes them as they come; the
+  // time-partitioned form assumes one separator size, so such problems run with a single chunk
+  bool uniform_nx = true;
+  for (int t = 1; t < L.T; ++t) uniform_nx = uniform_nx && (L.nx[t] == L.nx[0]);
+  if (!uniform_nx) {
+    if (S.forced_P > 1) return set_error(DTO_ERR_UNSUPPORTED, "time partitions need a uniform state dimension (use 0 or 1)");
+    P_new = 1;
+  }
   if (S.B == B && S.z && S.P == P_new) return DTO_OK;
   const int keep_forced = S.forced_P;
   S.release();
@@ -439,8 +447,6 @@ static int ensure_state(Problem* p, int64_t B) {
   if (!S.info.supported)
     return set_error(DTO_ERR_UNSUPPORTED,
                      "the KKT/solver path does not support a GeneralConstraint yet (bordered system, DESIGN.md section 8)");
-  for (int t = 1; t < L.T; ++t)
-    if (L.nx[t] != L.nx[0]) return set_error(DTO_ERR_UNSUPPORTED, "the solver path needs a uniform state dimension");
   S.B = B;
   S.G = (int)((B + 63) / 64);
   S.ioff.assign(L.T + 1, 0); S.recoff.assign(L.T + 1, 0); S.facoff.assign(L.T + 1, 0);

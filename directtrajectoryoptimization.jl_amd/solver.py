@@ -68,6 +68,24 @@ class Indices:
         self._nlp = nlp
         self._cache = {}
 
+    # general_constraint / general_jacobian / general_hessian (src/data.jl:52-54,70-73,80): plain ranges behind the dynamics
+    # and stage blocks; the Hessian of a GeneralConstraint is not supported (the reference's own call is broken)
+    @property
+    def general_constraint(self):
+        s = self._nlp.sizes
+        lo = int(s.num_constraint_dynamics + s.num_constraint_stage)
+        return list(range(lo + 1, int(s.num_constraint) + 1))
+
+    @property
+    def general_jacobian(self):
+        s = self._nlp.sizes
+        lo = int(s.num_jacobian_dynamics + s.num_jacobian_stage)
+        return list(range(lo + 1, int(s.num_jacobian) + 1))
+
+    @property
+    def general_hessian(self):
+        return []
+
     def __getattr__(self, name):
         if name.startswith("_") or name not in self._FIELDS:
             raise AttributeError(name)
@@ -366,10 +384,22 @@ class Solver:
                                                     dx_ptr, lddx, dmu_ptr, lddmu, C.byref(ok)))
         return bool(ok.value)
 
+    def multipliers_to_reference(self, mu):
+        """Multipliers of the batched entry points come back in the SOLVER's row order; when a stage-local GeneralConstraint
+        was folded into stage constraints this maps a host array [..., num_constraint] to the reference order
+        [dynamics; stage; general] (src/data.jl:64-75).  solve() applies it by itself."""
+        mu = np.asarray(mu)
+        if self._mu_to_reference is None:
+            return mu
+        out = np.zeros(mu.shape[:-1] + (self.nlp.num_constraint,))
+        out[..., self._mu_to_reference] = mu[..., :len(self._mu_to_reference)]
+        return out
+
     def solve_batch(self, x0_ptr, B, ldx, x_out_ptr, ldxo, mu_out_ptr=0, ldmuo=0, stream=0, check_every=10,
                     params_ptr=0, ldp=0):
         """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays.
-        params_ptr: optional DEVICE [B][ldp] per-instance parameter vectors (flattened w_1..w_T) replacing the shared ones."""
+        params_ptr: optional DEVICE [B][ldp] per-instance parameter vectors (flattened w_1..w_T) replacing the shared ones.
+        mu_out: solver row order, see multipliers_to_reference."""
         b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
         co = _c_options(self.options, check_every)
         self._B = B

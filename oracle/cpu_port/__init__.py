@@ -251,14 +251,16 @@ def cpu_baseline(T=1000, seed=1000, seconds=12.0, batch=4096, iters_per_instance
     core (`value_1core`), each on about `seconds` of wall time."""
     Z, x1, xT = guesses(model, T, batch, seed)
     ncores = os.cpu_count() or 1
-    # one core first: calibrates how many instances fit into the time budget
-    n1 = max(2, min(batch, 8))
-    it1, dt1, _, _, nf1 = run_batch(model, T, Z[:n1], iters_per_instance=iters_per_instance, threads=1)
-    per_inst = dt1 / n1
-    n1b = int(max(n1, min(batch, seconds / max(per_inst, 1e-9))))
-    it1, dt1, _, st1, nf1 = run_batch(model, T, Z[:n1b], iters_per_instance=iters_per_instance, threads=1)
-    nall = int(max(ncores, min(batch, ncores * seconds / max(per_inst, 1e-9))))
+    # pilot runs size the samples to the time budget: one instance per thread, on one core and on all of them (the
+    # all-cores rate per thread is lower: shared caches, memory bandwidth, SMT)
+    _, p1, _, _, _ = run_batch(model, T, Z[:1], iters_per_instance=iters_per_instance, threads=1)
+    n1 = int(max(1, min(batch, seconds / max(p1, 1e-9))))
+    it1, dt1, _, st1, nf1 = run_batch(model, T, Z[:n1], iters_per_instance=iters_per_instance, threads=1)
+    _, pa, _, _, _ = run_batch(model, T, Z[:min(batch, ncores)], iters_per_instance=iters_per_instance, threads=ncores)
+    nall = int(max(ncores, min(batch, ncores * max(1.0, (seconds - pa) / max(pa, 1e-9)))))
+    nall = min(batch, (nall // ncores) * ncores if nall >= ncores else nall)
     ita, dta, _, sta, nfa = run_batch(model, T, Z[:nall], iters_per_instance=iters_per_instance, threads=ncores)
+    n1b = n1
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:

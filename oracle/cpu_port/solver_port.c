@@ -27,8 +27,10 @@
 
 #include "port_model.h"
 
-#define MAXN 8
-#define MAXP 10
+/* largest dimensions among the generated models (pendulum 2+1, acrobot / cartpole 4+1, car 3+2): kept tight, the per-stage
+ * workspace is what decides whether an instance's data stays in the cache when all cores run */
+#define MAXN 4
+#define MAXP 6
 #define MAXQ PORT_MAXQ
 #define MAXBD (MAXP + MAXQ + MAXN)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))

@@ -184,3 +184,56 @@ def test_repack_of_running_instances_changes_nothing_but_the_cost():
     torch.cuda.synchronize()
     assert np.array_equal(st_c, st_a.astype(np.int32)) and np.array_equal(it_c, it_a.astype(np.int32)) and torch.equal(zc, za)
     assert len(set(it_a.tolist())) > 10                         # the instances really finished at different times
+
+
+def test_varying_state_dimensions_callbacks_kkt_step_and_solve():
+    """Per-stage state / action dimensions on the whole path (dimensions(), src/dynamics.jl:206-211; round-1 verdict: the
+    solver refused them): the five callbacks and one regularised KKT step against the oracle, then a converged solve whose
+    KKT conditions are evaluated with the oracle.  Such problems run the sequential sweep (one chunk)."""
+    import torch
+    import dto_amd
+    from dto_amd import capi
+    from oracle import dto_oracle as O
+    from test_layout import varying_dimension_problem
+    from test_solve_gpu import kkt_report
+    s = dto_amd.Solver(*varying_dimension_problem("product"), evaluate_hessian=True, name="varydims")
+    onlp = O.NLPData(*varying_dimension_problem("oracle"), evaluate_hessian=True)
+    n = s.nlp
+    nz, nc = n.num_variables, n.num_constraint
+    rng = np.random.default_rng(12)
+    z, mu = rng.random(nz), rng.random(nc)
+    rel = lambda got, ref: np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3 * max(1e-300, np.max(np.abs(ref)))))
+    g = np.zeros(nz); n.eval_objective_gradient(g, z)
+    c = np.zeros(nc); n.eval_constraint(c, z)
+    J = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(J, z)
+    H = np.zeros(int(n.sizes.nnz_hess_key)); n.eval_hessian_lagrangian(H, z, 0.7, mu)
+    assert abs(n.eval_objective(z) - onlp.eval_objective(z)) <= 1e-8 * abs(onlp.eval_objective(z))
+    assert rel(g, onlp.eval_objective_gradient(z)) < 1e-8 and rel(c, onlp.eval_constraint(z)) < 1e-8
+    assert rel(J, onlp.eval_constraint_jacobian(z)) < 1e-8 and rel(H, onlp.eval_hessian_lagrangian(z, 0.7, mu)) < 1e-8
+    # KKT step
+    B, dw, dc = 2, 20.0, 1e-6
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    dZ, dMU = torch.tensor(Z, device="cuda"), torch.tensor(MU, device="cuda")
+    dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    ok = s.kkt_step_batch(dZ.data_ptr(), B, nz, dMU.data_ptr(), nc, dw, dc, dx.data_ptr(), nz, dl.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert s.partitions() == 1
+    for b in range(B):
+        Hd, Jd = dense_blocks(onlp, Z[b], MU[b])
+        K = np.block([[Hd + dw * np.eye(nz), Jd.T], [Jd, -dc * np.eye(nc)]])
+        rhs = -np.concatenate([onlp.eval_objective_gradient(Z[b]) + Jd.T @ MU[b], onlp.eval_constraint(Z[b])])
+        sol = np.linalg.solve(K, rhs)
+        assert np.max(np.abs(np.concatenate([dx[b].cpu().numpy(), dl[b].cpu().numpy()]) - sol)) <= 1e-8 * np.max(np.abs(sol))
+    assert ok
+    with pytest.raises(capi.DtoError, match="uniform state dimension"):
+        s.set_partitions(3)
+        try:
+            s.kkt_step_batch(dZ.data_ptr(), B, nz, dMU.data_ptr(), nc, dw, dc, dx.data_ptr(), nz, dl.data_ptr(), nc)
+        finally:
+            s.set_partitions(0)
+    # solve
+    s._z0[:] = 0.1 * rng.standard_normal(nz)
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    rep = kkt_report(onlp, s._solution, s._duals)
+    assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["compl"] <= 1e-3 and rep["sign_ok"], rep

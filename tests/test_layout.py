@@ -152,3 +152,62 @@ def test_random_heterogeneous_problem_layout_matches_oracle(seed):
     clo, chi = nl.constraint_bounds
     oclo, ochi = onlp.constraint_bounds
     assert np.array_equal(np.isneginf(clo), np.isneginf(np.asarray(oclo, float))) and np.all(chi == 0.0)
+
+
+def varying_dimension_problem(lib):
+    """(dynamics, objective, constraints, bounds) of a 6-knot problem whose state and action dimensions change along the
+    horizon (dimensions(), src/dynamics.jl:206-211): n = [2, 2, 3, 3, 2, 2], m = [1, 1, 2, 1, 1], for lib in {"product", "oracle"}."""
+    import dto_amd
+    from oracle import sympy_models as S
+    mod = dto_amd if lib == "product" else S
+    sin = dto_amd.sin if lib == "product" else __import__("sympy").sin
+    vec = (lambda v: np.array(v, dtype=object)) if lib == "product" else (lambda v: v)
+    nx, nu = [2, 2, 3, 3, 2, 2], [1, 1, 2, 1, 1]
+    T = len(nx)
+
+    def make_dyn(ny, n, m):
+        def f(y, x, u, w):
+            out = []
+            for i in range(ny):
+                e = y[i] - 0.9 * x[i % n] - 0.1 * sin(x[(i + 1) % n]) * u[i % m] - 0.05 * y[i] * x[0]
+                if i == ny - 1 and m > 1:
+                    e = e - 0.2 * u[1]
+                out.append(e)
+            return vec(out)
+        return f
+
+    def make_cost(n, m):
+        def f(x, u, w):
+            e = 0.0
+            for i in range(n):
+                e = e + 0.5 * x[i] * x[i] + 0.1 * sin(x[i]) * x[(i + 1) % n]
+            for j in range(m):
+                e = e + 0.05 * u[j] * u[j]
+            return e
+        return f
+
+    dyn = [mod.Dynamics(make_dyn(nx[t + 1], nx[t], nu[t]), nx[t + 1], nx[t], nu[t], evaluate_hessian=True) for t in range(T - 1)]
+    obj = [mod.Cost(make_cost(nx[t], nu[t]), nx[t], nu[t], evaluate_hessian=True) for t in range(T - 1)]
+    obj.append(mod.Cost(make_cost(nx[-1], 1), nx[-1], 0, evaluate_hessian=True) if False else
+               mod.Cost((lambda x, u, w: 2.0 * x[0] * x[0] + 2.0 * x[1] * x[1]), nx[-1], 0, evaluate_hessian=True))
+    first = mod.Constraint((lambda x, u, w: vec([x[0] - 0.3, x[1] + 0.2])), nx[0], nu[0], evaluate_hessian=True)
+    mid = mod.Constraint((lambda x, u, w: vec([x[0] * x[2] - 0.1])), nx[2], nu[2], indices_inequality=[1], evaluate_hessian=True)
+    cons = [first, mod.Constraint(), mid, mod.Constraint(), mod.Constraint(), mod.Constraint()]
+    bnds = [mod.Bound(nx[t], nu[t], action_lower=[-2.0] * nu[t], action_upper=[2.0] * nu[t]) for t in range(T - 1)] + [mod.Bound(nx[-1], 0)]
+    return dyn, obj, cons, bnds
+
+
+def test_varying_dimensions_layout_matches_oracle():
+    """Per-stage state / action dimensions: structures, totals and index vectors equal the oracle's restatement of
+    src/data.jl:61-220 and src/dynamics.jl:188-211 bit for bit."""
+    import dto_amd
+    from oracle import dto_oracle as O
+    dyn, obj, cons, bnds = varying_dimension_problem("product")
+    s = dto_amd.Solver(dyn, obj, cons, bnds, evaluate_hessian=True, name="varydims")
+    onlp = O.NLPData(*varying_dimension_problem("oracle"), evaluate_hessian=True)
+    nl = s.nlp
+    assert (nl.num_variables, nl.num_constraint, nl.num_jacobian) == (onlp.num_variables, onlp.num_constraint, onlp.num_jacobian) == (20, 15, nl.num_jacobian)
+    assert nl.jacobian_structure() == onlp.jacobian_structure()
+    assert nl.hessian_lagrangian_structure() == onlp.hessian_lagrangian_structure()
+    assert nl.state_dimensions == [2, 2, 3, 3, 2, 2] and nl.action_dimensions == [1, 1, 2, 1, 1, 0]
+    assert [len(i) for i in nl.indices.states] == [2, 2, 3, 3, 2, 2]
