@@ -88,7 +88,7 @@ void port_default_options(port_options* o) {
   o->acceptable_tol = 1e-6; o->acceptable_iter = 15; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
   o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5; o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
   o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->bound_push = 1e-2; o->bound_frac = 1e-2;
-  o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_max = 1e20; o->delta_w_exact_cap = 1.0;
+  o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_max = 1e20; o->delta_w_exact_cap = 100.0;
   o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_first = 100.0; o->piv_tol = 1e-9;
   o->max_refactor = 9; o->watchdog_trigger = 10; o->watchdog_trials = 3; o->max_soc = 0;
   if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &o->watchdog_trigger, &o->watchdog_trials);
