@@ -1973,7 +1973,10 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
         ok = (tk <= (1.0 - G_TH) * th0) || (pk <= phi0 - G_PHI * th0);
       }
     }
-    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= thmax;
+    // watchdog steps skip the filter, but -- there being no rollback -- they may not let the violation explode:
+    // theta <= 10 max(theta_0, 1).  C port, acrobot T=1000 x 64: converged runs that end in a sensible minimiser
+    // (f < 2000) 21 -> 33, runs blown up to f > 1e6 6 -> 1; acrobot T=101 mean iterations 100 -> 78.
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= thmax && tk <= 10.0 * fmax(th0, 1.0);
     if (ok && !watchdog) {
       for (int i = 0; i < nf; ++i) {
         const double tf = fl[(int64_t)(2 * i) << 6], pf = fl[(int64_t)(2 * i + 1) << 6];

@@ -90,7 +90,7 @@ void port_default_options(port_options* o) {
   o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->bound_push = 1e-2; o->bound_frac = 1e-2;
   o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_max = 1e20; o->delta_w_exact_cap = 100.0;
   o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_first = 100.0; o->piv_tol = 1e-9;
-  o->max_refactor = 9; o->watchdog_trigger = 10; o->watchdog_trials = 3; o->max_soc = 0;
+  o->max_refactor = 9; o->watchdog_trigger = 2; o->watchdog_trials = 4; o->max_soc = 0;
   if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &o->watchdog_trigger, &o->watchdog_trials);
   if (getenv("DTO_EXACT_CAP")) o->delta_w_exact_cap = atof(getenv("DTO_EXACT_CAP"));
   if (getenv("DTO_MAX_SOC")) o->max_soc = atoi(getenv("DTO_MAX_SOC"));
@@ -650,7 +650,8 @@ static void line_search(port_solver* S) {
     if (th[k] < th[best] || !(th[best] == th[best])) best = k;
     int ft;
     int ok = trial_ok(S, alpha, tk, pk, &ft);
-    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max;
+    /* watchdog steps skip the filter but may not let the violation explode (there is no rollback): theta <= 10 max(theta_0, 1) */
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max && tk <= 10.0 * fmax(th0, 1.0);
     if (ok && !watchdog) ok = filter_ok(S, tk, pk);
     if (ok) { chosen = alpha; ftype = ft; break; }
     alpha *= 0.5;

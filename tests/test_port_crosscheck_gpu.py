@@ -63,8 +63,9 @@ def test_iteration_history_matches_cpu_port(model, T, seed):
     assert gh[-1][5] == 1 and ph[-1][5] == 1
     # identical decisions (step size, regularisation) and objective history while rounding has not yet
     # tipped a borderline inertia/filter decision: the whole run for the mildly nonconvex pendulum, at
-    # least the first 12 iterations of the long nonconvex acrobot path
-    need = len(ph) if model == "pendulum" else 12
+    # least the first 8 iterations of the long nonconvex acrobot path (the watchdog now fires after two shortened steps, so
+    # the first borderline filter decision comes early)
+    need = len(ph) if model == "pendulum" else 8
     agree = 0
     for a, b in zip(gh, ph):
         same = (a[0] == b[0] and abs(a[1] - b[1]) <= 1e-6 * max(1.0, abs(b[1])) and a[3] == b[3]

@@ -316,10 +316,11 @@ def test_initial_point_is_pushed_into_the_bounds():
 
 
 def test_watchdog_state_machine():
-    """Ipopt's watchdog (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3), rollback-free form of
-    k_ls_reduce: after 10 consecutive iterations whose step the filter cut below the fraction-to-the-boundary step, the
-    next 3 iterations take that step unfiltered (ls_kind 3, alpha == alpha_pmax) and do not touch the filter; then the
-    count starts again.  Cartpole T=200 is the case that needs it."""
+    """Ipopt's watchdog (its defaults: watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; here (2, 4), see
+    csrc/dto_solver.cpp:default_opts), rollback-free form of k_ls_reduce: after TRIGGER consecutive iterations whose step
+    the filter cut below the fraction-to-the-boundary step, the
+    next TRIALS iterations take that step unfiltered (ls_kind 3; shortened only if the violation would grow beyond
+    10 max(theta, 1): there is no rollback) and do not touch the filter; then the count starts again.  Cartpole T=200 is the case that needs it."""
     import torch
     import dto_amd
     s, p = product_solver("cartpole", 200)
@@ -332,6 +333,7 @@ def test_watchdog_state_machine():
     s.options.max_iter = 1000
     try:
         s.begin_batch(z0.data_ptr(), 1, nz)
+        TRIGGER, TRIALS = 2, 4
         streak, left, fired = 0, 0, 0
         for it in range(150):
             nf0 = float(s.scalar_batch("filter_n")[0])
@@ -341,7 +343,7 @@ def test_watchdog_state_machine():
                 break
             al, ap, kind = (float(s.scalar_batch(k)[0]) for k in ("alpha", "alpha_pmax", "ls_kind"))
             if left > 0:                                   # a watchdog iteration
-                assert kind == 3.0 and al == ap, (it, kind, al, ap)
+                assert kind == 3.0 and al <= ap, (it, kind, al, ap)       # full step unless it would blow the violation up 10x
                 if float(s.scalar_batch("mu")[0]) == mu0:  # (a barrier update resets the filter)
                     assert float(s.scalar_batch("filter_n")[0]) == nf0
                 left -= 1
@@ -350,8 +352,8 @@ def test_watchdog_state_machine():
             else:
                 assert kind != 3.0, (it, kind)
                 streak = streak + 1 if al < ap else 0
-                if streak >= 10:
-                    left, streak = 3, 0
+                if streak >= TRIGGER:
+                    left, streak = TRIALS, 0
             assert float(s.scalar_batch("watchdog")[0]) == left and float(s.scalar_batch("short_streak")[0]) == streak
         assert fired >= 3                                   # the mechanism was exercised
     finally:
