@@ -650,8 +650,8 @@ static void line_search(port_solver* S) {
     if (th[k] < th[best] || !(th[best] == th[best])) best = k;
     int ft;
     int ok = trial_ok(S, alpha, tk, pk, &ft);
-    /* watchdog steps skip the filter but may not let the violation explode (there is no rollback): theta <= 10 max(theta_0, 1) */
-    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max && tk <= 10.0 * fmax(th0, 1.0);
+    /* watchdog steps skip the filter but may not let the violation explode (there is no rollback): theta <= 3 max(theta_0, 1) */
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max && tk <= 3.0 * fmax(th0, 1.0);
     if (ok && !watchdog) ok = filter_ok(S, tk, pk);
     if (ok) { chosen = alpha; ftype = ft; break; }
     alpha *= 0.5;

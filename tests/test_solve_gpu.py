@@ -320,7 +320,7 @@ def test_watchdog_state_machine():
     csrc/dto_solver.cpp:default_opts), rollback-free form of k_ls_reduce: after TRIGGER consecutive iterations whose step
     the filter cut below the fraction-to-the-boundary step, the
     next TRIALS iterations take that step unfiltered (ls_kind 3; shortened only if the violation would grow beyond
-    10 max(theta, 1): there is no rollback) and do not touch the filter; then the count starts again.  Cartpole T=200 is the case that needs it."""
+    3 max(theta, 1): there is no rollback) and do not touch the filter; then the count starts again.  Cartpole T=200 is the case that needs it."""
     import torch
     import dto_amd
     s, p = product_solver("cartpole", 200)
@@ -343,7 +343,7 @@ def test_watchdog_state_machine():
                 break
             al, ap, kind = (float(s.scalar_batch(k)[0]) for k in ("alpha", "alpha_pmax", "ls_kind"))
             if left > 0:                                   # a watchdog iteration
-                assert kind == 3.0 and al <= ap, (it, kind, al, ap)       # full step unless it would blow the violation up 10x
+                assert kind == 3.0 and al <= ap, (it, kind, al, ap)       # full step unless it would blow the violation up 3x
                 if float(s.scalar_batch("mu")[0]) == mu0:  # (a barrier update resets the filter)
                     assert float(s.scalar_batch("filter_n")[0]) == nf0
                 left -= 1
