@@ -245,6 +245,7 @@ def main():
                       iteration_limit=int(np.sum(status_end == 2)), failed=int(np.sum((status_end == 3) | (status_end == 5))),
                       still_running=int(np.sum(status_end == 0)), instances=B,
                       iterations_median=float(np.median(it1)), iterations_mean=float(np.mean(it1)),
+                      converged_solves_per_sec=round(float(np.sum(status_end == 1)) / dt, 1),
                       profile=[dict(iterations=int(k), seconds=round(t, 3), running=r) for k, t, r in profile[:: max(1, len(profile) // 10)]]
                       + [dict(iterations=int(profile[-1][0]), seconds=round(profile[-1][1], 3), running=int(np.sum(status_end == 0)))],
                       note="rank 0's shard; status per instance after the timed iterations")
