@@ -146,9 +146,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed solver iterations (default: the reference's max_iter = a full solve)")
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=131072,
+    ap.add_argument("--batch", type=int, default=196608,
                     help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance; "
-                         ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD, DESIGN.md section 5)")
+                         ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD and the larger batch keeps the GPU "
+                         "filled while instances converge and leave, DESIGN.md sections 5, 7)")
     ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")
     ap.add_argument("--loop-only", action="store_true",
                     help="run only the headline loop (warm-up + timed iterations) and print value / ms_per_step: the command "
@@ -313,13 +314,14 @@ def main():
                     kernel_avg_launch_ms={kname[k]: round(v, 5) for k, v in avg_ms.items()})
 
     # ---- Jacobian assembly (the MOI callback, instance-major, reference COO order)
-    jout = torch.empty((B, nj), device=dev, dtype=torch.float64)
-    jfn = lambda: n.eval_constraint_jacobian_batch(z0.data_ptr(), B, nz, jout.data_ptr(), nj, st)
+    Bj = min(B, 32768)                                         # 6.8 GB of output: enough to fill the GPU, leaves HBM to the solver state
+    jout = torch.empty((Bj, nj), device=dev, dtype=torch.float64)
+    jfn = lambda: n.eval_constraint_jacobian_batch(z0.data_ptr(), Bj, nz, jout.data_ptr(), nj, st)
     for _ in range(3):
         jfn()
     jac_ms = event_time_ms(jfn, 20)
-    jac_bytes = B * (8 * nz + 8 * nj)
-    jac = dict(kernel="k_jac", nnz_per_sec=B * nj / (jac_ms * 1e-3), avg_launch_ms=round(jac_ms, 4),
+    jac_bytes = Bj * (8 * nz + 8 * nj)
+    jac = dict(kernel="k_jac", instances=Bj, nnz_per_sec=Bj * nj / (jac_ms * 1e-3), avg_launch_ms=round(jac_ms, 4),
                achieved_GBps=round(jac_bytes / (jac_ms * 1e-3) / 1e9, 1),
                frac_of_hbm_peak=round(jac_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     jt = torch.tensor([jac["nnz_per_sec"]], device=dev, dtype=torch.float64)
