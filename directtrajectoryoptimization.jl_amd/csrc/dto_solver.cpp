@@ -52,8 +52,13 @@ struct SolverState {
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
   double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr, *cpart = nullptr;
-  int P = 1;            // chunks of the time-partitioned factorisation
+  int P = 1;            // chunks of the time-partitioned factorisation (current)
+  int P0 = 1;           // ... as chosen when the batch was loaded; P_cap: what the chunk arrays are sized for
+  int P_cap = 1;
   int forced_P = 0;     // 0 = choose from the batch size
+  int n_simd = 1024;
+  int* d_cstart_all = nullptr;   // chunk boundaries for P = 1 .. P_cap back to back (a batch that started sequential may
+                                 // switch to 2 / 4 chunks when repacking has left too few tiles to fill the GPU)
   std::vector<int> cstart;
   int* d_cstart = nullptr;
   dto_kkt_info info{};
@@ -66,12 +71,12 @@ struct SolverState {
     for (void* p : {(void*)d_ioff, (void*)d_recoff, (void*)d_facoff, (void*)d_lo, (void*)d_hi, (void*)z, (void*)lam,
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
-                    (void*)cacc, (void*)cpart, (void*)d_cstart, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
+                    (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
                     (void*)d_src_slot, (void*)repack_tmp})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; wtile = nullptr; use_wtile = false;
+    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
     d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
     inst_of_slot.clear(); slot_of_inst.clear();
@@ -420,6 +425,18 @@ static int dev_alloc(T** p, size_t count) {
   return DTO_OK;
 }
 
+// switch the number of chunks among those the state was allocated for (dto_solver_repack; back to P0 when a batch is loaded)
+static void set_partitions_now(SolverState& S, int P) {
+  if (S.P_cap > S.P0) {            // blocks for q = 1 .. P_cap back to back: block q starts at sum_{r<q} (r + 1)
+    int off = 0;
+    for (int q = 1; q < P; ++q) off += q + 1;
+    S.d_cstart = S.d_cstart_all + off;
+  } else {
+    S.d_cstart = S.d_cstart_all;
+  }
+  S.P = P;
+}
+
 static int ensure_state(Problem* p, int64_t B) {
   int rc = p->ensure_device();
   if (rc) return rc;
@@ -445,11 +462,14 @@ static int ensure_state(Problem* p, int64_t B) {
     if (S.forced_P > 1) return set_error(DTO_ERR_UNSUPPORTED, "time partitions need a uniform state dimension (use 0 or 1)");
     P_new = 1;
   }
-  if (S.B == B && S.z && S.P == P_new) return DTO_OK;
+  if (S.B == B && S.z && S.P0 == P_new) { set_partitions_now(S, S.P0); return DTO_OK; }
   const int keep_forced = S.forced_P;
   S.release();
   S.forced_P = keep_forced;
-  S.P = P_new;
+  S.P = S.P0 = P_new;
+  S.n_simd = n_simd;
+  // a sequential batch (P = 1) with uniform dimensions may later run with up to 4 chunks (dto_solver_repack)
+  S.P_cap = (P_new == 1 && uniform_nx && S.forced_P == 0) ? std::max(1, std::min(4, L.T / 8)) : P_new;
   p->vt->kkt_info(&S.info);
   if (!S.info.supported)
     return set_error(DTO_ERR_UNSUPPORTED,
@@ -496,15 +516,25 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.lspart, lanes * (size_t)L.T * 2 * S.info.ls_trials))) return rc;
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
   if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
-  S.cstart.assign(S.P + 1, 0);
-  for (int c = 0; c <= S.P; ++c) S.cstart[c] = (int)(((int64_t)c * L.T) / S.P);
-  HIP_TRY(hipMalloc((void**)&S.d_cstart, (S.P + 1) * sizeof(int)));
-  HIP_TRY(hipMemcpy(S.d_cstart, S.cstart.data(), (S.P + 1) * sizeof(int), hipMemcpyHostToDevice));
-  if ((rc = dev_alloc(&S.csum, lanes * (size_t)S.P * S.info.chunk_sum_size))) return rc;
-  if ((rc = dev_alloc(&S.sfac, lanes * (size_t)S.P * S.info.sep_fac_size))) return rc;
-  if ((rc = dev_alloc(&S.xsep, lanes * (size_t)S.P * S.info.nx))) return rc;
-  if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P * 4))) return rc;
-  if ((rc = dev_alloc(&S.cpart, lanes * (size_t)S.P * 16))) return rc;
+  {
+    // chunk boundaries of every P in [1, P_cap] (or of the one fixed P), back to back: block q holds q + 1 entries
+    const int q_lo = (S.P_cap > S.P) ? 1 : S.P, q_hi = S.P_cap;
+    std::vector<int> all;
+    int off_cur = 0;
+    for (int q = q_lo; q <= q_hi; ++q) {
+      if (q == S.P) off_cur = (int)all.size();
+      for (int c = 0; c <= q; ++c) all.push_back((int)(((int64_t)c * L.T) / q));
+    }
+    S.cstart.assign(all.begin() + off_cur, all.begin() + off_cur + S.P + 1);
+    HIP_TRY(hipMalloc((void**)&S.d_cstart_all, all.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(S.d_cstart_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    S.d_cstart = S.d_cstart_all + off_cur;
+  }
+  if ((rc = dev_alloc(&S.csum, lanes * (size_t)S.P_cap * S.info.chunk_sum_size))) return rc;
+  if ((rc = dev_alloc(&S.sfac, lanes * (size_t)S.P_cap * S.info.sep_fac_size))) return rc;
+  if ((rc = dev_alloc(&S.xsep, lanes * (size_t)S.P_cap * S.info.nx))) return rc;
+  if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P_cap * 4))) return rc;
+  if ((rc = dev_alloc(&S.cpart, lanes * (size_t)S.P_cap * 16))) return rc;
   S.h_scal.assign(lanes * S.info.nscal, 0.0);
   // the zero fills and table copies above ran on the null stream; the kernels run on the caller's stream, which may be a
   // non-blocking one: order them once here (allocation time only)
@@ -653,6 +683,13 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   HIP_TRY(hipMemcpyAsync(S.d_inst_of_slot, S.inst_of_slot.data(), lanes * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));   // src / inst_new are host temporaries of this call
   S.G_active = g_new;
+  // too few tiles left for two wavefronts per SIMD: cut the horizon into chunks again (each chunk wave carries a spike, one
+  // wavefront per SIMD); the chunk arrays were sized for it when the batch was loaded
+  if (S.P_cap > S.P0) {
+    int P_new = 1;
+    while (P_new < S.P_cap && (int64_t)g_new * P_new * 8 <= (int64_t)S.n_simd * 7) P_new *= 2;   // fewer waves than ~7/8 of the SIMDs
+    set_partitions_now(S, std::min(P_new, S.P_cap));
+  }
   return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
 }
 
@@ -933,6 +970,7 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   S.opt.warm = 1;
   S.opt.mu_warm = mu0;
   S.G_active = S.G;   // every instance runs again (the slot map of an earlier dto_solver_repack stays valid)
+  dto::set_partitions_now(S, S.P0);
   S.use_sigx = S.use_sigc = S.assembled = false;
   hipStream_t st = (hipStream_t)b->stream;
   dto_kkt_args a;
