@@ -258,15 +258,19 @@ def main():
         torch.cuda.synchronize()
 
     # ---- per-kernel durations (HIP events on the launch stream): the launch sequence of an iteration is
-    #      replayed kernel by kernel for a few more iterations; averages are over ALL launches of a kernel,
-    #      including the rounds of k_kkt_fwd/k_kkt_sep that exit at once -- what `rocprofv3 --stats` reports.
+    #      replayed kernel by kernel for a few more iterations; averages are over ALL launches of a kernel (for the
+    #      time-partitioned form that includes the rounds of k_kkt_fwd/k_kkt_sep that exit at once) -- what
+    #      `rocprofv3 --stats` reports.
     fp = s.footprint()
     rounds = fp["factor_rounds"]
-    seq = (["eval", "conv"] + ["kkt_fwd", "kkt_sep"] * rounds + ["kkt_bwd", "kkt_post", "linesearch", "ls_reduce", "update"])
-    seq_sweep = s.partitions() == 1   # the plain sequential sweep has its own two-wavefront-per-SIMD instantiation
-    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd", kkt_sep="k_kkt_sep",
+    seq_sweep = s.partitions() == 1   # the sequential sweep: own two-wavefront-per-SIMD kernels, all rounds inside a launch, no k_kkt_sep
+    seq = (["eval", "conv"] + (["kkt_fwd"] * rounds if seq_sweep else ["kkt_fwd", "kkt_sep"] * rounds)
+           + ["kkt_bwd", "kkt_post", "linesearch", "ls_reduce", "update"])
+    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd",
                  kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd",
                  kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update")
+    if not seq_sweep:
+        kname["kkt_sep"] = "k_kkt_sep"
     tot = {k: 0.0 for k in kname}
     cnt = {k: 0 for k in kname}
     reps = 8
@@ -281,7 +285,9 @@ def main():
     avg_ms = {k: tot[k] / cnt[k] for k in kname}
     per_iter_ms = {k: tot[k] / reps for k in kname}
     nfact_per_iter = facts_done / max(iters_done, 1.0)
-    working = (nf_b - nf_a) / max(B * reps * rounds, 1)         # fraction of k_kkt_fwd launches x lanes that factorised
+    # factorisations per lane and k_kkt_fwd launch: < 1 for the time-partitioned sweep (one round per launch, launches of a
+    # finished tile exit at once), > 1 for the sequential sweep (every round of the inertia correction inside one launch)
+    working = (nf_b - nf_a) / max(B * reps * rounds, 1)
     # Algorithmic bytes per instance and launch.  The sweeps no longer read derivative values: they
     # re-evaluate them from the iterate.  What a sweep MUST move per stage is therefore: the iterate (p_t, x_{t+1}, lambda_t,
     # nu_t), the stage's right-hand side (record: r_p, d, c) and the carry that the backward sweep resumes from
@@ -293,7 +299,7 @@ def main():
     sweep_read = 8 * (nz + (T - 1) * nx_ + nc + rec_d)
     alg_bytes = dict(                                          # per instance and per launch
         eval=8 * (2 * nz + 2 * nc) + 8 * rec_d + 8 * 10 * T,   # iterate (+ previous stage for E'lambda), record and partials out
-        kkt_fwd=working * (sweep_read + 8 * carry_d),          # working launches only (the others exit at once)
+        kkt_fwd=working * (sweep_read + 8 * carry_d),          # per factorisation actually done by a lane
         kkt_bwd=sweep_read + 8 * carry_d + 8 * (nz + nc),      # + the step written
         linesearch=8 * (2 * nz + (T - 1) * 2 * nx_) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 10 * T, ls_reduce=8 * 16 * T,
         kkt_sep=8 * 64, kkt_post=8 * 4)
@@ -309,7 +315,8 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
                     algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
-                    working_fraction_of_launches=round(working, 4),
+                    factorizations_per_launch=round(working, 4),
+                    working_fraction_of_launches=round(min(1.0, (it_b - it_a) / max(B * reps, 1)) if rounds == 1 else working, 4),
                     kernel_ms_per_iteration={kname[k]: round(v, 4) for k, v in per_iter_ms.items()},
                     kernel_avg_launch_ms={kname[k]: round(v, 5) for k, v in avg_ms.items()})
 

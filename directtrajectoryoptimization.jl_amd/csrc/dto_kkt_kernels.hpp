@@ -126,6 +126,7 @@ struct dto_kkt_args {
   const double* rhs_x; int64_t ld_rhs_x; const double* rhs_c; int64_t ld_rhs_c;
   // slot -> instance map after dto_solver_repack moved the running instances to the front (NULL: identity)
   const int* inst_of_slot;
+  int fwd_rounds;  // sequential sweep: inertia-correction rounds per launch (0 = all)
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -1290,8 +1291,8 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   double Z[SPK ? BD * NX : 1];
   double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
   double dinv[BD];
-  // --- carry-in of this stage is all the backward sweep needs besides the stage record
-  if (need) {
+  // --- carry-in of this stage is all the backward sweep needs besides the stage record (not of a lost attempt)
+  if (need && (SPK || ok)) {
     double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NX * (NX + 1) / 2; ++i) fac[(int64_t)(D::F_P + i) << 6] = cy.P[i];
@@ -1302,7 +1303,13 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
       for (int i = 0; i < NX * NX; ++i) fac[(int64_t)(D::F_CX + i) << 6] = sp.Cx[i];
     }
   }
+  const int nneg_in = nneg;
   stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, nullptr);
+  // static pivot order: the primal pivots of the block come first and must be positive, the Q + NY constraint pivots
+  // negative; any other count means the inertia of the whole matrix is off (the sequential sweep gives up early on it)
+  if constexpr (!SPK) {
+    if (nneg - nneg_in != Q + NY) ok = false;
+  }
   // --- carry to the next stage: P = YY - X' D^-1 X, py = X' D^-1 w   (D^-1 X and D^-1 Z are formed once: the sweep is
   //     bound by dependent f64 arithmetic, not by memory)
   double XD[BD * (NY > 0 ? NY : 1)];
@@ -1379,70 +1386,130 @@ __device__ __attribute__((noinline)) void stage_forward_cold(const dto_kkt_args&
   okneg[1] = nneg;
 }
 
+// Outcome of one factorisation attempt of a lane: accept it, or put the next (delta_w, gamma) of the inertia-correction
+// ladder into SC_TRY_* and leave SC_NEED set.  Shared by k_kkt_sep (time-partitioned sweeps, one launch per round) and the
+// sequential sweep, which loops over its rounds inside one launch.
+__device__ __forceinline__ void retry_update(const dto_kkt_args& a, double* sc, bool ok, int nneg) {
+  const dto_solver_opts& o = a.opt;
+  // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
+  if (nneg != (int)a.Nc) ok = false;
+  sc[SC_NFACT << 6] += 1.0;
+  sc[SC_NNEG << 6] = (double)nneg;
+  double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
+  const double dlast = sc[SC_DELTA_LAST << 6];
+  const int attempt = (int)sc[SC_ATTEMPT << 6];
+  const bool done = ok || o.newton_only || attempt >= o.max_refactor;
+  if (done) {
+    sc[SC_NEED << 6] = 0.0;
+    sc[SC_DELTA_W << 6] = dw;
+    sc[SC_GAMMA << 6] = gam;
+    if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
+    if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
+    sc[SC_LS_FAIL << 6] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
+    sc[SC_QN_RESET << 6] = (gam == 0.0) ? 1.0 : 0.0;  // quasi-Newton: restart the element blocks after a fallback
+    return;
+  }
+  if (gam != 0.0) {
+    // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
+    // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
+    // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
+    const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
+    if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+    else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
+    if (skip_ladder || dw > o.delta_w_exact_cap) {
+      gam = 0.0;
+      dw = o.delta_w_init;
+    }
+  } else {
+    dw *= o.kappa_w_plus;
+    if (dw > o.delta_w_max) dw = o.delta_w_max;
+  }
+  sc[SC_TRY_DW << 6] = dw;
+  sc[SC_TRY_GAM << 6] = gam;
+  sc[SC_ATTEMPT << 6] = (double)(attempt + 1);
+}
+
 // CHUNKED = false: the plain sequential sweep (P = 1) without any spike code -- a separate instantiation because the
 // spike blocks are what pushes the register count of the chunked form beyond one wavefront per SIMD
 template <class M, bool CHUNKED>
 __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
   const int64_t g = blockIdx.x / a.P;
   const int p = blockIdx.x % a.P;
-  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
-  const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
-  if (!__any(need)) return;
-  const double mu = sc[SC_MU << 6];
-  const double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
-  const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
-  Carry<M> cy;
-  Spike<M> sp;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  // The sequential form owns its tile for the whole inertia-correction loop: sweep, judge the inertia, pick the next
+  // (delta_w, gamma) and sweep again until every lane of the tile has a factorisation -- no launch per round.  The
+  // time-partitioned form does one round per launch (k_kkt_sep joins its chunks in between).
+  for (int round = 0; CHUNKED || a.fwd_rounds <= 0 || round < a.fwd_rounds; ++round) {
+    const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
+    if (!__any(need)) return;
+    const double mu = sc[SC_MU << 6];
+    const double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
+    const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
+    Carry<M> cy;
+    Spike<M> sp;
 #pragma unroll
-  for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = sp.RLL[i] = 0.0;
+    for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = sp.RLL[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = sp.rL[i] = 0.0;
+    for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = sp.rL[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
-  bool ok = true;
-  int nneg = 0;
-  for (int t = t0; t < t1; ++t) {
-    if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
-    if (!CHUNKED || p == 0) {
-      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        constexpr int K = decltype(kc)::value;
-        if constexpr (!CHUNKED && heavy_kind<M, K>()) {
-          Carry<M> cyc = cy;
-          Spike<M> spc = sp;
-          int okneg[2] = {ok ? 1 : 0, nneg};
-          stage_forward_cold<M, K, false>(a, g, t, mu, dw, gam, false, need, &cyc, &spc, okneg);
-          cy = cyc;
-          ok = okneg[0] != 0;
-          nneg = okneg[1];
-        } else {
-          stage_forward<M, K, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
-        }
-      });
-    } else if constexpr (CHUNKED) {
-      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
-        // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
-        if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
-      });
+    for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
+    bool ok = true;
+    int nneg = 0;
+    for (int t = t0; t < t1; ++t) {
+      if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
+      if (!CHUNKED || p == 0) {
+        dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+          constexpr int K = decltype(kc)::value;
+          if constexpr (!CHUNKED && heavy_kind<M, K>()) {
+            Carry<M> cyc = cy;
+            Spike<M> spc = sp;
+            int okneg[2] = {ok ? 1 : 0, nneg};
+            // the callee gets its own copy of the argument block: handing out the address of the kernel's would move every
+            // pointer of the hot loop to the stack as well (reloads, generic instead of global addressing)
+            const dto_kkt_args acold = a;
+            stage_forward_cold<M, K, false>(acold, g, t, mu, dw, gam, false, need, &cyc, &spc, okneg);
+            cy = cyc;
+            ok = okneg[0] != 0;
+            nneg = okneg[1];
+          } else {
+            stage_forward<M, K, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+          }
+        });
+        // the attempt of a lane is lost with the first stage whose pivots have the wrong signs (stage_forward clears ok):
+        // once that has happened to every lane that asked for a factorisation the rest of the sweep is pointless
+        if (!CHUNKED && !__any(need && ok)) break;
+      } else if constexpr (CHUNKED) {
+        dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+          // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
+          if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
+            stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
+        });
+      }
+    }
+    if constexpr (!CHUNKED) {
+      if (need) retry_update(a, sc, ok, nneg);
+      if (a.opt.newton_only) return;  // one factorisation with the caller's delta_w
+    } else {
+      if (!need) return;
+      using CS = ChunkSum<M>;
+      double* cs = a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < CS::NT; ++i) {
+        cs[(int64_t)(CS::P + i) << 6] = cy.P[i];
+        cs[(int64_t)(CS::RLL + i) << 6] = sp.RLL[i];
+      }
+#pragma unroll
+      for (int i = 0; i < CS::N; ++i) {
+        cs[(int64_t)(CS::PY + i) << 6] = cy.py[i];
+        cs[(int64_t)(CS::RL + i) << 6] = sp.rL[i];
+      }
+#pragma unroll
+      for (int i = 0; i < CS::N * CS::N; ++i) cs[(int64_t)(CS::CX + i) << 6] = sp.Cx[i];
+      cs[(int64_t)CS::OK << 6] = ok ? 1.0 : 0.0;
+      cs[(int64_t)CS::NNEG << 6] = (double)nneg;
+      return;
     }
   }
-  if (!need) return;
-  using CS = ChunkSum<M>;
-  double* cs = a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < CS::NT; ++i) {
-    cs[(int64_t)(CS::P + i) << 6] = cy.P[i];
-    cs[(int64_t)(CS::RLL + i) << 6] = sp.RLL[i];
-  }
-#pragma unroll
-  for (int i = 0; i < CS::N; ++i) {
-    cs[(int64_t)(CS::PY + i) << 6] = cy.py[i];
-    cs[(int64_t)(CS::RL + i) << 6] = sp.rL[i];
-  }
-#pragma unroll
-  for (int i = 0; i < CS::N * CS::N; ++i) cs[(int64_t)(CS::CX + i) << 6] = sp.Cx[i];
-  cs[(int64_t)CS::OK << 6] = ok ? 1.0 : 0.0;
-  cs[(int64_t)CS::NNEG << 6] = (double)nneg;
 }
 
 template <class M>
@@ -1591,43 +1658,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
 #pragma unroll
     for (int i = 0; i < N; ++i) sn[i] = v[i];
   }
-  if (!need) return;
-  // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
-  if (nneg != (int)a.Nc) ok = false;
-  sc[SC_NFACT << 6] += 1.0;
-  sc[SC_NNEG << 6] = (double)nneg;
-  double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
-  const double dlast = sc[SC_DELTA_LAST << 6];
-  const int attempt = (int)sc[SC_ATTEMPT << 6];
-  const bool done = ok || o.newton_only || attempt >= o.max_refactor;
-  if (done) {
-    sc[SC_NEED << 6] = 0.0;
-    sc[SC_DELTA_W << 6] = dw;
-    sc[SC_GAMMA << 6] = gam;
-    if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
-    if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
-    sc[SC_LS_FAIL << 6] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
-    sc[SC_QN_RESET << 6] = (gam == 0.0) ? 1.0 : 0.0;  // quasi-Newton: restart the element blocks after a fallback
-    return;
-  }
-  if (gam != 0.0) {
-    // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
-    // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
-    // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
-    const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
-    if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
-    else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
-    if (skip_ladder || dw > o.delta_w_exact_cap) {
-      gam = 0.0;
-      dw = o.delta_w_init;
-    }
-  } else {
-    dw *= o.kappa_w_plus;
-    if (dw > o.delta_w_max) dw = o.delta_w_max;
-  }
-  sc[SC_TRY_DW << 6] = dw;
-  sc[SC_TRY_GAM << 6] = gam;
-  sc[SC_ATTEMPT << 6] = (double)(attempt + 1);
+  if (need) retry_update(a, sc, ok, nneg);
 }
 
 struct StepAcc {
@@ -1747,6 +1778,23 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   for (int i = 0; i < NX; ++i) xn[i] = v[i];
 }
 
+// out-of-line form for the heavy stage kinds (see stage_forward_cold)
+template <class M, int K>
+__device__ __attribute__((noinline)) void stage_backward_cold(const dto_kkt_args& a, int64_t g, int t, double mu, double tau, double dw,
+                                                             double gam, const double* xL, double* xn, StepAcc* acc) {
+  StepAcc ac = *acc;
+  double xl[M::MAX_NX], xv[M::MAX_NX];
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX; ++i) {
+    xl[i] = xL[i];
+    xv[i] = xn[i];
+  }
+  stage_backward<M, K, false>(a, g, t, mu, tau, dw, gam, false, xl, xv, ac);
+#pragma unroll
+  for (int i = 0; i < M::MAX_NX; ++i) xn[i] = xv[i];
+  *acc = ac;
+}
+
 template <class M, bool CHUNKED>
 __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   const int64_t g = blockIdx.x / a.P;
@@ -1771,7 +1819,17 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
     if (!CHUNKED || p == 0) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         constexpr int K = decltype(kc)::value;
-        {
+        if constexpr (!CHUNKED && heavy_kind<M, K>()) {
+          const dto_kkt_args acold = a;  // own copy: see kkt_fwd_body
+          double xnc[N];
+#pragma unroll
+          for (int i = 0; i < N; ++i) xnc[i] = xn[i];
+          StepAcc accc = acc;
+          stage_backward_cold<M, K>(acold, g, t, mu, tau, dw, gam, xL, xnc, &accc);
+#pragma unroll
+          for (int i = 0; i < N; ++i) xn[i] = xnc[i];
+          acc = accc;
+        } else {
           stage_backward<M, K, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
         }
       });
@@ -1794,8 +1852,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) { kkt_bwd_body
 template <class M>
 __global__ __launch_bounds__(WAVE, 2) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
 
-static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+__device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) {
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double apmax = 1.0, admax = 1.0, gphid = 0.0;
@@ -1810,10 +1867,8 @@ static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) {
   sc[SC_ALPHA_PMAX << 6] = apmax;
   sc[SC_ALPHA_DMAX << 6] = admax;
 }
+static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) { kkt_post_body(a, blockIdx.x); }
 
-// ------------------------------------------------------------------------------------------------
-// line search: merit partials of DTO_LS_TRIALS step sizes alpha_k = alpha_pmax * 2^-k per stage
-// ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
   // a wavefront walks DTO_SB consecutive stages and sums the merit partials of the eight trial step sizes in registers
@@ -2161,13 +2216,18 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_FACTOR_SOLVE: {
         const unsigned gp = (unsigned)((int64_t)a.G * a.P);
         const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
-        for (int r = 0; r < rounds; ++r) {
-          if (a.P > 1) hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
-          else hipLaunchKernelGGL(k_kkt_fwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
-          hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        if (a.P > 1) {
+          for (int r = 0; r < rounds; ++r) {
+            hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+            hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+          }
+          hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
+        } else {
+          // the sequential sweep loops over its rounds inside the launch, a.fwd_rounds at most per launch (0: all of them)
+          const int per = a.fwd_rounds > 0 ? a.fwd_rounds : rounds;
+          for (int r = 0; r < rounds; r += per) hipLaunchKernelGGL(k_kkt_fwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
         }
-        if (a.P > 1) hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
-        else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
         hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       }

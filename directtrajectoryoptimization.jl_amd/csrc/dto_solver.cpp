@@ -426,6 +426,13 @@ static int dev_alloc(T** p, size_t count) {
 }
 
 // switch the number of chunks among those the state was allocated for (dto_solver_repack; back to P0 when a batch is loaded)
+// Inertia-correction rounds the sequential sweep does per launch (0 = all of them in one launch).  DTO_FWD_ROUNDS is a
+// measurement knob (tools/), not part of the interface.
+static int fwd_rounds_per_launch() {
+  static const int v = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 static void set_partitions_now(SolverState& S, int P) {
   if (S.P_cap > S.P0) {            // blocks for q = 1 .. P_cap back to back: block q starts at sum_{r<q} (r + 1)
     int off = 0;
@@ -560,6 +567,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
   a.inst_of_slot = S.d_inst_of_slot;
+  a.fwd_rounds = fwd_rounds_per_launch();
   a.prof = nullptr;
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
@@ -854,7 +862,12 @@ int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni
   if (rec) *rec = p->solver->rec_total;
   if (fac) *fac = p->solver->fac_total;
   if (ni) *ni = p->solver->Ni;
-  if (rounds) *rounds = p->solver->opt.newton_only ? 1 : p->solver->opt.max_refactor + 1;
+  // launches of k_kkt_fwd per iteration: the sequential sweep runs several rounds (all, by default) inside one launch
+  if (rounds) {
+    const int all = p->solver->opt.newton_only ? 1 : p->solver->opt.max_refactor + 1;
+    const int per = (p->solver->P == 1) ? (dto::fwd_rounds_per_launch() > 0 ? dto::fwd_rounds_per_launch() : all) : 1;
+    *rounds = (all + per - 1) / per;
+  }
   return DTO_OK;
 }
 

@@ -391,6 +391,7 @@ static int forward_sweep(port_solver* S, double dw, double gam, const double* rh
     }
     if (!stage_ok) ok = 0;
     nneg += stage_neg;
+    if (stage_neg != q + ny) ok = 0; /* the block's primal pivots come first: exactly its q + ny constraint pivots are negative */
     for (int i = 1; i < bd; ++i)
       for (int k = 0; k < i; ++k) {
         const double l = A[i][k];
