@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed solver iterations (default: the reference's max_iter = a full solve)")
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=196608,
+    ap.add_argument("--batch", type=int, default=262144,
                     help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance; "
                          ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD and the larger batch keeps the GPU "
                          "filled while instances converge and leave, DESIGN.md sections 5, 7)")
@@ -237,7 +237,7 @@ def main():
     if a.loop_only:
         if rank == 0:
             print(json.dumps(dict(value=iters_done / dt, unit="SQP iterations/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=s.partitions(),
+                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=time_partitions,
                                   factorizations_per_iteration=round(facts_done / max(iters_done, 1.0), 3))), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -341,6 +341,12 @@ def main():
     status = torch.tensor(s.scalar_batch("status"), device=dev, dtype=torch.float64)
     gathered = gather_trajectories(zout, status, dist)
 
+    # the side measurements below build their own problems: hand the HBM of the headline batch back first
+    time_partitions, n_gathered = s.partitions(), int(gathered.shape[0])
+    del zout, jout, z0, status, gathered
+    s.close()
+    torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -379,8 +385,8 @@ def main():
             iteration_throughput=dict(value=float(thr0[0]), unit="SQP iterations/s",
                                       note=f"first {first_k} timed iterations, every instance still running"),
             solve=solve_info,
-            factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=s.partitions(),
-            gathered_trajectories=int(gathered.shape[0]),
+            factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=time_partitions,
+            gathered_trajectories=n_gathered,
             roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,
         )
         print(json.dumps(out), flush=True)

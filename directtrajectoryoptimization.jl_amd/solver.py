@@ -375,6 +375,12 @@ class Solver:
         return self.nlp.num_variables
 
     # ---- batched device entry points (torch tensors / raw device pointers)
+    def close(self):
+        """Give the device memory of this solver back (the problem handles and the batch state they own)."""
+        if self._solve_nlp is not self.nlp:
+            self._solve_nlp.close()
+        self.nlp.close()
+
     def kkt_step_batch(self, x_ptr, B, ldx, mu_ptr, ldmu, delta_w, delta_c, dx_ptr, lddx, dmu_ptr, lddmu, stream=0,
                        params_ptr=0, ldp=0):
         """One regularised Newton-KKT step (include/dto.h: dto_kkt_step_batch). Returns inertia_ok."""
