@@ -335,16 +335,19 @@ def main():
     if dist is not None:
         dist.all_reduce(jt, op=dist.ReduceOp.SUM)
 
-    # ---- converged trajectories: finish the solves of this shard and all-gather them (RCCL over xGMI)
+    # ---- converged trajectories: finish the solves of this shard and all-gather them (RCCL over xGMI).  The solver state
+    #      (and the bench's own buffers) go back first: at 8 ranks every rank receives 8 x 10.5 GB of trajectories, and the
+    #      side measurements below build their own problems.
     zout = torch.empty((B, nz), device=dev, dtype=torch.float64)
     s.end_batch(zout.data_ptr(), nz, stream=st)
     status = torch.tensor(s.scalar_batch("status"), device=dev, dtype=torch.float64)
-    gathered = gather_trajectories(zout, status, dist)
-
-    # the side measurements below build their own problems: hand the HBM of the headline batch back first
-    time_partitions, n_gathered = s.partitions(), int(gathered.shape[0])
-    del zout, jout, z0, status, gathered
+    time_partitions = s.partitions()
+    del jout, z0, jfn
     s.close()
+    torch.cuda.empty_cache()
+    gathered = gather_trajectories(zout, status, dist)
+    n_gathered = int(gathered.shape[0])
+    del zout, status, gathered
     torch.cuda.empty_cache()
 
     cpu = None

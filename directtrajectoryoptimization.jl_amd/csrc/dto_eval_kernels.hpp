@@ -302,19 +302,26 @@ __global__ __launch_bounds__(JAC_WAVES * WAVE) void k_jac(dto_eval_args a) {
 //   entry has its own slot), 3. the few cost / constraint entries and, after a barrier, the previous stage's y-row
 //   entries are added.  Fixed order per slot -> deterministic.
 constexpr int HOWN = WAVE - 1;  // stages owned by one wave; lane 0 is the halo (stage t0-1)
-constexpr int HESS_WAVES = 2;   // wavefronts per workgroup
-constexpr int HHALF = 32;       // stages per output image: the wave streams its 63 stages out in two images, which halves
-                                // the LDS footprint (~10 KiB per wave) and doubles the wavefronts a CU can hold
+constexpr int HESS_WAVES = 1;   // one wavefront per workgroup: the barriers between the deposit phases cost nothing
+// Stages per output image: as many as fit ~10 KiB of LDS (32 for the acrobot's 41 keys per stage -> the 63 stages of a
+// wave go out in two images).  Measured, acrobot T=1000, 8192 instances: 20.7 KiB (one image, 7 waves per CU) 0.98 ms,
+// 14 KiB 0.94 ms, 10 KiB (4 waves per SIMD at 116 VGPRs) 0.89 ms = 46 % of the HBM peak.  Round 1 form (two-wave
+// workgroups, per-entry "-1 -> trash slot" selects in both deposit passes, 207 VGPRs): 1.20 ms = 34 %.
+template <class M>
+constexpr int hess_span() {
+  constexpr int fit = (10 * 1024 / 8 - 2) / (M::MAX_KEY > 0 ? M::MAX_KEY : 1);
+  return fit >= HOWN ? HOWN : (fit < 4 ? 4 : fit);
+}
 
 template <class M>
 __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
-  // image + one trash slot per lane: entries that do not belong to the image (map value -1) are written there, which
-  // keeps the deposit loops free of branches, so the map loads of a lane are all in flight at once
+  // which of a dynamics' Hessian nonzeros go to the rows of its own stage and which to the next stage's is a literal
+  // table of the generated class (Dyn::hess_row_own), so the unrolled deposit loops touch exactly their entries
+  constexpr int HHALF = hess_span<M>();
   constexpr int IMG = HHALF * M::MAX_KEY + 2;
-  __shared__ __attribute__((aligned(16))) double s_img[HESS_WAVES][IMG + WAVE];
+  __shared__ __attribute__((aligned(16))) double s_img[HESS_WAVES][IMG];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* s_o = s_img[wv];
-  const int trash = IMG + lane;
   const int wpi = (a.T + HOWN - 1) / HOWN;
   const int bpi = (wpi + HESS_WAVES - 1) / HESS_WAVES;
   const int64_t b = blockIdx.x / bpi;
@@ -390,11 +397,9 @@ __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
           using D = typename M::template Dyn<KD::DYN>;
           if constexpr (D::NH > 0) {
             const int* mrow = a.hmap_dyn_own + decltype(kc)::value * a.hmap_stride;
-            int mo[D::NH];
 #pragma unroll
-            for (int i = 0; i < D::NH; ++i) mo[i] = mrow[i];
-#pragma unroll
-            for (int i = 0; i < D::NH; ++i) s_o[mo[i] >= 0 ? base + mo[i] : trash] = hv[i];
+            for (int i = 0; i < D::NH; ++i)
+              if (D::hess_row_own(i)) s_o[base + mrow[i]] = hv[i];
           }
         }
         if constexpr (M::template Cost<KD::COST>::NH > 0) {
@@ -425,12 +430,15 @@ __global__ __launch_bounds__(HESS_WAVES * WAVE) void k_hess(dto_eval_args a) {
             const int* mrow = a.hmap_dyn_next + a.kind[s + 1] * a.hmap_stride;
             int mo[D::NH];
 #pragma unroll
-            for (int i = 0; i < D::NH; ++i) mo[i] = mrow[i];
+            for (int i = 0; i < D::NH; ++i)
+              if (!D::hess_row_own(i)) mo[i] = base + mrow[i];
             double cur[D::NH];
 #pragma unroll
-            for (int i = 0; i < D::NH; ++i) cur[i] = s_o[mo[i] >= 0 ? base + mo[i] : trash];
+            for (int i = 0; i < D::NH; ++i)
+              if (!D::hess_row_own(i)) cur[i] = s_o[mo[i]];
 #pragma unroll
-            for (int i = 0; i < D::NH; ++i) s_o[mo[i] >= 0 ? base + mo[i] : trash] = cur[i] + hv[i];
+            for (int i = 0; i < D::NH; ++i)
+              if (!D::hess_row_own(i)) s_o[mo[i]] = cur[i] + hv[i];
           }
         }
       });

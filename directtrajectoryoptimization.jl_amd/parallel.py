@@ -28,20 +28,25 @@ def gather_trajectories(z_local, status_local, dist):
     Shards may have different sizes (B not divisible by the world size): they are padded to the largest
     shard for the collective and trimmed afterwards.  Returns a [B_total, Nz + 1] tensor on every rank,
     rows in global instance order; the last column is the per-instance solver status.
+
+    Memory: one staging copy of the local shard and ONE receive buffer of world x largest shard (the
+    collective writes into it directly); equal shards are returned as a view of that buffer.
     """
     import torch
-    packed = torch.cat([z_local, status_local.to(z_local.dtype).reshape(-1, 1)], dim=1).contiguous()
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return packed
+        return torch.cat([z_local, status_local.to(z_local.dtype).reshape(-1, 1)], dim=1)
     world = dist.get_world_size()
-    n_local = torch.tensor([packed.shape[0]], device=packed.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
-    nmax = max(counts)
-    if packed.shape[0] < nmax:
-        pad = torch.zeros((nmax - packed.shape[0], packed.shape[1]), device=packed.device, dtype=packed.dtype)
-        packed = torch.cat([packed, pad], dim=0)
-    out = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(out, packed)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    n_local = torch.tensor([z_local.shape[0]], device=z_local.device, dtype=torch.int64)
+    counts = torch.zeros(world, device=z_local.device, dtype=torch.int64)
+    dist.all_gather_into_tensor(counts, n_local)
+    counts = [int(c) for c in counts.tolist()]
+    nmax, width = max(counts), z_local.shape[1] + 1
+    packed = torch.zeros((nmax, width), device=z_local.device, dtype=z_local.dtype)
+    packed[: z_local.shape[0], :-1] = z_local
+    packed[: z_local.shape[0], -1] = status_local.to(z_local.dtype)
+    out = torch.empty((world * nmax, width), device=z_local.device, dtype=z_local.dtype)
+    dist.all_gather_into_tensor(out, packed)
+    del packed
+    if all(c == nmax for c in counts):
+        return out
+    return torch.cat([out[r * nmax: r * nmax + c] for r, c in enumerate(counts)], dim=0)

@@ -433,6 +433,12 @@ def generate_source(st: Structure, name: str) -> str:
         if nh:
             sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
             out.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+            # Hessian nonzero i belongs to the rows of its own stage (row in [x; u]) or of the next one (row in y): the
+            # same rule as csrc/dto_layout.hpp:build_hmaps, as a literal table so that k_hess's deposit loops fold it
+            own = ", ".join("1" if r <= d.num_state + d.num_action else "0" for r in d.hessian_sparsity[0])
+            out.append(f"  static constexpr __host__ __device__ bool hess_row_own(int i) {{ constexpr bool own[] = {{{own}}}; return own[i]; }}")
+        else:
+            out.append("  static constexpr __host__ __device__ bool hess_row_own(int) { return true; }")
         out.append(_scatter_dyn(d, h))
         out.append("};")
         tables.append(_int_array(f"dyn{i}_jr", d.jacobian_sparsity[0]))

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--B", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--sigma", type=float, default=1.0)
     a = ap.parse_args()
     p = getattr(P, f"build_{a.model}")(T=a.T, evaluate_hessian=True)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name=a.model)
@@ -39,7 +40,7 @@ def main():
         "eval_grad_f": (lambda: n.eval_objective_gradient_batch(z.data_ptr(), B, nz, out.data_ptr(), nz, st), 8 * nz + 8 * nz),
         "eval_g": (lambda: n.eval_constraint_batch(z.data_ptr(), B, nz, out.data_ptr(), nc, st), 8 * nz + 8 * nc),
         "eval_jac_g": (lambda: n.eval_constraint_jacobian_batch(z.data_ptr(), B, nz, out.data_ptr(), nj, st), 8 * nz + 8 * nj),
-        "eval_h": (lambda: n.eval_hessian_lagrangian_batch(z.data_ptr(), B, nz, 1.0, mu.data_ptr(), nc, out.data_ptr(), nh, st),
+        "eval_h": (lambda: n.eval_hessian_lagrangian_batch(z.data_ptr(), B, nz, a.sigma, mu.data_ptr(), nc, out.data_ptr(), nh, st),
                    8 * (nz + nc + 1) + 8 * nh),
     }
     for name, (fn, bytes_per_inst) in calls.items():
