@@ -237,7 +237,7 @@ def main():
     if a.loop_only:
         if rank == 0:
             print(json.dumps(dict(value=iters_done / dt, unit="SQP iterations/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=time_partitions,
+                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=s.partitions(),
                                   factorizations_per_iteration=round(facts_done / max(iters_done, 1.0), 3))), flush=True)
         if dist is not None:
             dist.destroy_process_group()

@@ -695,7 +695,10 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   // wavefront per SIMD); the chunk arrays were sized for it when the batch was loaded
   if (S.P_cap > S.P0) {
     int P_new = 1;
-    while (P_new < S.P_cap && (int64_t)g_new * P_new * 8 <= (int64_t)S.n_simd * 7) P_new *= 2;   // fewer waves than ~7/8 of the SIMDs
+    // only while the chunk waves (one per SIMD: 512-VGPR kernels) still fit the GPU at once; just above one residency the
+    // in-kernel round loop of the sequential form is faster (262 144 instances, full solves: 1.285 M it/s with the switch
+    // at 7/8 of the SIMDs, 1.295 M with this rule, 1.304 M without any switch -- the batch never gets that small)
+    while (P_new < S.P_cap && (int64_t)g_new * P_new * 2 <= (int64_t)S.n_simd) P_new *= 2;
     set_partitions_now(S, std::min(P_new, S.P_cap));
   }
   return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
