@@ -1055,9 +1055,11 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     using DY = typename M::template Dyn<KD::DYN>;
     double jv[DY::NJ], F[NY * NP];
     arr<DY::NW> wd;
+    arr<D::FUSED && (DY::NHL > 0) ? DY::NH : 0> hvd;  // Jacobian and Hessian values come out of one generated body
     if constexpr (D::FUSED) {
       load_params(wd, a, g, t);
-      DY::jac(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), jv);
+      if constexpr (DY::NHL > 0) DY::jac_hess(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), lamv.data(), jv, hvd.data());
+      else DY::jac(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), jv);
     } else {
 #pragma unroll
       for (int i = 0; i < DY::NJ; ++i) jv[i] = R(D::R_DJ + i);
@@ -1073,9 +1075,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     if constexpr (DY::NHL > 0) {
       double hl[DY::NHL];
       if constexpr (D::FUSED) {
-        arr<DY::NH> hv;
-        DY::hess(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), lamv.data(), hv.data());
-        DY::pack_hess_lower(hv.data(), hl);
+        DY::pack_hess_lower(hvd.data(), hl);
       } else {
 #pragma unroll
         for (int i = 0; i < DY::NHL; ++i) hl[i] = R(D::R_DH + i);

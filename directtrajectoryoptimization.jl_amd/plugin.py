@@ -433,6 +433,11 @@ def generate_source(st: Structure, name: str) -> str:
         if nh:
             sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
             out.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
+            # Jacobian and Hessian from ONE body: the solver's sweeps need both at every stage, and they share most of their
+            # work (the sin/cos pairs, the inverse mass matrix, ...)
+            sigjh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* jout, double* hout"
+            out.append(_fn("jac_hess", sigjh, emit_body(list(d.jacobian_expr) + list(d.hessian_expr),
+                                                        [("jout", len(d.jacobian_expr)), ("hout", len(d.hessian_expr))], va)))
             # Hessian nonzero i belongs to the rows of its own stage (row in [x; u]) or of the next one (row in y): the
             # same rule as csrc/dto_layout.hpp:build_hmaps, as a literal table so that k_hess's deposit loops fold it
             own = ", ".join("1" if r <= d.num_state + d.num_action else "0" for r in d.hessian_sparsity[0])

@@ -67,12 +67,17 @@ def structural_hashes(outputs: Sequence[Expr]) -> List[str]:
     return [memo[o.id] for o in outputs]
 
 
-def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str],
+def emit_body(outputs: Sequence[Expr], out_name, var_arrays: Dict[str, str],
               tmp_prefix: str = "t", indent: str = "    ", scale: str | None = None) -> str:
     """C statements assigning `out_name[k] = outputs[k]` for all k.
 
     var_arrays maps a VAR family name ('x', 'u', 'y', 'w', 'lam', 'z') to the C array it is read from.
+    out_name may be a list of (array name, count) pairs: `outputs` is then the concatenation of several output lists that
+    share ONE body (common subexpressions, sincos pairs) and are written to their own arrays.
     """
+    groups = [(out_name, len(outputs))] if isinstance(out_name, str) else list(out_name)
+    assert sum(c for _, c in groups) == len(outputs)
+    out_name = "+".join(f"{nm}:{c}" for nm, c in groups) if len(groups) > 1 else groups[0][0]
     if STRUCTURAL_KEYS:
         va = ",".join(f"{k}={v}" for k, v in sorted(var_arrays.items()))
         return f"{indent}// {out_name} {tmp_prefix} {scale} [{va}] " + " ".join(structural_hashes(outputs))
@@ -89,9 +94,23 @@ def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str]
             cos_of[n.args[0].id] = n
     paired = {aid for aid in sin_of if aid in cos_of}
     done_pairs = set()
+    uses: Dict[int, int] = {}
+    for n in order:
+        for a in n.args:
+            uses[a.id] = uses.get(a.id, 0) + 1
+    for o in outputs:
+        uses[o.id] = uses.get(o.id, 0) + 1
 
     def ref(a: Expr) -> str:
         return name[a.id]
+
+    def ensure_pair(a: Expr):
+        """names of (sin a, cos a); the sincos call is emitted where the pair is first needed"""
+        s, c = f"{tmp_prefix}{sin_of[a.id].id}", f"{tmp_prefix}{cos_of[a.id].id}"
+        if a.id not in done_pairs:
+            done_pairs.add(a.id)
+            lines.append(f"{indent}double {s}, {c}; sincos({ref(a)}, &{s}, &{c});")
+        return s, c
 
     for n in order:
         op = n.op
@@ -105,6 +124,26 @@ def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str]
             name[n.id] = f"(-{ref(n.args[0])})"
             continue
         t = f"{tmp_prefix}{n.id}"
+        if op == E.MUL:
+            # constants of a chain of single-use products are multiplied out here: c1 * (c2 * e) -> (c1 c2) * e (the chain rule
+            # through m = (x + y) / 2 leaves many 0.5 * (0.5 * e); the inner temporaries become dead code)
+            coef, factors, folded = 1.0, [], 0
+            stack = list(n.args)
+            while stack:
+                a = stack.pop()
+                if a.op == E.CONST:
+                    coef *= a.value
+                    folded += 1
+                elif a.op == E.MUL and uses[a.id] == 1 and any(k.op == E.CONST for k in a.args):
+                    stack.extend(a.args)
+                else:
+                    factors.append(a)
+            if folded >= 2 and factors:
+                factors.sort(key=lambda e: e.id)
+                rhs = " * ".join([_lit(coef)] + [ref(f) for f in factors])
+                lines.append(f"{indent}const double {t} = {rhs};")
+                name[n.id] = t
+                continue
         if op == E.ADD:
             rhs = f"{ref(n.args[0])} + {ref(n.args[1])}"
         elif op == E.SUB:
@@ -122,21 +161,39 @@ def emit_body(outputs: Sequence[Expr], out_name: str, var_arrays: Dict[str, str]
             rhs = f"({ref(n.args[0])} {'<' if n.fn == 'lt' else '<='} {ref(n.args[1])}) ? {ref(n.args[2])} : {ref(n.args[3])}"
         else:
             aid = n.args[0].id
+            arg = n.args[0]
+            if n.fn in ("sin", "cos") and aid in done_pairs:   # pair already produced by a sincos call (ensure_pair)
+                name[n.id] = t
+                continue
+            if (n.fn in ("sin", "cos") and arg.op in (E.ADD, E.SUB)
+                    and all(k.id in paired and k.op != E.CONST for k in arg.args)):
+                # sin / cos of a sum whose terms have their own sincos pairs in this body (acrobot: q1, q2, q1 + q2): the
+                # angle-addition identity costs two multiplications and an FMA instead of a ~100-instruction f64 sincos.
+                # Absolute accuracy ~1e-16, which is what dynamics values need (parity tolerance 1e-8).
+                (sa, ca), (sb, cb) = ensure_pair(arg.args[0]), ensure_pair(arg.args[1])
+                plus = arg.op == E.ADD
+                if n.fn == "sin":
+                    rhs = f"{sa} * {cb} {'+' if plus else '-'} {ca} * {sb}"
+                else:
+                    rhs = f"{ca} * {cb} {'-' if plus else '+'} {sa} * {sb}"
+                lines.append(f"{indent}const double {t} = {rhs};")
+                name[n.id] = t
+                continue
             if n.fn in ("sin", "cos") and aid in paired:
-                if aid not in done_pairs:
-                    done_pairs.add(aid)
-                    s, c = f"{tmp_prefix}{sin_of[aid].id}", f"{tmp_prefix}{cos_of[aid].id}"
-                    lines.append(f"{indent}double {s}, {c}; sincos({ref(n.args[0])}, &{s}, &{c});")
+                ensure_pair(arg)
                 name[n.id] = t
                 continue
             rhs = f"{_CFN[n.fn]}({ref(n.args[0])})"
         lines.append(f"{indent}const double {t} = {rhs};")
         name[n.id] = t
-    for k, o in enumerate(outputs):
-        v = name[o.id]
-        if scale is not None:
-            v = f"{scale} * ({v})"
-        lines.append(f"{indent}{out_name}[{k}] = {v};")
+    k0 = 0
+    for nm, cnt in groups:
+        for k in range(cnt):
+            v = name[outputs[k0 + k].id]
+            if scale is not None:
+                v = f"{scale} * ({v})"
+            lines.append(f"{indent}{nm}[{k}] = {v};")
+        k0 += cnt
     return "\n".join(lines)
 
 
