@@ -64,7 +64,7 @@ def event_time_ms(fn, iters):
 
 
 def full_solve_measurement(dev, T=101, B=1024):
-    """Time to solution on a workload where every instance converges: the reference example's own horizon
+    """Time to solution on a workload where (almost) every instance converges: the reference example's own horizon
     (examples/acrobot/acrobot.jl:12, T = 101), 1024 seeded guesses solved to the reference Options tolerances in one batch.
     (The headline workload, T = 1000, has non-isolated minimisers and is measured as iteration throughput: DESIGN.md 5.)"""
     import time as _time
@@ -82,9 +82,13 @@ def full_solve_measurement(dev, T=101, B=1024):
     status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, stream=st)
     torch.cuda.synchronize()
     dt = _time.perf_counter() - t0
+    # the batch returns when its last instance stops: an instance that runs into max_iter = 1000 (0-2 of the 1024, which ones
+    # depends on rounding) costs ~20x the median instance; iterations_p99 / iterations_max show that tail
     return dict(workload=f"acrobot swing-up T={T} (the reference example's horizon), {B} seeded guesses, solved to tol=1e-6",
-                converged=int(np.sum(status == 1)), instances=B, seconds=round(dt, 4), solves_per_sec=round(B / dt, 1),
-                iterations_median=float(np.median(iters)), sqp_iterations_per_sec=round(float(np.sum(iters)) / dt, 1))
+                converged=int(np.sum(status == 1)), iteration_limit=int(np.sum(status == 2)), instances=B, seconds=round(dt, 4),
+                solves_per_sec=round(float(np.sum(status == 1)) / dt, 1),
+                iterations_median=float(np.median(iters)), iterations_p99=float(np.percentile(iters, 99)),
+                iterations_max=int(np.max(iters)), sqp_iterations_per_sec=round(float(np.sum(iters)) / dt, 1))
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense FP64 matrix (no local guide figure)
