@@ -150,8 +150,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed solver iterations (default: the reference's max_iter = a full solve)")
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=262144,
-                    help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance; "
+    ap.add_argument("--batch", type=int, default=294912,
+                    help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.75 MB of solver state per instance, 45 GB stay free; "
                          ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD and the larger batch keeps the GPU "
                          "filled while instances converge and leave, DESIGN.md sections 5, 7)")
     ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")
@@ -343,6 +343,7 @@ def main():
     #      (and the bench's own buffers) go back first: at 8 ranks every rank receives 8 x 10.5 GB of trajectories, and the
     #      side measurements below build their own problems.
     zout = torch.empty((B, nz), device=dev, dtype=torch.float64)
+    hbm_free_min_gb = round(torch.cuda.mem_get_info(dev)[0] / 1e9, 1)   # the bench's high-water mark: solver state + z0 + Jacobian + zout
     s.end_batch(zout.data_ptr(), nz, stream=st)
     status = torch.tensor(s.scalar_batch("status"), device=dev, dtype=torch.float64)
     time_partitions = s.partitions()
@@ -393,7 +394,7 @@ def main():
                                       note=f"first {first_k} timed iterations, every instance still running"),
             solve=solve_info,
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=time_partitions,
-            gathered_trajectories=n_gathered,
+            gathered_trajectories=n_gathered, hbm_free_min_gb=hbm_free_min_gb,
             roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,
         )
         print(json.dumps(out), flush=True)
