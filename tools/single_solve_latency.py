@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dto_amd
 from dto_amd import problems as P
-for model, T, eh in (("pendulum", 11, True), ("pendulum", 50, True), ("cartpole", 101, False), ("acrobot", 101, False), ("car", 51, False)):
+for model, T, eh in (("pendulum", 11, True), ("pendulum", 50, True), ("cartpole", 101, False), ("acrobot", 101, False), ("car", 51, False),
+                     ("acrobot", 101, True), ("acrobot", 1000, True)):   # the last one: ONE instance of the bench workload
     p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=eh)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=eh, name=model)
     s.options.print_level = 0
