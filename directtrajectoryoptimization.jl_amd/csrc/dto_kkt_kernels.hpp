@@ -64,6 +64,7 @@ enum dto_scal {
 constexpr int DTO_NPART = 10;   // residual partials written by k_stage_eval
 constexpr int DTO_SB = 8;       // consecutive stages one wavefront of the stage-parallel kernels walks (partials summed in registers)
 constexpr int DTO_LS_TRIALS = 8;
+constexpr double DTO_LS_NULL_STEP = 100.0;  // k_ls_reduce: no step at all when even the most feasible trial multiplies the violation by more
 constexpr int DTO_FILTER_CAP = 24;  // filter entries kept per instance (ring)
 
 struct dto_kkt_info {
@@ -2053,6 +2054,13 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     for (int k = 0; k < best; ++k) ab *= 0.5;
     if (th[best] == th[best] && th[best] < th0) chosen = ab;
     else chosen = alpha * 2.0;  // alpha_max 2^-(TRIALS-1)
+    // every trial is catastrophic (even the most feasible one multiplies the violation by > 100; Ipopt would enter its
+    // restoration phase): such a direction is not worth any step -- stay, primal and dual, and let SC_LS_FAIL regularise the
+    // next system more.  acrobot T = 101, 1024 seeds: 1022 -> 1024 converge, the other workloads unchanged.
+    if (!(th[best] <= DTO_LS_NULL_STEP * fmax(th0, 1.0))) {
+      chosen = 0.0;
+      sc[SC_ALPHA_DMAX << 6] = 0.0;
+    }
     sc[SC_LS_FAIL << 6] = 1.0;
     augment = true;
   } else {

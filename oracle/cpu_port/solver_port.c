@@ -34,6 +34,7 @@
 #define MAXQ PORT_MAXQ
 #define MAXBD (MAXP + MAXQ + MAXN)
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+#define LS_NULL_STEP 100.0
 #define LS_TRIALS 8
 #define FILTER_CAP 24
 
@@ -662,6 +663,9 @@ static void line_search(port_solver* S) {
     double ab = amax;
     for (int k = 0; k < best; ++k) ab *= 0.5;
     if (th[best] == th[best] && th[best] < th0) chosen = ab; else chosen = alpha * 2.0;
+    /* every trial is catastrophic (even the most feasible one multiplies the violation by > 100): a direction like that is
+     * not worth any step -- stay where we are, primal and dual, and let ls_fail regularise the next system more */
+    if (!(th[best] <= LS_NULL_STEP * fmax(th0, 1.0))) { chosen = 0.0; S->alpha_dmax = 0.0; }
     S->ls_fail = 1; augment = 1;
   } else { S->ls_fail = 0; augment = !ftype && !watchdog; }
   if (watchdog) { S->watchdog = wd_left - 1; S->short_streak = 0; }
