@@ -532,9 +532,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
         lam[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
       }
-      DY::eval(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data());
       arr<DY::NJ> jv;
-      DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jv.data());
+      DY::eval_jac(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data(), jv.data());
       DY::jtlam(jv.data(), lam.data(), rp.data());
 #pragma unroll
       for (int i = 0; i < M::MAX_NX; ++i) enext[i] = 0.0;

@@ -430,6 +430,10 @@ def generate_source(st: Structure, name: str) -> str:
         sig = "const double* x, const double* u, const double* y, const double* w, double* out"
         out.append(_fn("eval", sig, emit_body(d.evaluate_expr, "out", va)))
         out.append(_fn("jac", sig, emit_body(d.jacobian_expr, "out", va)))
+        # residual and Jacobian from one body (k_stage_eval needs both at every stage)
+        sigej = "const double* x, const double* u, const double* y, const double* w, double* eout, double* jout"
+        out.append(_fn("eval_jac", sigej, emit_body(list(d.evaluate_expr) + list(d.jacobian_expr),
+                                                    [("eout", len(d.evaluate_expr)), ("jout", len(d.jacobian_expr))], va)))
         if nh:
             sigh = "const double* x, const double* u, const double* y, const double* w, const double* lam, double* out"
             out.append(_fn("hess", sigh, emit_body(d.hessian_expr, "out", va)))
