@@ -1919,9 +1919,35 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
         dsl[j] = *soa(a.ds, g, a.Ni, a.ioff[t] + j);
       }
     }
-    double alpha = amax;
+    // Trial points x + alpha_k dx, alpha_k = alpha_max 2^-k, visited from the SHORTEST step up.  Where every sin / cos
+    // argument of the dynamics is affine in (x, u, y) (Dyn::NTRIG > 0) the argument at trial k is a0 + 2^(7-k) da: sin / cos
+    // come from ONE sincos of a0 and one of da per argument, the angle-addition identity and the double-angle recurrence,
+    // instead of a library sincos per argument and trial (the trigonometry was most of this kernel's arithmetic).  The
+    // recurrence doubles the absolute error seven times: ~1e-14 at alpha_max, far below what the filter tests resolve.
+    constexpr int NTRIG = []() { if constexpr (KD::DYN >= 0) return M::template Dyn<KD::DYN>::NTRIG; else return 0; }();
+    double tS0[NTRIG > 0 ? NTRIG : 1], tC0[NTRIG > 0 ? NTRIG : 1], ts[NTRIG > 0 ? NTRIG : 1], tc[NTRIG > 0 ? NTRIG : 1];
+    const double amin = amax * (1.0 / (double)(1 << (DTO_LS_TRIALS - 1)));
+    if constexpr (NTRIG > 0) {
+      using DY = typename M::template Dyn<KD::DYN>;
+      arr<D::NP> pm;
+      arr<DY::NY> ym;
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) pm[i] = p[i] + amin * dp[i];
+#pragma unroll
+      for (int i = 0; i < DY::NY; ++i) ym[i] = y[i] + amin * dy[i];
+      double a0[NTRIG], a1[NTRIG];
+      DY::trig_args(p.data(), p.data() + DY::NX, y.data(), w.data(), a0);
+      DY::trig_args(pm.data(), pm.data() + DY::NX, ym.data(), w.data(), a1);
+#pragma unroll
+      for (int j = 0; j < NTRIG; ++j) {
+        sincos(a0[j], &tS0[j], &tC0[j]);
+        sincos(a1[j] - a0[j], &ts[j], &tc[j]);
+      }
+    }
+    double alpha = amin;
 #pragma unroll 1
-    for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+    for (int kk = 0; kk < DTO_LS_TRIALS; ++kk) {
+      const int k = DTO_LS_TRIALS - 1 - kk;
       arr<D::NP> pk;
       double phi, th = 0.0;
 #pragma unroll
@@ -1946,7 +1972,23 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
         arr<DY::NY> yk, d;
 #pragma unroll
         for (int i = 0; i < DY::NY; ++i) yk[i] = y[i] + alpha * dy[i];
-        DY::eval(pk.data(), pk.data() + DY::NX, yk.data(), w.data(), d.data());
+        if constexpr (NTRIG > 0) {
+          double sn[NTRIG], cs[NTRIG];
+#pragma unroll
+          for (int j = 0; j < NTRIG; ++j) {
+            sn[j] = tS0[j] * tc[j] + tC0[j] * ts[j];
+            cs[j] = tC0[j] * tc[j] - tS0[j] * ts[j];
+          }
+          DY::eval_trig(pk.data(), pk.data() + DY::NX, yk.data(), w.data(), sn, cs, d.data());
+#pragma unroll
+          for (int j = 0; j < NTRIG; ++j) {   // angle of the next (twice as long) step
+            const double s2 = 2.0 * ts[j] * tc[j];
+            tc[j] = 1.0 - 2.0 * ts[j] * ts[j];
+            ts[j] = s2;
+          }
+        } else {
+          DY::eval(pk.data(), pk.data() + DY::NX, yk.data(), w.data(), d.data());
+        }
 #pragma unroll
         for (int i = 0; i < DY::NY; ++i) th += fabs(d[i]);
       }
@@ -1967,7 +2009,7 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
       }
       acc[(2 * k) * WAVE] += phi;
       acc[(2 * k + 1) * WAVE] += th;
-      alpha *= 0.5;
+      alpha *= 2.0;
     }
   });
   }

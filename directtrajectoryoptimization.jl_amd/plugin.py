@@ -22,7 +22,7 @@ import subprocess
 from typing import Dict, List, Sequence, Tuple
 
 from .model import Constraint, Cost, Dynamics, GeneralConstraint
-from .symbolic.codegen import emit_body
+from .symbolic.codegen import emit_body, is_affine, trig_arguments
 from .symbolic import expr as E
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -430,6 +430,18 @@ def generate_source(st: Structure, name: str) -> str:
         sig = "const double* x, const double* u, const double* y, const double* w, double* out"
         out.append(_fn("eval", sig, emit_body(d.evaluate_expr, "out", va)))
         out.append(_fn("jac", sig, emit_body(d.jacobian_expr, "out", va)))
+        # Line evaluation (k_linesearch evaluates the residual at 8 points x + alpha_k dx): when every sin / cos argument is an
+        # affine function of (x, u, y) the kernel gets the arguments (trig_args) and a residual that takes the sin / cos values
+        # from the caller (eval_trig), and produces them for all trial points from two sincos per argument
+        targs = trig_arguments(d.evaluate_expr)
+        memo: Dict[int, bool] = {}
+        if targs and len(targs) <= 8 and all(is_affine(a_, memo) for a_ in targs):
+            out.append(f"  static constexpr int NTRIG = {len(targs)};")
+            out.append(_fn("trig_args", sig, emit_body(targs, "out", va)))
+            sigt = "const double* x, const double* u, const double* y, const double* w, const double* sn, const double* cs, double* out"
+            out.append(_fn("eval_trig", sigt, emit_body(d.evaluate_expr, "out", va, trig_override={a_.id: j for j, a_ in enumerate(targs)})))
+        else:
+            out.append("  static constexpr int NTRIG = 0;")
         # residual and Jacobian from one body (k_stage_eval needs both at every stage)
         sigej = "const double* x, const double* u, const double* y, const double* w, double* eout, double* jout"
         out.append(_fn("eval_jac", sigej, emit_body(list(d.evaluate_expr) + list(d.jacobian_expr),

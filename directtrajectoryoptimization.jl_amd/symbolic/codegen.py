@@ -67,8 +67,47 @@ def structural_hashes(outputs: Sequence[Expr]) -> List[str]:
     return [memo[o.id] for o in outputs]
 
 
+def is_affine(e: Expr, memo: Dict[int, bool] | None = None) -> bool:
+    """e is an affine function of the VAR leaves (constants and parameters 'w' count as coefficients)."""
+    memo = {} if memo is None else memo
+
+    def is_coef(x: Expr) -> bool:      # free of x / u / y / z variables
+        return all(n.op != E.VAR or n.name == "w" for n in E.topo_order([x]))
+
+    def rec(x: Expr) -> bool:
+        if x.id in memo:
+            return memo[x.id]
+        if x.op in (E.CONST, E.VAR):
+            r = True
+        elif x.op in (E.ADD, E.SUB):
+            r = rec(x.args[0]) and rec(x.args[1])
+        elif x.op == E.NEG:
+            r = rec(x.args[0])
+        elif x.op == E.MUL:
+            r = (is_coef(x.args[0]) and rec(x.args[1])) or (is_coef(x.args[1]) and rec(x.args[0]))
+        elif x.op == E.DIV:
+            r = is_coef(x.args[1]) and rec(x.args[0])
+        else:
+            r = is_coef(x)
+        memo[x.id] = r
+        return r
+
+    return rec(e)
+
+
+def trig_arguments(outputs: Sequence[Expr]) -> List[Expr]:
+    """Distinct argument nodes of the sin / cos calls in `outputs`, in first-use order."""
+    seen, args = set(), []
+    for n in E.topo_order(outputs):
+        if n.op == E.FUNC and n.fn in ("sin", "cos") and n.args[0].id not in seen:
+            seen.add(n.args[0].id)
+            args.append(n.args[0])
+    return args
+
+
 def emit_body(outputs: Sequence[Expr], out_name, var_arrays: Dict[str, str],
-              tmp_prefix: str = "t", indent: str = "    ", scale: str | None = None) -> str:
+              tmp_prefix: str = "t", indent: str = "    ", scale: str | None = None,
+              trig_override: Dict[int, int] | None = None) -> str:
     """C statements assigning `out_name[k] = outputs[k]` for all k.
 
     var_arrays maps a VAR family name ('x', 'u', 'y', 'w', 'lam', 'z') to the C array it is read from.
@@ -80,7 +119,7 @@ def emit_body(outputs: Sequence[Expr], out_name, var_arrays: Dict[str, str],
     out_name = "+".join(f"{nm}:{c}" for nm, c in groups) if len(groups) > 1 else groups[0][0]
     if STRUCTURAL_KEYS:
         va = ",".join(f"{k}={v}" for k, v in sorted(var_arrays.items()))
-        return f"{indent}// {out_name} {tmp_prefix} {scale} [{va}] " + " ".join(structural_hashes(outputs))
+        return f"{indent}// {out_name} {tmp_prefix} {scale} {'trig' if trig_override is not None else ''} [{va}] " + " ".join(structural_hashes(outputs))
     order = E.topo_order(outputs)
     name: Dict[int, str] = {}
     lines: List[str] = []
@@ -162,6 +201,10 @@ def emit_body(outputs: Sequence[Expr], out_name, var_arrays: Dict[str, str],
         else:
             aid = n.args[0].id
             arg = n.args[0]
+            if trig_override is not None and n.fn in ("sin", "cos") and aid in trig_override:
+                # the caller supplies sin / cos of this argument (line evaluation: csrc k_linesearch)
+                name[n.id] = f"{'sn' if n.fn == 'sin' else 'cs'}[{trig_override[aid]}]"
+                continue
             if n.fn in ("sin", "cos") and aid in done_pairs:   # pair already produced by a sincos call (ensure_pair)
                 name[n.id] = t
                 continue
