@@ -519,8 +519,10 @@ static int ensure_state(Problem* p, int64_t B) {
   if ((rc = dev_alloc(&S.ds, lanes * S.Ni))) return rc;
   if ((rc = dev_alloc(&S.rec, lanes * S.rec_total))) return rc;
   if ((rc = dev_alloc(&S.fac, lanes * S.fac_total))) return rc;
-  if ((rc = dev_alloc(&S.part, lanes * (size_t)L.T * S.info.npart))) return rc;
-  if ((rc = dev_alloc(&S.lspart, lanes * (size_t)L.T * 2 * S.info.ls_trials))) return rc;
+  // residual / merit partials: one row set per block of DTO_SB stages (k_stage_eval, k_linesearch), not per stage
+  const size_t nblk = ((size_t)L.T + DTO_SB - 1) / DTO_SB;
+  if ((rc = dev_alloc(&S.part, lanes * nblk * S.info.npart))) return rc;
+  if ((rc = dev_alloc(&S.lspart, lanes * nblk * 2 * S.info.ls_trials))) return rc;
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
   if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
   {
