@@ -266,7 +266,7 @@ struct StageBounds {
 };
 template <int NP>
 __device__ __forceinline__ void load_stage_bounds(const dto_kkt_args& a, int64_t g, int z0, StageBounds<NP>& b) {
-  const bool duals = a.n_bnd > 0;
+  const bool duals = a.zl != nullptr;   // allocated iff some variable has a finite, non-fixing bound
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     b.lo[i] = a.lo[z0 + i];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
           }
           if (fl) zl = mu0 / (v - lo);
           if (fh) zu = mu0 / (hi - v);
-          if (o.warm) {
+          if (o.warm && a.zl) {
             const double pl = *soa(a.zl, g, a.Nz, z0 + i), pu = *soa(a.zu, g, a.Nz, z0 + i);
             if (fl && pl > 0.0) zl = pl;
             if (fh && pu > 0.0) zu = pu;
@@ -364,8 +364,10 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
       }
       p[i] = v;
       *soa(a.z, g, a.Nz, z0 + i) = v;
-      *soa(a.zl, g, a.Nz, z0 + i) = zl;
-      *soa(a.zu, g, a.Nz, z0 + i) = zu;
+      if (a.zl) {
+        *soa(a.zl, g, a.Nz, z0 + i) = zl;
+        *soa(a.zu, g, a.Nz, z0 + i) = zu;
+      }
     }
     // multipliers: lam = 0; inequality rows: slack from c(z), nu = zs = mu0 / s
     // (newton_only keeps the caller's multipliers: dto_kkt_step evaluates at a given (z, lam); a warm start keeps them too)
@@ -2248,7 +2250,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
           case 11: n = a.Nc; buf = const_cast<double*>(a.sigc); break;
           default: return -1;
         }
-        if (n == 0) break;
+        if (n == 0 || !buf) break;   // vectors the problem does not have (no slacks, no bound multipliers)
         dim3 grid((unsigned)((n + 3) / 4), (unsigned)a.G);
         if (op == DTO_KKT_PACK) hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, n, buf);
         else hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, a, n, (const double*)buf);

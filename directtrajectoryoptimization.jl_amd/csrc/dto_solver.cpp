@@ -510,8 +510,12 @@ static int ensure_state(Problem* p, int64_t B) {
   HIP_TRY(hipMemcpy(S.d_hi, L.var_hi.data(), L.Nz * sizeof(double), hipMemcpyHostToDevice));
   if ((rc = dev_alloc(&S.z, lanes * L.Nz))) return rc;
   if ((rc = dev_alloc(&S.lam, lanes * L.Nc))) return rc;
-  if ((rc = dev_alloc(&S.zl, lanes * L.Nz))) return rc;
-  if ((rc = dev_alloc(&S.zu, lanes * L.Nz))) return rc;
+  // bound multipliers exist only where a variable has a finite bound that is not a fixing pair (the acrobot has none: 80 KB
+  // per instance, 31 GB at the default bench batch); the kernels test the pointer
+  if (S.n_bnd > S.Ni) {
+    if ((rc = dev_alloc(&S.zl, lanes * L.Nz))) return rc;
+    if ((rc = dev_alloc(&S.zu, lanes * L.Nz))) return rc;
+  }
   if ((rc = dev_alloc(&S.s, lanes * S.Ni))) return rc;
   if ((rc = dev_alloc(&S.zs, lanes * S.Ni))) return rc;
   if ((rc = dev_alloc(&S.dz, lanes * L.Nz))) return rc;
@@ -895,6 +899,11 @@ int dto_solver_peek(dto_problem* h, int which, double* out, int64_t ld, void* st
   SolverState& S = *p->solver;
   const int64_t n = (which == 0 || which == 2 || which == 5 || which == 6) ? p->L.Nz : (which == 1 || which == 3) ? p->L.Nc : S.Ni;
   if (ld < n) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  if ((which == 5 || which == 6) && !S.zl) {   // no finite variable bounds: the bound multipliers are identically zero
+    if (hipMemset2DAsync(out, (size_t)ld * sizeof(double), 0, (size_t)n * sizeof(double), (size_t)S.B, (hipStream_t)stream) != hipSuccess)
+      return set_error(DTO_ERR_DEVICE, "hipMemset2DAsync");
+    return DTO_OK;
+  }
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
   return dto::unpack(p, a, which, out, ld, (hipStream_t)stream);
