@@ -161,8 +161,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed solver iterations (default: the reference's max_iter = a full solve)")
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=393216,
-                    help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.49 MB of solver state per instance, ~60 GB stay free; "
+    ap.add_argument("--batch", type=int, default=524288,
+                    help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.36 MB of solver state per instance, ~70 GB stay free; "
                          ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD and the larger batch keeps the GPU "
                          "filled while instances converge and leave, DESIGN.md sections 5, 7)")
     ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")

@@ -72,6 +72,7 @@ struct dto_kkt_info {
   int n_kind;
   int rec_size[16];   // doubles per stage record, by kind
   int fac_size[16];   // doubles per stage factor record, by kind
+  int fac_size_seq[16];  // the same without the spike coupling: all a batch that only ever runs the sequential sweep stores
   int n_ineq[16];     // inequality rows (slacks) by kind
   int npart, nscal, ls_trials, filter_cap;
   int chunk_sum_size, sep_fac_size, nx;  // per (tile, chunk) doubles of the partitioned factorisation
@@ -221,6 +222,7 @@ void fill_info(dto_kkt_info* o) {
     using D = KindDims<M, K>;
     o->rec_size[K] = D::REC;
     o->fac_size[K] = D::FAC;
+    o->fac_size_seq[K] = D::F_CX;
     o->n_ineq[K] = D::QI;
     fill_info<M, K + 1>(o);
   }
@@ -230,7 +232,7 @@ template <class M>
 int kkt_info(dto_kkt_info* out) {
   out->supported = (M::N_KIND <= 16 && !M::HAS_GENERAL) ? 1 : 0;
   out->n_kind = M::N_KIND;
-  for (int i = 0; i < 16; ++i) out->rec_size[i] = out->fac_size[i] = out->n_ineq[i] = 0;
+  for (int i = 0; i < 16; ++i) out->rec_size[i] = out->fac_size[i] = out->fac_size_seq[i] = out->n_ineq[i] = 0;
   fill_info<M>(out);
   out->npart = DTO_NPART;
   out->nscal = SC_COUNT;

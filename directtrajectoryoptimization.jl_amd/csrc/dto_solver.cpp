@@ -475,8 +475,13 @@ static int ensure_state(Problem* p, int64_t B) {
   S.forced_P = keep_forced;
   S.P = S.P0 = P_new;
   S.n_simd = n_simd;
-  // a sequential batch (P = 1) with uniform dimensions may later run with up to 4 chunks (dto_solver_repack)
-  S.P_cap = (P_new == 1 && uniform_nx && S.forced_P == 0) ? std::max(1, std::min(4, L.T / 8)) : P_new;
+  // a sequential batch (P = 1) with uniform dimensions may later run with up to 4 chunks (dto_solver_repack) -- unless it
+  // is so large (more than two residencies of the sequential sweep) that the switch, which waits for <= 512 tiles, would
+  // hardly ever come: such a batch stays sequential and stores its carries without the spike coupling (14 instead of 30
+  // rows per acrobot stage: 128 KB per instance at T = 1000)
+  S.P_cap = (P_new == 1 && uniform_nx && S.forced_P == 0 && (int64_t)G_new <= 2 * (int64_t)n_simd)
+                ? std::max(1, std::min(4, L.T / 8)) : P_new;
+  const bool seq_only = S.P_cap == 1;
   p->vt->kkt_info(&S.info);
   if (!S.info.supported)
     return set_error(DTO_ERR_UNSUPPORTED,
@@ -488,7 +493,7 @@ static int ensure_state(Problem* p, int64_t B) {
     const int k = L.kind[t];
     S.ioff[t + 1] = S.ioff[t] + S.info.n_ineq[k];
     S.recoff[t + 1] = S.recoff[t] + S.info.rec_size[k];
-    S.facoff[t + 1] = S.facoff[t] + S.info.fac_size[k];
+    S.facoff[t + 1] = S.facoff[t] + (seq_only ? S.info.fac_size_seq[k] : S.info.fac_size[k]);
   }
   S.Ni = S.ioff[L.T]; S.rec_total = S.recoff[L.T]; S.fac_total = S.facoff[L.T];
   S.n_bnd = S.Ni;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 profile of the headline loop ALONE (acrobot T=1000, default batch): kernel statistics and the two HBM traffic
 # passes.  Run on the GPU box from the repo root: bash tools/profile_headline.sh [batch] ; results under gpurun_out/prof_r02/
-B=${1:-393216}
+B=${1:-524288}
 OUT=gpurun_out/prof_r02
 mkdir -p $OUT
 export TMPDIR=/tmp
