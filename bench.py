@@ -193,6 +193,15 @@ def main():
     from dto_amd.parallel import gather_trajectories
 
     T, B = a.horizon, a.batch
+    # Safety net for the memory-sized default: solver state (~0.36 MB per instance at T = 1000, 0.49 MB when the batch may
+    # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 30 GB to spare; shrink by whole
+    # residencies of the sequential sweep (131 072 instances) if another process holds part of the HBM.
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    per_inst = (0.37e6 if B > 131072 else 0.50e6) * (T / 1000.0) + 2 * 8.0 * 5 * T
+    while B > 131072 and B * per_inst + 7e9 > free_b - 30e9:
+        B -= 131072
+    if B != a.batch and rank == 0:
+        print(f"[bench] batch reduced from {a.batch} to {B} instances: only {free_b / 1e9:.0f} GB of HBM free", file=sys.stderr, flush=True)
     p = P.build_acrobot(T=T, evaluate_hessian=True)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
     n = s.nlp
