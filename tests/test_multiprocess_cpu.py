@@ -66,3 +66,18 @@ def test_single_process_gather_is_identity():
     st = torch.tensor([1.0, 0.0, 2.0], dtype=torch.float64)
     out = gather_trajectories(z, st, None)
     assert out.shape == (3, 5) and torch.equal(out[:, :4], z) and torch.equal(out[:, 4], st)
+
+
+def test_chunked_guess_generation_is_the_same_stream():
+    """bench.py builds the guesses of its (memory-sized) batch on the device 32 768 instances at a time; the chunks continue
+    one seeded stream, so the batch is bit-identical to generating it in one piece (and a rank's instances do not depend on
+    the chunk size)."""
+    import numpy as np
+    import torch
+    from conftest import product_solver
+    from bench import make_guesses, make_guesses_device
+    s, p = product_solver("acrobot", 12)
+    whole = make_guesses(s, p, 23, seed=5)
+    for chunk in (1, 7, 23, 100):
+        got = make_guesses_device(s, p, 23, 5, torch.device("cpu"), chunk=chunk).numpy()
+        assert np.array_equal(got, whole), chunk
