@@ -279,6 +279,46 @@ __device__ __forceinline__ void load_stage_bounds(const dto_kkt_args& a, int64_t
   }
 }
 
+// How the sweeps reach the data of one stage.  SoaIO: the SoA tiles of this file (lane = column of the tile).  The
+// instance-major engine (dto_im_kernels.hpp) implements the same interface over stage records staged in LDS, so that the
+// block algebra below (stage_factor / stage_forward / stage_backward) exists once.
+template <class M, int K>
+struct SoaIO {
+  using D = KindDims<M, K>;
+  const dto_kkt_args& a;
+  const int64_t g;
+  const int t, z0;
+  const double* recp;
+  double* facp;
+  __device__ __forceinline__ SoaIO(const dto_kkt_args& a_, int64_t g_, int t_)
+      : a(a_), g(g_), t(t_), z0(a_.zoff[t_]), recp(a_.rec + ((g_ * a_.rec_total + a_.recoff[t_]) << 6) + threadIdx.x),
+        facp(a_.fac + ((g_ * a_.fac_total + a_.facoff[t_]) << 6) + threadIdx.x) {}
+  __device__ __forceinline__ double rec(int e) const { return recp[(int64_t)e << 6]; }
+  __device__ __forceinline__ double p(int i) const { return *soa(a.z, g, a.Nz, z0 + i); }
+  __device__ __forceinline__ double y(int i) const { return *soa(a.z, g, a.Nz, a.zoff[t + 1] + i); }
+  __device__ __forceinline__ double lam(int k) const { return *soa(a.lam, g, a.Nc, a.cdoff[t] + k); }
+  __device__ __forceinline__ double nu(int j) const { return *soa(a.lam, g, a.Nc, a.ccoff[t] + j); }
+  template <int N>
+  __device__ __forceinline__ void params(arr<N>& w) const { load_params(w, a, g, t); }
+  __device__ __forceinline__ void bounds(StageBounds<D::NP>& b) const { load_stage_bounds<D::NP>(a, g, z0, b); }
+  __device__ __forceinline__ bool has_sigx() const { return a.sigx != nullptr; }
+  __device__ __forceinline__ bool has_sigc() const { return a.sigc != nullptr; }
+  __device__ __forceinline__ double sigx(int i) const { return *soa(a.sigx, g, a.Nz, z0 + i); }
+  __device__ __forceinline__ double sigc_con(int j) const { return *soa(a.sigc, g, a.Nc, a.ccoff[t] + j); }
+  __device__ __forceinline__ double sigc_dyn(int k) const { return *soa(a.sigc, g, a.Nc, a.cdoff[t] + k); }
+  __device__ __forceinline__ double slack(int j) const { return *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)); }
+  __device__ __forceinline__ double slack_mult(int j) const { return *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)); }
+  // carry-in record of the stage (written by the forward sweep, read by the backward sweep)
+  __device__ __forceinline__ void put_carry(int i, double v) const { facp[(int64_t)i << 6] = v; }
+  __device__ __forceinline__ double carry(int i) const { return facp[(int64_t)i << 6]; }
+  // the step
+  __device__ __forceinline__ void put_dp(int i, double v) const { *soa(a.dz, g, a.Nz, z0 + i) = v; }
+  __device__ __forceinline__ void put_dnu(int j, double v) const { *soa(a.dlam, g, a.Nc, a.ccoff[t] + j) = v; }
+  __device__ __forceinline__ void put_dlam(int k, double v) const { *soa(a.dlam, g, a.Nc, a.cdoff[t] + k) = v; }
+  __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j)) = v; }
+  __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
+};
+
 // wave-uniform kind dispatch (all lanes of a tile are at the same stage)
 template <class M, int K = 0, class F>
 __device__ __forceinline__ void dispatch_uniform(int kind, F&& f) {
@@ -294,11 +334,11 @@ __device__ __forceinline__ bool finite_hi(double v) { return v < 1e300; }
 // ------------------------------------------------------------------------------------------------
 // pack / unpack between the C-ABI's instance-major buffers and SoA tiles
 // ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, double* dst) {
-  // grid: (ceil(n/4), G); block 256 = 4 rows x 64 lanes
-  const int64_t tile = blockIdx.y;
+static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, double* dst, unsigned nrb) {
+  // grid: G * nrb, nrb = ceil(n/4) row blocks (tile index in grid.x: grid.y is limited to 65535); block 256 = 4 rows x 64 lanes
+  const int64_t tile = blockIdx.x / nrb;
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)(blockIdx.x % nrb) * 4 + (threadIdx.x >> 6);
   const int64_t slot = tile * 64 + lane;
   const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   if (i >= n) return;
@@ -307,10 +347,10 @@ static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, 
   dst[((tile * n + i) << 6) + lane] = v;
 }
 
-static __global__ __launch_bounds__(256) void k_unpack(dto_kkt_args a, int64_t n, const double* src) {
-  const int64_t tile = blockIdx.y;
+static __global__ __launch_bounds__(256) void k_unpack(dto_kkt_args a, int64_t n, const double* src, unsigned nrb) {
+  const int64_t tile = blockIdx.x / nrb;
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)(blockIdx.x % nrb) * 4 + (threadIdx.x >> 6);
   const int64_t slot = tile * 64 + lane;
   const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   if (i >= n || inst >= a.B) return;
@@ -802,9 +842,100 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
 // reduce the stage partials in stage order (deterministic), test convergence, update mu.
 // grid = G waves.
 // ------------------------------------------------------------------------------------------------
+// Convergence test, barrier update and the factorisation request of one instance, given the residual norms of its current
+// iterate (summed over the stages by the caller).  SH as in retry_update_t.
+struct ConvSums {
+  double f, th1, thinf, dinf, szmax, iszmax, slam, sz, lb, xmax;
+};
+template <int SH>
+__device__ __forceinline__ void conv_body(const dto_solver_opts& o, double* sc, const ConvSums& cs, int64_t n_mult, int64_t n_bnd) {
+  const double f = cs.f, th1 = cs.th1, thinf = cs.thinf, dinf = cs.dinf, szmax = cs.szmax, iszmax = cs.iszmax, slam = cs.slam,
+               sz = cs.sz, lb = cs.lb, xmax = cs.xmax;
+  double mu = sc[SC_MU << SH];
+  const double sd = fmax(o.s_max, (slam + sz) / (double)(n_mult + n_bnd > 0 ? n_mult + n_bnd : 1)) / o.s_max;
+  const double scn = fmax(o.s_max, sz / (double)(n_bnd > 0 ? n_bnd : 1)) / o.s_max;
+  // max |s_i z_i - m| over all bound / slack pairs, for any m
+  const double szmin = iszmax > 0.0 ? 1.0 / iszmax : 1e300;
+  auto compl_at = [&](double m) { return n_bnd > 0 ? fmax(szmax - m, m - szmin) : 0.0; };
+  // Ipopt's mu_target: the termination tests measure complementarity against the target barrier parameter
+  const double c0 = compl_at(o.mu_target);
+  const double e0 = fmax(fmax(dinf / sd, thinf), c0 / scn);
+  sc[SC_F << SH] = f;
+  sc[SC_THETA1 << SH] = th1;
+  sc[SC_THETA_INF << SH] = thinf;
+  sc[SC_DINF << SH] = dinf;
+  sc[SC_COMPL << SH] = c0;
+  sc[SC_E0 << SH] = e0;
+  sc[SC_LOGBAR << SH] = lb;
+  sc[SC_XMAX << SH] = xmax;
+  const double iter = sc[SC_ITER << SH];
+  const bool nonfinite = !(f == f) || !(th1 == th1) || !(dinf == dinf) || fabs(f) > 1e300 || th1 > 1e300;
+  // Ipopt's acceptable level (OptimalityErrorConvergenceCheck::CurrentIsAcceptable), counted over consecutive iterations
+  const double f_last = sc[SC_F_LAST << SH];
+  const bool acceptable = o.acceptable_iter > 0 && e0 <= o.acceptable_tol && dinf <= o.acceptable_dual_inf_tol &&
+                          thinf <= o.acceptable_constr_viol_tol && c0 <= o.acceptable_compl_inf_tol &&
+                          fabs(f - f_last) / fmax(1.0, fabs(f)) <= o.acceptable_obj_change_tol;
+  const double acc_count = acceptable ? sc[SC_ACC_COUNT << SH] + 1.0 : 0.0;
+  sc[SC_ACC_COUNT << SH] = acc_count;
+  sc[SC_F_LAST << SH] = f;
+  if (nonfinite) {
+    sc[SC_STATUS << SH] = 3.0;
+  } else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) {
+    sc[SC_STATUS << SH] = 1.0;
+  } else if (o.acceptable_iter > 0 && acc_count >= (double)o.acceptable_iter) {
+    sc[SC_STATUS << SH] = 4.0;
+  } else if (!o.newton_only && xmax > o.diverging_iterates_tol) {
+    sc[SC_STATUS << SH] = 5.0;
+  } else if (iter >= (double)o.max_iter) {
+    sc[SC_STATUS << SH] = 2.0;
+  } else if (n_bnd > 0) {
+    // monotone barrier update (Ipopt MonotoneMuUpdate, mu_allow_fast_monotone_decrease = yes): while the barrier problem is
+    // solved to kappa_eps * mu the parameter drops, but never below max(mu_target, min(tol, compl_inf_tol) / (kappa_eps + 1))
+    const double mu_floor = fmax(o.mu_target, fmin(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
+    bool changed = false;
+    for (int k = 0; k < 8; ++k) {
+      const double emu = fmax(fmax(dinf / sd, thinf), compl_at(mu) / scn);
+      if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
+      mu = fmax(mu_floor, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+      changed = true;
+    }
+    if (changed) {
+      sc[SC_MU << SH] = mu;
+      sc[SC_FILTER_N << SH] = 0.0;  // new barrier problem: the filter is reset (Ipopt, step A-3)
+    }
+  }
+  if (sc[SC_THETA_MAX << SH] < 0.0) {
+    sc[SC_THETA_MAX << SH] = 1e4 * fmax(1.0, th1);
+    sc[SC_THETA_MIN << SH] = 1e-4 * fmax(1.0, th1);
+  }
+  // merit value of the current iterate with the (possibly updated) barrier parameter
+  sc[SC_MERIT0 << SH] = f - mu * lb;
+  // factorisation request of this iteration (consumed by k_kkt_fwd / k_kkt_sep)
+  sc[SC_NEED << SH] = (o.newton_only || sc[SC_STATUS << SH] == 0.0) ? 1.0 : 0.0;
+  sc[SC_ATTEMPT << SH] = 0.0;
+  sc[SC_TRY_GAM << SH] = 1.0;  // exact Hessian of the Lagrangian first
+  if (o.newton_only) {
+    sc[SC_TRY_DW << SH] = o.fixed_delta_w;
+  } else {
+    const double dlast = sc[SC_DELTA_LAST << SH];
+    // Ipopt's Algorithm IC: always try the unmodified matrix first (unless the last line search failed)
+    // after a failed line search start from a larger regularisation -- but never beyond the exact-Hessian cap: without
+    // the cap an instance whose trials keep being rejected by the filter multiplies delta_w by 10 every iteration
+    // (1e163 was observed), its steps vanish and it can never leave that state
+    if (sc[SC_LS_FAIL << SH] != 0.0) sc[SC_TRY_DW << SH] = fmin(o.delta_w_exact_cap, fmax(10.0 * dlast, o.delta_w_init));
+    // Ipopt's Algorithm IC probes delta_w = 0 in every iteration.  While the last iteration needed a regularisation well
+    // above the floor that probe almost always fails and costs a whole factorisation, so it is skipped and the ladder is
+    // entered at kappa_w^- delta_last directly; 0 is probed again once delta_w has decayed to the floor or after two
+    // consecutive full steps (fast local convergence needs the unmodified matrix).  C port, acrobot: T=101 -18 %
+    // factorisations, -7 % iterations; T=301 -31 % / -10 %; pendulum unchanged; every instance still converges.
+    else if (dlast > 1.1 * o.delta_w_init && sc[SC_FULL_STREAK << SH] < 2.0)
+      sc[SC_TRY_DW << SH] = fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+    else sc[SC_TRY_DW << SH] = 0.0;
+  }
+}
+
 static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_mult, int64_t n_bnd) {
   const int64_t g = blockIdx.x;
-  const dto_solver_opts& o = a.opt;
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double f = 0, th1 = 0, thinf = 0, dinf = 0, szmax = 0, iszmax = 0, slam = 0, sz = 0, lb = 0, xmax = 0;
@@ -821,87 +952,7 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
     lb += part[8 << 6];
     xmax = fmax(xmax, part[9 << 6]);
   }
-  double mu = sc[SC_MU << 6];
-  const double sd = fmax(o.s_max, (slam + sz) / (double)(n_mult + n_bnd > 0 ? n_mult + n_bnd : 1)) / o.s_max;
-  const double scn = fmax(o.s_max, sz / (double)(n_bnd > 0 ? n_bnd : 1)) / o.s_max;
-  // max |s_i z_i - m| over all bound / slack pairs, for any m
-  const double szmin = iszmax > 0.0 ? 1.0 / iszmax : 1e300;
-  auto compl_at = [&](double m) { return n_bnd > 0 ? fmax(szmax - m, m - szmin) : 0.0; };
-  // Ipopt's mu_target: the termination tests measure complementarity against the target barrier parameter
-  const double c0 = compl_at(o.mu_target);
-  const double e0 = fmax(fmax(dinf / sd, thinf), c0 / scn);
-  sc[SC_F << 6] = f;
-  sc[SC_THETA1 << 6] = th1;
-  sc[SC_THETA_INF << 6] = thinf;
-  sc[SC_DINF << 6] = dinf;
-  sc[SC_COMPL << 6] = c0;
-  sc[SC_E0 << 6] = e0;
-  sc[SC_LOGBAR << 6] = lb;
-  sc[SC_XMAX << 6] = xmax;
-  const double iter = sc[SC_ITER << 6];
-  const bool nonfinite = !(f == f) || !(th1 == th1) || !(dinf == dinf) || fabs(f) > 1e300 || th1 > 1e300;
-  // Ipopt's acceptable level (OptimalityErrorConvergenceCheck::CurrentIsAcceptable), counted over consecutive iterations
-  const double f_last = sc[SC_F_LAST << 6];
-  const bool acceptable = o.acceptable_iter > 0 && e0 <= o.acceptable_tol && dinf <= o.acceptable_dual_inf_tol &&
-                          thinf <= o.acceptable_constr_viol_tol && c0 <= o.acceptable_compl_inf_tol &&
-                          fabs(f - f_last) / fmax(1.0, fabs(f)) <= o.acceptable_obj_change_tol;
-  const double acc_count = acceptable ? sc[SC_ACC_COUNT << 6] + 1.0 : 0.0;
-  sc[SC_ACC_COUNT << 6] = acc_count;
-  sc[SC_F_LAST << 6] = f;
-  if (nonfinite) {
-    sc[SC_STATUS << 6] = 3.0;
-  } else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) {
-    sc[SC_STATUS << 6] = 1.0;
-  } else if (o.acceptable_iter > 0 && acc_count >= (double)o.acceptable_iter) {
-    sc[SC_STATUS << 6] = 4.0;
-  } else if (!o.newton_only && xmax > o.diverging_iterates_tol) {
-    sc[SC_STATUS << 6] = 5.0;
-  } else if (iter >= (double)o.max_iter) {
-    sc[SC_STATUS << 6] = 2.0;
-  } else if (n_bnd > 0) {
-    // monotone barrier update (Ipopt MonotoneMuUpdate, mu_allow_fast_monotone_decrease = yes): while the barrier problem is
-    // solved to kappa_eps * mu the parameter drops, but never below max(mu_target, min(tol, compl_inf_tol) / (kappa_eps + 1))
-    const double mu_floor = fmax(o.mu_target, fmin(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
-    bool changed = false;
-    for (int k = 0; k < 8; ++k) {
-      const double emu = fmax(fmax(dinf / sd, thinf), compl_at(mu) / scn);
-      if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
-      mu = fmax(mu_floor, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-      changed = true;
-    }
-    if (changed) {
-      sc[SC_MU << 6] = mu;
-      sc[SC_FILTER_N << 6] = 0.0;  // new barrier problem: the filter is reset (Ipopt, step A-3)
-    }
-  }
-  if (sc[SC_THETA_MAX << 6] < 0.0) {
-    sc[SC_THETA_MAX << 6] = 1e4 * fmax(1.0, th1);
-    sc[SC_THETA_MIN << 6] = 1e-4 * fmax(1.0, th1);
-  }
-  // merit value of the current iterate with the (possibly updated) barrier parameter
-  sc[SC_MERIT0 << 6] = f - mu * lb;
-  // factorisation request of this iteration (consumed by k_kkt_fwd / k_kkt_sep)
-  sc[SC_NEED << 6] = (o.newton_only || sc[SC_STATUS << 6] == 0.0) ? 1.0 : 0.0;
-  sc[SC_ATTEMPT << 6] = 0.0;
-  sc[SC_TRY_GAM << 6] = 1.0;  // exact Hessian of the Lagrangian first
-  if (o.newton_only) {
-    sc[SC_TRY_DW << 6] = o.fixed_delta_w;
-  } else {
-    const double dlast = sc[SC_DELTA_LAST << 6];
-    // Ipopt's Algorithm IC: always try the unmodified matrix first (unless the last line search failed)
-    // after a failed line search start from a larger regularisation -- but never beyond the exact-Hessian cap: without
-    // the cap an instance whose trials keep being rejected by the filter multiplies delta_w by 10 every iteration
-    // (1e163 was observed), its steps vanish and it can never leave that state
-    if (sc[SC_LS_FAIL << 6] != 0.0) sc[SC_TRY_DW << 6] = fmin(o.delta_w_exact_cap, fmax(10.0 * dlast, o.delta_w_init));
-    // Ipopt's Algorithm IC probes delta_w = 0 in every iteration.  While the last iteration needed a regularisation well
-    // above the floor that probe almost always fails and costs a whole factorisation, so it is skipped and the ladder is
-    // entered at kappa_w^- delta_last directly; 0 is probed again once delta_w has decayed to the floor or after two
-    // consecutive full steps (fast local convergence needs the unmodified matrix).  C port, acrobot: T=101 -18 %
-    // factorisations, -7 % iterations; T=301 -31 % / -10 %; pendulum unchanged; every instance still converges.
-    else if (dlast > 1.1 * o.delta_w_init && sc[SC_FULL_STREAK << 6] < 2.0)
-      sc[SC_TRY_DW << 6] = fmax(o.delta_w_init, o.kappa_w_minus * dlast);
-    else sc[SC_TRY_DW << 6] = 0.0;
-  }
+  conv_body<6>(a.opt, sc, ConvSums{f, th1, thinf, dinf, szmax, iszmax, slam, sz, lb, xmax}, n_mult, n_bnd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,43 +1029,41 @@ struct Spike {
 //     v_t = L^-T D^-1 L^-1 (y - O xn - C xL),
 // and the panels X = L^-1 O, Z = L^-1 C are never formed: the backward sweep needs neither their registers (72 doubles for
 // the acrobot) nor their substitutions.
-template <class M, int K, bool SPK, bool BWD = false>
-__device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, int t, double mu, double dw, double gam,
+template <class M, int K, bool SPK, bool BWD = false, class IO>
+__device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO& io, double mu, double dw, double gam,
                                              bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
                                              double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
                                              bool& ok, int& nneg, double* keep, const double* xn = nullptr,
                                              const double* xL = nullptr) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
-  const dto_solver_opts& o = a.opt;
   using KD = typename D::KD;
   using CO = typename M::template Cost<KD::COST>;
-  const int z0 = a.zoff[t];
   // the stage record (residuals; plus the quasi-Newton blocks of models without exact Hessians): every row is requested
   // before any is used, together with the iterate the derivative code below needs -- one memory latency per stage
-  const double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
   double rr[D::REC > 0 ? D::REC : 1];
 #pragma unroll
-  for (int i = 0; i < D::REC; ++i) rr[i] = rec[(int64_t)i << 6];
+  for (int i = 0; i < D::REC; ++i) rr[i] = io.rec(i);
   auto R = [&](int e) { return rr[e]; };
   arr<NP> pv;
   arr<NY> yv, lamv;
   arr<Q> nuv;
   if constexpr (D::FUSED) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) pv[i] = *soa(a.z, g, a.Nz, z0 + i);
+    for (int i = 0; i < NP; ++i) pv[i] = io.p(i);
     if constexpr (KD::DYN >= 0) {
 #pragma unroll
       for (int i = 0; i < NY; ++i) {
-        yv[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
-        lamv[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
+        yv[i] = io.y(i);
+        lamv[i] = io.lam(i);
       }
     }
 #pragma unroll
-    for (int j = 0; j < Q; ++j) nuv[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+    for (int j = 0; j < Q; ++j) nuv[j] = io.nu(j);
   }
-  long long tq_ = (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? clock64() : 0;
-#define DTO_KKT_TICK(slot) do { if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) { const long long n_ = clock64(); a.prof[slot] += n_ - tq_; tq_ = n_; } } while (0)
+  long long* const prof_ = io.prof();
+  long long tq_ = prof_ ? clock64() : 0;
+#define DTO_KKT_TICK(slot) do { if (prof_) { const long long n_ = clock64(); prof_[slot] += n_ - tq_; tq_ = n_; } } while (0)
 
 #pragma unroll
   for (int i = 0; i < BD * (BD + 1) / 2; ++i) S[i] = 0.0;
@@ -1027,7 +1076,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     double hl[CO::NHL];
     if constexpr (D::FUSED) {
       arr<CO::NW> wc;
-      load_params(wc, a, g, t);
+      io.params(wc);
       arr<CO::SNH> hv;
       CO::shess(pv.data(), pv.data() + CO::NX, wc.data(), hv.data());
       CO::pack_hess_lower(hv.data(), hl);
@@ -1061,7 +1110,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     arr<DY::NW> wd;
     arr<D::FUSED && (DY::NHL > 0) ? DY::NH : 0> hvd;  // Jacobian and Hessian values come out of one generated body
     if constexpr (D::FUSED) {
-      load_params(wd, a, g, t);
+      io.params(wd);
       if constexpr (DY::NHL > 0) DY::jac_hess(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), lamv.data(), jv, hvd.data());
       else DY::jac(pv.data(), pv.data() + DY::NX, yv.data(), wd.data(), jv);
     } else {
@@ -1092,7 +1141,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
     double jv[CN::NJ > 0 ? CN::NJ : 1], G[Q * NP > 0 ? Q * NP : 1];
     arr<CN::NW> wk;
     if constexpr (D::FUSED) {
-      load_params(wk, a, g, t);
+      io.params(wk);
       CN::jac(pv.data(), pv.data() + CN::NX, wk.data(), jv);
     } else {
 #pragma unroll
@@ -1126,13 +1175,13 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   }
   bool fixed[NP > 0 ? NP : 1];
   StageBounds<NP> sb;
-  if (!o.newton_only) load_stage_bounds<NP>(a, g, z0, sb);
+  if (!o.newton_only) io.bounds(sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double rp = R(D::R_RP + i);
     double sig = dw;
     fixed[i] = false;
-    if (o.newton_only && a.sigx) sig += *soa(a.sigx, g, a.Nz, z0 + i);
+    if (o.newton_only && io.has_sigx()) sig += io.sigx(i);
     if (!o.newton_only) {
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo == hi) {
@@ -1159,11 +1208,11 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   for (int j = 0; j < Q; ++j) {
     double dc = o.delta_c;
     double r = R(D::R_C + j);
-    if (o.newton_only && a.sigc) dc += *soa(a.sigc, g, a.Nc, a.ccoff[t] + j);
+    if (o.newton_only && io.has_sigc()) dc += io.sigc_con(j);
     if (!o.newton_only && D::ineq(j)) {
-      const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
-      const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
-      const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+      const double sv = io.slack(j);
+      const double zv = io.slack_mult(j);
+      const double nu = io.nu(j);
       dc += sv / zv;
       r -= (sv / zv) * (nu - mu / sv);
     }
@@ -1174,7 +1223,7 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
 #pragma unroll
   for (int k = 0; k < NY; ++k) {
     double dc = o.delta_c;
-    if (o.newton_only && a.sigc) dc += *soa(a.sigc, g, a.Nc, a.cdoff[t] + k);
+    if (o.newton_only && io.has_sigc()) dc += io.sigc_dyn(k);
     S[tri(NP + Q + k, NP + Q + k)] = -dc;
     y[NP + Q + k] = -R(D::R_D + k);
   }
@@ -1282,10 +1331,10 @@ __device__ __forceinline__ void stage_factor(const dto_kkt_args& a, int64_t g, i
   DTO_KKT_TICK(5);
 }
 
-template <class M, int K, bool SPK>
-__device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, int t, double mu, double dw,
+template <class M, int K, bool SPK, class IO>
+__device__ __forceinline__ void stage_forward(const dto_solver_opts& o, const IO& io, double mu, double dw,
                                               double gam, bool first, bool need, Carry<M>& cy, Spike<M>& sp,
-                                              bool& ok, int& nneg) {
+                                              bool& ok, int& nneg, bool keep_lost = false) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
   double S[BD * (BD + 1) / 2];
@@ -1296,19 +1345,20 @@ __device__ __forceinline__ void stage_forward(const dto_kkt_args& a, int64_t g, 
   double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
   double dinv[BD];
   // --- carry-in of this stage is all the backward sweep needs besides the stage record (not of a lost attempt)
-  if (need && (SPK || ok)) {
-    double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
+  // `keep_lost`: the last attempt of the ladder (or the single attempt of the linear-solver entry points) is swept through and
+  // stored even with the wrong inertia -- it is the factorisation the backward sweep will use
+  if (need && (SPK || ok || keep_lost)) {
 #pragma unroll
-    for (int i = 0; i < NX * (NX + 1) / 2; ++i) fac[(int64_t)(D::F_P + i) << 6] = cy.P[i];
+    for (int i = 0; i < NX * (NX + 1) / 2; ++i) io.put_carry(D::F_P + i, cy.P[i]);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) fac[(int64_t)(D::F_PY + i) << 6] = cy.py[i];
+    for (int i = 0; i < NX; ++i) io.put_carry(D::F_PY + i, cy.py[i]);
     if constexpr (SPK) {
 #pragma unroll
-      for (int i = 0; i < NX * NX; ++i) fac[(int64_t)(D::F_CX + i) << 6] = sp.Cx[i];
+      for (int i = 0; i < NX * NX; ++i) io.put_carry(D::F_CX + i, sp.Cx[i]);
     }
   }
   const int nneg_in = nneg;
-  stage_factor<M, K, SPK>(a, g, t, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, nullptr);
+  stage_factor<M, K, SPK>(o, io, mu, dw, gam, first, cy, sp, S, y, X, YYl, Z, cx_direct, dinv, ok, nneg, nullptr);
   // static pivot order: the primal pivots of the block come first and must be positive, the Q + NY constraint pivots
   // negative; any other count means the inertia of the whole matrix is off (the sequential sweep gives up early on it)
   if constexpr (!SPK) {
@@ -1385,7 +1435,8 @@ __device__ __attribute__((noinline)) void stage_forward_cold(const dto_kkt_args&
                                                             bool first, bool need, Carry<M>* cy, Spike<M>* sp, int* okneg) {
   bool ok = okneg[0] != 0;
   int nneg = okneg[1];
-  stage_forward<M, K, SPK>(a, g, t, mu, dw, gam, first, need, *cy, *sp, ok, nneg);
+  const bool keep_lost = okneg[2] != 0;
+  stage_forward<M, K, SPK>(a.opt, SoaIO<M, K>(a, g, t), mu, dw, gam, first, need, *cy, *sp, ok, nneg, keep_lost);
   okneg[0] = ok ? 1 : 0;
   okneg[1] = nneg;
 }
@@ -1393,31 +1444,33 @@ __device__ __attribute__((noinline)) void stage_forward_cold(const dto_kkt_args&
 // Outcome of one factorisation attempt of a lane: accept it, or put the next (delta_w, gamma) of the inertia-correction
 // ladder into SC_TRY_* and leave SC_NEED set.  Shared by k_kkt_sep (time-partitioned sweeps, one launch per round) and the
 // sequential sweep, which loops over its rounds inside one launch.
-__device__ __forceinline__ void retry_update(const dto_kkt_args& a, double* sc, bool ok, int nneg) {
-  const dto_solver_opts& o = a.opt;
+// SH: log2 of the stride between the scalar slots of one instance (6: column of an SoA tile; 0: the instance-major engine's
+// contiguous block)
+template <int SH>
+__device__ __forceinline__ void retry_update_t(const dto_solver_opts& o, int Nc, double* sc, bool ok, int nneg) {
   // inertia of the whole KKT matrix must be (n_primal, n_dual, 0): exactly Nc negative pivots
-  if (nneg != (int)a.Nc) ok = false;
-  sc[SC_NFACT << 6] += 1.0;
-  sc[SC_NNEG << 6] = (double)nneg;
-  double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
-  const double dlast = sc[SC_DELTA_LAST << 6];
-  const int attempt = (int)sc[SC_ATTEMPT << 6];
+  if (nneg != Nc) ok = false;
+  sc[SC_NFACT << SH] += 1.0;
+  sc[SC_NNEG << SH] = (double)nneg;
+  double dw = sc[SC_TRY_DW << SH], gam = sc[SC_TRY_GAM << SH];
+  const double dlast = sc[SC_DELTA_LAST << SH];
+  const int attempt = (int)sc[SC_ATTEMPT << SH];
   const bool done = ok || o.newton_only || attempt >= o.max_refactor;
   if (done) {
-    sc[SC_NEED << 6] = 0.0;
-    sc[SC_DELTA_W << 6] = dw;
-    sc[SC_GAMMA << 6] = gam;
-    if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << 6] = dw;  // last nonzero regularisation of the exact Hessian
-    if (dw == 0.0) sc[SC_DELTA_LAST << 6] = 0.0;
-    sc[SC_LS_FAIL << 6] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
-    sc[SC_QN_RESET << 6] = (gam == 0.0) ? 1.0 : 0.0;  // quasi-Newton: restart the element blocks after a fallback
+    sc[SC_NEED << SH] = 0.0;
+    sc[SC_DELTA_W << SH] = dw;
+    sc[SC_GAMMA << SH] = gam;
+    if (dw > 0.0 && gam != 0.0) sc[SC_DELTA_LAST << SH] = dw;  // last nonzero regularisation of the exact Hessian
+    if (dw == 0.0) sc[SC_DELTA_LAST << SH] = 0.0;
+    sc[SC_LS_FAIL << SH] = ok ? 0.0 : 1.0;  // not ok: regularisation cap reached, force growth next time
+    sc[SC_QN_RESET << SH] = (gam == 0.0) ? 1.0 : 0.0;  // quasi-Newton: restart the element blocks after a fallback
     return;
   }
   if (gam != 0.0) {
     // Ipopt's Algorithm IC on the exact Hessian, but only up to a moderate delta_w: beyond it the
     // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
     // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
-    const bool skip_ladder = (sc[SC_GAMMA << 6] == 0.0) && (((int)sc[SC_ITER << 6]) % 4 != 0);
+    const bool skip_ladder = (sc[SC_GAMMA << SH] == 0.0) && (((int)sc[SC_ITER << SH]) % 4 != 0);
     if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
     else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
     if (skip_ladder || dw > o.delta_w_exact_cap) {
@@ -1428,9 +1481,13 @@ __device__ __forceinline__ void retry_update(const dto_kkt_args& a, double* sc, 
     dw *= o.kappa_w_plus;
     if (dw > o.delta_w_max) dw = o.delta_w_max;
   }
-  sc[SC_TRY_DW << 6] = dw;
-  sc[SC_TRY_GAM << 6] = gam;
-  sc[SC_ATTEMPT << 6] = (double)(attempt + 1);
+  sc[SC_TRY_DW << SH] = dw;
+  sc[SC_TRY_GAM << SH] = gam;
+  sc[SC_ATTEMPT << SH] = (double)(attempt + 1);
+}
+
+__device__ __forceinline__ void retry_update(const dto_kkt_args& a, double* sc, bool ok, int nneg) {
+  retry_update_t<6>(a.opt, (int)a.Nc, sc, ok, nneg);
 }
 
 // CHUNKED = false: the plain sequential sweep (P = 1) without any spike code -- a separate instantiation because the
@@ -1459,6 +1516,8 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     for (int i = 0; i < M::MAX_NX * M::MAX_NX; ++i) sp.Cx[i] = 0.0;
     bool ok = true;
     int nneg = 0;
+    // the attempt after which retry_update stops whatever the inertia: its factorisation is the one that gets used
+    const bool keep_lost = a.opt.newton_only || (int)sc[SC_ATTEMPT << 6] >= a.opt.max_refactor;
     for (int t = t0; t < t1; ++t) {
       if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
       if (!CHUNKED || p == 0) {
@@ -1467,7 +1526,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
           if constexpr (!CHUNKED && heavy_kind<M, K>()) {
             Carry<M> cyc = cy;
             Spike<M> spc = sp;
-            int okneg[2] = {ok ? 1 : 0, nneg};
+            int okneg[3] = {ok ? 1 : 0, nneg, keep_lost ? 1 : 0};
             // the callee gets its own copy of the argument block: handing out the address of the kernel's would move every
             // pointer of the hot loop to the stack as well (reloads, generic instead of global addressing)
             const dto_kkt_args acold = a;
@@ -1476,17 +1535,18 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
             ok = okneg[0] != 0;
             nneg = okneg[1];
           } else {
-            stage_forward<M, K, false>(a, g, t, mu, dw, gam, false, need, cy, sp, ok, nneg);
+            stage_forward<M, K, false>(a.opt, SoaIO<M, K>(a, g, t), mu, dw, gam, false, need, cy, sp, ok, nneg, keep_lost);
           }
         });
         // the attempt of a lane is lost with the first stage whose pivots have the wrong signs (stage_forward clears ok):
         // once that has happened to every lane that asked for a factorisation the rest of the sweep is pointless
-        if (!CHUNKED && !__any(need && ok)) break;
+        if (!CHUNKED && !__any(need && (ok || keep_lost))) break;
       } else if constexpr (CHUNKED) {
         dispatch_uniform<M>(a.kind[t], [&](auto kc) {
           // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
           if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-            stage_forward<M, decltype(kc)::value, true>(a, g, t, mu, dw, gam, t == t0, need, cy, sp, ok, nneg);
+            stage_forward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, dw, gam, t == t0, need,
+                                                        cy, sp, ok, nneg);
         });
       }
     }
@@ -1669,14 +1729,12 @@ struct StepAcc {
   double apmax, admax, gphid, rlam;
 };
 
-template <class M, int K, bool SPK>
-__device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g, int t, double mu, double tau,
+template <class M, int K, bool SPK, class IO>
+__device__ __forceinline__ void stage_backward(const dto_solver_opts& o, const IO& io, double mu, double tau,
                                                double dw, double gam, bool first, const double* xL, double* xn,
                                                StepAcc& acc) {
   using D = KindDims<M, K>;
   constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD, NX = D::NX;
-  const dto_solver_opts& o = a.opt;
-  const double* fac = a.fac + ((g * a.fac_total + a.facoff[t]) << 6) + threadIdx.x;
   // residuals of the record, copied to registers by stage_factor before the LDS buffer is handed to the next stage
   double keep[BD];
   auto R = [&](int e) { return e >= D::R_C ? keep[NP + (e - D::R_C)] : (e >= D::R_D ? keep[NP + Q + (e - D::R_D)] : keep[e - D::R_RP]); };
@@ -1684,12 +1742,12 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   Carry<M> cy;
   Spike<M> sp;
 #pragma unroll
-  for (int i = 0; i < NX * (NX + 1) / 2; ++i) cy.P[i] = fac[(int64_t)(D::F_P + i) << 6];
+  for (int i = 0; i < NX * (NX + 1) / 2; ++i) cy.P[i] = io.carry(D::F_P + i);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) cy.py[i] = fac[(int64_t)(D::F_PY + i) << 6];
+  for (int i = 0; i < NX; ++i) cy.py[i] = io.carry(D::F_PY + i);
   if constexpr (SPK) {
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) sp.Cx[i] = fac[(int64_t)(D::F_CX + i) << 6];
+    for (int i = 0; i < NX * NX; ++i) sp.Cx[i] = io.carry(D::F_CX + i);
   }
   double S[BD * (BD + 1) / 2];
   double w[BD];
@@ -1700,7 +1758,7 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
   double dinv[BD];
   bool ok_unused = true;
   int nneg_unused = 0;
-  stage_factor<M, K, SPK, true>(a, g, t, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, keep,
+  stage_factor<M, K, SPK, true>(o, io, mu, dw, gam, first, cy, sp, S, w, X, YYl, Z, cx_direct, dinv, ok_unused, nneg_unused, keep,
                                 xn, xL);
   double v[BD];
 #pragma unroll
@@ -1716,14 +1774,13 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
       for (int i = 0; i < NX; ++i) v[i] = xL[i];  // the head stage's x is the separator itself
     }
   }
-  const int z0 = a.zoff[t];
   // primal step, fraction to the boundary, barrier directional derivative
   StageBounds<NP> sb;
-  if (!o.newton_only) load_stage_bounds<NP>(a, g, z0, sb);
+  if (!o.newton_only) io.bounds(sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const double dp = v[i];
-    *soa(a.dz, g, a.Nz, z0 + i) = dp;
+    io.put_dp(i, dp);
     acc.gphid += R(D::R_RP + i) * dp;
     if (!o.newton_only) {
       const double lo = sb.lo[i], hi = sb.hi[i];
@@ -1752,16 +1809,16 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     const double dnu = v[NP + j];
-    const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+    const double nu = io.nu(j);
     const double r = R(D::R_C + j);
-    *soa(a.dlam, g, a.Nc, a.ccoff[t] + j) = dnu;
+    io.put_dnu(j, dnu);
     double dsv = 0.0;
     if (!o.newton_only && D::ineq(j)) {
-      const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
-      const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+      const double sv = io.slack(j);
+      const double zv = io.slack_mult(j);
       dsv = -(sv / zv) * (nu - mu / sv + dnu);
       const double dzs = mu / sv - zv - (zv / sv) * dsv;
-      *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j)) = dsv;
+      io.put_ds(j, dsv);
       if (dsv < 0.0) acc.apmax = fmin(acc.apmax, -tau * sv / dsv);
       if (dzs < 0.0) acc.admax = fmin(acc.admax, -tau * zv / dzs);
       acc.gphid -= mu / sv * dsv;
@@ -1772,9 +1829,9 @@ __device__ __forceinline__ void stage_backward(const dto_kkt_args& a, int64_t g,
 #pragma unroll
   for (int k = 0; k < NY; ++k) {
     const double dl = v[NP + Q + k];
-    const double lam = *soa(a.lam, g, a.Nc, a.cdoff[t] + k);
+    const double lam = io.lam(k);
     const double r = R(D::R_D + k);
-    *soa(a.dlam, g, a.Nc, a.cdoff[t] + k) = dl;
+    io.put_dlam(k, dl);
     acc.gphid += lam * (r - o.delta_c * dl);
     acc.rlam += r * (lam + dl);
   }
@@ -1793,7 +1850,7 @@ __device__ __attribute__((noinline)) void stage_backward_cold(const dto_kkt_args
     xl[i] = xL[i];
     xv[i] = xn[i];
   }
-  stage_backward<M, K, false>(a, g, t, mu, tau, dw, gam, false, xl, xv, ac);
+  stage_backward<M, K, false>(a.opt, SoaIO<M, K>(a, g, t), mu, tau, dw, gam, false, xl, xv, ac);
 #pragma unroll
   for (int i = 0; i < M::MAX_NX; ++i) xn[i] = xv[i];
   *acc = ac;
@@ -1834,13 +1891,14 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
           for (int i = 0; i < N; ++i) xn[i] = xnc[i];
           acc = accc;
         } else {
-          stage_backward<M, K, false>(a, g, t, mu, tau, dw, gam, false, xL, xn, acc);
+          stage_backward<M, K, false>(a.opt, SoaIO<M, K>(a, g, t), mu, tau, dw, gam, false, xL, xn, acc);
         }
       });
     } else if constexpr (CHUNKED) {
       dispatch_uniform<M>(a.kind[t], [&](auto kc) {
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_backward<M, decltype(kc)::value, true>(a, g, t, mu, tau, dw, gam, t == t0, xL, xn, acc);
+          stage_backward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, tau, dw, gam, t == t0, xL, xn,
+                                                       acc);
       });
     }
   }
@@ -2022,33 +2080,20 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
   for (int k = 0; k < 2 * DTO_LS_TRIALS; ++k) out[(int64_t)k << 6] = acc[k * WAVE];
 }
 
-static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
-  // Filter line search of Ipopt (Waechter & Biegler 2006, Algorithm A, steps A-5..A-8) over the
-  // precomputed trial step sizes alpha_k = alpha_max 2^-k; no restoration phase: if every trial is
-  // rejected the most feasible trial is taken and more regularisation is requested.
-  const int64_t g = blockIdx.x;
-  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
-  if (sc[SC_STATUS << 6] != 0.0) return;
-  double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
-#pragma unroll
-  for (int k = 0; k < DTO_LS_TRIALS; ++k) phi[k] = th[k] = 0.0;
-  for (int c = 0; c < a.P; ++c) {
-    const double* in = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < DTO_LS_TRIALS; ++k) {
-      phi[k] += in[(int64_t)(2 * k) << 6];
-      th[k] += in[(int64_t)(2 * k + 1) << 6];
-    }
-  }
+// Filter line search of Ipopt (Waechter & Biegler 2006, Algorithm A, steps A-5..A-8) over the precomputed trial step sizes
+// alpha_k = alpha_max 2^-k (phi / th: barrier objective and l1 violation of the trials, summed over the stages by the
+// caller); no restoration phase: if every trial is rejected the most feasible trial is taken and more regularisation is
+// requested.  fl: the instance's filter entries, same stride as the scalars.  SH as in retry_update_t.
+template <int SH>
+__device__ __forceinline__ void ls_reduce_body(const dto_solver_opts& o, double* sc, double* fl, const double* phi, const double* th) {
   constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8, DELTA = 1.0;
-  const double th0 = sc[SC_THETA1 << 6];
-  const double phi0 = sc[SC_MERIT0 << 6];
-  const double dphi = sc[SC_DMERIT << 6];
-  const double thmax = sc[SC_THETA_MAX << 6], thmin = sc[SC_THETA_MIN << 6];
-  double* fl = a.filt + ((g * (2 * DTO_FILTER_CAP)) << 6) + threadIdx.x;
-  const int nf_total = (int)sc[SC_FILTER_N << 6];
+  const double th0 = sc[SC_THETA1 << SH];
+  const double phi0 = sc[SC_MERIT0 << SH];
+  const double dphi = sc[SC_DMERIT << SH];
+  const double thmax = sc[SC_THETA_MAX << SH], thmin = sc[SC_THETA_MIN << SH];
+  const int nf_total = (int)sc[SC_FILTER_N << SH];
   const int nf = nf_total < DTO_FILTER_CAP ? nf_total : DTO_FILTER_CAP;
-  double alpha = sc[SC_ALPHA_PMAX << 6];
+  double alpha = sc[SC_ALPHA_PMAX << SH];
   double chosen = -1.0;
   bool ftype = false;
   int best = 0;
@@ -2057,7 +2102,7 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
   // fraction-to-the-boundary step without consulting the filter (only theta <= theta_max), then the filter decides again
   // from wherever that led.  Ipopt keeps the watchdog iterate and returns to it if the trial iterations end outside the
   // filter; here there is no rollback (no second copy of the iterate per instance).  Effect: DESIGN.md section 5.
-  const int wd_left = (int)sc[SC_WATCHDOG << 6];
+  const int wd_left = (int)sc[SC_WATCHDOG << SH];
   const bool watchdog = wd_left > 0;
 #pragma unroll 1
   for (int k = 0; k < DTO_LS_TRIALS; ++k) {
@@ -2081,7 +2126,7 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= thmax && tk <= 3.0 * fmax(th0, 1.0);
     if (ok && !watchdog) {
       for (int i = 0; i < nf; ++i) {
-        const double tf = fl[(int64_t)(2 * i) << 6], pf = fl[(int64_t)(2 * i + 1) << 6];
+        const double tf = fl[(int64_t)(2 * i) << SH], pf = fl[(int64_t)(2 * i + 1) << SH];
         if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
       }
     }
@@ -2095,7 +2140,7 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
   bool augment = false;
   if (chosen < 0.0) {
     // no acceptable trial: take the most feasible one if it improves feasibility, else the shortest step
-    double ab = sc[SC_ALPHA_PMAX << 6];
+    double ab = sc[SC_ALPHA_PMAX << SH];
     for (int k = 0; k < best; ++k) ab *= 0.5;
     if (th[best] == th[best] && th[best] < th0) chosen = ab;
     else chosen = alpha * 2.0;  // alpha_max 2^-(TRIALS-1)
@@ -2104,36 +2149,54 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     // next system more.  acrobot T = 101, 1024 seeds: 1022 -> 1024 converge, the other workloads unchanged.
     if (!(th[best] <= DTO_LS_NULL_STEP * fmax(th0, 1.0))) {
       chosen = 0.0;
-      sc[SC_ALPHA_DMAX << 6] = 0.0;
+      sc[SC_ALPHA_DMAX << SH] = 0.0;
     }
-    sc[SC_LS_FAIL << 6] = 1.0;
+    sc[SC_LS_FAIL << SH] = 1.0;
     augment = true;
   } else {
-    sc[SC_LS_FAIL << 6] = 0.0;
+    sc[SC_LS_FAIL << SH] = 0.0;
     augment = !ftype && !watchdog;
   }
   if (watchdog) {
-    sc[SC_WATCHDOG << 6] = (double)(wd_left - 1);
-    sc[SC_SHORT_STREAK << 6] = 0.0;
-  } else if (a.opt.watchdog_trigger > 0) {
-    const double streak = (chosen < sc[SC_ALPHA_PMAX << 6]) ? sc[SC_SHORT_STREAK << 6] + 1.0 : 0.0;
-    if (streak >= (double)a.opt.watchdog_trigger) {
-      sc[SC_WATCHDOG << 6] = (double)a.opt.watchdog_trials;
-      sc[SC_SHORT_STREAK << 6] = 0.0;
+    sc[SC_WATCHDOG << SH] = (double)(wd_left - 1);
+    sc[SC_SHORT_STREAK << SH] = 0.0;
+  } else if (o.watchdog_trigger > 0) {
+    const double streak = (chosen < sc[SC_ALPHA_PMAX << SH]) ? sc[SC_SHORT_STREAK << SH] + 1.0 : 0.0;
+    if (streak >= (double)o.watchdog_trigger) {
+      sc[SC_WATCHDOG << SH] = (double)o.watchdog_trials;
+      sc[SC_SHORT_STREAK << SH] = 0.0;
     } else {
-      sc[SC_SHORT_STREAK << 6] = streak;
+      sc[SC_SHORT_STREAK << SH] = streak;
     }
   }
   if (augment) {
     const int slot = nf_total % DTO_FILTER_CAP;
-    fl[(int64_t)(2 * slot) << 6] = (1.0 - G_TH) * th0;
-    fl[(int64_t)(2 * slot + 1) << 6] = phi0 - G_PHI * th0;
-    sc[SC_FILTER_N << 6] = (double)(nf_total + 1);
+    fl[(int64_t)(2 * slot) << SH] = (1.0 - G_TH) * th0;
+    fl[(int64_t)(2 * slot + 1) << SH] = phi0 - G_PHI * th0;
+    sc[SC_FILTER_N << SH] = (double)(nf_total + 1);
   }
-  sc[SC_LS_KIND << 6] = chosen < 0.0 ? -1.0 : (watchdog ? 3.0 : (ftype ? 1.0 : 2.0));
-  sc[SC_ALPHA << 6] = chosen;
+  sc[SC_LS_KIND << SH] = chosen < 0.0 ? -1.0 : (watchdog ? 3.0 : (ftype ? 1.0 : 2.0));
+  sc[SC_ALPHA << SH] = chosen;
   // consecutive full (fraction-to-the-boundary) steps: consulted by k_conv when it picks the first delta_w to try
-  sc[SC_FULL_STREAK << 6] = (chosen >= sc[SC_ALPHA_PMAX << 6]) ? sc[SC_FULL_STREAK << 6] + 1.0 : 0.0;
+  sc[SC_FULL_STREAK << SH] = (chosen >= sc[SC_ALPHA_PMAX << SH]) ? sc[SC_FULL_STREAK << SH] + 1.0 : 0.0;
+}
+
+static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
+#pragma unroll
+  for (int k = 0; k < DTO_LS_TRIALS; ++k) phi[k] = th[k] = 0.0;
+  for (int c = 0; c < a.P; ++c) {
+    const double* in = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+      phi[k] += in[(int64_t)(2 * k) << 6];
+      th[k] += in[(int64_t)(2 * k + 1) << 6];
+    }
+  }
+  ls_reduce_body<6>(a.opt, sc, a.filt + ((g * (2 * DTO_FILTER_CAP)) << 6) + threadIdx.x, phi, th);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2253,9 +2316,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
           default: return -1;
         }
         if (n == 0 || !buf) break;   // vectors the problem does not have (no slacks, no bound multipliers)
-        dim3 grid((unsigned)((n + 3) / 4), (unsigned)a.G);
-        if (op == DTO_KKT_PACK) hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, n, buf);
-        else hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, a, n, (const double*)buf);
+        const unsigned nrb = (unsigned)((n + 3) / 4);
+        if ((uint64_t)nrb * (uint64_t)a.G > 0x7fffffffull) return (int)hipErrorInvalidValue;
+        const dim3 grid(nrb * (unsigned)a.G);
+        if (op == DTO_KKT_PACK) hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, a, n, buf, nrb);
+        else hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, a, n, (const double*)buf, nrb);
         break;
       }
       case DTO_KKT_INIT: hipLaunchKernelGGL(k_init<M>, dim3(gt), dim3(WAVE), 0, st, a); break;

@@ -13,7 +13,7 @@
 
 #include <stdint.h>
 
-#define DTO_PLUGIN_ABI 4
+#define DTO_PLUGIN_ABI 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -101,6 +101,8 @@ struct dto_kkt_args;
 struct dto_kkt_info;
 struct dto_wide_args;
 struct dto_wide_info;
+struct dto_im_args;
+struct dto_im_info;
 
 typedef struct dto_model_vtable {
   int abi;            /* DTO_PLUGIN_ABI */
@@ -122,6 +124,9 @@ typedef struct dto_model_vtable {
    * `launch`/`launch_kkt` are NULL for wide models */
   int (*launch_wide)(int op, const struct dto_wide_args* args, void* stream);
   int (*wide_info)(struct dto_wide_info* out);
+  /* instance-major engine of the solver path (dto_im_kernels.hpp); NULL where a plugin has none */
+  int (*launch_im)(int op, const struct dto_im_args* args, void* stream);
+  int (*im_info)(struct dto_im_info* out);
 } dto_model_vtable;
 
 /* the one symbol every plugin exports */

@@ -14,6 +14,7 @@ int set_error(int code, const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
 
 struct SolverState;  // dto_solver.cpp
+struct ImState;      // dto_solver.cpp: instance-major engine
 
 struct Problem {
   void* dl = nullptr;
@@ -31,6 +32,9 @@ struct Problem {
   size_t scratch_len = 0;
   hipStream_t stream = nullptr;
   SolverState* solver = nullptr;
+  ImState* im = nullptr;
+  int engine_req = 0;      // dto_solver_set_engine: 0 automatic, 1 SoA tiles, 2 instance-major
+  bool im_active = false;  // which engine holds the batch that was begun last
   // factor storage and inertia flags of the wide-stage KKT kernels
   double* wide_fac = nullptr;
   size_t wide_fac_len = 0;

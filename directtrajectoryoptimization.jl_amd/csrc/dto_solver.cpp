@@ -16,6 +16,7 @@
 
 #include "../../include/dto.h"
 #include "dto_kkt_kernels.hpp"
+#include "dto_im_kernels.hpp"
 #include "dto_wide_kernels.hpp"
 #include "dto_problem.hpp"
 
@@ -84,11 +85,52 @@ struct SolverState {
   }
 };
 
+// Device state of the instance-major engine (dto_im_kernels.hpp)
+struct ImState {
+  int64_t B = 0;
+  dto_im_info info{};
+  std::vector<int> aoff, doff, coff, boff, ioff;
+  int *d_aoff = nullptr, *d_doff = nullptr, *d_coff = nullptr, *d_boff = nullptr, *d_ioff = nullptr;
+  int64_t a_total = 0, d_total = 0, c_total = 0, b_total = 0, Ni = 0, n_bnd = 0;
+  double *d_lo = nullptr, *d_hi = nullptr;
+  double *A = nullptr, *R = nullptr, *D = nullptr, *C = nullptr, *Bd = nullptr;
+  double *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr, *wbuf = nullptr;
+  bool use_w = false;
+  int* phase = nullptr;
+  int* lists = nullptr;   // 3 x B
+  int* ctr = nullptr;     // [0..2] list lengths, [3..4] sweep tickets, [5..6] running / work left
+  int* h_ctr = nullptr;   // pinned host mirror
+  int nwin_e = 1, nwin_l = 1;
+  dto_solver_opts opt{};
+  dto_options user{};
+  bool begun = false;
+  int iter_base = 0;      // iterations requested so far through dto_solver_iterate
+  int64_t passes = 0;     // passes launched since dto_solver_begin (diagnostic)
+  std::vector<double> h_scal;
+
+  void release() {
+    for (void* q : {(void*)d_aoff, (void*)d_doff, (void*)d_coff, (void*)d_boff, (void*)d_ioff, (void*)d_lo, (void*)d_hi, (void*)A,
+                    (void*)R, (void*)D, (void*)C, (void*)Bd, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)wbuf,
+                    (void*)phase, (void*)lists, (void*)ctr})
+      if (q) (void)hipFree(q);
+    if (h_ctr) (void)hipHostFree(h_ctr);
+    d_aoff = d_doff = d_coff = d_boff = d_ioff = nullptr; d_lo = d_hi = nullptr;
+    A = R = D = C = Bd = part = lspart = scal = filt = wbuf = nullptr;
+    phase = lists = ctr = h_ctr = nullptr;
+    B = 0; begun = false; use_w = false;
+  }
+};
+
 void Problem::free_solver() {
   if (solver) {
     solver->release();
     delete solver;
     solver = nullptr;
+  }
+  if (im) {
+    im->release();
+    delete im;
+    im = nullptr;
   }
 }
 
@@ -469,18 +511,21 @@ static int ensure_state(Problem* p, int64_t B) {
     if (S.forced_P > 1) return set_error(DTO_ERR_UNSUPPORTED, "time partitions need a uniform state dimension (use 0 or 1)");
     P_new = 1;
   }
-  if (S.B == B && S.z && S.P0 == P_new) { set_partitions_now(S, S.P0); return DTO_OK; }
+  // what the chunk arrays would be sized for: a sequential batch (P = 1) with uniform dimensions may later run with up to
+  // 4 chunks (dto_solver_repack) -- unless it is so large (more than two residencies of the sequential sweep) that the
+  // switch, which waits for <= 512 tiles, would hardly ever come: such a batch stays sequential and stores its carries
+  // without the spike coupling (14 instead of 30 rows per acrobot stage: 128 KB per instance at T = 1000)
+  const int P_cap_new = (P_new == 1 && uniform_nx && S.forced_P == 0 && (int64_t)G_new <= 2 * (int64_t)n_simd)
+                            ? std::max(1, std::min(4, L.T / 8)) : P_new;
+  // the state is reused only if the chunk layout is the same too (a dto_solver_set_partitions between two batches of one
+  // size changes P_cap and with it the carry records: ADVICE r2)
+  if (S.B == B && S.z && S.P0 == P_new && S.P_cap == P_cap_new) { set_partitions_now(S, S.P0); return DTO_OK; }
   const int keep_forced = S.forced_P;
   S.release();
   S.forced_P = keep_forced;
   S.P = S.P0 = P_new;
   S.n_simd = n_simd;
-  // a sequential batch (P = 1) with uniform dimensions may later run with up to 4 chunks (dto_solver_repack) -- unless it
-  // is so large (more than two residencies of the sequential sweep) that the switch, which waits for <= 512 tiles, would
-  // hardly ever come: such a batch stays sequential and stores its carries without the spike coupling (14 instead of 30
-  // rows per acrobot stage: 128 KB per instance at T = 1000)
-  S.P_cap = (P_new == 1 && uniform_nx && S.forced_P == 0 && (int64_t)G_new <= 2 * (int64_t)n_simd)
-                ? std::max(1, std::min(4, L.T / 8)) : P_new;
+  S.P_cap = P_cap_new;
   const bool seq_only = S.P_cap == 1;
   p->vt->kkt_info(&S.info);
   if (!S.info.supported)
@@ -635,11 +680,12 @@ static void reset_slot_map(SolverState& S) {
   S.G_active = S.G;
 }
 
-static __global__ void k_gather_rows(double* dst, const double* src, int64_t n, const int* src_slot) {
-  // grid (ceil(n / 4), G); block 256 = 4 rows x 64 lanes: dst[tile][i][lane] = src[tile'][i][lane'], (tile', lane') = src_slot
-  const int64_t tile = blockIdx.y;
+static __global__ void k_gather_rows(double* dst, const double* src, int64_t n, const int* src_slot, unsigned nrb) {
+  // grid G * nrb (nrb = ceil(n / 4) row blocks; the tile index lives in grid.x: grid.y is limited to 65535);
+  // block 256 = 4 rows x 64 lanes: dst[tile][i][lane] = src[tile'][i][lane'], (tile', lane') = src_slot
+  const int64_t tile = blockIdx.x / nrb;
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)(blockIdx.x % nrb) * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const int ss = src_slot[tile * 64 + lane];
   dst[((tile * n + i) << 6) + lane] = src[((((int64_t)(ss >> 6)) * n + i) << 6) + (ss & 63)];
@@ -672,7 +718,11 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   if (!S.d_src_slot) HIP_TRY(hipMalloc((void**)&S.d_src_slot, lanes * sizeof(int)));
   if (!S.d_inst_of_slot) HIP_TRY(hipMalloc((void**)&S.d_inst_of_slot, lanes * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(S.d_src_slot, src.data(), lanes * sizeof(int), hipMemcpyHostToDevice, st));
-  const size_t need = (size_t)lanes * (size_t)std::max<int64_t>(std::max<int64_t>(L.Nz, L.Nc), std::max<int64_t>(S.info.nscal, L.Nw));
+  // the staging buffer must hold the widest vector that moves: iterates, multipliers, slacks, filter (2 * filter_cap
+  // rows), scalars, per-instance parameters (the filter rows were missing from the maximum)
+  int64_t widest = std::max<int64_t>(std::max<int64_t>(L.Nz, L.Nc), std::max<int64_t>(S.info.nscal, L.Nw));
+  widest = std::max<int64_t>(widest, std::max<int64_t>(S.Ni, 2 * (int64_t)S.info.filter_cap));
+  const size_t need = (size_t)lanes * (size_t)widest;
   if (S.repack_tmp_len < need) {
     if (S.repack_tmp) (void)hipFree(S.repack_tmp);
     S.repack_tmp = nullptr; S.repack_tmp_len = 0;
@@ -681,8 +731,11 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   }
   auto move = [&](double* buf, int64_t n) -> int {
     if (!buf || n <= 0) return DTO_OK;
-    dim3 grid((unsigned)((n + 3) / 4), (unsigned)S.G);
-    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, S.repack_tmp, (const double*)buf, n, (const int*)S.d_src_slot);
+    const unsigned nrb = (unsigned)((n + 3) / 4);
+    if ((uint64_t)nrb * (uint64_t)S.G > 0x7fffffffull) return set_error(DTO_ERR_INVALID, "batch too large to repack");
+    hipLaunchKernelGGL(k_gather_rows, dim3(nrb * (unsigned)S.G), dim3(256), 0, st, S.repack_tmp, (const double*)buf, n,
+                       (const int*)S.d_src_slot, nrb);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(buf, S.repack_tmp, (size_t)lanes * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return DTO_OK;
   };
@@ -715,11 +768,276 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
 }
 
+// ------------------------------------------------------------------------------------------------
+// instance-major engine: host side.  One PASS = [list EVAL -> residuals, convergence test] [list FACT -> one factorisation
+// attempt each] [list STEP -> back substitution, line search, update]; nothing of it waits for the host.
+// ------------------------------------------------------------------------------------------------
+// engine choice: 0 automatic (instance-major where the SoA engine would run its plain sequential sweep, i.e. at least one
+// tile per SIMD), 1 SoA tiles, 2 instance-major.  DTO_ENGINE=soa|im overrides the automatic choice (measurements, tests).
+static bool im_supported(Problem* p) {
+  if (!p->vt->launch_im || !p->vt->im_info) return false;
+  dto_im_info info;
+  p->vt->im_info(&info);
+  return info.supported != 0;
+}
+
+static bool use_im(Problem* p, int64_t B) {
+  if (!im_supported(p)) return false;
+  int eng = p->engine_req;
+  if (eng == 0) {
+    if (const char* e = getenv("DTO_ENGINE")) eng = !strcmp(e, "im") ? 2 : (!strcmp(e, "soa") ? 1 : 0);
+  }
+  if (eng == 2) return true;
+  if (eng == 1) return false;
+  if (p->solver && p->solver->forced_P > 0) return false;   // an explicit partition request addresses the SoA engine
+  int dev = 0, cus = 0, n_simd = 1024;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+    n_simd = 4 * cus;
+  return (B + 63) / 64 >= n_simd;
+}
+
+static int ensure_im_state(Problem* p, int64_t B) {
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  if (!p->im) p->im = new ImState();
+  ImState& S = *p->im;
+  const Layout& L = p->L;
+  if (S.B == B && S.A) return DTO_OK;
+  S.release();
+  p->vt->im_info(&S.info);
+  if (!S.info.supported) return set_error(DTO_ERR_UNSUPPORTED, "the instance-major engine needs an exact-Hessian model without GeneralConstraint");
+  S.B = B;
+  const int T = L.T;
+  S.aoff.assign(T + 1, 0); S.doff.assign(T + 1, 0); S.coff.assign(T + 1, 0); S.boff.assign(T + 1, 0); S.ioff.assign(T + 1, 0);
+  for (int t = 0; t < T; ++t) {
+    const int k = L.kind[t];
+    S.aoff[t + 1] = S.aoff[t] + S.info.a_size[k];
+    S.doff[t + 1] = S.doff[t] + S.info.d_size[k];
+    S.coff[t + 1] = S.coff[t] + S.info.c_size[k];
+    S.boff[t + 1] = S.boff[t] + S.info.b_size[k];
+    S.ioff[t + 1] = S.ioff[t] + S.info.n_ineq[k];
+  }
+  S.a_total = S.aoff[T]; S.d_total = S.doff[T]; S.c_total = S.coff[T]; S.b_total = S.boff[T]; S.Ni = S.ioff[T];
+  S.n_bnd = S.Ni;
+  for (int64_t i = 0; i < L.Nz; ++i) {
+    if (L.var_lo[i] == L.var_hi[i]) continue;
+    if (std::isfinite(L.var_lo[i])) ++S.n_bnd;
+    if (std::isfinite(L.var_hi[i])) ++S.n_bnd;
+  }
+  S.nwin_e = (T + S.info.own_eval - 1) / S.info.own_eval;
+  S.nwin_l = (T + S.info.own_ls - 1) / S.info.own_ls;
+  auto table = [&](int** d, const std::vector<int>& h) -> int {
+    HIP_TRY(hipMalloc((void**)d, h.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    return DTO_OK;
+  };
+  if ((rc = table(&S.d_aoff, S.aoff)) || (rc = table(&S.d_doff, S.doff)) || (rc = table(&S.d_coff, S.coff)) ||
+      (rc = table(&S.d_boff, S.boff)) || (rc = table(&S.d_ioff, S.ioff)))
+    return rc;
+  HIP_TRY(hipMalloc((void**)&S.d_lo, std::max<size_t>(1, L.Nz) * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&S.d_hi, std::max<size_t>(1, L.Nz) * sizeof(double)));
+  HIP_TRY(hipMemcpy(S.d_lo, L.var_lo.data(), L.Nz * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.d_hi, L.var_hi.data(), L.Nz * sizeof(double), hipMemcpyHostToDevice));
+  const size_t nb = (size_t)B;
+  // + one record of slack at the end: the sweeps form (never read) the address of the record after the last stage
+  if ((rc = dev_alloc(&S.A, nb * (size_t)S.a_total + 16))) return rc;
+  if ((rc = dev_alloc(&S.R, nb * (size_t)S.a_total + 16))) return rc;
+  if ((rc = dev_alloc(&S.D, nb * (size_t)S.d_total + 16))) return rc;
+  if ((rc = dev_alloc(&S.C, nb * (size_t)S.c_total + 16))) return rc;
+  if (S.n_bnd > 0 && (rc = dev_alloc(&S.Bd, nb * (size_t)S.b_total + 16))) return rc;
+  if ((rc = dev_alloc(&S.part, nb * (size_t)S.nwin_e * S.info.npart))) return rc;
+  if ((rc = dev_alloc(&S.lspart, nb * (size_t)S.nwin_l * 2 * S.info.ls_trials))) return rc;
+  if ((rc = dev_alloc(&S.scal, nb * (size_t)S.info.nscal))) return rc;
+  if ((rc = dev_alloc(&S.filt, nb * 2 * (size_t)S.info.filter_cap))) return rc;
+  if ((rc = dev_alloc(&S.phase, nb))) return rc;
+  if ((rc = dev_alloc(&S.lists, 3 * nb))) return rc;
+  if ((rc = dev_alloc(&S.ctr, (size_t)8))) return rc;
+  HIP_TRY(hipHostMalloc((void**)&S.h_ctr, 8 * sizeof(int)));
+  S.h_scal.assign(nb * S.info.nscal, 0.0);
+  HIP_TRY(hipDeviceSynchronize());
+  return DTO_OK;
+}
+
+static void fill_im_args(Problem* p, dto_im_args& a) {
+  ImState& S = *p->im;
+  const Layout& L = p->L;
+  std::memset(&a, 0, sizeof(a));
+  a.T = L.T; a.B = S.B;
+  a.Nz = L.Nz; a.Nc = L.Nc; a.Ni = S.Ni; a.Nw = L.Nw;
+  a.n_mult = L.Nc; a.n_bnd = S.n_bnd;
+  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.ccoff = p->d_ccoff; a.ioff = S.d_ioff;
+  a.aoff = S.d_aoff; a.doff = S.d_doff; a.coff = S.d_coff; a.boff = S.d_boff;
+  a.a_total = S.a_total; a.d_total = S.d_total; a.c_total = S.c_total; a.b_total = S.b_total;
+  a.lo = S.d_lo; a.hi = S.d_hi; a.params = p->d_params;
+  a.wpi = S.use_w ? S.wbuf : nullptr; a.ldw = L.Nw;
+  a.A = S.A; a.R = S.R; a.D = S.D; a.C = S.C; a.Bd = S.Bd;
+  a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt; a.phase = S.phase;
+  a.nwin_e = S.nwin_e; a.nwin_l = S.nwin_l;
+  a.iter_target = -1;
+  a.ticket = S.ctr + 3; a.running = S.ctr + 5;
+  a.opt = S.opt;
+}
+
+static int im_launch(Problem* p, int op, const dto_im_args& a, hipStream_t st) {
+  const int rc = p->vt->launch_im(op, &a, (void*)st);
+  if (rc != 0) return hip_fail((hipError_t)rc, "instance-major kernel launch");
+  return DTO_OK;
+}
+
+static int im_set_params(Problem* p, const dto_batch* b, hipStream_t st) {
+  ImState& S = *p->im;
+  S.use_w = false;
+  if (!b->params || p->L.Nw == 0) return DTO_OK;
+  if (b->ldp < p->L.Nw) return set_error(DTO_ERR_INVALID, "ldp < num_parameters");
+  if (!S.wbuf) {
+    int rc = dev_alloc(&S.wbuf, (size_t)S.B * (size_t)p->L.Nw);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpy2DAsync(S.wbuf, p->L.Nw * sizeof(double), b->params, b->ldp * sizeof(double), p->L.Nw * sizeof(double),
+                           (size_t)S.B, hipMemcpyDeviceToDevice, st));
+  S.use_w = true;
+  return DTO_OK;
+}
+
+static int im_begin(Problem* p, const dto_options* opt, const dto_batch* b, bool warm, double mu0) {
+  ImState& S = *p->im;
+  hipStream_t st = (hipStream_t)b->stream;
+  int rc;
+  if ((rc = im_set_params(p, b, st))) return rc;
+  dto_options u;
+  if (opt) u = *opt; else dto_options_default(&u);
+  S.user = u;
+  default_opts(S.opt, u);
+  S.opt.warm = warm ? 1 : 0;
+  S.opt.mu_warm = mu0;
+  dto_im_args a;
+  fill_im_args(p, a);
+  a.aos_in = b->x; a.ld_aos = b->ldx;
+  if ((rc = im_launch(p, DTO_IM_INIT, a, st))) return rc;
+  S.opt.warm = 0;
+  S.begun = true;
+  S.iter_base = 0;
+  S.passes = 0;
+  return DTO_OK;
+}
+
+// one pass; iter_target < 0: no iteration limit besides max_iter
+static int im_pass(Problem* p, hipStream_t st, int iter_target) {
+  ImState& S = *p->im;
+  dto_im_args a;
+  fill_im_args(p, a);
+  a.iter_target = iter_target;
+  int rc;
+  HIP_TRY(hipMemsetAsync(S.ctr, 0, 5 * sizeof(int), st));
+  auto with_list = [&](int k) { a.list = S.lists + (size_t)k * S.B; a.count = S.ctr + k; };
+  auto compact = [&](int k, int phase) -> int {
+    a.list_out = S.lists + (size_t)k * S.B; a.count_out = S.ctr + k; a.phase_sel = phase;
+    return im_launch(p, DTO_IM_COMPACT, a, st);
+  };
+  if ((rc = compact(0, DTO_IM_PH_EVAL))) return rc;
+  with_list(0);
+  if ((rc = im_launch(p, DTO_IM_EVAL, a, st))) return rc;
+  if ((rc = im_launch(p, DTO_IM_CONV, a, st))) return rc;
+  if ((rc = compact(1, DTO_IM_PH_FACT))) return rc;
+  with_list(1);
+  a.ticket = S.ctr + 3;
+  if ((rc = im_launch(p, DTO_IM_FWD, a, st))) return rc;
+  if ((rc = compact(2, DTO_IM_PH_STEP))) return rc;
+  with_list(2);
+  a.ticket = S.ctr + 4;
+  if ((rc = im_launch(p, DTO_IM_BWD, a, st))) return rc;
+  if ((rc = im_launch(p, DTO_IM_LINESEARCH, a, st))) return rc;
+  if ((rc = im_launch(p, DTO_IM_LS_REDUCE, a, st))) return rc;
+  if ((rc = im_launch(p, DTO_IM_UPDATE, a, st))) return rc;
+  ++S.passes;
+  return DTO_OK;
+}
+
+// [0] running instances, [1] those of them with work left below the iteration target (host values after the call)
+static int im_count(Problem* p, hipStream_t st, int iter_target, int* running, int* work) {
+  ImState& S = *p->im;
+  dto_im_args a;
+  fill_im_args(p, a);
+  a.iter_target = iter_target;
+  HIP_TRY(hipMemsetAsync(S.ctr + 5, 0, 2 * sizeof(int), st));
+  int rc;
+  if ((rc = im_launch(p, DTO_IM_COUNT, a, st))) return rc;
+  HIP_TRY(hipMemcpyAsync(S.h_ctr, S.ctr, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (running) *running = S.h_ctr[5];
+  if (work) *work = S.h_ctr[6];
+  return DTO_OK;
+}
+
+static int im_fetch_scalars(Problem* p, hipStream_t st) {
+  ImState& S = *p->im;
+  HIP_TRY(hipMemcpyAsync(S.h_scal.data(), S.scal, S.h_scal.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return DTO_OK;
+}
+
+static inline double im_hscal(const ImState& S, int64_t inst, int slot) { return S.h_scal[(size_t)inst * S.info.nscal + slot]; }
+
+static int im_unpack(Problem* p, int which, double* out, int64_t ld, hipStream_t st) {
+  dto_im_args a;
+  fill_im_args(p, a);
+  a.aos_out = out; a.ld_aos = ld; a.aos_which = which;
+  return im_launch(p, DTO_IM_UNPACK, a, st);
+}
+
+// every running instance advances by n iterations (instances that terminate on the way stop earlier)
+static int im_iterate(Problem* p, int n, hipStream_t st) {
+  ImState& S = *p->im;
+  S.iter_base += n;
+  const int target = S.iter_base;
+  const int group = std::max(1, std::min(S.user.check_every > 0 ? S.user.check_every : 10, n));
+  int rc, work = 1;
+  // an iteration takes one pass plus one per rejected factorisation: max_refactor + 1 passes at most
+  const int64_t pass_cap = (int64_t)n * (S.opt.max_refactor + 2) + 2;
+  for (int64_t done = 0; work > 0 && done < pass_cap;) {
+    for (int k = 0; k < group; ++k, ++done)
+      if ((rc = im_pass(p, st, target))) return rc;
+    if ((rc = im_count(p, st, target, nullptr, &work))) return rc;
+  }
+  return DTO_OK;
+}
+
+static int im_run(Problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations,
+                  hipStream_t st) {
+  ImState& S = *p->im;
+  int rc, running = 1;
+  const int group = std::max(1, S.user.check_every);
+  const auto t_start = std::chrono::steady_clock::now();
+  const int64_t pass_cap = ((int64_t)S.user.max_iter + 1) * (S.opt.max_refactor + 2) + 2;
+  for (int64_t done = 0; running > 0 && done < pass_cap;) {
+    for (int k = 0; k < group; ++k, ++done)
+      if ((rc = im_pass(p, st, -1))) return rc;
+    if ((rc = im_count(p, st, -1, &running, nullptr))) return rc;
+    if (S.user.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time)
+      break;
+  }
+  if (x_out) {
+    if (ldxo < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldxo < num_variables");
+    if ((rc = im_unpack(p, 0, x_out, ldxo, st))) return rc;
+  }
+  if (mu_out) {
+    if (ldmuo < p->L.Nc) return set_error(DTO_ERR_INVALID, "ldmuo < num_constraint");
+    if ((rc = im_unpack(p, 1, mu_out, ldmuo, st))) return rc;
+  }
+  if ((rc = im_fetch_scalars(p, st))) return rc;
+  for (int64_t i = 0; i < S.B; ++i) {
+    if (status) status[i] = (int32_t)im_hscal(S, i, SC_STATUS);
+    if (iterations) iterations[i] = (int32_t)im_hscal(S, i, SC_ITER);
+  }
+  return DTO_OK;
+}
+
 }  // namespace dto
 
 using dto::Problem;
 using dto::set_error;
 using dto::SolverState;
+using dto::ImState;
 
 extern "C" {
 
@@ -746,6 +1064,7 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   }
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
+  p->im_active = false;   // the Newton-KKT entry points live on the SoA engine
   SolverState& S = *p->solver;
   if ((rc = dto::set_batch_params(p, b, (hipStream_t)b->stream))) return rc;
   dto_options u;
@@ -784,7 +1103,16 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !b || !b->x) return set_error(DTO_ERR_INVALID, "null argument");
   if (b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
-  int rc = dto::ensure_state(p, b->B);
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  p->im_active = dto::use_im(p, b->B);
+  if (p->im_active) {
+    if ((rc = dto::ensure_im_state(p, b->B))) return rc;
+    if (p->solver) p->solver->begun = false;
+    return dto::im_begin(p, opt, b, false, 0.0);
+  }
+  if (p->im) p->im->begun = false;
+  rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
   dto::reset_slot_map(S);
@@ -807,6 +1135,7 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
 
 int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->begun) return dto::im_iterate(p, n, (hipStream_t)stream);
   if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin has not been called");
   hipStream_t st = (hipStream_t)stream;
   dto_kkt_args a;
@@ -827,6 +1156,23 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
 int dto_solver_stats(dto_problem* h, int32_t* status, int32_t* iterations, double* objective, double* constr_viol,
                      double* dual_inf, double* mu, double* delta_w, double* alpha) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->A) {
+    ImState& I = *p->im;
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = dto::im_fetch_scalars(p, p->stream);
+    if (rc) return rc;
+    for (int64_t i = 0; i < I.B; ++i) {
+      if (status) status[i] = (int32_t)dto::im_hscal(I, i, SC_STATUS);
+      if (iterations) iterations[i] = (int32_t)dto::im_hscal(I, i, SC_ITER);
+      if (objective) objective[i] = dto::im_hscal(I, i, SC_F);
+      if (constr_viol) constr_viol[i] = dto::im_hscal(I, i, SC_THETA_INF);
+      if (dual_inf) dual_inf[i] = dto::im_hscal(I, i, SC_DINF);
+      if (mu) mu[i] = dto::im_hscal(I, i, SC_MU);
+      if (delta_w) delta_w[i] = dto::im_hscal(I, i, SC_DELTA_W);
+      if (alpha) alpha[i] = dto::im_hscal(I, i, SC_ALPHA);
+    }
+    return DTO_OK;
+  }
   if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
   SolverState& S = *p->solver;
   HIP_TRY(hipDeviceSynchronize());
@@ -847,6 +1193,19 @@ int dto_solver_stats(dto_problem* h, int32_t* status, int32_t* iterations, doubl
 
 int dto_solver_launch_op(dto_problem* h, int op, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->begun) {
+    // instance-major engine: op = 100 + enum dto_im_op, launched on the list its last pass built for it (diagnostic: timing)
+    ImState& I = *p->im;
+    const int iop = op - 100;
+    if (iop < DTO_IM_EVAL || iop > DTO_IM_UPDATE) return set_error(DTO_ERR_INVALID, "op out of range (instance-major engine: 100 + dto_im_op)");
+    dto_im_args a;
+    dto::fill_im_args(p, a);
+    const int k = (iop == DTO_IM_EVAL || iop == DTO_IM_CONV) ? 0 : (iop == DTO_IM_FWD ? 1 : 2);
+    a.list = I.lists + (size_t)k * I.B; a.count = I.ctr + k;
+    a.ticket = I.ctr + (iop == DTO_IM_BWD ? 4 : 3);
+    HIP_TRY(hipMemsetAsync(I.ctr + 3, 0, 2 * sizeof(int), (hipStream_t)stream));
+    return dto::im_launch(p, iop, a, (hipStream_t)stream);
+  }
   if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin has not been called");
   if (op < DTO_KKT_EVAL || op >= DTO_KKT_OP_COUNT) return set_error(DTO_ERR_INVALID, "op out of range");
   dto_kkt_args a;
@@ -863,6 +1222,35 @@ int dto_solver_set_partitions(dto_problem* h, int partitions) {
   return DTO_OK;
 }
 
+int dto_solver_release(dto_problem* h) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p) return set_error(DTO_ERR_INVALID, "null argument");
+  const int forced = p->solver ? p->solver->forced_P : 0;
+  p->free_solver();
+  p->im_active = false;
+  if (forced > 0) {   // the partition request outlives the state it was stored with
+    p->solver = new SolverState();
+    p->solver->forced_P = forced;
+  }
+  return DTO_OK;
+}
+
+int dto_solver_set_engine(dto_problem* h, int engine) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || engine < 0 || engine > 2) return set_error(DTO_ERR_INVALID, "engine must be 0 (automatic), 1 (SoA tiles) or 2 (instance-major)");
+  if (engine == 2 && !dto::im_supported(p))
+    return set_error(DTO_ERR_UNSUPPORTED, "the instance-major engine needs an exact-Hessian register-path model without GeneralConstraint");
+  p->engine_req = engine;
+  return DTO_OK;
+}
+
+int dto_solver_engine(dto_problem* h, int* engine) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !engine) return set_error(DTO_ERR_INVALID, "null argument");
+  *engine = p->im_active ? 2 : 1;
+  return DTO_OK;
+}
+
 int dto_solver_partitions(dto_problem* h, int* partitions) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !partitions) return set_error(DTO_ERR_INVALID, "no solver state");
@@ -872,6 +1260,13 @@ int dto_solver_partitions(dto_problem* h, int* partitions) {
 
 int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni, int* rounds) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->A) {
+    if (rec) *rec = p->im->a_total;   // residual records
+    if (fac) *fac = p->im->c_total;   // carries
+    if (ni) *ni = p->im->Ni;
+    if (rounds) *rounds = 1;
+    return DTO_OK;
+  }
   if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
   if (rec) *rec = p->solver->rec_total;
   if (fac) *fac = p->solver->fac_total;
@@ -887,6 +1282,15 @@ int dto_solver_footprint(dto_problem* h, int64_t* rec, int64_t* fac, int64_t* ni
 
 int dto_solver_scalar(dto_problem* h, int slot, double* out) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && out && p->im_active && p->im && p->im->A) {
+    ImState& I = *p->im;
+    if (slot < 0 || slot >= I.info.nscal) return set_error(DTO_ERR_INVALID, "slot out of range");
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = dto::im_fetch_scalars(p, p->stream);
+    if (rc) return rc;
+    for (int64_t i = 0; i < I.B; ++i) out[i] = dto::im_hscal(I, i, slot);
+    return DTO_OK;
+  }
   if (!p || !p->solver || !p->solver->z || !out) return set_error(DTO_ERR_INVALID, "no solver state");
   SolverState& S = *p->solver;
   if (slot < 0 || slot >= S.info.nscal) return set_error(DTO_ERR_INVALID, "slot out of range");
@@ -899,6 +1303,19 @@ int dto_solver_scalar(dto_problem* h, int slot, double* out) {
 
 int dto_solver_peek(dto_problem* h, int which, double* out, int64_t ld, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && out && p->im_active && p->im && p->im->A) {
+    if (which < 0 || which > 9 || which == 4) return set_error(DTO_ERR_INVALID, "unknown vector");
+    ImState& I = *p->im;
+    const int64_t n = (which == 0 || which == 2 || which == 5 || which == 6) ? p->L.Nz : (which == 1 || which == 3) ? p->L.Nc : I.Ni;
+    if (ld < n) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+    if (n == 0) return DTO_OK;
+    if ((which == 5 || which == 6) && !I.Bd) {
+      if (hipMemset2DAsync(out, (size_t)ld * sizeof(double), 0, (size_t)n * sizeof(double), (size_t)I.B, (hipStream_t)stream) != hipSuccess)
+        return set_error(DTO_ERR_DEVICE, "hipMemset2DAsync");
+      return DTO_OK;
+    }
+    return dto::im_unpack(p, which, out, ld, (hipStream_t)stream);
+  }
   if (!p || !p->solver || !p->solver->z || !out) return set_error(DTO_ERR_INVALID, "no solver state");
   if (which < 0 || which > 9 || which == 4) return set_error(DTO_ERR_INVALID, "unknown vector");
   SolverState& S = *p->solver;
@@ -916,6 +1333,18 @@ int dto_solver_peek(dto_problem* h, int which, double* out, int64_t ld, void* st
 
 int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->A) {
+    int rc;
+    if (x_out) {
+      if (ldxo < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldxo < num_variables");
+      if ((rc = dto::im_unpack(p, 0, x_out, ldxo, (hipStream_t)stream))) return rc;
+    }
+    if (mu_out && p->L.Nc > 0) {
+      if (ldmuo < p->L.Nc) return set_error(DTO_ERR_INVALID, "ldmuo < num_constraint");
+      if ((rc = dto::im_unpack(p, 1, mu_out, ldmuo, (hipStream_t)stream))) return rc;
+    }
+    return DTO_OK;
+  }
   if (!p || !p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "no solver state");
   hipStream_t st = (hipStream_t)stream;
   dto_kkt_args a;
@@ -935,6 +1364,7 @@ int dto_solver_end(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
 int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, int32_t* status,
                    int32_t* iterations, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  if (p && p->im_active && p->im && p->im->begun) return dto::im_run(p, x_out, ldxo, mu_out, ldmuo, status, iterations, (hipStream_t)stream);
   if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin[_warm] has not been called");
   SolverState& S = *p->solver;
   hipStream_t st = (hipStream_t)stream;
@@ -969,6 +1399,8 @@ int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
 
 int dto_solver_repack(dto_problem* h, int* num_running, void* stream) {
   Problem* p = reinterpret_cast<Problem*>(h);
+  // instance-major engine: nothing to move (work lists are rebuilt every pass); only the count is reported
+  if (p && p->im_active && p->im && p->im->begun) return dto::im_count(p, (hipStream_t)stream, -1, num_running, nullptr);
   if (!p || !p->solver || !p->solver->begun) return set_error(DTO_ERR_INVALID, "dto_solver_begin[_warm] has not been called");
   int rc = dto::fetch_scalars(p, (hipStream_t)stream);
   if (rc) return rc;
@@ -989,6 +1421,11 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !b) return set_error(DTO_ERR_INVALID, "null argument");
   if (p->vt->launch_wide) return set_error(DTO_ERR_UNSUPPORTED, "warm starts are not available for wide-stage models");
+  if (p->im_active && p->im && p->im->A) {
+    if (p->im->B != b->B) return set_error(DTO_ERR_INVALID, "dto_solver_begin_warm needs the device state of a previous solve of the same batch size");
+    if (b->x && b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
+    return dto::im_begin(p, opt, b, true, mu0);
+  }
   if (!p->solver || !p->solver->z || p->solver->B != b->B)
     return set_error(DTO_ERR_INVALID, "dto_solver_begin_warm needs the device state of a previous solve of the same batch size");
   if (b->x && b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
@@ -1023,6 +1460,7 @@ int dto_kkt_assemble(dto_problem* h, const dto_batch* b, const dto_kkt_system* s
   if ((sys->sigma_x && sys->ldsx < p->L.Nz) || (sys->sigma_c && sys->ldsc < p->L.Nc)) return set_error(DTO_ERR_INVALID, "leading dimension too small");
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
+  p->im_active = false;
   SolverState& S = *p->solver;
   dto::reset_slot_map(S);
   hipStream_t st = (hipStream_t)b->stream;

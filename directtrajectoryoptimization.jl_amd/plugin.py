@@ -371,7 +371,7 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, nullptr, {1 if st.evaluate_hessian else 0},")
-    out.append(f"  {max_key}, launch, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>")
+    out.append(f"  {max_key}, launch, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>, nullptr, nullptr")
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')
@@ -386,6 +386,7 @@ def generate_source(st: Structure, name: str) -> str:
     out.append(f"// generated by directtrajectoryoptimization.jl_amd/plugin.py (v{GENERATOR_VERSION}) -- do not edit")
     out.append('#include "dto_eval_kernels.hpp"')
     out.append('#include "dto_kkt_kernels.hpp"')
+    out.append('#include "dto_im_kernels.hpp"')
     out.append("namespace {")
     mx = lambda xs: max([0] + [int(x) for x in xs])
     max_nx = mx([d.num_state for d in st.dyn] + [d.num_next_state for d in st.dyn] + [c.num_state for c in st.cost])
@@ -557,10 +558,11 @@ def generate_source(st: Structure, name: str) -> str:
                    f"{g.num_jacobian}, {nh}, gen_jr, gen_jc, gen_hr, gen_hc, {len(g.indices_inequality)}, gen_iq}};")
     out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::launch_eval<Model>(op, a, s); }")
     out.append("static int launch_kkt(int op, const dto_kkt_args* a, void* s) { return dto::launch_kkt<Model>(op, a, s); }")
+    out.append("static int launch_im(int op, const dto_im_args* a, void* s) { return dto::im::launch_im<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, {'&k_general' if g is not None else 'nullptr'}, {1 if h else 0},")
-    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>, nullptr, nullptr")
+    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>, nullptr, nullptr, launch_im, dto::im::im_info<Model>")
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')

@@ -487,13 +487,34 @@ class Solver:
         """Chunks of the time-partitioned factorisation (0 = automatic, 1 = sequential)."""
         capi.check(self._solve_nlp._lib.dto_solver_set_partitions(self._solve_nlp._h, int(partitions)))
 
+    ENGINES = dict(auto=0, soa=1, im=2)
+
+    def set_engine(self, engine):
+        """Engine of the batched solver entry points (include/dto.h: dto_solver_set_engine): 'auto', 'soa' (SoA tiles) or
+        'im' (instance-major stage records + work lists); takes effect at the next begin_batch / solve_batch."""
+        capi.check(self._solve_nlp._lib.dto_solver_set_engine(self._solve_nlp._h, self.ENGINES.get(engine, engine)))
+
+    def engine(self) -> str:
+        v = C.c_int(0)
+        capi.check(self._solve_nlp._lib.dto_solver_engine(self._solve_nlp._h, C.byref(v)))
+        return {1: "soa", 2: "im"}[v.value]
+
+    def release_state(self):
+        """Free the device state of the batched solver entry points (dto_solver_release)."""
+        capi.check(self._solve_nlp._lib.dto_solver_release(self._solve_nlp._h))
+
+    IM_OPS = dict(eval=103, conv=104, fwd=105, bwd=106, linesearch=107, ls_reduce=108, update=109)
+
     def partitions(self) -> int:
         v = C.c_int(0)
         capi.check(self._solve_nlp._lib.dto_solver_partitions(self._solve_nlp._h, C.byref(v)))
         return v.value
 
     def launch_op(self, name: str, stream=0):
-        capi.check(self._solve_nlp._lib.dto_solver_launch_op(self._solve_nlp._h, self.KKT_OPS[name], stream or None))
+        """Launch one kernel of the iteration (diagnostic / timing).  `name`: a key of KKT_OPS (SoA engine) or 'im_' + a key of
+        IM_OPS (instance-major engine: on the work list its last pass built)."""
+        op = self.IM_OPS[name[3:]] if name.startswith("im_") else self.KKT_OPS[name]
+        capi.check(self._solve_nlp._lib.dto_solver_launch_op(self._solve_nlp._h, op, stream or None))
 
     def footprint(self):
         r, f, n, k = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()

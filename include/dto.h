@@ -242,6 +242,15 @@ int dto_solver_launch_op(dto_problem* p, int op, void* stream);
  * tiles x chunks fills the GPU's SIMDs; 1 = plain sequential sweep.  Takes effect at the next begin/step. */
 int dto_solver_set_partitions(dto_problem* p, int partitions);
 int dto_solver_partitions(dto_problem* p, int* partitions);
+/* Engine behind dto_solver_begin / dto_solve_batch: 0 = automatic, 1 = SoA tiles (64 instances share a wavefront for the whole
+ * solve; time-partitioned sweeps for small batches), 2 = instance-major (csrc/dto_im_kernels.hpp: per-instance stage records,
+ * work lists, one factorisation attempt per instance and pass; exact-Hessian models).  Automatic = instance-major where the
+ * batch fills the GPU with plain sequential sweeps (>= 64 instances per SIMD), SoA tiles below.  Takes effect at the next
+ * dto_solver_begin.  dto_solver_engine reports the engine of the batch begun last (1 or 2). */
+int dto_solver_set_engine(dto_problem* p, int engine);
+/* free the device state of the solver entry points (both engines); the next dto_solver_begin allocates again */
+int dto_solver_release(dto_problem* p);
+int dto_solver_engine(dto_problem* p, int* engine);
 /* per-instance footprint of the solver state in doubles: stage records, factors (for roofline arithmetic) */
 int dto_solver_footprint(dto_problem* p, int64_t* record_doubles, int64_t* factor_doubles, int64_t* num_slacks,
                          int* factor_rounds /* (k_kkt_fwd, k_kkt_sep) launch pairs per iteration */);
