@@ -77,6 +77,7 @@ struct dto_im_args {
   int iter_target;                      // instances that have done this many iterations are not evaluated again (< 0: no limit)
   int* ticket;                          // sweeps: next chunk of 64 list entries (dynamic distribution over the resident wavefronts)
   int* running;                         // DTO_IM_COUNT: [0] running instances, [1] of them: work left below iter_target
+  int sweep_occ;                        // wavefronts per SIMD of the sweep kernels (2 or 1: register budget 256 / 512)
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;
   dto_solver_opts opt;
 };
@@ -132,6 +133,16 @@ constexpr int max_as() {
   if constexpr (K < M::N_KIND) {
     constexpr int rest = max_as<M, K + 1>();
     return Rec<M, K>::AS > rest ? Rec<M, K>::AS : rest;
+  } else {
+    return 2;
+  }
+}
+
+template <class M, int K = 0>
+constexpr int max_ds() {
+  if constexpr (K < M::N_KIND) {
+    constexpr int rest = max_ds<M, K + 1>();
+    return Rec<M, K>::DS > rest ? Rec<M, K>::DS : rest;
   } else {
     return 2;
   }
@@ -201,8 +212,10 @@ struct DirectIO {
   __device__ __forceinline__ long long* prof() const { return nullptr; }
 };
 
-// out-of-line forms for the heavy stage kinds (see stage_forward_cold in dto_kkt_kernels.hpp)
-template <class M, int K>
+// out-of-line forms for the heavy stage kinds (see stage_forward_cold in dto_kkt_kernels.hpp).  TAG: one copy per calling
+// kernel variant -- a callee shared by kernels with different register budgets is compiled for the laxest of them, and its
+// register count then lowers the occupancy of the stricter kernel
+template <class M, int K, int TAG>
 __device__ __attribute__((noinline)) void im_forward_cold(const dto_im_args& a, int64_t inst, int t, double mu, double dw, double gam,
                                                           bool need, Carry<M>* cy, int* okneg) {
   bool ok = okneg[0] != 0;
@@ -212,7 +225,7 @@ __device__ __attribute__((noinline)) void im_forward_cold(const dto_im_args& a, 
   okneg[0] = ok ? 1 : 0;
   okneg[1] = nneg;
 }
-template <class M, int K>
+template <class M, int K, int TAG>
 __device__ __attribute__((noinline)) void im_backward_cold(const dto_im_args& a, int64_t inst, int t, double mu, double tau, double dw,
                                                            double gam, double* xn, StepAcc* acc) {
   StepAcc ac = *acc;
@@ -423,6 +436,7 @@ __device__ __forceinline__ double wave_max(double v) {
 template <class M>
 __global__ __launch_bounds__(WAVE) void kim_eval(dto_im_args a) {
   __shared__ __attribute__((aligned(16))) double s_r[OWN_EVAL * max_as<M>() + 2];
+  __shared__ __attribute__((aligned(16))) double s_a[(OWN_EVAL + 2) * max_as<M>() + 2];
   const int64_t n_item = (int64_t)(*a.count) * a.nwin_e;
   for (int64_t item = blockIdx.x; item < n_item; item += gridDim.x) {
   const int e = (int)(item / a.nwin_e);
@@ -435,6 +449,11 @@ __global__ __launch_bounds__(WAVE) void kim_eval(dto_im_args a) {
   const bool live = s >= 0 && s < tend;
   const bool own = live && s >= t0;
   const int r0 = a.aoff[t0];
+  // the A records of the halo, the owned knots and the knot after them (its head is y of the last owned knot) are one
+  // contiguous range of the instance: one coalesced copy into LDS, lanes read their records from there
+  const int a0 = a.aoff[t0 > 0 ? t0 - 1 : 0];
+  wave_load(s_a, a.A + inst * a.a_total + a0, a.aoff[min(tend + 1, a.T)] - a0);
+  __syncthreads();
   double f = 0.0, th1 = 0.0, thinf = 0.0, dinf = 0.0, szmax = 0.0, iszmax = 0.0, sumlam = 0.0, sumz = 0.0, logbar = 0.0, xmax = 0.0;
   double enext[M::MAX_NX];
 #pragma unroll
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(WAVE) void kim_eval(dto_im_args a) {
       using KD = typename D::KD;
       using RC = Rec<M, K>;
       using CO = typename M::template Cost<KD::COST>;
-      const double* Ap = a.A + inst * a.a_total + a.aoff[s];
+      const double* Ap = s_a + (a.aoff[s] - a0);
       arr<D::NP> p;
 #pragma unroll
       for (int i = 0; i < D::NP; ++i) p[i] = Ap[i];
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(WAVE) void kim_eval(dto_im_args a) {
       }
       if constexpr (KD::DYN >= 0) {
         using DY = typename M::template Dyn<KD::DYN>;
-        const double* An = a.A + inst * a.a_total + a.aoff[s + 1];
+        const double* An = s_a + (a.aoff[s + 1] - a0);
         arr<DY::NY> y, lam, d;
         arr<DY::NW> w;
         im_params(w, a, inst, s);
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(WAVE) void kim_eval(dto_im_args a) {
       using D = KindDims<M, K>;
       using KD = typename D::KD;
       using RC = Rec<M, K>;
-      const double* Ap = a.A + inst * a.a_total + a.aoff[s];
+      const double* Ap = s_a + (a.aoff[s] - a0);
       const double* Bp = a.Bd ? a.Bd + inst * a.b_total + a.boff[s] : nullptr;
       if constexpr (KD::PREV >= 0) {
         using DP = typename M::template Dyn<KD::PREV>;
@@ -609,23 +628,172 @@ static __global__ __launch_bounds__(WAVE) void kim_conv(dto_im_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Record staging of the sweeps.  A lane's stage record is a few contiguous 16-byte pieces somewhere in HBM (its instance);
+// 64 lanes reading "their own" record one double at a time means 64 partly used sectors per load and read-modify-write
+// stores (measured with exactly that form: the backward sweep 4x, the forward sweep 1.5x slower per sweep than the SoA
+// engine's).  Instead the WAVE moves the 64 records together: wave-instruction k moves the pieces q = 64 k + lane, piece q
+// being piece (q mod NPC) of the record of lane (q div NPC) -- neighbouring lanes move neighbouring 16 bytes of one record,
+// every fetched sector is used whole -- by LDS-DMA (global_load_lds_dwordx4: no destination registers, the source address
+// is per lane, the LDS image is piece-linear = record-contiguous with pitch NPC * 16 bytes) one stage AHEAD of its use, so
+// that the copy of stage t+1's records runs under the arithmetic of stage t.  A lane then reads its record out of LDS.
+// Stores go the other way: lanes deposit their record in LDS, the wave stores the pieces with full 16-byte lanes.
+// Stage kinds with outsized blocks (heavy_kind: the end stages that carry the pin constraints) are not staged: they run
+// out of line on direct loads (DirectIO) -- sizing the LDS slots for them would cost the hot stages their occupancy.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// NPC: 16-byte pieces per record (record doubles / 2).  `inst`: the lane's instance; `slot`: wave-uniform LDS address.
+template <int NPC>
+__device__ __forceinline__ void gather_records(double* slot, const double* base, int64_t stride, int off, int inst) {
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) {
+    const int q = k * WAVE + (int)threadIdx.x;
+    const int r = q / NPC, pc = q - r * NPC;
+    const int64_t ir = __shfl(inst, r, WAVE);
+    const double* src = base + ir * stride + off + 2 * pc;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(slot + k * (2 * WAVE)), 16, 0, 0);
+  }
+}
+// the reverse: records deposited in `slot` (lane l at slot + l * 2 * NPC doubles) go to HBM; `mask`: lanes whose record is stored
+template <int NPC>
+__device__ __forceinline__ void scatter_records(const double* slot, double* base, int64_t stride, int off, int inst,
+                                                unsigned long long mask) {
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) {
+    const int q = k * WAVE + (int)threadIdx.x;
+    const int r = q / NPC, pc = q - r * NPC;
+    const int64_t ir = __shfl(inst, r, WAVE);
+    const double2 v = *reinterpret_cast<const double2*>(slot + 2 * q);
+    if ((mask >> r) & 1ull) *reinterpret_cast<double2*>(base + ir * stride + off + 2 * pc) = v;
+  }
+}
+
+// slot sizes: the largest record among the kinds that are staged
+template <class M, int K = 0>
+constexpr int hot_max(int which) {
+  if constexpr (K < M::N_KIND) {
+    using RC = Rec<M, K>;
+    const int rest = hot_max<M, K + 1>(which);
+    const int mine = heavy_kind<M, K>() ? 0 : (which == 0 ? RC::AS : (which == 1 ? RC::CS : RC::DS));
+    return mine > rest ? mine : rest;
+  } else {
+    return 2;
+  }
+}
+// A-record size of a kind if it is staged, 0 if it is a heavy kind (wave-uniform run-time lookup)
+template <class M, int K = 0>
+__device__ __forceinline__ int staged_as(int kind) {
+  if constexpr (K < M::N_KIND) return (kind == K) ? (heavy_kind<M, K>() ? 0 : Rec<M, K>::AS) : staged_as<M, K + 1>(kind);
+  else return 0;
+}
+
+// stage data out of LDS (register copies made at construction: the slots are refilled right afterwards)
+template <class M, int K>
+struct LdsIO {
+  using D = KindDims<M, K>;
+  using RC = Rec<M, K>;
+  const dto_im_args& a;
+  const int64_t inst;
+  const int t, z0;
+  double av[RC::AS], rv[RC::AS], yv[D::NY > 0 ? D::NY : 1], cv[RC::CS];
+  double* dstage;      // the lane's D record in the LDS staging slot (backward sweep), else NULL
+  const double* Bp;
+  // la / lr / lc: the lane's records in LDS (lc NULL in the forward sweep); ly: x_{t+1} in LDS or registers
+  __device__ __forceinline__ LdsIO(const dto_im_args& a_, int64_t inst_, int t_, const double* la, const double* lr, const double* lc,
+                                   const double* ly, double* dstage_)
+      : a(a_), inst(inst_), t(t_), z0(a_.zoff[t_]), dstage(dstage_),
+        Bp(a_.Bd ? a_.Bd + inst_ * a_.b_total + a_.boff[t_] : nullptr) {
+#pragma unroll
+    for (int i = 0; i < RC::AS; ++i) av[i] = la[i];
+#pragma unroll
+    for (int i = 0; i < RC::AS; ++i) rv[i] = lr[i];
+    if (lc) {
+#pragma unroll
+      for (int i = 0; i < RC::CS; ++i) cv[i] = lc[i];
+    }
+    if constexpr (D::NY > 0) {
+#pragma unroll
+      for (int i = 0; i < D::NY; ++i) yv[i] = ly[i];
+    }
+  }
+  __device__ __forceinline__ double rec(int e) const { return rv[e]; }
+  __device__ __forceinline__ double p(int i) const { return av[i]; }
+  __device__ __forceinline__ double y(int i) const { return yv[i]; }
+  __device__ __forceinline__ double lam(int k) const { return av[RC::A_LAM + k]; }
+  __device__ __forceinline__ double nu(int j) const { return av[RC::A_NU + j]; }
+  template <int N>
+  __device__ __forceinline__ void params(arr<N>& w) const { im_params(w, a, inst, t); }
+  __device__ __forceinline__ void bounds(StageBounds<D::NP>& b) const {
+    const bool duals = Bp != nullptr;
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) {
+      b.lo[i] = a.lo[z0 + i];
+      b.hi[i] = a.hi[z0 + i];
+      b.p[i] = av[i];
+      b.zl[i] = duals ? Bp[i] : 0.0;
+      b.zu[i] = duals ? Bp[RC::B_ZU + i] : 0.0;
+    }
+  }
+  __device__ __forceinline__ bool has_sigx() const { return false; }
+  __device__ __forceinline__ bool has_sigc() const { return false; }
+  __device__ __forceinline__ double sigx(int) const { return 0.0; }
+  __device__ __forceinline__ double sigc_con(int) const { return 0.0; }
+  __device__ __forceinline__ double sigc_dyn(int) const { return 0.0; }
+  __device__ __forceinline__ double slack(int j) const { return Bp[RC::B_S + D::slack(j)]; }
+  __device__ __forceinline__ double slack_mult(int j) const { return Bp[RC::B_ZS + D::slack(j)]; }
+  __device__ __forceinline__ void put_carry(int, double) const {}   // the kernel stores the carry-in itself (staged)
+  __device__ __forceinline__ double carry(int i) const { return cv[i]; }
+  __device__ __forceinline__ void put_dp(int i, double v) const { dstage[i] = v; }
+  __device__ __forceinline__ void put_dlam(int k, double v) const { dstage[RC::A_LAM + k] = v; }
+  __device__ __forceinline__ void put_dnu(int j, double v) const { dstage[RC::A_NU + j] = v; }
+  __device__ __forceinline__ void put_ds(int j, double v) const { dstage[RC::D_DS + D::slack(j)] = v; }
+  __device__ __forceinline__ long long* prof() const { return nullptr; }
+};
+
+// issue the LDS-DMA of stage tt's A / R / C records (whichever slot pointers are non-NULL) unless tt is out of range or of a
+// heavy kind (those stages load directly)
+template <class M>
+__device__ __forceinline__ void prefetch_stage(const dto_im_args& a, int tt, int inst, double* slot_a, double* slot_r, double* slot_c) {
+  if (tt < 0 || tt >= a.T) return;
+  dispatch_uniform<M>(a.kind[tt], [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using RC = Rec<M, K>;
+    if constexpr (!heavy_kind<M, K>()) {
+      if (slot_a) gather_records<RC::AS / 2>(slot_a, a.A, a.a_total, a.aoff[tt], inst);
+      if (slot_r) gather_records<RC::AS / 2>(slot_r, a.R, a.a_total, a.aoff[tt], inst);
+      if (slot_c) gather_records<RC::CS / 2>(slot_c, a.C, a.c_total, a.coff[tt], inst);
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
 // one factorisation attempt of every listed instance (lane = list entry): forward sweep with the (delta_w, gamma) the
 // instance's ladder is at, inertia judged at the end; success moves the instance to phase STEP, failure leaves it in
-// phase FACT with the next rung.  grid = ceil(n_grid / 64) single-wave blocks.
+// phase FACT with the next rung.  Chunks of 64 list entries are handed out by a ticket.
+// LDS: two A slots (stages t and t+1: y = x_{t+1} is the head of the next record) and one slot that holds R(t) on arrival
+// and then stages the carry-in C(t) on its way out.
 // ------------------------------------------------------------------------------------------------
-template <class M>
-__global__ __launch_bounds__(WAVE, 2) void kim_fwd(dto_im_args a) {
+// WPS: wavefronts per SIMD the register allocation is asked to fit (2: 256 VGPRs with spills to scratch; 1: 512 registers)
+template <class M, int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void kim_fwd(dto_im_args a) {
+  constexpr int HA = hot_max<M>(0), HC = hot_max<M>(1), HRC = HA > HC ? HA : HC;
+  __shared__ __attribute__((aligned(16))) double s_a[2][WAVE * HA];
+  __shared__ __attribute__((aligned(16))) double s_rc[WAVE * HRC];
   const int n = *a.count;
+  const int lane = threadIdx.x;
   for (;;) {
   // chunks of 64 list entries are handed out dynamically: attempts end early or late (a lane's attempt is lost at the first
   // stage with the wrong pivot signs), and the resident wavefronts should not wait for a static share
   int chunk = 0;
-  if (threadIdx.x == 0) chunk = atomicAdd(a.ticket, 1);
+  if (lane == 0) chunk = atomicAdd(a.ticket, 1);
   chunk = __shfl(chunk, 0, WAVE);
   if ((int64_t)chunk * WAVE >= n) return;
-  const int e = chunk * WAVE + threadIdx.x;
+  const int e = chunk * WAVE + lane;
   const bool need = e < n;
-  const int64_t inst = a.list[need ? e : chunk * WAVE];  // lanes beyond the list shadow a listed instance (reads only)
+  const int inst32 = a.list[need ? e : chunk * WAVE];  // lanes beyond the list shadow a listed instance (reads only)
+  const int64_t inst = inst32;
   double* sc = a.scal + inst * SC_COUNT;
   const double mu = sc[SC_MU];
   const double dw = sc[SC_TRY_DW], gam = sc[SC_TRY_GAM];
@@ -637,24 +805,51 @@ __global__ __launch_bounds__(WAVE, 2) void kim_fwd(dto_im_args a) {
   for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = 0.0;
   bool ok = true;
   int nneg = 0;
+  wait_lds();   // the previous chunk's LDS reads are complete before its slots are refilled
+  prefetch_stage<M>(a, 0, inst32, s_a[0], s_rc, nullptr);
+  prefetch_stage<M>(a, 1, inst32, s_a[1], nullptr, nullptr);
   for (int t = 0; t < a.T; ++t) {
+    wait_vm();   // what was issued a stage ago has landed (and that stage's stores have left)
+    const int as_next = (t + 1 < a.T) ? staged_as<M>(a.kind[t + 1]) : 0;
+    const unsigned long long store_mask = __ballot(need && (ok || keep_lost));
     dispatch_uniform<M>(a.kind[t], [&](auto kc) {
       constexpr int K = decltype(kc)::value;
+      using D = KindDims<M, K>;
+      using RC = Rec<M, K>;
       if constexpr (heavy_kind<M, K>()) {
+        prefetch_stage<M>(a, t + 1, inst32, nullptr, s_rc, nullptr);
+        prefetch_stage<M>(a, t + 2, inst32, s_a[t & 1], nullptr, nullptr);
         Carry<M> cyc = cy;
         int okneg[3] = {ok ? 1 : 0, nneg, keep_lost ? 1 : 0};
         const dto_im_args acold = a;
-        im_forward_cold<M, K>(acold, inst, t, mu, dw, gam, need, &cyc, okneg);
+        im_forward_cold<M, K, WPS>(acold, inst, t, mu, dw, gam, need, &cyc, okneg);
         cy = cyc;
         ok = okneg[0] != 0;
         nneg = okneg[1];
       } else {
+        // y = x_{t+1}: head of the next A record -- in LDS if that stage is staged, else straight from HBM
+        const double* ly = as_next > 0 ? s_a[(t + 1) & 1] + lane * as_next : a.A + inst * a.a_total + a.aoff[t + 1];
+        const LdsIO<M, K> io(a, inst, t, s_a[t & 1] + lane * RC::AS, s_rc + lane * RC::AS, nullptr, ly, nullptr);
+        wait_lds();
+        // carry-in of this stage (all the backward sweep needs besides the records): staged in the R slot, stored by the wave
+        double* cst = s_rc + lane * RC::CS;
+#pragma unroll
+        for (int i = 0; i < D::NX * (D::NX + 1) / 2; ++i) cst[D::F_P + i] = cy.P[i];
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) cst[D::F_PY + i] = cy.py[i];
+        if constexpr (RC::CS > D::NX * (D::NX + 1) / 2 + D::NX) cst[RC::CS - 1] = 0.0;
+        wait_lds();
+        scatter_records<RC::CS / 2>(s_rc, a.C, a.c_total, a.coff[t], inst32, store_mask);
+        wait_lds();
+        prefetch_stage<M>(a, t + 1, inst32, nullptr, s_rc, nullptr);
+        prefetch_stage<M>(a, t + 2, inst32, s_a[t & 1], nullptr, nullptr);
         Spike<M> sp;
-        stage_forward<M, K, false>(a.opt, DirectIO<M, K>(a, inst, t), mu, dw, gam, false, need, cy, sp, ok, nneg, keep_lost);
+        stage_forward<M, K, false>(a.opt, io, mu, dw, gam, false, need, cy, sp, ok, nneg, keep_lost);
       }
     });
     if (!__any(need && (ok || keep_lost))) break;
   }
+  wait_vm();    // prefetches of an abandoned sweep must not land in the next chunk's slots
   if (need) {
     retry_update_t<0>(a.opt, (int)a.Nc, sc, ok, nneg);
     if (sc[SC_NEED] == 0.0) a.phase[inst] = DTO_IM_PH_STEP;
@@ -662,49 +857,84 @@ __global__ __launch_bounds__(WAVE, 2) void kim_fwd(dto_im_args a) {
   }
 }
 
-// back substitution of the listed instances (their last attempt was accepted): lane = list entry
-template <class M>
-__global__ __launch_bounds__(WAVE, 2) void kim_bwd(dto_im_args a) {
+// ------------------------------------------------------------------------------------------------
+// back substitution of the listed instances (their last attempt was accepted): lane = list entry.  LDS: A, R and C slots
+// (refilled for stage t-1 as soon as stage t has copied its records to registers; x_{t+1} stays in registers from the stage
+// before) and a staging slot for the step record D(t) on its way out.
+// ------------------------------------------------------------------------------------------------
+template <class M, int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void kim_bwd(dto_im_args a) {
+  constexpr int HA = hot_max<M>(0), HC = hot_max<M>(1), HD = hot_max<M>(2);
+  __shared__ __attribute__((aligned(16))) double s_a[WAVE * HA];
+  __shared__ __attribute__((aligned(16))) double s_r[WAVE * HA];
+  __shared__ __attribute__((aligned(16))) double s_c[WAVE * HC];
+  __shared__ __attribute__((aligned(16))) double s_d[WAVE * HD];
   const int n = *a.count;
   const dto_solver_opts& o = a.opt;
+  const int lane = threadIdx.x;
   for (;;) {
   int chunk = 0;
-  if (threadIdx.x == 0) chunk = atomicAdd(a.ticket, 1);
+  if (lane == 0) chunk = atomicAdd(a.ticket, 1);
   chunk = __shfl(chunk, 0, WAVE);
   if ((int64_t)chunk * WAVE >= n) return;
-  const int e = chunk * WAVE + threadIdx.x;
-  if (e < n) {   // the back substitution stores its step: lanes beyond the list do nothing
-  const int64_t inst = a.list[e];
+  const int e = chunk * WAVE + lane;
+  const bool live = e < n;
+  const int inst32 = a.list[live ? e : chunk * WAVE];   // lanes beyond the list shadow a listed instance; they store nothing
+  const int64_t inst = inst32;
+  const unsigned long long live_mask = __ballot(live);
   double* sc = a.scal + inst * SC_COUNT;
   constexpr int N = M::MAX_NX;
   const double mu = sc[SC_MU];
   const double tau = fmax(o.tau_min, 1.0 - mu);
   const double dw = sc[SC_DELTA_W], gam = sc[SC_GAMMA];
-  double xL[N], xn[N];
+  double xL[N], xn[N], ycar[N];   // ycar: x_{t+1} itself (the y argument of stage t's dynamics)
 #pragma unroll
-  for (int i = 0; i < N; ++i) xL[i] = xn[i] = 0.0;
+  for (int i = 0; i < N; ++i) xL[i] = xn[i] = ycar[i] = 0.0;
   StepAcc acc{1.0, 1.0, 0.0, 0.0};
+  wait_lds();
+  prefetch_stage<M>(a, a.T - 1, inst32, s_a, s_r, s_c);
   for (int t = a.T - 1; t >= 0; --t) {
+    wait_vm();
     dispatch_uniform<M>(a.kind[t], [&](auto kc) {
       constexpr int K = decltype(kc)::value;
+      using D = KindDims<M, K>;
+      using RC = Rec<M, K>;
       if constexpr (heavy_kind<M, K>()) {
-        const dto_im_args acold = a;
-        double xnc[N];
+        prefetch_stage<M>(a, t - 1, inst32, s_a, s_r, s_c);
+        if (live) {
+          const dto_im_args acold = a;
+          double xnc[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) xnc[i] = xn[i];
-        StepAcc accc = acc;
-        im_backward_cold<M, K>(acold, inst, t, mu, tau, dw, gam, xnc, &accc);
+          for (int i = 0; i < N; ++i) xnc[i] = xn[i];
+          StepAcc accc = acc;
+          im_backward_cold<M, K, WPS>(acold, inst, t, mu, tau, dw, gam, xnc, &accc);
 #pragma unroll
-        for (int i = 0; i < N; ++i) xn[i] = xnc[i];
-        acc = accc;
+          for (int i = 0; i < N; ++i) xn[i] = xnc[i];
+          acc = accc;
+        }
+        const double* Ap = a.A + inst * a.a_total + a.aoff[t];
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) ycar[i] = Ap[i];
       } else {
-        stage_backward<M, K, false>(a.opt, DirectIO<M, K>(a, inst, t), mu, tau, dw, gam, false, xL, xn, acc);
+        double* dst = s_d + lane * RC::DS;
+        const LdsIO<M, K> io(a, inst, t, s_a + lane * RC::AS, s_r + lane * RC::AS, s_c + lane * RC::CS, ycar, dst);
+        wait_lds();
+        prefetch_stage<M>(a, t - 1, inst32, s_a, s_r, s_c);
+        stage_backward<M, K, false>(a.opt, io, mu, tau, dw, gam, false, xL, xn, acc);
+        if constexpr (RC::DS > RC::BD + RC::QI) dst[RC::DS - 1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) ycar[i] = io.p(i);
+        wait_lds();
+        scatter_records<RC::DS / 2>(s_d, a.D, a.d_total, a.doff[t], inst32, live_mask);
+        wait_lds();   // the staging slot is rewritten by the next stage
       }
     });
   }
-  sc[SC_DMERIT] = acc.gphid;
-  sc[SC_ALPHA_PMAX] = acc.apmax;
-  sc[SC_ALPHA_DMAX] = acc.admax;
+  wait_vm();
+  if (live) {
+    sc[SC_DMERIT] = acc.gphid;
+    sc[SC_ALPHA_PMAX] = acc.apmax;
+    sc[SC_ALPHA_DMAX] = acc.admax;
   }
   }
 }
@@ -716,6 +946,8 @@ __global__ __launch_bounds__(WAVE, 2) void kim_bwd(dto_im_args a) {
 template <class M>
 __global__ __launch_bounds__(WAVE) void kim_linesearch(dto_im_args a) {
   __shared__ double s_acc[2 * DTO_LS_TRIALS * WAVE];
+  __shared__ __attribute__((aligned(16))) double s_a[(OWN_LS + 1) * max_as<M>() + 2];
+  __shared__ __attribute__((aligned(16))) double s_d[(OWN_LS + 1) * max_ds<M>() + 2];
   const int64_t n_item = (int64_t)(*a.count) * a.nwin_l;
   for (int64_t item = blockIdx.x; item < n_item; item += gridDim.x) {
   const int e = (int)(item / a.nwin_l);
@@ -723,6 +955,13 @@ __global__ __launch_bounds__(WAVE) void kim_linesearch(dto_im_args a) {
   const int64_t inst = a.list[e];
   const int lane = threadIdx.x;
   const double* sc = a.scal + inst * SC_COUNT;
+  // iterate and step of the window's knots plus the knot after them (y and dy of the last one): coalesced copies into LDS
+  const int t0w = win * OWN_LS, tendw = min(t0w + OWN_LS + 1, a.T);
+  const int a0 = a.aoff[t0w], d0 = a.doff[t0w];
+  __syncthreads();   // the previous item's reads of the images are complete
+  wave_load(s_a, a.A + inst * a.a_total + a0, a.aoff[tendw] - a0);
+  wave_load(s_d, a.D + inst * a.d_total + d0, a.doff[tendw] - d0);
+  __syncthreads();
   const double mu = sc[SC_MU];
   const double amax = sc[SC_ALPHA_PMAX];
   double* acc = s_acc + lane;
@@ -737,8 +976,8 @@ __global__ __launch_bounds__(WAVE) void kim_linesearch(dto_im_args a) {
       using RC = Rec<M, K>;
       using CO = typename M::template Cost<KD::COST>;
       const int z0 = a.zoff[t];
-      const double* Ap = a.A + inst * a.a_total + a.aoff[t];
-      const double* Dp = a.D + inst * a.d_total + a.doff[t];
+      const double* Ap = s_a + (a.aoff[t] - a0);
+      const double* Dp = s_d + (a.doff[t] - d0);
       const double* Bp = a.Bd ? a.Bd + inst * a.b_total + a.boff[t] : nullptr;
       arr<D::NP> p, dp;
       arr<D::NY> y, dy;
@@ -748,8 +987,8 @@ __global__ __launch_bounds__(WAVE) void kim_linesearch(dto_im_args a) {
         dp[i] = Dp[i];
       }
       if constexpr (D::NY > 0) {
-        const double* An = a.A + inst * a.a_total + a.aoff[t + 1];
-        const double* Dn = a.D + inst * a.d_total + a.doff[t + 1];
+        const double* An = s_a + (a.aoff[t + 1] - a0);
+        const double* Dn = s_d + (a.doff[t + 1] - d0);
 #pragma unroll
         for (int i = 0; i < D::NY; ++i) {
           y[i] = An[i];
@@ -891,6 +1130,10 @@ static __global__ __launch_bounds__(WAVE) void kim_ls_reduce(dto_im_args a) {
 // ------------------------------------------------------------------------------------------------
 template <class M>
 __global__ __launch_bounds__(WAVE) void kim_update(dto_im_args a) {
+  // the A and D records of the window's knots are contiguous ranges of the instance: coalesced copies into LDS images, the
+  // lanes update their record in the A image, the image goes back with full-line stores
+  __shared__ __attribute__((aligned(16))) double s_a[OWN_LS * max_as<M>() + 2];
+  __shared__ __attribute__((aligned(16))) double s_d[OWN_LS * max_ds<M>() + 2];
   const int64_t n_item = (int64_t)(*a.count) * a.nwin_l;
   for (int64_t item = blockIdx.x; item < n_item; item += gridDim.x) {
   const int e = (int)(item / a.nwin_l);
@@ -901,15 +1144,20 @@ __global__ __launch_bounds__(WAVE) void kim_update(dto_im_args a) {
   const double al = sc[SC_ALPHA];
   const double ad = sc[SC_ALPHA_DMAX];
   constexpr double KSIG = 1e10;
-  const int t = win * OWN_LS + threadIdx.x;
+  const int t0 = win * OWN_LS, tend = min(t0 + OWN_LS, a.T);
+  const int t = t0 + threadIdx.x;
+  const int a0 = a.aoff[t0], d0 = a.doff[t0];
+  wave_load(s_a, a.A + inst * a.a_total + a0, a.aoff[tend] - a0);
+  wave_load(s_d, a.D + inst * a.d_total + d0, a.doff[tend] - d0);
+  __syncthreads();
   if (t < a.T) {
     dispatch_kind<M>(a.kind[t], [&](auto kc) {
       constexpr int K = decltype(kc)::value;
       using D = KindDims<M, K>;
       using RC = Rec<M, K>;
       const int z0 = a.zoff[t];
-      double* Ap = a.A + inst * a.a_total + a.aoff[t];
-      const double* Dp = a.D + inst * a.d_total + a.doff[t];
+      double* Ap = s_a + (a.aoff[t] - a0);
+      const double* Dp = s_d + (a.doff[t] - d0);
       double* Bp = a.Bd ? a.Bd + inst * a.b_total + a.boff[t] : nullptr;
       double v[RC::BD], dv[RC::BD];
 #pragma unroll
@@ -961,10 +1209,13 @@ __global__ __launch_bounds__(WAVE) void kim_update(dto_im_args a) {
       for (int i = D::NP; i < RC::BD; ++i) Ap[i] = v[i] + al * dv[i];
     });
   }
+  __syncthreads();
+  wave_store_image(a.A + inst * a.a_total + a0, s_a, a.aoff[tend] - a0, threadIdx.x);
   if (win == 0 && threadIdx.x == 0) {
     sc[SC_ITER] += 1.0;
     a.phase[inst] = DTO_IM_PH_EVAL;
   }
+  __syncthreads();   // the images are refilled by the next item
   }
 }
 
@@ -986,7 +1237,8 @@ int launch_im(int op, const dto_im_args* args, void* stream_) {
     const unsigned g_stage_e = (unsigned)std::min<int64_t>(a.B * a.nwin_e, 1 << 16);
     const unsigned g_stage_l = (unsigned)std::min<int64_t>(a.B * a.nwin_l, 1 << 16);
     const unsigned g_entry = (unsigned)std::min<int64_t>((a.B + WAVE - 1) / WAVE, 1 << 14);
-    const unsigned g_sweep = (unsigned)std::min<int64_t>((a.B + WAVE - 1) / WAVE, 2048);
+    const unsigned g_sweep = (unsigned)std::min<int64_t>((a.B + WAVE - 1) / WAVE, 2048);   // resident wavefronts: 2 / 1 per SIMD
+    const unsigned g_sweep1 = (unsigned)std::min<int64_t>((a.B + WAVE - 1) / WAVE, 1024);
     switch (op) {
       case DTO_IM_INIT: hipLaunchKernelGGL(kim_init<M>, dim3(g_all), dim3(WAVE), 0, st, a); break;
       case DTO_IM_UNPACK: hipLaunchKernelGGL(kim_unpack<M>, dim3(g_all), dim3(WAVE), 0, st, a); break;
@@ -994,8 +1246,14 @@ int launch_im(int op, const dto_im_args* args, void* stream_) {
       case DTO_IM_COUNT: hipLaunchKernelGGL(kim_count, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, st, a); break;
       case DTO_IM_EVAL: hipLaunchKernelGGL(kim_eval<M>, dim3(g_stage_e), dim3(WAVE), 0, st, a); break;
       case DTO_IM_CONV: hipLaunchKernelGGL(kim_conv, dim3(g_entry), dim3(WAVE), 0, st, a); break;
-      case DTO_IM_FWD: hipLaunchKernelGGL(kim_fwd<M>, dim3(g_sweep), dim3(WAVE), 0, st, a); break;
-      case DTO_IM_BWD: hipLaunchKernelGGL(kim_bwd<M>, dim3(g_sweep), dim3(WAVE), 0, st, a); break;
+      case DTO_IM_FWD:
+        if (a.sweep_occ == 1) hipLaunchKernelGGL((kim_fwd<M, 1>), dim3(g_sweep1), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL((kim_fwd<M, 2>), dim3(g_sweep), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_IM_BWD:
+        if (a.sweep_occ == 1) hipLaunchKernelGGL((kim_bwd<M, 1>), dim3(g_sweep1), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL((kim_bwd<M, 2>), dim3(g_sweep), dim3(WAVE), 0, st, a);
+        break;
       case DTO_IM_LINESEARCH: hipLaunchKernelGGL(kim_linesearch<M>, dim3(g_stage_l), dim3(WAVE), 0, st, a); break;
       case DTO_IM_LS_REDUCE: hipLaunchKernelGGL(kim_ls_reduce, dim3(g_entry), dim3(WAVE), 0, st, a); break;
       case DTO_IM_UPDATE: hipLaunchKernelGGL(kim_update<M>, dim3(g_stage_l), dim3(WAVE), 0, st, a); break;

@@ -146,6 +146,17 @@ __device__ __forceinline__ const double* soa(const double* base, int64_t tile, i
   return base + ((tile * n + i) << 6) + threadIdx.x;
 }
 
+// Read-only tables that every lane indexes with the same (wave-uniform) index -- stage kinds, offsets, the shared variable
+// bounds and parameters -- are read through the CONSTANT address space: the compiler then uses the scalar memory path
+// (s_load into SGPRs, scalar compares and branches) instead of a vector load per lane.  Measured reason (profiles/r03, SQ
+// counters + ISA of k_kkt_bwd_seq): as plain global loads the look-ups compiled to per-lane global_load_dword whose result
+// fed the ADDRESS of the data loads, and the bound tests to a chain of basic blocks each waiting for its own small load --
+// six to ten dependent memory round trips per stage; the sweeps sat in s_waitcnt for 58 % of their cycles.
+template <class T>
+__device__ __forceinline__ T uload(const T* p, int64_t i) {
+  return ((const __attribute__((address_space(4))) T*)p)[i];
+}
+
 template <class M, int K>
 struct KindDims {
   using KD = typename M::template Kind<K>;
@@ -250,11 +261,13 @@ int kkt_info(dto_kkt_info* out) {
 template <int N>
 __device__ __forceinline__ void load_params(arr<N>& w, const dto_kkt_args& a, int64_t g, int t) {
   if (a.wtile) {
-    const double* src = a.wtile + ((g * a.Nw + a.woff[t]) << 6) + threadIdx.x;
+    const double* src = a.wtile + ((g * a.Nw + uload(a.woff, t)) << 6) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < N; ++i) w[i] = src[(int64_t)i << 6];
   } else {
-    gmem_load(w, a.params + a.woff[t]);
+    const int w0 = uload(a.woff, t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = uload(a.params, w0 + i);
   }
 }
 
@@ -271,8 +284,8 @@ __device__ __forceinline__ void load_stage_bounds(const dto_kkt_args& a, int64_t
   const bool duals = a.zl != nullptr;   // allocated iff some variable has a finite, non-fixing bound
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    b.lo[i] = a.lo[z0 + i];
-    b.hi[i] = a.hi[z0 + i];
+    b.lo[i] = uload(a.lo, z0 + i);
+    b.hi[i] = uload(a.hi, z0 + i);
     b.p[i] = duals ? *soa(a.z, g, a.Nz, z0 + i) : 0.0;
     b.zl[i] = duals ? *soa(a.zl, g, a.Nz, z0 + i) : 0.0;
     b.zu[i] = duals ? *soa(a.zu, g, a.Nz, z0 + i) : 0.0;
@@ -291,31 +304,31 @@ struct SoaIO {
   const double* recp;
   double* facp;
   __device__ __forceinline__ SoaIO(const dto_kkt_args& a_, int64_t g_, int t_)
-      : a(a_), g(g_), t(t_), z0(a_.zoff[t_]), recp(a_.rec + ((g_ * a_.rec_total + a_.recoff[t_]) << 6) + threadIdx.x),
-        facp(a_.fac + ((g_ * a_.fac_total + a_.facoff[t_]) << 6) + threadIdx.x) {}
+      : a(a_), g(g_), t(t_), z0(uload(a_.zoff, t_)), recp(a_.rec + ((g_ * a_.rec_total + uload(a_.recoff, t_)) << 6) + threadIdx.x),
+        facp(a_.fac + ((g_ * a_.fac_total + uload(a_.facoff, t_)) << 6) + threadIdx.x) {}
   __device__ __forceinline__ double rec(int e) const { return recp[(int64_t)e << 6]; }
   __device__ __forceinline__ double p(int i) const { return *soa(a.z, g, a.Nz, z0 + i); }
-  __device__ __forceinline__ double y(int i) const { return *soa(a.z, g, a.Nz, a.zoff[t + 1] + i); }
-  __device__ __forceinline__ double lam(int k) const { return *soa(a.lam, g, a.Nc, a.cdoff[t] + k); }
-  __device__ __forceinline__ double nu(int j) const { return *soa(a.lam, g, a.Nc, a.ccoff[t] + j); }
+  __device__ __forceinline__ double y(int i) const { return *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i); }
+  __device__ __forceinline__ double lam(int k) const { return *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + k); }
+  __device__ __forceinline__ double nu(int j) const { return *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j); }
   template <int N>
   __device__ __forceinline__ void params(arr<N>& w) const { load_params(w, a, g, t); }
   __device__ __forceinline__ void bounds(StageBounds<D::NP>& b) const { load_stage_bounds<D::NP>(a, g, z0, b); }
   __device__ __forceinline__ bool has_sigx() const { return a.sigx != nullptr; }
   __device__ __forceinline__ bool has_sigc() const { return a.sigc != nullptr; }
   __device__ __forceinline__ double sigx(int i) const { return *soa(a.sigx, g, a.Nz, z0 + i); }
-  __device__ __forceinline__ double sigc_con(int j) const { return *soa(a.sigc, g, a.Nc, a.ccoff[t] + j); }
-  __device__ __forceinline__ double sigc_dyn(int k) const { return *soa(a.sigc, g, a.Nc, a.cdoff[t] + k); }
-  __device__ __forceinline__ double slack(int j) const { return *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)); }
-  __device__ __forceinline__ double slack_mult(int j) const { return *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)); }
+  __device__ __forceinline__ double sigc_con(int j) const { return *soa(a.sigc, g, a.Nc, uload(a.ccoff, t) + j); }
+  __device__ __forceinline__ double sigc_dyn(int k) const { return *soa(a.sigc, g, a.Nc, uload(a.cdoff, t) + k); }
+  __device__ __forceinline__ double slack(int j) const { return *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j)); }
+  __device__ __forceinline__ double slack_mult(int j) const { return *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j)); }
   // carry-in record of the stage (written by the forward sweep, read by the backward sweep)
   __device__ __forceinline__ void put_carry(int i, double v) const { facp[(int64_t)i << 6] = v; }
   __device__ __forceinline__ double carry(int i) const { return facp[(int64_t)i << 6]; }
   // the step
   __device__ __forceinline__ void put_dp(int i, double v) const { *soa(a.dz, g, a.Nz, z0 + i) = v; }
-  __device__ __forceinline__ void put_dnu(int j, double v) const { *soa(a.dlam, g, a.Nc, a.ccoff[t] + j) = v; }
-  __device__ __forceinline__ void put_dlam(int k, double v) const { *soa(a.dlam, g, a.Nc, a.cdoff[t] + k) = v; }
-  __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j)) = v; }
+  __device__ __forceinline__ void put_dnu(int j, double v) const { *soa(a.dlam, g, a.Nc, uload(a.ccoff, t) + j) = v; }
+  __device__ __forceinline__ void put_dlam(int k, double v) const { *soa(a.dlam, g, a.Nc, uload(a.cdoff, t) + k) = v; }
+  __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = v; }
   __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
 };
 
@@ -370,16 +383,16 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
   // parameter too unless the caller resets it.  Only entries that are unusable (non-positive) are re-initialised.
   const double mu_prev = *soa(a.scal, g, SC_COUNT, SC_MU);
   const double mu0 = !o.warm ? o.mu_init : (o.mu_warm > 0.0 ? o.mu_warm : (mu_prev > 0.0 ? mu_prev : o.mu_init));
-  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
     using KD = typename D::KD;
-    const int z0 = a.zoff[t];
+    const int z0 = uload(a.zoff, t);
     arr<D::NP> p;
 #pragma unroll
     for (int i = 0; i < D::NP; ++i) {
       double v = *soa(a.z, g, a.Nz, z0 + i);
-      const double lo = a.lo[z0 + i], hi = a.hi[z0 + i];
+      const double lo = uload(a.lo, z0 + i), hi = uload(a.hi, z0 + i);
       double zl = 0.0, zu = 0.0;
       if (!o.newton_only) {
         if (lo == hi) {
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     if constexpr (KD::DYN >= 0) {
       if (!o.newton_only && !o.warm) {
 #pragma unroll
-        for (int i = 0; i < D::NY; ++i) *soa(a.lam, g, a.Nc, a.cdoff[t] + i) = 0.0;
+        for (int i = 0; i < D::NY; ++i) *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + i) = 0.0;
       }
     }
     if constexpr (KD::CON >= 0) {
@@ -427,20 +440,20 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
-        double nu = o.warm ? *soa(a.lam, g, a.Nc, a.ccoff[t] + j) : 0.0;
+        double nu = o.warm ? *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j) : 0.0;
         if (D::ineq(j)) {
           double sv = fmax(-c[j], o.bound_push * fmax(1.0, fabs(c[j])));
           double zv = mu0 / sv;
           if (o.warm) {
-            const double ps = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)), pz = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+            const double ps = *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j)), pz = *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j));
             if (ps > 0.0 && pz > 0.0) { sv = ps; zv = pz; } else nu = zv;
           } else {
             nu = zv;
           }
-          *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) = sv;
-          *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = zv;
+          *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = sv;
+          *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = zv;
         }
-        *soa(a.lam, g, a.Nc, a.ccoff[t] + j) = nu;
+        *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j) = nu;
       }
       }
     }
@@ -482,18 +495,18 @@ __global__ __launch_bounds__(WAVE) void k_rhs_record(dto_kkt_args a) {
   const int64_t slot = g * 64 + threadIdx.x;
   const int64_t inst = a.inst_of_slot ? a.inst_of_slot[slot] : slot;
   const bool live = inst < a.B;
-  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
-    double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + threadIdx.x;
     const double* rx = a.rhs_x + inst * a.ld_rhs_x;
     const double* rc = a.rhs_c + inst * a.ld_rhs_c;
 #pragma unroll
-    for (int i = 0; i < D::NP; ++i) rec[(int64_t)(D::R_RP + i) << 6] = live ? -rx[a.zoff[t] + i] : 0.0;
+    for (int i = 0; i < D::NP; ++i) rec[(int64_t)(D::R_RP + i) << 6] = live ? -rx[uload(a.zoff, t) + i] : 0.0;
 #pragma unroll
-    for (int k = 0; k < D::NY; ++k) rec[(int64_t)(D::R_D + k) << 6] = live ? -rc[a.cdoff[t] + k] : 0.0;
+    for (int k = 0; k < D::NY; ++k) rec[(int64_t)(D::R_D + k) << 6] = live ? -rc[uload(a.cdoff, t) + k] : 0.0;
 #pragma unroll
-    for (int j = 0; j < D::Q; ++j) rec[(int64_t)(D::R_C + j) << 6] = live ? -rc[a.ccoff[t] + j] : 0.0;
+    for (int j = 0; j < D::Q; ++j) rec[(int64_t)(D::R_C + j) << 6] = live ? -rc[uload(a.ccoff, t) + j] : 0.0;
   });
 }
 
@@ -525,13 +538,13 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   bool have_carry = false;
   const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
   for (int t = blk * DTO_SB; t < t_end; ++t) {
-  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
     using KD = typename D::KD;
     using CO = typename M::template Cost<KD::COST>;
-    const int z0 = a.zoff[t];
-    double* rec = a.rec + ((g * a.rec_total + a.recoff[t]) << 6) + threadIdx.x;
+    const int z0 = uload(a.zoff, t);
+    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + threadIdx.x;
     auto put = [&](int e, double v) { rec[(int64_t)e << 6] = v; };
 
     arr<D::NP> p;
@@ -573,8 +586,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       load_params(w, a, g, t);
 #pragma unroll
       for (int i = 0; i < DY::NY; ++i) {
-        y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
-        lam[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
+        y[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i);
+        lam[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + i);
       }
       arr<DY::NJ> jv;
       DY::eval_jac(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data(), jv.data());
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       arr<C::NW> w; arr<C::NC> c, nu; arr<C::NJ> jv;
       load_params(w, a, g, t);
 #pragma unroll
-      for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+      for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j);
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
       C::jac(p.data(), p.data() + C::NX, w.data(), jv.data());
       C::jtlam(jv.data(), nu.data(), rp.data());
@@ -630,8 +643,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       for (int j = 0; j < C::NC; ++j) {
         double r = c[j];
         if (!o.newton_only && D::ineq(j)) {
-          const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
-          const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
+          const double sv = *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j));
+          const double zv = *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j));
           r = c[j] + sv;
           dinf = fmax(dinf, fabs(nu[j] - zv));
           szmax = fmax(szmax, sv * zv);
@@ -656,9 +669,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       arr<DP::NX + DP::NU> pp; arr<DP::NY> lamp; arr<DP::NW> w; arr<DP::NJ> jv;
       load_params(w, a, g, t - 1);
 #pragma unroll
-      for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = *soa(a.z, g, a.Nz, a.zoff[t - 1] + i);
+      for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t - 1) + i);
 #pragma unroll
-      for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, a.cdoff[t - 1] + i);
+      for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t - 1) + i);
       DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
       DP::etlam(jv.data(), lamp.data(), rp.data());
       }
@@ -690,9 +703,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         load_params(w, a, g, t);
 #pragma unroll
         for (int i = 0; i < DY::NY; ++i) {
-          y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
-          lam[i] = *soa(a.lam, g, a.Nc, a.cdoff[t] + i);
-          sv[D::NP + i] = alpha * *soa(a.dz, g, a.Nz, a.zoff[t + 1] + i);
+          y[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i);
+          lam[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + i);
+          sv[D::NP + i] = alpha * *soa(a.dz, g, a.Nz, uload(a.zoff, t + 1) + i);
         }
         DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jn.data());
 #pragma unroll
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         arr<C::NW> w; arr<C::NC> nu; arr<C::NJ> jn, jo;
         load_params(w, a, g, t);
 #pragma unroll
-        for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
+        for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j);
         C::jac(p.data(), p.data() + C::NX, w.data(), jn.data());
 #pragma unroll
         for (int i = 0; i < C::NJ; ++i) jo[i] = qn_old_kj[i];
@@ -824,7 +837,7 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
   for (int k = 0; k < NV; ++k) acc[k] = 0.0;
   // a block of DTO_SB stages belongs to the chunk that holds its first stage (every block is counted exactly once)
   const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
-  const int b0 = (a.cstart[p] + DTO_SB - 1) / DTO_SB, b1 = (a.cstart[p + 1] + DTO_SB - 1) / DTO_SB;
+  const int b0 = (uload(a.cstart, p) + DTO_SB - 1) / DTO_SB, b1 = (uload(a.cstart, p + 1) + DTO_SB - 1) / DTO_SB;
   for (int t = b0; t < b1; ++t) {
     const double* row = in + (((g * nblk + t) * NV) << 6) + threadIdx.x;
 #pragma unroll
@@ -1505,7 +1518,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     if (!__any(need)) return;
     const double mu = sc[SC_MU << 6];
     const double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
-    const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
+    const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
     Carry<M> cy;
     Spike<M> sp;
 #pragma unroll
@@ -1521,7 +1534,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     for (int t = t0; t < t1; ++t) {
       if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
       if (!CHUNKED || p == 0) {
-        dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
           constexpr int K = decltype(kc)::value;
           if constexpr (!CHUNKED && heavy_kind<M, K>()) {
             Carry<M> cyc = cy;
@@ -1542,7 +1555,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
         // once that has happened to every lane that asked for a factorisation the rest of the sweep is pointless
         if (!CHUNKED && !__any(need && (ok || keep_lost))) break;
       } else if constexpr (CHUNKED) {
-        dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
           // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
           if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
             stage_forward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, dw, gam, t == t0, need,
@@ -1613,18 +1626,18 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
     for (int i = 0; i < NT; ++i) Dg[i] = cl[(int64_t)(CS::P + i) << 6] + cr[(int64_t)(CS::RLL + i) << 6];
 #pragma unroll
     for (int i = 0; i < N; ++i) r[i] = cr[(int64_t)(CS::RL + i) << 6] - cl[(int64_t)(CS::PY + i) << 6];
-    const int z0 = a.zoff[a.cstart[p]];
+    const int z0 = uload(a.zoff, uload(a.cstart, p));
     bool fx[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) fx[i] = !o.newton_only && (a.lo[z0 + i] == a.hi[z0 + i]);
+    for (int i = 0; i < N; ++i) fx[i] = !o.newton_only && (uload(a.lo, z0 + i) == uload(a.hi, z0 + i));
     if (p > 1) {
       // coupling with the previous separator: rows = this separator (x_R of chunk p-1), cols = previous (x_L)
       const double* cx = csp(p - 1) + ((int64_t)CS::CX << 6);
       double Mm[N * N];  // Mm = L_{p-1}^-1 B', B'[c][aa] = cx[aa][c]
-      const int zp = a.zoff[a.cstart[p - 1]];
+      const int zp = uload(a.zoff, uload(a.cstart, p - 1));
 #pragma unroll
       for (int c = 0; c < N; ++c) {
-        const bool fc = !o.newton_only && (a.lo[zp + c] == a.hi[zp + c]);
+        const bool fc = !o.newton_only && (uload(a.lo, zp + c) == uload(a.hi, zp + c));
 #pragma unroll
         for (int aa = 0; aa < N; ++aa) Mm[c * N + aa] = (fc || fx[aa]) ? 0.0 : cx[(int64_t)(aa * N + c) << 6];
       }
@@ -1868,7 +1881,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   const double mu = sc[SC_MU << 6];
   const double tau = fmax(o.tau_min, 1.0 - mu);
   const double dw = sc[SC_DELTA_W << 6], gam = sc[SC_GAMMA << 6];  // the accepted factorisation
-  const int t0 = a.cstart[p], t1 = a.cstart[p + 1];
+  const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
   double xL[N], xn[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -1878,7 +1891,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   StepAcc acc{1.0, 1.0, 0.0, 0.0};
   for (int t = t1 - 1; t >= t0; --t) {
     if (!CHUNKED || p == 0) {
-      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+      dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
         constexpr int K = decltype(kc)::value;
         if constexpr (!CHUNKED && heavy_kind<M, K>()) {
           const dto_kkt_args acold = a;  // own copy: see kkt_fwd_body
@@ -1895,7 +1908,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
         }
       });
     } else if constexpr (CHUNKED) {
-      dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+      dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
         if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
           stage_backward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, tau, dw, gam, t == t0, xL, xn,
                                                        acc);
@@ -1950,12 +1963,12 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
   for (int k = 0; k < 2 * DTO_LS_TRIALS; ++k) acc[k * WAVE] = 0.0;
   const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
   for (int t = blk * DTO_SB; t < t_end; ++t) {
-  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
     using KD = typename D::KD;
     using CO = typename M::template Cost<KD::COST>;
-    const int z0 = a.zoff[t];
+    const int z0 = uload(a.zoff, t);
     arr<D::NP> p, dp;
     arr<D::NY> y, dy;
 #pragma unroll
@@ -1965,20 +1978,20 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
     }
 #pragma unroll
     for (int i = 0; i < D::NY; ++i) {
-      y[i] = *soa(a.z, g, a.Nz, a.zoff[t + 1] + i);
-      dy[i] = *soa(a.dz, g, a.Nz, a.zoff[t + 1] + i);
+      y[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i);
+      dy[i] = *soa(a.dz, g, a.Nz, uload(a.zoff, t + 1) + i);
     }
     arr<CO::NW> w;
     load_params(w, a, g, t);
     double blo[D::NP > 0 ? D::NP : 1], bhi[D::NP > 0 ? D::NP : 1];  // bounds: loaded once, not once per trial
 #pragma unroll
-    for (int i = 0; i < D::NP; ++i) { blo[i] = a.lo[z0 + i]; bhi[i] = a.hi[z0 + i]; }
+    for (int i = 0; i < D::NP; ++i) { blo[i] = uload(a.lo, z0 + i); bhi[i] = uload(a.hi, z0 + i); }
     double sl[D::QI > 0 ? D::QI : 1], dsl[D::QI > 0 ? D::QI : 1];
     if (!o.newton_only) {
 #pragma unroll
       for (int j = 0; j < D::QI; ++j) {
-        sl[j] = *soa(a.s, g, a.Ni, a.ioff[t] + j);
-        dsl[j] = *soa(a.ds, g, a.Ni, a.ioff[t] + j);
+        sl[j] = *soa(a.s, g, a.Ni, uload(a.ioff, t) + j);
+        dsl[j] = *soa(a.ds, g, a.Ni, uload(a.ioff, t) + j);
       }
     }
     // Trial points x + alpha_k dx, alpha_k = alpha_max 2^-k, visited from the SHORTEST step up.  Where every sin / cos
@@ -2214,11 +2227,11 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
   const double al = sc[SC_ALPHA << 6];
   const double ad = sc[SC_ALPHA_DMAX << 6];
   constexpr double KSIG = 1e10;
-  dispatch_uniform<M>(a.kind[t], [&](auto kc) {
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
     if (!running) return;
-    const int z0 = a.zoff[t];
+    const int z0 = uload(a.zoff, t);
     StageBounds<D::NP> sb;
     load_stage_bounds<D::NP>(a, g, z0, sb);
     double dpv[D::NP > 0 ? D::NP : 1], pv[D::NP > 0 ? D::NP : 1];
@@ -2259,25 +2272,25 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
     }
 #pragma unroll
     for (int j = 0; j < D::Q; ++j) {
-      const double nu = *soa(a.lam, g, a.Nc, a.ccoff[t] + j);
-      const double dnu = *soa(a.dlam, g, a.Nc, a.ccoff[t] + j);
+      const double nu = *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j);
+      const double dnu = *soa(a.dlam, g, a.Nc, uload(a.ccoff, t) + j);
       if (!o.newton_only && D::ineq(j)) {
-        const double sv = *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j));
-        const double zv = *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j));
-        const double dsv = *soa(a.ds, g, a.Ni, a.ioff[t] + D::slack(j));
+        const double sv = *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j));
+        const double zv = *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j));
+        const double dsv = *soa(a.ds, g, a.Ni, uload(a.ioff, t) + D::slack(j));
         const double dzs = mu / sv - zv - (zv / sv) * dsv;
         const double sn = sv + al * dsv;
         double zn = zv + ad * dzs;
         zn = fmin(fmax(zn, mu / (KSIG * sn)), KSIG * mu / sn);
-        *soa(a.s, g, a.Ni, a.ioff[t] + D::slack(j)) = sn;
-        *soa(a.zs, g, a.Ni, a.ioff[t] + D::slack(j)) = zn;
+        *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = sn;
+        *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = zn;
       }
-      *soa(a.lam, g, a.Nc, a.ccoff[t] + j) = nu + al * dnu;
+      *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j) = nu + al * dnu;
     }
 #pragma unroll
     for (int k = 0; k < D::NY; ++k) {
-      const double lam = *soa(a.lam, g, a.Nc, a.cdoff[t] + k);
-      *soa(a.lam, g, a.Nc, a.cdoff[t] + k) = lam + al * *soa(a.dlam, g, a.Nc, a.cdoff[t] + k);
+      const double lam = *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + k);
+      *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + k) = lam + al * *soa(a.dlam, g, a.Nc, uload(a.cdoff, t) + k);
     }
   });
   if (t == 0 && running) sc[SC_ITER << 6] += 1.0;

@@ -789,11 +789,11 @@ static bool use_im(Problem* p, int64_t B) {
   }
   if (eng == 2) return true;
   if (eng == 1) return false;
-  if (p->solver && p->solver->forced_P > 0) return false;   // an explicit partition request addresses the SoA engine
-  int dev = 0, cus = 0, n_simd = 1024;
-  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-    n_simd = 4 * cus;
-  return (B + 63) / 64 >= n_simd;
+  // automatic: the SoA engine.  Measured (MI355X, acrobot T = 1000, 131 072 instances, 25 iterations): SoA tiles 67 ms per
+  // iteration, instance-major 112 ms -- its forward sweep does pay for attempts only (30-34 ms against 35 ms), but its
+  // stage kernels (lane = knot) and its backward sweep are 2-2.5x slower than the lane = instance forms; DESIGN.md section 4.4
+  (void)B;
+  return false;
 }
 
 static int ensure_im_state(Problem* p, int64_t B) {
@@ -875,6 +875,9 @@ static void fill_im_args(Problem* p, dto_im_args& a) {
   a.nwin_e = S.nwin_e; a.nwin_l = S.nwin_l;
   a.iter_target = -1;
   a.ticket = S.ctr + 3; a.running = S.ctr + 5;
+  // measurement knob: register budget of the sweeps
+  static const int occ = [] { const char* e = getenv("DTO_IM_OCC"); return e ? atoi(e) : 2; }();
+  a.sweep_occ = occ;
   a.opt = S.opt;
 }
 

@@ -244,8 +244,8 @@ int dto_solver_set_partitions(dto_problem* p, int partitions);
 int dto_solver_partitions(dto_problem* p, int* partitions);
 /* Engine behind dto_solver_begin / dto_solve_batch: 0 = automatic, 1 = SoA tiles (64 instances share a wavefront for the whole
  * solve; time-partitioned sweeps for small batches), 2 = instance-major (csrc/dto_im_kernels.hpp: per-instance stage records,
- * work lists, one factorisation attempt per instance and pass; exact-Hessian models).  Automatic = instance-major where the
- * batch fills the GPU with plain sequential sweeps (>= 64 instances per SIMD), SoA tiles below.  Takes effect at the next
+ * work lists, one factorisation attempt per instance and pass; exact-Hessian models).  Automatic = SoA tiles (the faster one
+ * on every measured workload) unless the environment says DTO_ENGINE=im.  Takes effect at the next
  * dto_solver_begin.  dto_solver_engine reports the engine of the batch begun last (1 or 2). */
 int dto_solver_set_engine(dto_problem* p, int engine);
 /* free the device state of the solver entry points (both engines); the next dto_solver_begin allocates again */

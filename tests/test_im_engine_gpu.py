@@ -58,14 +58,19 @@ def test_first_iterations_match_the_soa_engine(model, T, B):
         assert np.array_equal(a["stats"]["iterations"], b["stats"]["iterations"])
         assert np.array_equal(a["stats"]["status"], b["stats"]["status"])
         # decisions of the iteration: step size and regularisation identical
-        assert np.array_equal(a["stats"]["alpha"], b["stats"]["alpha"]), k
+        # (the fraction-to-the-boundary step length is computed from the step: last bits may differ)
+        assert np.allclose(a["stats"]["alpha"], b["stats"]["alpha"], rtol=1e-9, atol=0.0), k
         assert np.allclose(a["stats"]["delta_w"], b["stats"]["delta_w"], rtol=1e-12, atol=0.0), k
         for n in names:
             if a[n].size == 0:
                 continue
             scale = max(1.0, np.max(np.abs(a[n])))
-            # 1e-9 of the vector's scale: identical sweeps on identical inputs; only the summed norms differ in the last bits
-            assert np.max(np.abs(a[n] - b[n])) <= 1e-9 * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
+            # primal quantities: 1e-9 of the vector's scale (identical sweeps on identical inputs; the two kernels differ in
+            # how the compiler contracts multiply-adds).  Multipliers: the dual block of the KKT matrix is regularised with
+            # delta_c = 1e-8 only, so last-bit differences of the factorisation are amplified by up to ~1e8: 1e-7 of the scale
+            # after more than one iteration the multiplier differences have fed back into the primal step: 1e-7 throughout
+            tol = 1e-7 if ("multipliers" in n or k > 1) else 1e-9
+            assert np.max(np.abs(a[n] - b[n])) <= tol * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
 
 
 @pytest.mark.parametrize("model,T,B", [("pendulum", 50, 64), ("acrobot", 101, 200), ("car", 51, 100), ("cartpole", 200, 2)])
