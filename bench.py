@@ -32,7 +32,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
+
+
+class _LazyTorch:
+    """torch is imported on first use: main() starts the CPU-baseline child process BEFORE torch / HIP are loaded into this
+    process (the all-cores leg of the baseline ran inside a process that already held torch's OpenMP runtime)."""
+    _m = None
+
+    def __getattr__(self, name):
+        if _LazyTorch._m is None:
+            import torch as _t
+            _LazyTorch._m = _t
+        return getattr(_LazyTorch._m, name)
+
+
+torch = _LazyTorch()
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
@@ -177,6 +191,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ---- CPU baseline (rank 0, N = 1 only): its own process, started and finished before torch / HIP are loaded here
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.loop_only:
+        import subprocess
+        try:
+            iters = 0 if a.steps + a.warmup >= 1000 else a.steps + a.warmup
+            res = subprocess.run([sys.executable, "-m", "oracle.cpu_port.baseline", "--horizon", str(a.horizon), "--seed", "1000",
+                                  "--seconds", "12", "--iters", str(iters)], cwd=ROOT, capture_output=True, text=True, timeout=240)
+            cpu = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as e:  # the baseline is a reported extra, never part of the measured path
+            cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -197,9 +222,13 @@ def main():
     # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 30 GB to spare; shrink by whole
     # residencies of the sequential sweep (131 072 instances) if another process holds part of the HBM.
     free_b = torch.cuda.mem_get_info(dev)[0]
-    per_inst = (0.37e6 if B > 131072 else 0.50e6) * (T / 1000.0) + 2 * 8.0 * 5 * T
-    while B > 131072 and B * per_inst + 7e9 > free_b - 30e9:
+    per_inst_of = lambda b: (0.37e6 if b > 131072 else 0.50e6) * (T / 1000.0) + 2 * 8.0 * 5 * T
+    while B > 131072 and B * per_inst_of(B) + 7e9 > free_b - 30e9:
         B -= 131072
+    if dist is not None:   # every rank runs the same shard size: the smallest any of them could take
+        bt = torch.tensor([B], device=dev, dtype=torch.int64)
+        dist.all_reduce(bt, op=dist.ReduceOp.MIN)
+        B = int(bt[0])
     if B != a.batch and rank == 0:
         print(f"[bench] batch reduced from {a.batch} to {B} instances: only {free_b / 1e9:.0f} GB of HBM free", file=sys.stderr, flush=True)
     p = P.build_acrobot(T=T, evaluate_hessian=True)
@@ -260,7 +289,7 @@ def main():
     if a.loop_only:
         if rank == 0:
             print(json.dumps(dict(value=iters_done / dt, unit="SQP iterations/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=s.partitions(),
+                                  ms_per_step=dt / a.steps * 1e3, instances_per_gpu=B, time_partitions=s.partitions(), engine=s.engine(),
                                   factorizations_per_iteration=round(facts_done / max(iters_done, 1.0), 3))), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -328,14 +357,20 @@ def main():
         kkt_sep=8 * 64, kkt_post=8 * 4)
     dom = max(per_iter_ms, key=per_iter_ms.get)
     achieved = B * alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/, tools/pmc_summary.py)
-        with open(os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_acrobot_T{T}_B{B}.json")) as f:
-            traffic = json.load(f)["kernels"][kname[dom]]["hbm_bytes_per_launch_mean"]
-    except Exception:
-        traffic = None
+    # HBM bytes per launch: NOT measured in this run (PMC counters need a profiler pass) -- taken from the committed
+    # rocprofv3 --pmc passes of this same command and batch size if there are any, with the file named; else null
+    traffic, traffic_source = None, None
+    for rnd in ("r03", "r02"):
+        fn = os.path.join("profiles", rnd, f"pmc_traffic_acrobot_T{T}_B{B}.json")
+        try:
+            with open(os.path.join(ROOT, fn)) as f:
+                traffic = json.load(f)["kernels"][kname[dom]]["hbm_bytes_per_launch_mean"]
+            traffic_source = fn + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --loop-only, tools/profile_headline.sh)"
+            break
+        except Exception:
+            continue
     roofline = dict(kernel=kname[dom], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
                     algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
                     factorizations_per_launch=round(working, 4),
@@ -366,23 +401,18 @@ def main():
     s.end_batch(zout.data_ptr(), nz, stream=st)
     status = torch.tensor(s.scalar_batch("status"), device=dev, dtype=torch.float64)
     time_partitions = s.partitions()
+    engine_name = s.engine()
     del jout, z0, jfn
     s.close()
     torch.cuda.empty_cache()
-    gathered = gather_trajectories(zout, status, dist)
-    n_gathered = int(gathered.shape[0])
-    del zout, status, gathered
+    # bounded exchange (dto_amd/parallel.py): <= 8 GiB of receive buffer per collective, every chunk consumed at once (here: a
+    # checksum) -- at the default batch a rank holds its own 21 GB of trajectories + <= 9 GB of exchange buffers
+    gsum = torch.zeros((), device=dev, dtype=torch.float64)
+    def _sink(g0, rows):
+        gsum.add_(rows[:, -1].sum())
+    n_gathered = int(gather_trajectories(zout, status, dist, sink=_sink))
+    del zout, status
     torch.cuda.empty_cache()
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        try:
-            from oracle.cpu_port import cpu_baseline
-            # the same workload on the host: full solves when the GPU run was one, else the same number of iterations
-            cpu = cpu_baseline(T=T, seed=1000, seconds=12.0,
-                               iters_per_instance=0 if a.steps + a.warmup >= 1000 else a.steps + a.warmup)
-        except Exception as e:  # the baseline is a reported extra, never part of the measured path
-            cpu = dict(value=None, unit="SQP iterations/s", cores=1, kind="port", sample=f"unavailable: {e}")
 
     full = None
     if rank == 0 and world == 1 and not a.no_full_solves:
@@ -413,7 +443,7 @@ def main():
                                       note=f"first {first_k} timed iterations, every instance still running"),
             solve=solve_info,
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=time_partitions,
-            gathered_trajectories=n_gathered, hbm_free_min_gb=hbm_free_min_gb,
+            gathered_trajectories=n_gathered, gathered_status_sum=float(gsum), hbm_free_min_gb=hbm_free_min_gb, engine=engine_name,
             roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,
         )
         print(json.dumps(out), flush=True)

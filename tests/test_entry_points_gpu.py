@@ -136,6 +136,26 @@ def test_warm_started_mpc_resolve_keeps_the_interior_point_state():
     assert np.all(st_w == 1) and np.all(st_c == 1), (st_w, st_c)
     assert np.max(np.abs(zw.cpu().numpy() - zc.cpu().numpy())) < 1e-5
     assert it_w.sum() < it_c.sum(), (it_w, it_c)
+    # ... and the warm-started solutions are KKT points by the ORACLE's derivatives (this test used to compare
+    # HIP solves with each other only).  The MPC family is the oracle's pendulum with the pins x_1 = w[0:2], x_T = (w[2], 0):
+    # same Jacobian and gradient, constraint values shifted by the pin data.
+    from test_solve_gpu import oracle_for
+    lw = torch.empty((B, nc), device="cuda", dtype=torch.float64)
+    s.end_batch(zw.data_ptr(), nz, lw.data_ptr(), nc)
+    torch.cuda.synchronize()
+    onlp = oracle_for("pendulum", T)
+    nd = 2 * (T - 1)
+    for b in range(B):
+        z, lam = zw[b].cpu().numpy(), lw[b].cpu().numpy()
+        J = np.zeros((nc, nz))
+        for (r, c_), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
+            J[r - 1, c_ - 1] = v
+        c = onlp.eval_constraint(z).copy()
+        x1b, goal = W2[b][:2], W2[b][2]
+        c[nd:nd + 2] -= x1b                       # oracle pins x_1 at the origin
+        c[nd + 2] += np.pi - goal                 # ... and x_T at (pi, 0)
+        assert np.max(np.abs(c)) <= 1e-6, (b, np.max(np.abs(c)))
+        assert np.max(np.abs(onlp.eval_objective_gradient(z) + J.T @ lam)) <= 1e-5, b
     # a batch of another size has no state to continue from
     from dto_amd import capi
     with pytest.raises(capi.DtoError, match="same batch size"):
@@ -178,6 +198,12 @@ def test_repack_of_running_instances_changes_nothing_but_the_cost():
     assert counts[0] > counts[-1] and sorted(counts, reverse=True) == counts      # instances only ever leave
     assert np.array_equal(st_a, st_b) and np.array_equal(it_a, it_b) and np.all(st_a == 1)
     assert torch.equal(za, zb) and torch.equal(la, lb)
+    # the repacked solves are KKT points by the oracle (not only equal to the unrepacked HIP solves)
+    from test_solve_gpu import kkt_report, oracle_for
+    onlp = oracle_for("acrobot", 101)
+    for b in range(0, B, 25):
+        rep = kkt_report(onlp, zb[b].cpu().numpy(), lb[b].cpu().numpy())
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5, (b, rep)
     # (c) the one-call solve (repacks by itself)
     zc = torch.empty_like(z0)
     st_c, it_c = s.solve_batch(z0.data_ptr(), B, nz, zc.data_ptr(), nz)

@@ -39,6 +39,14 @@ WORKER = textwrap.dedent("""
     exp = np.array([[100.0 * b + i for i in range(nz)] + [float(b % 3)] for b in range(B)])
     assert out.shape == (B, nz + 1), out.shape
     assert np.array_equal(out.numpy(), exp)
+    # bounded-memory forms: a receive budget of two rows per collective -> chunks; with a sink nothing is assembled
+    got = np.full((B, nz + 1), np.nan)
+    def sink(g0, rows):
+        got[g0:g0 + rows.shape[0]] = rows.numpy()
+    n = gather_trajectories(z, status, dist, sink=sink, max_bytes=2 * world * (nz + 1) * 8)
+    assert n == B and np.array_equal(got, exp)
+    out2 = gather_trajectories(z, status, dist, max_bytes=world * (nz + 1) * 8)      # one row per collective, assembled on the host
+    assert out2.shape == (B, nz + 1) and np.array_equal(out2.numpy(), exp)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
