@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
         "dto_eval_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
         "dto_eval_jac_g_batch": [vp, C.POINTER(Batch), vp, C.c_int64],
         "dto_eval_h_batch": [vp, C.POINTER(Batch), C.c_double, vp, C.c_int64, vp, C.c_int64],
+        "dto_kkt_csr_structure": [vp, c_int64_p, c_int64_p, c_int64_p, c_int64_p],
+        "dto_kkt_csr_values_batch": [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_double, C.c_double, vp, C.c_int64, vp],
         "dto_options_default": [C.POINTER(COptions)],
         "dto_kkt_step_batch": [vp, C.POINTER(Batch), vp, C.c_int64, C.c_double, C.c_double, vp, C.c_int64, vp, C.c_int64,
                                C.POINTER(C.c_int)],

@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -119,7 +121,75 @@ int Problem::launch(int op, const dto_eval_args& a, hipStream_t s) {
   return DTO_OK;
 }
 
+// ---- KKT matrix in CSR form -------------------------------------------------------------------------------------------
+// K = [ H + delta_w I   J' ;  J   -delta_c I ] over [z; constraint rows] -- the matrix the reference's scratch builds with
+// spzeros + index loops (examples/pendulum/pendulum.jl:138-198) and hands to QDLDL.  Pattern: Hessian key (row-major sorted,
+// both triangles: src/data.jl:184) merged with the primal diagonal, J' to the right of it, J below, the dual diagonal.
+int Problem::build_kkt_csr() {
+  if (!csr_rowptr.empty()) return DTO_OK;
+  if (!L.hessian) return set_error(DTO_ERR_UNSUPPORTED, "the KKT matrix needs the Hessian of the Lagrangian (evaluate_hessian = true)");
+  const int64_t n = L.Nz, m = L.Nc, dim = n + m;
+  struct Ent { int64_t col; int h, j; signed char d; };
+  std::vector<std::vector<Ent>> rows((size_t)dim);
+  for (int64_t k = 0; k < L.nnzH; ++k) rows[(size_t)(L.hess_rows[k] - 1)].push_back({L.hess_cols[k] - 1, (int)k, -1, 0});
+  for (int64_t i = 0; i < n; ++i) rows[(size_t)i].push_back({i, -1, -1, 1});
+  for (int64_t k = 0; k < L.nnzJ; ++k) {
+    const int64_t r = L.jac_rows[k] - 1, c = L.jac_cols[k] - 1;
+    rows[(size_t)c].push_back({n + r, -1, (int)k, 0});       // J' block
+    rows[(size_t)(n + r)].push_back({c, -1, (int)k, 0});     // J block
+  }
+  for (int64_t r = 0; r < m; ++r) rows[(size_t)(n + r)].push_back({n + r, -1, -1, 2});
+  std::vector<int> sh, sj;
+  std::vector<signed char> sd;
+  csr_rowptr.assign((size_t)dim + 1, 1);
+  for (int64_t i = 0; i < dim; ++i) {
+    auto& rw = rows[(size_t)i];
+    std::stable_sort(rw.begin(), rw.end(), [](const Ent& a, const Ent& b) { return a.col < b.col; });
+    for (size_t k = 0; k < rw.size(); ++k) {
+      if (k > 0 && rw[k].col == rw[k - 1].col) {   // the diagonal entry meets a Hessian key entry: one slot, both sources
+        if (rw[k].h >= 0) sh.back() = rw[k].h;
+        if (rw[k].j >= 0) sj.back() = rw[k].j;
+        if (rw[k].d) sd.back() = rw[k].d;
+        continue;
+      }
+      csr_col.push_back(rw[k].col + 1);
+      sh.push_back(rw[k].h); sj.push_back(rw[k].j); sd.push_back(rw[k].d);
+    }
+    csr_rowptr[(size_t)i + 1] = (int64_t)csr_col.size() + 1;
+  }
+  int rc = ensure_device();
+  if (rc) { csr_rowptr.clear(); csr_col.clear(); return rc; }
+  const size_t nnz = csr_col.size();
+  HIP_TRY(hipMalloc((void**)&d_csr_h, std::max<size_t>(1, nnz) * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&d_csr_j, std::max<size_t>(1, nnz) * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&d_csr_diag, std::max<size_t>(1, nnz)));
+  HIP_TRY(hipMemcpy(d_csr_h, sh.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_csr_j, sj.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_csr_diag, sd.data(), nnz, hipMemcpyHostToDevice));
+  return DTO_OK;
+}
+
+// one thread per CSR slot and instance: a gather, so every instance's value row is written with full coalescing
+static __global__ void k_kkt_csr_values(int64_t nnz, const int* src_h, const int* src_j, const signed char* diag, const double* H,
+                                        int64_t ldh, const double* J, int64_t ldj, double delta_w, double delta_c, double* vals,
+                                        int64_t ldv) {
+  const int64_t b = blockIdx.y;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  double v = 0.0;
+  const int h = src_h[s], j = src_j[s];
+  if (h >= 0) v += H[b * ldh + h];
+  if (j >= 0) v += J[b * ldj + j];
+  const signed char d = diag[s];
+  if (d == 1) v += delta_w;
+  else if (d == 2) v -= delta_c;
+  vals[b * ldv + s] = v;
+}
+
 Problem::~Problem() {
+  if (d_csr_h) (void)hipFree(d_csr_h);
+  if (d_csr_j) (void)hipFree(d_csr_j);
+  if (d_csr_diag) (void)hipFree(d_csr_diag);
   for (int* p : {d_kind, d_zoff, d_woff, d_cdoff, d_ccoff, d_jdoff, d_jcoff, d_hoff, d_hmap_cost, d_hmap_dyn_own,
                  d_hmap_dyn_next, d_hmap_con})
     if (p) (void)hipFree(p);
@@ -292,6 +362,34 @@ int dto_eval_g_batch(dto_problem* h, const dto_batch* b, double* c, int64_t ldc)
   a.out = c; a.ldout = ldc;
   if ((rc = p->launch(DTO_OP_CON, a, (hipStream_t)b->stream))) return rc;
   if (p->L.Ngen) return p->launch(DTO_OP_GENERAL_CON, a, (hipStream_t)b->stream);
+  return DTO_OK;
+}
+
+int dto_kkt_csr_structure(dto_problem* h, int64_t* row_ptr, int64_t* col_ind, int64_t* dim, int64_t* nnz) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p) return set_error(DTO_ERR_INVALID, "null argument");
+  int rc = p->build_kkt_csr();
+  if (rc) return rc;
+  if (dim) *dim = p->L.Nz + p->L.Nc;
+  if (nnz) *nnz = (int64_t)p->csr_col.size();
+  if (row_ptr) std::copy(p->csr_rowptr.begin(), p->csr_rowptr.end(), row_ptr);
+  if (col_ind) std::copy(p->csr_col.begin(), p->csr_col.end(), col_ind);
+  return DTO_OK;
+}
+
+int dto_kkt_csr_values_batch(dto_problem* h, int64_t B, const double* H, int64_t ldh, const double* J, int64_t ldj,
+                             double delta_w, double delta_c, double* vals, int64_t ldv, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !H || !J || !vals || B < 1) return set_error(DTO_ERR_INVALID, "null argument");
+  int rc = p->build_kkt_csr();
+  if (rc) return rc;
+  const int64_t nnz = (int64_t)p->csr_col.size();
+  if (ldh < p->L.nnzH || ldj < p->L.nnzJ || ldv < nnz) return set_error(DTO_ERR_INVALID, "leading dimension too small");
+  if (B > 65535) return set_error(DTO_ERR_INVALID, "at most 65535 instances per call");
+  dim3 grid((unsigned)((nnz + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(dto::k_kkt_csr_values, grid, dim3(256), 0, (hipStream_t)stream, nnz, (const int*)p->d_csr_h,
+                     (const int*)p->d_csr_j, (const signed char*)p->d_csr_diag, H, ldh, J, ldj, delta_w, delta_c, vals, ldv);
+  HIP_TRY(hipGetLastError());
   return DTO_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "dto_layout.hpp"
 #include "dto_model_plugin.h"
@@ -40,6 +41,12 @@ struct Problem {
   size_t wide_fac_len = 0;
   int* wide_flags = nullptr;
   size_t wide_flags_len = 0;
+
+  // CSR pattern of the KKT matrix in the reference ordering (dto_kkt_csr_structure / dto_kkt_csr_values_batch), built on first use
+  std::vector<int64_t> csr_rowptr, csr_col;   // 1-based
+  int *d_csr_h = nullptr, *d_csr_j = nullptr;  // per CSR slot: 0-based index into the Hessian key / Jacobian values, -1 = none
+  signed char* d_csr_diag = nullptr;           // per CSR slot: 1 = primal diagonal (+delta_w), 2 = dual diagonal (-delta_c), 0 = off-diagonal
+  int build_kkt_csr();
 
   int ensure_device();
   int ensure_scratch(int64_t B);

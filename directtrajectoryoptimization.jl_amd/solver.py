@@ -319,6 +319,20 @@ class NLPData:
         b = self._batch(x_ptr, B, ldx, stream)
         capi.check(self._lib.dto_eval_h_batch(self._h, C.byref(b), float(sigma), mu_ptr, ldmu, out_ptr, ldo))
 
+    def kkt_csr_structure(self):
+        """(row_ptr [dim + 1], col_ind [nnz]) of K = [H + dw I, J'; J, -dc I] in the reference ordering, 1-based
+        (include/dto.h: dto_kkt_csr_structure; the matrix of examples/pendulum/pendulum.jl:138-198)."""
+        dim, nnz = C.c_int64(0), C.c_int64(0)
+        capi.check(self._lib.dto_kkt_csr_structure(self._h, None, None, C.byref(dim), C.byref(nnz)))
+        rp = np.zeros(dim.value + 1, dtype=np.int64)
+        ci = np.zeros(max(1, nnz.value), dtype=np.int64)
+        capi.check(self._lib.dto_kkt_csr_structure(self._h, rp.ctypes.data_as(capi.c_int64_p), ci.ctypes.data_as(capi.c_int64_p), None, None))
+        return rp, ci[:nnz.value]
+
+    def kkt_csr_values_batch(self, B, h_ptr, ldh, j_ptr, ldj, delta_w, delta_c, out_ptr, ldo, stream=0):
+        capi.check(self._lib.dto_kkt_csr_values_batch(self._h, int(B), h_ptr, ldh, j_ptr, ldj, float(delta_w), float(delta_c),
+                                                      out_ptr, ldo, stream or None))
+
 
 def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
     c = capi.COptions()

@@ -88,6 +88,17 @@ int dto_features_available(const dto_problem* p, int* feature_bits);
 int dto_jacobian_structure(const dto_problem* p, int64_t* rows, int64_t* cols);
 /* MOI.hessian_lagrangian_structure (src/moi.jl:125): rows/cols [nnz_hess_key], 1-based */
 int dto_hessian_structure(const dto_problem* p, int64_t* rows, int64_t* cols);
+/* The KKT matrix of the reference's scratch (examples/pendulum/pendulum.jl:138-198, built there with spzeros + index loops and
+ * handed to QDLDL), in CSR form and in the reference ordering [z; dynamics rows; stage rows; general rows]:
+ *     K = [ H + delta_w I   J' ;  J   -delta_c I ],   dimension num_variables + num_constraint,
+ * full symmetric pattern (both triangles, like the Hessian key: src/data.jl:184), columns sorted inside every row, 1-based.
+ * dto_kkt_csr_structure: row_ptr [dim + 1], col_ind [nnz]; either may be NULL to query *dim / *nnz only (HOST arrays).
+ * dto_kkt_csr_values_batch: values [B][ldv] (DEVICE) from evaluated Hessian-of-the-Lagrangian values H [B][ldh] (order of
+ * dto_hessian_structure: dto_eval_h_batch) and Jacobian values J [B][ldj] (dto_eval_jac_g_batch): one gather per CSR slot,
+ * fully coalesced stores -- for a caller that wants K itself (an A/B against QDLDL / MUMPS, or its own factorisation). */
+int dto_kkt_csr_structure(dto_problem* p, int64_t* row_ptr, int64_t* col_ind, int64_t* dim, int64_t* nnz);
+int dto_kkt_csr_values_batch(dto_problem* p, int64_t B, const double* H, int64_t ldh, const double* J, int64_t ldj,
+                             double delta_w, double delta_c, double* values, int64_t ldv, void* stream);
 /* nlp.variable_bounds / nlp.constraint_bounds (src/data.jl:123-148) */
 int dto_variable_bounds(const dto_problem* p, double* lower, double* upper);
 int dto_constraint_bounds(const dto_problem* p, double* lower, double* upper);
