@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-2 profile of the headline loop ALONE (acrobot T=1000, default batch): kernel statistics and the two HBM traffic
-# passes.  Run on the GPU box from the repo root: bash tools/profile_headline.sh [batch] ; results under gpurun_out/prof_r02/
+# Profile (rounds 2 and 3) of the headline loop ALONE (acrobot T=1000, default batch): kernel statistics and the two HBM traffic
+# passes.  Run on the GPU box from the repo root: bash tools/profile_headline.sh [batch] ; results under gpurun_out/prof_r03/
 B=${1:-524288}
-OUT=gpurun_out/prof_r02
+OUT=gpurun_out/prof_r03
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="bench.py --loop-only --steps 40 --warmup 5 --batch $B"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_B$B -- python3 $CMD > $OUT/loop_B$B.json 2> $OUT/stats_B$B.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_B$B -- python3 $CMD > /dev/null 2> $OUT/fetch_B$B.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_B$B -- python3 $CMD > /dev/null 2> $OUT/write_B$B.err
+timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_B$B -- python3 $CMD > $OUT/loop_B$B.json 2> $OUT/stats_B$B.err
+timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_B$B -- python3 $CMD > /dev/null 2> $OUT/fetch_B$B.err
+timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_B$B -- python3 $CMD > /dev/null 2> $OUT/write_B$B.err
 find $OUT -name "*kernel_stats.csv" | head; find $OUT -name "*counter_collection.csv" | head
 cat $OUT/loop_B$B.json
 F=$(find $OUT/fetch_B$B -name "*counter_collection.csv" | head -1); W=$(find $OUT/write_B$B -name "*counter_collection.csv" | head -1)
