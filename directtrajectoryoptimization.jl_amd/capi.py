@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
         "dto_solver_set_engine": [vp, C.c_int],
         "dto_solver_engine": [vp, C.POINTER(C.c_int)],
         "dto_solver_release": [vp],
+        "dto_solver_shift": [vp, C.c_int, vp],
         "dto_solve": [vp, C.POINTER(COptions), c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p],
         "dto_device_alloc": [C.POINTER(vp), C.c_int64],
         "dto_device_free": [vp],

@@ -77,6 +77,8 @@ struct dto_kkt_info {
   int npart, nscal, ls_trials, filter_cap;
   int chunk_sum_size, sep_fac_size, nx;  // per (tile, chunk) doubles of the partitioned factorisation
   int quasi_newton;                      // 1: the stage records hold persistent quasi-Newton blocks
+  int has_general;                       // 1: the model has GeneralConstraint rows -- the kernels cover the stage part of K, the
+                                         //    host adds the border (dto_solver.cpp: bordered_step)
 };
 
 struct dto_solver_opts {
@@ -241,7 +243,8 @@ void fill_info(dto_kkt_info* o) {
 
 template <class M>
 int kkt_info(dto_kkt_info* out) {
-  out->supported = (M::N_KIND <= 16 && !M::HAS_GENERAL) ? 1 : 0;
+  out->supported = (M::N_KIND <= 16) ? 1 : 0;
+  out->has_general = M::HAS_GENERAL ? 1 : 0;
   out->n_kind = M::N_KIND;
   for (int i = 0; i < 16; ++i) out->rec_size[i] = out->fac_size[i] = out->fac_size_seq[i] = out->n_ineq[i] = 0;
   fill_info<M>(out);
@@ -2305,9 +2308,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
   const dto_kkt_args& a = *args;
   const unsigned gt = (unsigned)((int64_t)a.G * a.T);
   const unsigned gb = (unsigned)((int64_t)a.G * ((a.T + DTO_SB - 1) / DTO_SB));  // blocks of DTO_SB stages
-  if constexpr (M::HAS_GENERAL) {
-    return (int)hipErrorNotSupported;
-  } else {
+  {
     switch (op) {
       case DTO_KKT_PACK:
       case DTO_KKT_UNPACK: {

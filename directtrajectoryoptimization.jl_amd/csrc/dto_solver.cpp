@@ -162,6 +162,12 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.warm = 0; o.mu_warm = 0.0;
 }
 
+struct BorderStats;
+static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
+                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed = false);
+static int general_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                               double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations);
+
 // ---- wide-stage models (dto_wide_kernels.hpp): one workgroup per instance, AoS buffers used as they are
 static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, double delta_w, double delta_c,
                      double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* inertia_ok) {
@@ -486,7 +492,7 @@ static void set_partitions_now(SolverState& S, int P) {
   S.P = P;
 }
 
-static int ensure_state(Problem* p, int64_t B) {
+static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   int rc = p->ensure_device();
   if (rc) return rc;
   if (!p->vt->kkt_info || !p->vt->launch_kkt) return set_error(DTO_ERR_UNSUPPORTED, "plugin has no KKT kernels");
@@ -519,7 +525,12 @@ static int ensure_state(Problem* p, int64_t B) {
                             ? std::max(1, std::min(4, L.T / 8)) : P_new;
   // the state is reused only if the chunk layout is the same too (a dto_solver_set_partitions between two batches of one
   // size changes P_cap and with it the carry records: ADVICE r2)
-  if (S.B == B && S.z && S.P0 == P_new && S.P_cap == P_cap_new) { set_partitions_now(S, S.P0); return DTO_OK; }
+  if (S.B == B && S.z && S.P0 == P_new && S.P_cap == P_cap_new) {
+    if (S.info.has_general && !allow_general)
+      return set_error(DTO_ERR_UNSUPPORTED, "the in-kernel interior-point iteration has no border for GeneralConstraint rows");
+    set_partitions_now(S, S.P0);
+    return DTO_OK;
+  }
   const int keep_forced = S.forced_P;
   S.release();
   S.forced_P = keep_forced;
@@ -528,9 +539,10 @@ static int ensure_state(Problem* p, int64_t B) {
   S.P_cap = P_cap_new;
   const bool seq_only = S.P_cap == 1;
   p->vt->kkt_info(&S.info);
-  if (!S.info.supported)
-    return set_error(DTO_ERR_UNSUPPORTED,
-                     "the KKT/solver path does not support a GeneralConstraint yet (bordered system, DESIGN.md section 8)");
+  if (!S.info.supported) return set_error(DTO_ERR_UNSUPPORTED, "the KKT/solver path supports at most 16 stage kinds");
+  if (S.info.has_general && !allow_general)
+    return set_error(DTO_ERR_UNSUPPORTED, "the in-kernel interior-point iteration has no border for GeneralConstraint rows that couple "
+                                          "several knots: such problems are solved by the bordered path of dto_solve_batch");
   S.B = B;
   S.G = (int)((B + 63) / 64);
   S.ioff.assign(L.T + 1, 0); S.recoff.assign(L.T + 1, 0); S.facoff.assign(L.T + 1, 0);
@@ -610,7 +622,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   const Layout& L = p->L;
   std::memset(&a, 0, sizeof(a));
   a.T = L.T; a.B = S.B; a.G = S.G;
-  a.Nz = L.Nz; a.Nc = L.Nc; a.Ni = S.Ni;
+  a.Nz = L.Nz; a.Nc = L.Nc - L.Ngen; a.Ni = S.Ni;   // GeneralConstraint rows (the tail of the multiplier vector) are the host's border
   a.n_mult = L.Nc; a.n_bnd = S.n_bnd;
   a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.ccoff = p->d_ccoff;
   a.ioff = S.d_ioff; a.recoff = S.d_recoff; a.facoff = S.d_facoff;
@@ -1035,6 +1047,359 @@ static int im_run(Problem* p, double* x_out, int64_t ldxo, double* mu_out, int64
   return DTO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bordered system: GeneralConstraint rows that couple several knots (src/general_constraint.jl:18-59; rows appended behind
+// the stage rows, src/data.jl:72-75).  With the stage-interleaved ordering these rows are a dense border of the
+// block-tridiagonal matrix:
+//     [ K_s   G' ] [ v  ]   [ r_s ]        K_s: stage part (variables, dynamics rows, stage rows) -- the device kernels
+//     [ G   -dc I ] [ drho] = [ r_g ]      G:   Jacobian of the general rows (constant pattern, few rows)
+// solved by the Schur complement on the border:  Y = K_s^-1 [G'; 0]  (one forward + backward sweep per general row, all
+// instances at once, through dto_kkt_assemble / factor / solve),  S = -(G Y_x + dc I),  S drho = r_g - G v0_x,
+// v = v0 - Y drho.  The border algebra (n_g x n_g per instance, n_g = a handful) and the products with G run on the host:
+// everything of size O(T) stays on the GPU.  The general rows must be Hessian-free (the layout refuses others: the
+// reference's own Hessian call for them is broken, src/general_constraint.jl:87).
+// dw: per-instance primal regularisation (host [B]); ok_out (host [B]): inertia of the whole bordered matrix is (Nz, Nc).
+// stats (optional, host): per instance f-gradient / residual vectors the solve loop needs.
+// ------------------------------------------------------------------------------------------------
+struct BorderStats {
+  std::vector<double> grad, c, rx, dz, dmu;   // [B][Nz], [B][Nc], [B][Nz], [B][Nz], [B][Nc]
+};
+
+static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
+                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed) {
+  const Layout& L = p->L;
+  const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc, ng = L.Ngen, Ns = Nc - ng, nnzJ = L.nnzJ;
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_problem* h = reinterpret_cast<dto_problem*>(p);
+  int rc;
+  double *dJ = nullptr, *dC = nullptr, *dG = nullptr, *dSig = nullptr, *dRx = nullptr, *dRc = nullptr, *dSx = nullptr, *dSc = nullptr;
+  auto cleanup = [&]() {
+    for (double* q : {dJ, dC, dG, dSig, dRx, dRc, dSx, dSc}) if (q) (void)hipFree(q);
+  };
+#define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
+#define BRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
+  BTRY(hipMalloc((void**)&dJ, (size_t)B * nnzJ * sizeof(double)));
+  BTRY(hipMalloc((void**)&dC, (size_t)B * Nc * sizeof(double)));
+  BTRY(hipMalloc((void**)&dG, (size_t)B * Nz * sizeof(double)));
+  BTRY(hipMalloc((void**)&dSig, (size_t)B * Nz * sizeof(double)));
+  BTRY(hipMalloc((void**)&dRx, (size_t)B * Nz * sizeof(double)));
+  BTRY(hipMalloc((void**)&dRc, (size_t)B * Nc * sizeof(double)));
+  BTRY(hipMalloc((void**)&dSx, (size_t)B * Nz * sizeof(double)));
+  BTRY(hipMalloc((void**)&dSc, (size_t)B * Nc * sizeof(double)));
+  // ---- derivatives at (x, mu): callbacks on the device, the small vectors come to the host
+  BRC(dto_eval_jac_g_batch(h, b, dJ, nnzJ));
+  BRC(dto_eval_g_batch(h, b, dC, Nc));
+  BRC(dto_eval_grad_f_batch(h, b, dG, Nz));
+  std::vector<double> J((size_t)B * nnzJ), c((size_t)B * Nc), g((size_t)B * Nz), m((size_t)B * Nc);
+  BTRY(hipMemcpyAsync(J.data(), dJ, J.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  BTRY(hipMemcpyAsync(c.data(), dC, c.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  BTRY(hipMemcpyAsync(g.data(), dG, g.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  BTRY(hipMemcpy2DAsync(m.data(), Nc * sizeof(double), mu, ldmu * sizeof(double), Nc * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
+  BTRY(hipStreamSynchronize(st));
+  // r_x = grad f + J' mu (all rows, general ones included); the general rows of J as dense vectors
+  std::vector<double> rx((size_t)B * Nz), Grow((size_t)ng * B * Nz, 0.0);
+  for (int64_t i = 0; i < B; ++i) {
+    double* r = &rx[(size_t)i * Nz];
+    for (int64_t k = 0; k < Nz; ++k) r[k] = g[(size_t)i * Nz + k];
+    for (int64_t k = 0; k < nnzJ; ++k) {
+      const int64_t row = L.jac_rows[(size_t)k] - 1, col = L.jac_cols[(size_t)k] - 1;
+      const double v = J[(size_t)i * nnzJ + k];
+      r[col] += v * m[(size_t)i * Nc + row];
+      if (row >= Ns) Grow[((size_t)(row - Ns) * B + i) * Nz + col] += v;
+    }
+  }
+  // ---- stage part: assemble, factor (per-instance delta_w through the sigma_x diagonal), solve for the 1 + n_g right-hand sides
+  std::vector<double> sig((size_t)B * Nz);
+  for (int64_t i = 0; i < B; ++i)
+    for (int64_t k = 0; k < Nz; ++k)   // pin_fixed: a variable with lo == hi keeps its value (a huge diagonal entry: its step is ~1e-16 r)
+      sig[(size_t)i * Nz + k] = (pin_fixed && L.var_lo[(size_t)k] == L.var_hi[(size_t)k]) ? 1e16 : dw[i];
+  BTRY(hipMemcpyAsync(dSig, sig.data(), sig.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  dto_kkt_system sys;
+  sys.mu = mu; sys.ldmu = ldmu; sys.sigma_x = dSig; sys.ldsx = Nz; sys.sigma_c = nullptr; sys.ldsc = 0;
+  sys.delta_w = 0.0; sys.delta_c = delta_c;
+  BRC(dto_kkt_assemble(h, b, &sys));
+  std::vector<int32_t> iok((size_t)B, 1);
+  BRC(dto_kkt_factor(h, iok.data(), nullptr, (void*)st));
+  std::vector<double> rhsx((size_t)B * Nz), rhsc((size_t)B * Nc, 0.0), solx((size_t)B * Nz), solc((size_t)B * Nc);
+  std::vector<double> Yx((size_t)ng * B * Nz), Yc((size_t)ng * B * Nc);
+  auto solve = [&](const double* hx, const double* hc, double* ox, double* oc) -> int {
+    HIP_TRY(hipMemcpyAsync(dRx, hx, (size_t)B * Nz * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dRc, hc, (size_t)B * Nc * sizeof(double), hipMemcpyHostToDevice, st));
+    int r = dto_kkt_solve(h, dRx, Nz, dRc, Nc, dSx, Nz, dSc, Nc, (void*)st);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(ox, dSx, (size_t)B * Nz * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(oc, dSc, (size_t)B * Nc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DTO_OK;
+  };
+  for (size_t k = 0; k < rhsx.size(); ++k) rhsx[k] = -rx[k];
+  for (int64_t i = 0; i < B; ++i)
+    for (int64_t k = 0; k < Ns; ++k) rhsc[(size_t)i * Nc + k] = -c[(size_t)i * Nc + k];
+  BRC(solve(rhsx.data(), rhsc.data(), solx.data(), solc.data()));
+  std::vector<double> zero_c((size_t)B * Nc, 0.0);
+  for (int64_t j = 0; j < ng; ++j)
+    BRC(solve(&Grow[(size_t)j * B * Nz], zero_c.data(), &Yx[(size_t)j * B * Nz], &Yc[(size_t)j * B * Nc]));
+  // ---- border: S drho = r_g - G v0_x per instance (dense n_g x n_g, Gaussian elimination with partial pivoting); S must be
+  //      negative definite for the inertia of the bordered matrix to be (Nz, Nc)
+  std::vector<double> hdx((size_t)B * Nz), hdm((size_t)B * Nc);
+  std::vector<double> Sm((size_t)ng * ng), rg((size_t)ng), Lc((size_t)ng * ng);
+  for (int64_t i = 0; i < B; ++i) {
+    auto gdot = [&](int64_t row, const double* v) {
+      const double* gr = &Grow[((size_t)row * B + i) * Nz];
+      double acc = 0.0;
+      for (int64_t k = 0; k < Nz; ++k) acc += gr[k] * v[k];
+      return acc;
+    };
+    for (int64_t a = 0; a < ng; ++a) {
+      for (int64_t q = 0; q < ng; ++q) Sm[(size_t)a * ng + q] = -gdot(a, &Yx[((size_t)q * B + i) * Nz]) - (a == q ? delta_c : 0.0);
+      rg[(size_t)a] = -c[(size_t)i * Nc + Ns + a] - gdot(a, &solx[(size_t)i * Nz]);
+    }
+    // negative definiteness: Cholesky of -S (symmetrised)
+    bool negdef = true;
+    for (int64_t a = 0; a < ng && negdef; ++a)
+      for (int64_t q = 0; q <= a; ++q) {
+        double acc = -0.5 * (Sm[(size_t)a * ng + q] + Sm[(size_t)q * ng + a]);
+        for (int64_t k = 0; k < q; ++k) acc -= Lc[(size_t)a * ng + k] * Lc[(size_t)q * ng + k];
+        if (a == q) { if (!(acc > 0.0)) { negdef = false; break; } Lc[(size_t)a * ng + a] = std::sqrt(acc); }
+        else Lc[(size_t)a * ng + q] = acc / Lc[(size_t)q * ng + q];
+      }
+    // solve S drho = rg
+    std::vector<double> A(Sm), x(rg);
+    for (int64_t k = 0; k < ng; ++k) {
+      int64_t piv = k;
+      for (int64_t r = k + 1; r < ng; ++r) if (std::fabs(A[(size_t)r * ng + k]) > std::fabs(A[(size_t)piv * ng + k])) piv = r;
+      if (piv != k) { for (int64_t q = 0; q < ng; ++q) std::swap(A[(size_t)k * ng + q], A[(size_t)piv * ng + q]); std::swap(x[(size_t)k], x[(size_t)piv]); }
+      const double d = A[(size_t)k * ng + k];
+      if (d == 0.0) { negdef = false; continue; }
+      for (int64_t r = k + 1; r < ng; ++r) {
+        const double f = A[(size_t)r * ng + k] / d;
+        for (int64_t q = k; q < ng; ++q) A[(size_t)r * ng + q] -= f * A[(size_t)k * ng + q];
+        x[(size_t)r] -= f * x[(size_t)k];
+      }
+    }
+    for (int64_t k = ng - 1; k >= 0; --k) {
+      double acc = x[(size_t)k];
+      for (int64_t q = k + 1; q < ng; ++q) acc -= A[(size_t)k * ng + q] * x[(size_t)q];
+      x[(size_t)k] = A[(size_t)k * ng + k] != 0.0 ? acc / A[(size_t)k * ng + k] : 0.0;
+    }
+    if (ok_out) ok_out[i] = (iok[(size_t)i] != 0 && negdef) ? 1 : 0;
+    for (int64_t k = 0; k < Nz; ++k) {
+      double v = solx[(size_t)i * Nz + k];
+      for (int64_t q = 0; q < ng; ++q) v -= Yx[((size_t)q * B + i) * Nz + k] * x[(size_t)q];
+      hdx[(size_t)i * Nz + k] = v;
+    }
+    for (int64_t k = 0; k < Ns; ++k) {
+      double v = solc[(size_t)i * Nc + k];
+      for (int64_t q = 0; q < ng; ++q) v -= Yc[((size_t)q * B + i) * Nc + k] * x[(size_t)q];
+      hdm[(size_t)i * Nc + k] = v;
+    }
+    for (int64_t q = 0; q < ng; ++q) hdm[(size_t)i * Nc + Ns + q] = x[(size_t)q];
+  }
+  BTRY(hipMemcpy2DAsync(dx, lddx * sizeof(double), hdx.data(), Nz * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyHostToDevice, st));
+  BTRY(hipMemcpy2DAsync(dmu, lddmu * sizeof(double), hdm.data(), Nc * sizeof(double), Nc * sizeof(double), (size_t)B, hipMemcpyHostToDevice, st));
+  BTRY(hipStreamSynchronize(st));
+  if (stats) {
+    stats->grad.swap(g); stats->c.swap(c); stats->rx.swap(rx); stats->dz.swap(hdx); stats->dmu.swap(hdm);
+  }
+  cleanup();
+#undef BTRY
+#undef BRC
+  return DTO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Solve for models with multi-knot GeneralConstraint rows: the filter line-search SQP iteration of the other paths, driven
+// from the host like the wide-stage solver, with bordered_step as its linear solver.  Scope: equality rows (dynamics, stage,
+// general) and variables that are free or fixed by equal bounds -- no barrier.
+// ------------------------------------------------------------------------------------------------
+static int general_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
+                               double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
+  int rc = p->ensure_device();
+  if (rc) return rc;
+  const Layout& L = p->L;
+  const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc;
+  for (int64_t i = 0; i < Nz; ++i)
+    if (L.var_lo[i] != L.var_hi[i] && (std::isfinite(L.var_lo[i]) || std::isfinite(L.var_hi[i])))
+      return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: variables may be free or fixed (lo == hi), not bounded");
+  for (int64_t i = 0; i < Nc; ++i)
+    if (L.con_lo[i] != L.con_hi[i]) return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: equality rows only");
+  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: shared parameters only");
+  dto_options u;
+  if (opt) u = *opt; else dto_options_default(&u);
+  dto_solver_opts o;
+  default_opts(o, u);
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_problem* h = reinterpret_cast<dto_problem*>(p);
+  double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *zt = nullptr, *df = nullptr, *dc = nullptr, *dal = nullptr;
+  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal}) if (q) (void)hipFree(q); };
+#define GTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
+#define GRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
+  GTRY(hipMalloc((void**)&z, (size_t)B * Nz * sizeof(double)));
+  GTRY(hipMalloc((void**)&lam, (size_t)B * Nc * sizeof(double)));
+  GTRY(hipMalloc((void**)&dz, (size_t)B * Nz * sizeof(double)));
+  GTRY(hipMalloc((void**)&dlam, (size_t)B * Nc * sizeof(double)));
+  GTRY(hipMalloc((void**)&zt, (size_t)B * Nz * sizeof(double)));
+  GTRY(hipMalloc((void**)&df, (size_t)B * sizeof(double)));
+  GTRY(hipMalloc((void**)&dc, (size_t)B * Nc * sizeof(double)));
+  GTRY(hipMalloc((void**)&dal, (size_t)B * sizeof(double)));
+  // the guess, with the fixed variables put on their values
+  std::vector<double> hz((size_t)B * Nz);
+  GTRY(hipMemcpy2DAsync(hz.data(), Nz * sizeof(double), b->x, b->ldx * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
+  GTRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < B; ++i)
+    for (int64_t k = 0; k < Nz; ++k)
+      if (L.var_lo[k] == L.var_hi[k]) hz[(size_t)i * Nz + k] = L.var_lo[k];
+  GTRY(hipMemcpyAsync(z, hz.data(), hz.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  GTRY(hipMemsetAsync(lam, 0, (size_t)B * Nc * sizeof(double), st));
+  struct Inst {
+    int status = 0, iter = 0, ls_fail = 0, filter_n = 0;
+    double dlast = 0.0, theta_max = -1.0, theta_min = -1.0;
+    std::vector<double> filt;
+  };
+  std::vector<Inst> I((size_t)B);
+  std::vector<double> dwv((size_t)B), hf((size_t)B), hc((size_t)B * Nc), hal((size_t)B);
+  std::vector<int> okv((size_t)B);
+  constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
+  constexpr int TRIALS = DTO_LS_TRIALS;
+  dto_batch bz = *b;
+  bz.x = z; bz.ldx = Nz; bz.params = nullptr; bz.ldp = 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  for (;;) {
+    // ---- step at the current point: delta_w ladder per instance (Algorithm IC), all instances share the sweeps
+    for (int64_t i = 0; i < B; ++i) {
+      Inst& s = I[(size_t)i];
+      dwv[(size_t)i] = s.ls_fail ? std::min(o.delta_w_exact_cap, std::max(10.0 * s.dlast, o.delta_w_init)) : 0.0;
+    }
+    BorderStats bs;
+    for (int attempt = 0;; ++attempt) {
+      GRC(bordered_step(p, &bz, lam, Nc, dwv.data(), o.delta_c, dz, Nz, dlam, Nc, okv.data(), &bs, true));
+      bool again = false;
+      for (int64_t i = 0; i < B; ++i) {
+        Inst& s = I[(size_t)i];
+        if (s.status != 0 || okv[(size_t)i] || attempt >= o.max_refactor) continue;
+        double& dw = dwv[(size_t)i];
+        dw = (dw == 0.0) ? ((s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast))
+                         : dw * ((s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus);
+        again = true;
+      }
+      if (!again) break;
+    }
+    // ---- convergence test (Ipopt's scaled error, reference Options), at the point the step was computed at
+    GRC(dto_eval_f_batch(h, &bz, df));
+    GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<double> hm((size_t)B * Nc);
+    GTRY(hipMemcpyAsync(hm.data(), lam, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    GTRY(hipStreamSynchronize(st));
+    bool any = false;
+    std::vector<double> th0((size_t)B), gphid((size_t)B);
+    for (int64_t i = 0; i < B; ++i) {
+      Inst& s = I[(size_t)i];
+      if (s.status != 0) continue;
+      double th1 = 0, thinf = 0, dinf = 0, slam = 0, gd = 0;
+      for (int64_t k = 0; k < Nc; ++k) { const double v = std::fabs(bs.c[(size_t)i * Nc + k]); th1 += v; thinf = std::max(thinf, v); slam += std::fabs(hm[(size_t)i * Nc + k]); }
+      for (int64_t k = 0; k < Nz; ++k) {
+        if (L.var_lo[k] != L.var_hi[k]) dinf = std::max(dinf, std::fabs(bs.rx[(size_t)i * Nz + k]));
+        gd += bs.grad[(size_t)i * Nz + k] * bs.dz[(size_t)i * Nz + k];
+      }
+      const double sd = std::max(o.s_max, slam / (double)std::max<int64_t>(1, Nc)) / o.s_max;
+      const double e0 = std::max(dinf / sd, thinf);
+      const double f = hf[(size_t)i];
+      if (!(f == f) || !(th1 == th1) || !(dinf == dinf)) s.status = 3;
+      else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol) s.status = 1;
+      else if (s.iter >= o.max_iter) s.status = 2;
+      if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
+      th0[(size_t)i] = th1; gphid[(size_t)i] = gd;
+      if (s.status == 0) {
+        any = true;
+        if (dwv[(size_t)i] > 0.0) s.dlast = dwv[(size_t)i]; else s.dlast = 0.0;
+        if (!okv[(size_t)i]) s.ls_fail = 1;
+      }
+    }
+    if (!any) break;
+    // ---- filter line search over alpha = 2^-k: objective and violation of the trial points from the callbacks
+    std::vector<double> phi((size_t)B * TRIALS), th((size_t)B * TRIALS);
+    for (int k = 0; k < TRIALS; ++k) {
+      const double alpha = std::ldexp(1.0, -k);
+      for (int64_t i = 0; i < B; ++i) hal[(size_t)i] = I[(size_t)i].status == 0 ? alpha : 0.0;
+      GTRY(hipMemcpyAsync(zt, z, (size_t)B * Nz * sizeof(double), hipMemcpyDeviceToDevice, st));
+      GTRY(hipMemcpyAsync(dal, hal.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, zt, (const double*)dz, (const double*)dal, Nz, Nz, Nz);
+      dto_batch bt = bz;
+      bt.x = zt;
+      GRC(dto_eval_f_batch(h, &bt, df));
+      GRC(dto_eval_g_batch(h, &bt, dc, Nc));
+      GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(hc.data(), dc, hc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipStreamSynchronize(st));
+      for (int64_t i = 0; i < B; ++i) {
+        double t1 = 0.0;
+        for (int64_t q = 0; q < Nc; ++q) t1 += std::fabs(hc[(size_t)i * Nc + q]);
+        phi[(size_t)i * TRIALS + k] = hf[(size_t)i];
+        th[(size_t)i * TRIALS + k] = t1;
+      }
+    }
+    GRC(dto_eval_f_batch(h, &bz, df));
+    GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+    GTRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < B; ++i) {
+      hal[(size_t)i] = 0.0;
+      Inst& s = I[(size_t)i];
+      if (s.status != 0) continue;
+      const double t0 = th0[(size_t)i], phi0 = hf[(size_t)i], dphi = gphid[(size_t)i];
+      const int nf = std::min(s.filter_n, DTO_FILTER_CAP);
+      double alpha = 1.0, chosen = -1.0;
+      bool ftype = false;
+      int best = 0;
+      for (int k = 0; k < TRIALS; ++k) {
+        const double pk = phi[(size_t)i * TRIALS + k], tk = th[(size_t)i * TRIALS + k];
+        if (tk < th[(size_t)i * TRIALS + best] || !(th[(size_t)i * TRIALS + best] == th[(size_t)i * TRIALS + best])) best = k;
+        bool ok = (tk == tk) && (pk == pk) && tk <= s.theta_max;
+        const bool sw = dphi < 0.0 && alpha * std::pow(-dphi, S_PHI) > std::pow(t0, S_TH);
+        if (ok) {
+          if (sw && t0 <= s.theta_min) ok = pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0);
+          else ok = (tk <= (1.0 - G_TH) * t0) || (pk <= phi0 - G_PHI * t0);
+        }
+        if (ok)
+          for (int q = 0; q < nf; ++q) {
+            const double tf = s.filt[2 * q], pf = s.filt[2 * q + 1];
+            if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
+          }
+        if (ok) { chosen = alpha; ftype = sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0)); break; }
+        alpha *= 0.5;
+      }
+      bool augment;
+      if (chosen < 0.0) {
+        chosen = (th[(size_t)i * TRIALS + best] < t0) ? std::ldexp(1.0, -best) : alpha * 2.0;
+        s.ls_fail = 1; augment = true;
+      } else { s.ls_fail = okv[(size_t)i] ? 0 : 1; augment = !ftype; }
+      if (augment) {
+        if ((int)s.filt.size() < 2 * DTO_FILTER_CAP) s.filt.resize(2 * DTO_FILTER_CAP, 0.0);
+        const int slot = s.filter_n % DTO_FILTER_CAP;
+        s.filt[2 * slot] = (1.0 - G_TH) * t0;
+        s.filt[2 * slot + 1] = phi0 - G_PHI * t0;
+        s.filter_n++;
+      }
+      s.iter++;
+      hal[(size_t)i] = chosen;
+    }
+    GTRY(hipMemcpyAsync(dal, hal.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, (const double*)dz, (const double*)dal, Nz, Nz, Nz);
+    hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, lam, (const double*)dlam, (const double*)dal, Nc, Nc, Nc);
+    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
+  }
+  GTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, st));
+  if (mu_out) GTRY(hipMemcpy2DAsync(mu_out, ldmuo * sizeof(double), lam, Nc * sizeof(double), Nc * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, st));
+  GTRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < B; ++i) {
+    if (status) status[i] = I[(size_t)i].status;
+    if (iterations) iterations[i] = I[(size_t)i].iter;
+  }
+  cleanup();
+#undef GTRY
+#undef GRC
+  return DTO_OK;
+}
+
 }  // namespace dto
 
 using dto::Problem;
@@ -1064,6 +1429,14 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   if (p->vt->launch_wide) {
     if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
     return dto::wide_step(p, b, mu, ldmu, delta_w, delta_c, dx, lddx, dmu, lddmu, inertia_ok);
+  }
+  if (p->L.Ngen > 0) {   // GeneralConstraint rows coupling several knots: bordered system, Schur complement on the border
+    std::vector<double> dwv((size_t)b->B, delta_w);
+    std::vector<int> okv((size_t)b->B, 1);
+    int rcg = dto::bordered_step(p, b, mu, ldmu, dwv.data(), delta_c, dx, lddx, dmu, lddmu, okv.data(), nullptr);
+    if (rcg) return rcg;
+    if (inertia_ok) { *inertia_ok = 1; for (int v : okv) if (!v) *inertia_ok = 0; }
+    return DTO_OK;
   }
   int rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
@@ -1222,6 +1595,76 @@ int dto_solver_set_partitions(dto_problem* h, int partitions) {
   if (partitions > p->L.T) return set_error(DTO_ERR_INVALID, "more partitions than stages");
   if (!p->solver) p->solver = new SolverState();
   p->solver->forced_P = partitions;
+  return DTO_OK;
+}
+
+// ---- receding horizon: shift the device-resident iterate by whole knots -------------------------------------------------
+// instance-major work buffers: v[b][n], stage-major with a uniform stride per knot; out[b][..] = shifted copy
+static __global__ void k_shift_knots(const double* in, double* out, int64_t ld, int T_blocks, int stride, int last_len, int k) {
+  // block t of `out` = block min(t + k, last full block) of `in`; the trailing short block (x_T without an action: last_len
+  // entries, 0 = none) takes the head of block min(T_blocks + k, ...) -- i.e. the final state is held
+  const int64_t b = blockIdx.y;
+  const int t = blockIdx.x;                      // 0 .. T_blocks (the last index addresses the short block)
+  const int i = threadIdx.x;
+  const double* src = in + b * ld;
+  double* dst = out + b * ld;
+  if (t < T_blocks) {
+    const int ts = t + k < T_blocks ? t + k : T_blocks - 1;
+    if (i < stride) {
+      // states of a block beyond the horizon: the final state (head of the short block) is held, the action repeats
+      double v = src[(int64_t)ts * stride + i];
+      if (t + k >= T_blocks && i < last_len) v = src[(int64_t)T_blocks * stride + i];
+      dst[(int64_t)t * stride + i] = v;
+    }
+  } else if (i < last_len) {
+    dst[(int64_t)T_blocks * stride + i] = src[(int64_t)T_blocks * stride + i];
+  }
+}
+
+int dto_solver_shift(dto_problem* h, int knots, void* stream) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || knots < 0) return set_error(DTO_ERR_INVALID, "bad arguments");
+  if (p->im_active) return set_error(DTO_ERR_UNSUPPORTED, "dto_solver_shift: SoA engine only");
+  if (!p->solver || !p->solver->z) return set_error(DTO_ERR_INVALID, "dto_solver_shift needs the device state of a previous solve");
+  if (knots == 0) return DTO_OK;
+  SolverState& S = *p->solver;
+  const dto::Layout& L = p->L;
+  const int T = L.T;
+  if (knots >= T - 1) return set_error(DTO_ERR_INVALID, "shift by fewer knots than the horizon has");
+  for (int t = 1; t < T; ++t)
+    if (L.nx[t] != L.nx[0] || (t < T - 1 && L.nu[t] != L.nu[0]))
+      return set_error(DTO_ERR_UNSUPPORTED, "dto_solver_shift needs the same state / action dimensions at every knot");
+  const int nx = L.nx[0], nu = L.nu[0];
+  if (L.Ndyn != (int64_t)(T - 1) * nx) return set_error(DTO_ERR_UNSUPPORTED, "dto_solver_shift: unexpected dynamics row count");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = S.B, Nz = L.Nz, Nc = L.Nc;
+  double *a = nullptr, *b = nullptr;
+  const size_t n = (size_t)B * (size_t)std::max<int64_t>(Nz, Nc);
+  HIP_TRY(hipMalloc((void**)&a, n * sizeof(double)));
+  if (hipMalloc((void**)&b, n * sizeof(double)) != hipSuccess) { (void)hipFree(a); return set_error(DTO_ERR_DEVICE, "hipMalloc"); }
+  dto_kkt_args ka;
+  dto::fill_kkt_args(p, ka);
+  int rc = DTO_OK;
+  auto shift = [&](int which, int64_t ld, int blocks, int stride, int last_len) -> int {
+    int r;
+    if ((r = dto::unpack(p, ka, which, a, ld, st))) return r;
+    HIP_TRY(hipMemcpyAsync(b, a, (size_t)B * ld * sizeof(double), hipMemcpyDeviceToDevice, st));   // rows beyond the shifted part (stage rows of the multipliers) stay
+    hipLaunchKernelGGL(k_shift_knots, dim3((unsigned)(blocks + 1), (unsigned)B), dim3(64), 0, st, (const double*)a, b, ld, blocks,
+                       stride, last_len, knots);
+    HIP_TRY(hipGetLastError());
+    return dto::pack(p, ka, which, b, ld, st);
+  };
+  if (B > 65535 || nx + nu > 64) rc = set_error(DTO_ERR_UNSUPPORTED, "dto_solver_shift: at most 65535 instances and 64 variables per knot");
+  // primal iterate: T - 1 blocks [x_t; u_t] and the final state
+  if (!rc) rc = shift(0, Nz, T - 1, nx + nu, nx);
+  // dynamics multipliers: T - 1 blocks of nx rows (the stage-constraint multipliers behind them belong to their knots: kept)
+  if (!rc && Nc > 0) rc = shift(1, Nc, T - 1, nx, 0);
+  // bound multipliers follow their variables
+  if (!rc && S.zl) { rc = shift(5, Nz, T - 1, nx + nu, nx); if (!rc) rc = shift(6, Nz, T - 1, nx + nu, nx); }
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(a); (void)hipFree(b);
+  if (rc) return rc;
+  if (e != hipSuccess) return dto::hip_fail(e, "dto_solver_shift");
   return DTO_OK;
 }
 
@@ -1415,6 +1858,8 @@ int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, 
   Problem* p = reinterpret_cast<Problem*>(h);
   if (p && b && b->x && x_out && p->vt->launch_wide)
     return dto::wide_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
+  if (p && b && b->x && x_out && p->L.Ngen > 0)
+    return dto::general_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
   int rc = dto_solver_begin(h, opt, b);
   if (rc) return rc;
   return dto_solver_run(h, x_out, ldxo, mu_out, ldmuo, status, iterations, b->stream);
@@ -1461,7 +1906,8 @@ int dto_kkt_assemble(dto_problem* h, const dto_batch* b, const dto_kkt_system* s
   if (p->vt->launch_wide) return set_error(DTO_ERR_UNSUPPORTED, "dto_kkt_assemble/factor/solve: use dto_kkt_step_batch for wide-stage models");
   if (b->ldx < p->L.Nz || sys->ldmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
   if ((sys->sigma_x && sys->ldsx < p->L.Nz) || (sys->sigma_c && sys->ldsc < p->L.Nc)) return set_error(DTO_ERR_INVALID, "leading dimension too small");
-  int rc = dto::ensure_state(p, b->B);
+  // models with GeneralConstraint rows: this is the STAGE part of K (dynamics + stage rows); the border is the caller's
+  int rc = dto::ensure_state(p, b->B, true);
   if (rc) return rc;
   p->im_active = false;
   SolverState& S = *p->solver;

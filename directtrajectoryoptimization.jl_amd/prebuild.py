@@ -22,6 +22,8 @@ def _entries():
         ("ref_hesslag", P.build_ref_hesslag, {}),
         ("ref_general", P.build_ref_general, dict(user_jacobian=False)),
         ("ref_general", P.build_ref_general, dict(user_jacobian=True)),
+        ("ref_general_coupled", P.build_ref_general_coupled, {}),
+        ("acrobot_coupled", P.build_acrobot_coupled, dict(T=8)),
         ("param_pendulum", P.build_param_pendulum, dict(T=8)),
         ("ref_userjac", P.build_ref_userjac, {}),
         ("mpc_pendulum", P.build_mpc_pendulum, dict(T=5)),

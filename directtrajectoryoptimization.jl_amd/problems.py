@@ -371,6 +371,41 @@ def build_ref_general(user_jacobian=False):
                 bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=eh)
 
 
+def build_ref_general_coupled():
+    """test/solve.jl:227-296 extended with a row that couples two knots: GeneralConstraint
+    (z, w) -> [z[end-1:end] - xT; x_4[1] + x_8[1] - 0.9] (positions at knots 4 and 8 add up to 0.9).  The terminal rows alone
+    would be folded into a stage constraint; the coupling row cannot: the solver's bordered path (dto_solver.cpp:
+    bordered_step / general_solve_batch) takes the whole GeneralConstraint as the border of the block-tridiagonal system."""
+    from .model import GeneralConstraint
+    T, n, m = 11, 2, 1
+    x1 = np.array([0.0, 0.0])
+    xT = np.array([1.0, 0.0])
+    dt = Dynamics(double_integrator, n, n, m, evaluate_hessian=True)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x, x) + 0.1 * dot(u, u), n, m, evaluate_hessian=True)
+    cT = Cost(lambda x, u, w: 0.1 * dot(x, x), n, 0, evaluate_hessian=True)
+    nz = n * T + m * (T - 1)
+    i4, i8 = 3 * (n + m), 7 * (n + m)          # 0-based offsets of x_4 and x_8 in z
+    gc = GeneralConstraint(lambda z, w: np.array([z[nz - 2] - xT[0], z[nz - 1] - xT[1], z[i4] + z[i8] - 0.9], dtype=object),
+                           nz, 0, evaluate_hessian=True)
+    bounds = [Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2) + [Bound(n, 0)]
+    return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
+                bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=True, coupling=(i4, i8, 0.9))
+
+
+def build_acrobot_coupled(T=8):
+    """The acrobot (nonlinear dynamics, pinned endpoints) with two GeneralConstraint rows that couple knots: q1 at knot 3 minus
+    q1 at knot 6 equals 0.2; q2 at knots 2 and 7 plus the action at knot 4 add up to zero.  Used for the bordered KKT step."""
+    from .model import GeneralConstraint
+    p = build_acrobot(T=T, evaluate_hessian=True)
+    n, m = p["n"], p["m"]
+    nz = n * T + m * (T - 1)
+    off = lambda t: (t - 1) * (n + m)          # 0-based offset of x_t (t 1-based)
+    gc = GeneralConstraint(lambda z, w: np.array([z[off(3)] - z[off(6)] - 0.2, z[off(2) + 1] + z[off(7) + 1] + z[off(4) + n]], dtype=object),
+                           nz, 0, evaluate_hessian=True)
+    p["general_constraint"] = gc
+    return p
+
+
 def build_ref_userjac():
     """test/solve.jl:140-226: double integrator, T = 11, user-provided dense dynamics Jacobian, both endpoints fixed by
     bounds, Solver(...) in its default mode (no exact Hessians)."""

@@ -444,6 +444,10 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_solver_begin_warm(self._solve_nlp._h, C.byref(co), C.byref(b), float(mu0)))
         self._B = B
 
+    def shift_batch(self, knots: int = 1, stream=0):
+        """dto_solver_shift: move the device-resident iterate `knots` knots forward (receding-horizon warm start)."""
+        capi.check(self._solve_nlp._lib.dto_solver_shift(self._solve_nlp._h, int(knots), stream or None))
+
     def repack_batch(self, stream=0) -> int:
         """dto_solver_repack: close the gaps finished instances leave in the tiles; returns the number still running."""
         n = C.c_int(0)

@@ -234,6 +234,12 @@ int dto_solver_begin(dto_problem* p, const dto_options* opt, const dto_batch* b)
  * final iterate) replaces the primal iterate (e.g. the shifted trajectory), b->params the parameters (e.g. the newly
  * measured state); b->B must equal the previous batch size.  mu0 > 0 resets the barrier parameter, mu0 <= 0 keeps it. */
 int dto_solver_begin_warm(dto_problem* p, const dto_options* opt, const dto_batch* b, double mu0);
+/* Receding horizon: shift the device-resident iterate of the previous solve forward by `knots` knots -- x_t <- x_{t+k},
+ * u_t <- u_{t+k}, dynamics multipliers and bound multipliers with them; the knots that enter at the end of the horizon hold the
+ * final state and repeat the last action (the usual MPC warm start).  Stage-constraint multipliers stay with their knots.
+ * Follow with dto_solver_begin_warm(x = NULL, params = the newly measured state) and dto_solver_run.  Needs the same state /
+ * action dimensions at every knot. */
+int dto_solver_shift(dto_problem* p, int knots, void* stream);
 /* Move the instances that are still running to the leading tiles of the batch so that the following iterations only cover
  * tiles with work (a batch otherwise pays for every tile until its last lane has terminated); results keep coming back in
  * the caller's instance order.  dto_solver_run / dto_solve_batch do this by themselves; a caller that drives

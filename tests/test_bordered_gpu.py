@@ -1,0 +1,97 @@
+"""GeneralConstraint rows that couple several knots on the solver path: the rows are the
+dense border of the block-tridiagonal KKT matrix; the stage part is solved by the device kernels, the border by a Schur
+complement (csrc/dto_solver.cpp: bordered_step / general_solve_batch).  Reference: src/general_constraint.jl:18-59 (rows
+appended behind the stage rows: src/data.jl:72-75); test/solve.jl:227-296 is the reference's own (stage-local) use."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_acrobot_coupled(T):
+    from oracle import dto_oracle as O, sympy_models as S
+    p = S.build("acrobot", T, evaluate_hessian=True)
+    n, m = 4, 1
+    nz = n * T + m * (T - 1)
+    off = lambda t: (t - 1) * (n + m)
+    gc = S.GeneralConstraint(lambda z, w: [z[off(3)] - z[off(6)] - S.fl(0.2), z[off(2) + 1] + z[off(7) + 1] + z[off(4) + n]],
+                             nz, 0, evaluate_hessian=True)
+    return O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, general_constraint=gc)
+
+
+def test_bordered_kkt_step_matches_dense_solve_of_the_oracles_matrix():
+    """One regularised Newton-KKT step at random (x, mu) of the acrobot with two coupling rows: dto_kkt_step_batch against a
+    dense solve of K = [H + dw I, J'; J, -dc I] assembled from the ORACLE's derivatives, general rows included.  1e-8 of the
+    solution norm (the tolerance of every KKT-step test)."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    T, B = 8, 3
+    p = P.build_acrobot_coupled(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       general_constraint=p["general_constraint"], name="acrobot_coupled")
+    n = s.nlp
+    nz, nc = n.num_variables, n.num_constraint
+    onlp = _oracle_acrobot_coupled(T)
+    assert (onlp.num_variables, onlp.num_constraint) == (nz, nc) and nc == 4 * (T - 1) + 8 + 2
+    rng = np.random.default_rng(1)
+    Z = 0.5 * rng.standard_normal((B, nz))
+    MU = rng.standard_normal((B, nc))
+    dw, dc = 0.8, 1e-6
+    z, mu = torch.tensor(Z, device="cuda"), torch.tensor(MU, device="cuda")
+    dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    ok = s.kkt_step_batch(z.data_ptr(), B, nz, mu.data_ptr(), nc, dw, dc, dx.data_ptr(), nz, dl.data_ptr(), nc)
+    torch.cuda.synchronize()
+    for b in range(B):
+        K = np.zeros((nz + nc, nz + nc))
+        for (r, c), v in zip(onlp.hessian_lagrangian_structure(), onlp.eval_hessian_lagrangian(Z[b], 1.0, MU[b])):
+            K[r - 1, c - 1] += v
+        J = np.zeros((nc, nz))
+        for (r, c), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(Z[b])):
+            J[r - 1, c - 1] = v
+        K[:nz, :nz] += dw * np.eye(nz)
+        K[nz:, :nz] = J
+        K[:nz, nz:] = J.T
+        K[nz:, nz:] = -dc * np.eye(nc)
+        rhs = -np.concatenate([onlp.eval_objective_gradient(Z[b]) + J.T @ MU[b], onlp.eval_constraint(Z[b])])
+        sol = np.linalg.solve(K, rhs)
+        scale = np.max(np.abs(sol))
+        assert np.max(np.abs(dx[b].cpu().numpy() - sol[:nz])) <= 1e-8 * scale, np.max(np.abs(dx[b].cpu().numpy() - sol[:nz])) / scale
+        assert np.max(np.abs(dl[b].cpu().numpy() - sol[nz:])) <= 1e-8 * scale
+        ev = np.linalg.eigvalsh(K)
+        assert ok == bool(np.sum(ev < 0) == nc)      # the reported inertia is that of the whole bordered matrix
+
+
+def test_reference_general_constraint_solve_with_a_row_coupling_two_knots():
+    """test/solve.jl:227-296 (double integrator, T = 11, x_1 fixed by bounds, terminal state through the GeneralConstraint)
+    with one more general row coupling knots 4 and 8.  Same asserts as the reference plus: the coupling holds, and the
+    returned point is stationary for the full Lagrangian (multipliers in the reference order [dynamics; stage; general])."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_ref_general_coupled()
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       general_constraint=p["general_constraint"], name="ref_general_coupled")
+    rng = np.random.Generator(np.random.PCG64(5))
+    dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
+    dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3          # test/solve.jl:294
+    assert np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3         # test/solve.jl:295
+    i4, i8, tot = p["coupling"]
+    z = s._solution
+    assert abs(z[i4] + z[i8] - tot) < 1e-6
+    n = s.nlp
+    g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    J = np.zeros((n.num_constraint, n.num_variables))
+    for (r, c), v in zip(n.jacobian_structure(), Jv):
+        J[r - 1, c - 1] = v
+    c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
+    assert np.max(np.abs(c)) < 1e-6
+    r = g + J.T @ s._duals
+    free = np.ones(n.num_variables, bool); free[:2] = False     # x_1 is fixed by bounds
+    assert np.max(np.abs(r[free])) < 1e-5
+    # a convex QP with linear constraints: Newton's method needs a handful of iterations
+    assert s.iterations <= 10

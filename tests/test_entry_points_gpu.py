@@ -263,3 +263,74 @@ def test_varying_state_dimensions_callbacks_kkt_step_and_solve():
     assert dto_amd.solve(s) == 1, (s.status, s.iterations)
     rep = kkt_report(onlp, s._solution, s._duals)
     assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["compl"] <= 1e-3 and rep["sign_ok"], rep
+
+
+def test_receding_horizon_stream_shift_and_warm_resolve():
+    """An MPC loop on the device-resident state ("no shift/stream loop"): solve, apply the first
+    action to the plant, dto_solver_shift by one knot, re-solve warm with the measured state as the new parameter -- ten times,
+    a batch of rollouts at once.  Every re-solve is checked against the oracle's KKT conditions (pendulum with the pins moved),
+    the plant follows the plan (the plant is the model plus a small disturbance), and the streamed re-solves need far fewer
+    iterations than the first, cold one."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    from test_solve_gpu import oracle_for
+    T, B, STEPS, h = 30, 5, 10, 0.05
+    rng = np.random.default_rng(11)
+    p = P.build_mpc_pendulum(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=p["parameters"], name="mpc_pendulum")
+    nz, nc, nw = s.nlp.num_variables, s.nlp.num_constraint, s.nlp.num_parameters
+    onlp = oracle_for("pendulum", T)
+    nd = 2 * (T - 1)
+
+    def plant(x, u):   # the model's implicit midpoint step, solved by fixed-point iteration (the "real" system of this test)
+        y = x.copy()
+        for _ in range(50):
+            m = 0.5 * (x + y)
+            f = np.array([m[1], u / 0.25 - 9.81 * np.sin(m[0]) / 0.5 - 0.1 * m[1] / 0.25])
+            y = x + h * f
+        return y
+
+    def kkt_ok(z, lam, x1b, goal):
+        J = np.zeros((nc, nz))
+        for (r, c_), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(z)):
+            J[r - 1, c_ - 1] = v
+        c = onlp.eval_constraint(z).copy()
+        c[nd:nd + 2] -= x1b
+        c[nd + 2] += np.pi - goal
+        return np.max(np.abs(c)) <= 1e-6 and np.max(np.abs(onlp.eval_objective_gradient(z) + J.T @ lam)) <= 1e-5
+
+    x = 0.2 * rng.standard_normal((B, 2))
+    goals = np.pi * (0.6 + 0.4 * rng.random(B))
+    W = np.stack([np.tile([x[b, 0], x[b, 1], goals[b]], T) for b in range(B)])
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        dto_amd.initialize_states(s, dto_amd.linear_interpolation(x[b], np.array([goals[b], 0.0]), T))
+        dto_amd.initialize_controls(s, [0.1 * rng.standard_normal(1) for _ in range(T - 1)])
+        Z[b] = s._z0
+    z0, w = torch.tensor(Z, device="cuda"), torch.tensor(W, device="cuda")
+    zo = torch.empty_like(z0)
+    lo = torch.empty((B, nc), device="cuda", dtype=torch.float64)
+    st, it_first = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc, params_ptr=w.data_ptr(), ldp=nw)
+    assert np.all(st == 1)
+    warm_iters = []
+    for k in range(STEPS):
+        Zk, Lk = zo.cpu().numpy(), lo.cpu().numpy()
+        for b in range(B):
+            assert kkt_ok(Zk[b], Lk[b], W[b][:2], goals[b]), (k, b)
+        # plant step with the first action (+ a disturbance), horizon shifted by one knot, measured state as the new pin
+        for b in range(B):
+            x[b] = plant(x[b], Zk[b][2]) + 0.002 * rng.standard_normal(2)
+            assert np.linalg.norm(x[b] - Zk[b][3:5]) < 0.02, (k, b)      # the plan's x_2 is where the plant went
+            W[b].reshape(T, 3)[:, :2] = x[b]
+        w = torch.tensor(W, device="cuda")
+        s.shift_batch(1)
+        zs = s.peek_batch("z")
+        assert np.allclose(zs[:, :nz - 3 - 2], Zk[:, 3:nz - 2])          # knots moved forward by one (x, u stride 3)
+        s.begin_warm_batch(B, params_ptr=w.data_ptr(), ldp=nw)
+        st, itw = s.run_batch(zo.data_ptr(), nz, lo.data_ptr(), nc)
+        assert np.all(st == 1), (k, st)
+        warm_iters.append(itw.sum())
+    # streaming pays: a warm re-solve costs a fraction of the first (cold) solve
+    assert np.mean(warm_iters) < 0.6 * it_first.sum(), (warm_iters, it_first.sum())
