@@ -99,6 +99,16 @@ struct dto_solver_opts {
   double mu_warm;
 };
 
+struct dto_stage_run {
+  int kind, t0, t1;                     // stages [t0, t1) are of this kind
+  int z0, cd0, cc0, io0, w0;            // offsets of stage t0 (rows of z, dynamics rows, stage rows, slacks, parameters)
+  int zs, cds, ccs, ios, ws;            // ... and their strides per stage
+  int bounded;                          // 1: some variable of the run is fixed or has a finite bound
+  long long rec0, fac0, recs, facs;     // record / carry offsets of stage t0 and strides (byte 56 on)
+  int pad_, pad2_;
+};
+static_assert(sizeof(dto_stage_run) == 96, "load_run reads the fields by position");
+
 struct dto_kkt_args {
   int T;
   int64_t B;
@@ -110,6 +120,9 @@ struct dto_kkt_args {
   const int64_t* recoff;  // [T+1] record offsets (doubles per lane)
   const int64_t* facoff;  // [T+1]
   int64_t rec_total, fac_total;
+  // the horizon as runs of consecutive stages of one kind (the sequential sweeps walk runs: inside a run every offset advances
+  // by a constant stride, so the hot loop has no table look-ups and no kind dispatch)
+  const struct dto_stage_run* runs; int n_runs;
   const double* lo; const double* hi;  // [Nz] shared variable bounds
   const double* params;                // shared parameters
   const double* wtile;                 // per-instance parameters as SoA tiles [G][Nw][64], or NULL (then `params` is used)
@@ -158,6 +171,35 @@ template <class T>
 __device__ __forceinline__ T uload(const T* p, int64_t i) {
   return ((const __attribute__((address_space(4))) T*)p)[i];
 }
+
+// One SoA array of ONE tile as a buffer resource (rows of 64 doubles).  Every access is
+//     buffer_load/store_dwordx2  v, v_lane, s[rsrc], s_row  offen
+// -- resource and row offset in SGPRs (scalar ALU), ONE VGPR (8 x lane) shared by every array.  Measured reason
+// (profiles/r03: ISA of the sweeps + SQ/TCP counters): with pointer arithmetic the compiler kept one 64-bit VGPR pointer per
+// array and per offset class alive across the stage loop (loop strength reduction), the sweeps needed more than the 256
+// VGPRs two wavefronts per SIMD allow, and the spills landed INSIDE the stage loop: 16-44 scratch reloads per stage, each
+// followed by s_waitcnt vmcnt(0), i.e. a full drain of the in-order vector-memory counter (average 270 cycles) -- 35 drains
+// per stage were the 58 % of the wave cycles the sweeps spent waiting.  An array that does not exist (base = NULL: zero
+// bytes) reads as 0 and drops writes; the row offset itself travels in the scalar offset, which the hardware's range check
+// does not include -- callers pass valid rows only.
+typedef int dto_v2i __attribute__((ext_vector_type(2)));
+struct TileBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ void bind(const double* base, int64_t tile, int64_t rows) {
+    const int64_t bytes = base ? rows * 512 : 0;   // the host refuses state whose tile arrays reach 2 GiB (ensure_state)
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base + ((tile * rows) << 6)), 0, (int)bytes, 0x00020000);
+  }
+  __device__ __forceinline__ double ld(int row) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, threadIdx.x * 8u, row << 9, 0));
+  }
+  __device__ __forceinline__ void st(int row, double v) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dto_v2i, v), r, threadIdx.x * 8u, row << 9, 0);
+  }
+};
+struct SoaBufs {
+  TileBuf z, lam, zl, zu, s, zs, dz, dlam, ds, rec, fac, sigx, sigc, wt;
+  __device__ __forceinline__ SoaBufs(const dto_kkt_args& a, int64_t g);
+};
 
 template <class M, int K>
 struct KindDims {
@@ -259,6 +301,13 @@ int kkt_info(dto_kkt_info* out) {
   return 0;
 }
 
+__device__ __forceinline__ SoaBufs::SoaBufs(const dto_kkt_args& a, int64_t g) {
+  z.bind(a.z, g, a.Nz); lam.bind(a.lam, g, a.Nc); zl.bind(a.zl, g, a.Nz); zu.bind(a.zu, g, a.Nz);
+  s.bind(a.s, g, a.Ni); zs.bind(a.zs, g, a.Ni); dz.bind(a.dz, g, a.Nz); dlam.bind(a.dlam, g, a.Nc); ds.bind(a.ds, g, a.Ni);
+  rec.bind(a.rec, g, a.rec_total); fac.bind(a.fac, g, a.fac_total);
+  sigx.bind(a.sigx, g, a.Nz); sigc.bind(a.sigc, g, a.Nc); wt.bind(a.wtile, g, a.Nw);
+}
+
 // parameters w_t of stage t: shared by all instances (the reference's one `parameters` vector, src/solver.jl:10), or one
 // set per instance (dto_batch.params: MPC rollouts that differ in initial state / target)
 template <int N>
@@ -334,6 +383,179 @@ struct SoaIO {
   __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = v; }
   __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
 };
+
+// SoaIO for a stage inside a run (dto_stage_run): every offset is arithmetic -- offset of the run's first stage + stride x
+// position -- so nothing has to be looked up before the stage's rows can be requested.  Measured background (profiles/r03):
+// with look-ups, a stage of the sweeps began with a chain of dependent memory round trips (kind -> offsets -> rows) that no
+// other instruction of the wavefront could overlap; a wavefront sat in s_waitcnt for 58 % of its cycles.  BOUNDED = false:
+// the run has no fixed variable and no finite bound, the bound tests of the block algebra fold away at compile time.
+template <class M, int K, bool BOUNDED>
+struct SoaRunIO {
+  using D = KindDims<M, K>;
+  const dto_kkt_args& a;
+  const SoaBufs& b;
+  const int t, z0, cd0, cc0, io0, w0, rec0, fac0;
+  __device__ __forceinline__ SoaRunIO(const dto_kkt_args& a_, const SoaBufs& b_, const dto_stage_run& r, int t_)
+      : a(a_), b(b_), t(t_), z0(r.z0 + (t_ - r.t0) * r.zs), cd0(r.cd0 + (t_ - r.t0) * r.cds), cc0(r.cc0 + (t_ - r.t0) * r.ccs),
+        io0(r.io0 + (t_ - r.t0) * r.ios), w0(r.w0 + (t_ - r.t0) * r.ws), rec0((int)r.rec0 + (t_ - r.t0) * (int)r.recs),
+        fac0((int)r.fac0 + (t_ - r.t0) * (int)r.facs) {}
+  __device__ __forceinline__ double rec(int e) const { return b.rec.ld(rec0 + e); }
+  __device__ __forceinline__ double p(int i) const { return b.z.ld(z0 + i); }
+  __device__ __forceinline__ double y(int i) const { return b.z.ld(z0 + D::NP + i); }   // x_{t+1} follows [x_t; u_t]
+  __device__ __forceinline__ double lam(int k) const { return b.lam.ld(cd0 + k); }
+  __device__ __forceinline__ double nu(int j) const { return b.lam.ld(cc0 + j); }
+  template <int N>
+  __device__ __forceinline__ void params(arr<N>& w) const {
+    if (a.wtile) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) w[i] = b.wt.ld(w0 + i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) w[i] = uload(a.params, w0 + i);
+    }
+  }
+  __device__ __forceinline__ void bounds(StageBounds<D::NP>& sb) const {
+    if constexpr (BOUNDED) {
+      const bool duals = a.zl != nullptr;   // allocated iff some variable has a finite, non-fixing bound
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) {
+        sb.lo[i] = uload(a.lo, z0 + i);
+        sb.hi[i] = uload(a.hi, z0 + i);
+        sb.p[i] = duals ? b.z.ld(z0 + i) : 0.0;
+        sb.zl[i] = b.zl.ld(z0 + i);   // zero rows when the arrays do not exist: reads 0
+        sb.zu[i] = b.zu.ld(z0 + i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) {
+        sb.lo[i] = -__builtin_huge_val();
+        sb.hi[i] = __builtin_huge_val();
+        sb.p[i] = sb.zl[i] = sb.zu[i] = 0.0;
+      }
+    }
+  }
+  __device__ __forceinline__ bool has_sigx() const { return a.sigx != nullptr; }
+  __device__ __forceinline__ bool has_sigc() const { return a.sigc != nullptr; }
+  __device__ __forceinline__ double sigx(int i) const { return b.sigx.ld(z0 + i); }
+  __device__ __forceinline__ double sigc_con(int j) const { return b.sigc.ld(cc0 + j); }
+  __device__ __forceinline__ double sigc_dyn(int k) const { return b.sigc.ld(cd0 + k); }
+  __device__ __forceinline__ double slack(int j) const { return b.s.ld(io0 + D::slack(j)); }
+  __device__ __forceinline__ double slack_mult(int j) const { return b.zs.ld(io0 + D::slack(j)); }
+  __device__ __forceinline__ void put_carry(int i, double v) const { b.fac.st(fac0 + i, v); }
+  __device__ __forceinline__ double carry(int i) const { return b.fac.ld(fac0 + i); }
+  __device__ __forceinline__ void put_dp(int i, double v) const { b.dz.st(z0 + i, v); }
+  __device__ __forceinline__ void put_dnu(int j, double v) const { b.dlam.st(cc0 + j, v); }
+  __device__ __forceinline__ void put_dlam(int k, double v) const { b.dlam.st(cd0 + k, v); }
+  __device__ __forceinline__ void put_ds(int j, double v) const { b.ds.st(io0 + D::slack(j), v); }
+  __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
+};
+
+// Everything the block algebra reads of one stage, in registers.  The sequential sweeps request the rows of stage t+1
+// (t-1 going backwards) BEFORE they start the arithmetic of stage t: with one wavefront per SIMD (512 registers, nothing
+// spilled) the ~4000 cycles of arithmetic of a stage cover the memory latency of the next one, which nothing else would --
+// the sweeps are one dependent chain per instance.
+#ifndef DTO_SEQ_FWD_OCC
+#define DTO_SEQ_FWD_OCC 1
+#endif
+#ifndef DTO_SEQ_BWD_OCC
+#define DTO_SEQ_BWD_OCC 1
+#endif
+#ifndef DTO_SEQ_PREFETCH_FWD
+#define DTO_SEQ_PREFETCH_FWD 1
+#endif
+#ifndef DTO_SEQ_PREFETCH_BWD
+#define DTO_SEQ_PREFETCH_BWD 1
+#endif
+template <class M, int K, bool BOUNDED, bool BWD>
+struct StageIn {
+  using D = KindDims<M, K>;
+  static constexpr int NP = D::NP, NY = D::NY, Q = D::Q, NCAR = BWD ? D::F_CX : 0;
+  static constexpr bool HAS_P = D::FUSED || BOUNDED;
+  double rec[D::REC > 0 ? D::REC : 1], p[HAS_P && NP > 0 ? NP : 1], y[D::FUSED && NY > 0 ? NY : 1], lam[NY > 0 ? NY : 1],
+      nu[Q > 0 ? Q : 1], zl[BOUNDED && NP > 0 ? NP : 1], zu[BOUNDED && NP > 0 ? NP : 1], s[Q > 0 ? Q : 1], zs[Q > 0 ? Q : 1],
+      car[NCAR > 0 ? NCAR : 1];
+  __device__ __forceinline__ void load(const SoaBufs& b, const dto_stage_run& r, int t) {
+    const int n = t - r.t0;
+    const int z0 = r.z0 + n * r.zs, cd0 = r.cd0 + n * r.cds, cc0 = r.cc0 + n * r.ccs, io0 = r.io0 + n * r.ios;
+    const int rec0 = (int)r.rec0 + n * (int)r.recs, fac0 = (int)r.fac0 + n * (int)r.facs;
+#pragma unroll
+    for (int i = 0; i < NCAR; ++i) car[i] = b.fac.ld(fac0 + i);
+#pragma unroll
+    for (int i = 0; i < D::REC; ++i) rec[i] = b.rec.ld(rec0 + i);
+    if constexpr (HAS_P) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) p[i] = b.z.ld(z0 + i);
+    }
+    if constexpr (D::FUSED) {
+#pragma unroll
+      for (int i = 0; i < NY; ++i) y[i] = b.z.ld(z0 + NP + i);
+    }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) lam[i] = b.lam.ld(cd0 + i);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      nu[j] = b.lam.ld(cc0 + j);
+      if (D::slack(j) >= 0) {
+        s[j] = b.s.ld(io0 + D::slack(j));
+        zs[j] = b.zs.ld(io0 + D::slack(j));
+      }
+    }
+    if constexpr (BOUNDED) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        zl[i] = b.zl.ld(z0 + i);   // arrays that do not exist read as 0
+        zu[i] = b.zu.ld(z0 + i);
+      }
+    }
+  }
+};
+
+// SoaRunIO whose reads come out of a StageIn (writes, the linear-solver extras and the parameters stay direct)
+template <class M, int K, bool BOUNDED, bool BWD>
+struct SoaPreIO : SoaRunIO<M, K, BOUNDED> {
+  using Base = SoaRunIO<M, K, BOUNDED>;
+  using D = KindDims<M, K>;
+  using In = StageIn<M, K, BOUNDED, BWD>;
+  const In& in;
+  __device__ __forceinline__ SoaPreIO(const dto_kkt_args& a_, const SoaBufs& b_, const dto_stage_run& r, int t_, const In& in_)
+      : Base(a_, b_, r, t_), in(in_) {}
+  __device__ __forceinline__ double rec(int e) const { return in.rec[e]; }
+  __device__ __forceinline__ double p(int i) const { return in.p[i]; }
+  __device__ __forceinline__ double y(int i) const { return in.y[i]; }
+  __device__ __forceinline__ double lam(int k) const { return in.lam[k]; }
+  __device__ __forceinline__ double nu(int j) const { return in.nu[j]; }
+  __device__ __forceinline__ double slack(int j) const { return in.s[j]; }
+  __device__ __forceinline__ double slack_mult(int j) const { return in.zs[j]; }
+  __device__ __forceinline__ double carry(int i) const { return in.car[i]; }
+  __device__ __forceinline__ void bounds(StageBounds<D::NP>& sb) const {
+    if constexpr (BOUNDED) {
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) {
+        sb.lo[i] = uload(this->a.lo, this->z0 + i);
+        sb.hi[i] = uload(this->a.hi, this->z0 + i);
+        sb.p[i] = in.p[i];
+        sb.zl[i] = in.zl[i];
+        sb.zu[i] = in.zu[i];
+      }
+    } else {
+      Base::bounds(sb);
+    }
+  }
+};
+
+// one entry of the run table through scalar loads
+__device__ __forceinline__ dto_stage_run load_run(const dto_stage_run* runs, int r) {
+  const int* q = reinterpret_cast<const int*>(runs + r);
+  const long long* ql = reinterpret_cast<const long long*>(runs + r);
+  dto_stage_run o;
+  o.kind = uload(q, 0); o.t0 = uload(q, 1); o.t1 = uload(q, 2);
+  o.z0 = uload(q, 3); o.cd0 = uload(q, 4); o.cc0 = uload(q, 5); o.io0 = uload(q, 6); o.w0 = uload(q, 7);
+  o.zs = uload(q, 8); o.cds = uload(q, 9); o.ccs = uload(q, 10); o.ios = uload(q, 11); o.ws = uload(q, 12);
+  o.bounded = uload(q, 13);
+  o.rec0 = uload(ql, 7); o.fac0 = uload(ql, 8); o.recs = uload(ql, 9); o.facs = uload(ql, 10);
+  o.pad_ = 0;
+  return o;
+}
 
 // wave-uniform kind dispatch (all lanes of a tile are at the same stage)
 template <class M, int K = 0, class F>
@@ -1534,30 +1756,58 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     int nneg = 0;
     // the attempt after which retry_update stops whatever the inertia: its factorisation is the one that gets used
     const bool keep_lost = a.opt.newton_only || (int)sc[SC_ATTEMPT << 6] >= a.opt.max_refactor;
-    for (int t = t0; t < t1; ++t) {
-      if (a.prof && blockIdx.x == 1 && threadIdx.x == 0) a.prof[7] += 1;
-      if (!CHUNKED || p == 0) {
-        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+    if constexpr (!CHUNKED) {
+      // walk the horizon run by run: kind dispatch and table look-ups once per run, arithmetic offsets inside
+      const SoaBufs bufs(a, g);
+      bool lost = false;
+      for (int r = 0; r < a.n_runs && !lost; ++r) {
+        const dto_stage_run run = load_run(a.runs, r);
+        dispatch_uniform<M>(run.kind, [&](auto kc) {
           constexpr int K = decltype(kc)::value;
-          if constexpr (!CHUNKED && heavy_kind<M, K>()) {
-            Carry<M> cyc = cy;
-            Spike<M> spc = sp;
-            int okneg[3] = {ok ? 1 : 0, nneg, keep_lost ? 1 : 0};
-            // the callee gets its own copy of the argument block: handing out the address of the kernel's would move every
-            // pointer of the hot loop to the stack as well (reloads, generic instead of global addressing)
-            const dto_kkt_args acold = a;
-            stage_forward_cold<M, K, false>(acold, g, t, mu, dw, gam, false, need, &cyc, &spc, okneg);
-            cy = cyc;
-            ok = okneg[0] != 0;
-            nneg = okneg[1];
+          if constexpr (heavy_kind<M, K>()) {
+            for (int t = run.t0; t < run.t1; ++t) {
+              Carry<M> cyc = cy;
+              Spike<M> spc = sp;
+              int okneg[3] = {ok ? 1 : 0, nneg, keep_lost ? 1 : 0};
+              // the callee gets its own copy of the argument block: handing out the address of the kernel's would move every
+              // pointer of the hot loop to the stack as well (reloads, generic instead of global addressing)
+              const dto_kkt_args acold = a;
+              stage_forward_cold<M, K, false>(acold, g, t, mu, dw, gam, false, need, &cyc, &spc, okneg);
+              cy = cyc;
+              ok = okneg[0] != 0;
+              nneg = okneg[1];
+              if (!__any(need && (ok || keep_lost))) { lost = true; break; }
+            }
           } else {
-            stage_forward<M, K, false>(a.opt, SoaIO<M, K>(a, g, t), mu, dw, gam, false, need, cy, sp, ok, nneg, keep_lost);
+            auto sweep = [&](auto bounded) {
+              using IO = SoaPreIO<M, K, decltype(bounded)::value, false>;
+              typename IO::In nxt, cur;
+              if (DTO_SEQ_PREFETCH_FWD) nxt.load(bufs, run, run.t0);
+              for (int t = run.t0; t < run.t1; ++t) {
+                if (DTO_SEQ_PREFETCH_FWD) {
+                  cur = nxt;
+                  nxt.load(bufs, run, min(t + 1, run.t1 - 1));   // in flight while stage t is worked on
+                } else {
+                  cur.load(bufs, run, t);
+                }
+                stage_forward<M, K, false>(a.opt, IO(a, bufs, run, t, cur), mu, dw, gam, false, need, cy, sp, ok, nneg, keep_lost);
+                // the attempt of a lane is lost with the first stage whose pivots have the wrong signs (stage_forward clears
+                // ok): once that has happened to every lane that asked for a factorisation the rest of the sweep is pointless
+                if (!__any(need && (ok || keep_lost))) { lost = true; break; }
+              }
+            };
+            if (run.bounded) sweep(std::integral_constant<bool, true>{}); else sweep(std::integral_constant<bool, false>{});
           }
         });
-        // the attempt of a lane is lost with the first stage whose pivots have the wrong signs (stage_forward clears ok):
-        // once that has happened to every lane that asked for a factorisation the rest of the sweep is pointless
-        if (!CHUNKED && !__any(need && (ok || keep_lost))) break;
-      } else if constexpr (CHUNKED) {
+      }
+    } else {
+    for (int t = t0; t < t1; ++t) {
+      if (p == 0) {
+        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+          stage_forward<M, decltype(kc)::value, false>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, dw, gam, false, need, cy, sp,
+                                                       ok, nneg, keep_lost);
+        });
+      } else {
         dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
           // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
           if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
@@ -1565,6 +1815,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
                                                         cy, sp, ok, nneg);
         });
       }
+    }
     }
     if constexpr (!CHUNKED) {
       if (need) retry_update(a, sc, ok, nneg);
@@ -1597,7 +1848,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) { kkt_fwd_body
 // the plain sequential sweep is asked to fit two wavefronts per SIMD (256 VGPRs): nothing else hides its memory and
 // dependent-issue latencies
 template <class M>
-__global__ __launch_bounds__(WAVE, 2) void k_kkt_fwd_seq(dto_kkt_args a) { kkt_fwd_body<M, false>(a); }
+__global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_args a) { kkt_fwd_body<M, false>(a); }
 
 // reduced system over the separators + inertia + retry state machine.  grid = G waves.
 template <class M>
@@ -1892,30 +2143,57 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
     xn[i] = (p < a.P - 1) ? a.xsep[(((g * a.P + p + 1) * N + i) << 6) + threadIdx.x] : 0.0;
   }
   StepAcc acc{1.0, 1.0, 0.0, 0.0};
-  for (int t = t1 - 1; t >= t0; --t) {
-    if (!CHUNKED || p == 0) {
-      dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+  if constexpr (!CHUNKED) {
+    const SoaBufs bufs(a, g);
+    for (int r = a.n_runs - 1; r >= 0; --r) {
+      const dto_stage_run run = load_run(a.runs, r);
+      dispatch_uniform<M>(run.kind, [&](auto kc) {
         constexpr int K = decltype(kc)::value;
-        if constexpr (!CHUNKED && heavy_kind<M, K>()) {
-          const dto_kkt_args acold = a;  // own copy: see kkt_fwd_body
-          double xnc[N];
+        if constexpr (heavy_kind<M, K>()) {
+          for (int t = run.t1 - 1; t >= run.t0; --t) {
+            const dto_kkt_args acold = a;  // own copy: see kkt_fwd_body
+            double xnc[N];
 #pragma unroll
-          for (int i = 0; i < N; ++i) xnc[i] = xn[i];
-          StepAcc accc = acc;
-          stage_backward_cold<M, K>(acold, g, t, mu, tau, dw, gam, xL, xnc, &accc);
+            for (int i = 0; i < N; ++i) xnc[i] = xn[i];
+            StepAcc accc = acc;
+            stage_backward_cold<M, K>(acold, g, t, mu, tau, dw, gam, xL, xnc, &accc);
 #pragma unroll
-          for (int i = 0; i < N; ++i) xn[i] = xnc[i];
-          acc = accc;
+            for (int i = 0; i < N; ++i) xn[i] = xnc[i];
+            acc = accc;
+          }
         } else {
-          stage_backward<M, K, false>(a.opt, SoaIO<M, K>(a, g, t), mu, tau, dw, gam, false, xL, xn, acc);
+          auto sweep = [&](auto bounded) {
+            using IO = SoaPreIO<M, K, decltype(bounded)::value, true>;
+            typename IO::In nxt, cur;
+            if (DTO_SEQ_PREFETCH_BWD) nxt.load(bufs, run, run.t1 - 1);
+            for (int t = run.t1 - 1; t >= run.t0; --t) {
+              if (DTO_SEQ_PREFETCH_BWD) {
+                cur = nxt;
+                nxt.load(bufs, run, max(t - 1, run.t0));   // in flight while stage t is worked on
+              } else {
+                cur.load(bufs, run, t);
+              }
+              stage_backward<M, K, false>(a.opt, IO(a, bufs, run, t, cur), mu, tau, dw, gam, false, xL, xn, acc);
+            }
+          };
+          if (run.bounded) sweep(std::integral_constant<bool, true>{}); else sweep(std::integral_constant<bool, false>{});
         }
       });
-    } else if constexpr (CHUNKED) {
-      dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
-        if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
-          stage_backward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, tau, dw, gam, t == t0, xL, xn,
-                                                       acc);
-      });
+    }
+  } else {
+    for (int t = t1 - 1; t >= t0; --t) {
+      if (p == 0) {
+        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+          stage_backward<M, decltype(kc)::value, false>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, tau, dw, gam, false, xL, xn,
+                                                        acc);
+        });
+      } else {
+        dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+          if constexpr (M::template Kind<decltype(kc)::value>::PREV >= 0)
+            stage_backward<M, decltype(kc)::value, true>(a.opt, SoaIO<M, decltype(kc)::value>(a, g, t), mu, tau, dw, gam, t == t0, xL,
+                                                         xn, acc);
+        });
+      }
     }
   }
   double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
@@ -1928,7 +2206,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) { kkt_bwd_body<M, true>(a); }
 template <class M>
-__global__ __launch_bounds__(WAVE, 2) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
+__global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
 
 __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) {
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;

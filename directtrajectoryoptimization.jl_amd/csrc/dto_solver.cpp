@@ -47,6 +47,8 @@ struct SolverState {
   std::vector<int64_t> recoff, facoff;
   int* d_ioff = nullptr;
   int64_t *d_recoff = nullptr, *d_facoff = nullptr;
+  dto_stage_run* d_runs = nullptr;   // the horizon as runs of one stage kind with constant strides (sequential sweeps)
+  int n_runs = 0;
   double *d_lo = nullptr, *d_hi = nullptr;
   // SoA state
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
@@ -73,9 +75,9 @@ struct SolverState {
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
-                    (void*)d_src_slot, (void*)repack_tmp})
+                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs})
       if (p) (void)hipFree(p);
-    d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr;
+    d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
     csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
@@ -553,11 +555,51 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
     S.facoff[t + 1] = S.facoff[t] + (seq_only ? S.info.fac_size_seq[k] : S.info.fac_size[k]);
   }
   S.Ni = S.ioff[L.T]; S.rec_total = S.recoff[L.T]; S.fac_total = S.facoff[L.T];
+  // the sweeps address a tile's arrays through 32-bit buffer offsets (rows of 512 bytes): 2^22 rows per array and tile
+  for (int64_t rows : {(int64_t)L.Nz, (int64_t)L.Nc, (int64_t)L.Nw, (int64_t)S.Ni, S.rec_total, S.fac_total})
+    if (rows >= (int64_t)1 << 22)
+      return set_error(DTO_ERR_UNSUPPORTED, "problem too large for the solver path: an array of one instance exceeds 4194303 rows");
   S.n_bnd = S.Ni;
   for (int64_t i = 0; i < L.Nz; ++i) {
     if (L.var_lo[i] == L.var_hi[i]) continue;
     if (std::isfinite(L.var_lo[i])) ++S.n_bnd;
     if (std::isfinite(L.var_hi[i])) ++S.n_bnd;
+  }
+  {
+    // runs of consecutive stages of one kind whose offsets advance by constant strides
+    std::vector<dto_stage_run> runs;
+    auto bounded = [&](int t) {
+      for (int i = L.zoff[t]; i < L.zoff[t] + L.nx[t] + L.nu[t]; ++i)
+        if (L.var_lo[i] == L.var_hi[i] || std::isfinite(L.var_lo[i]) || std::isfinite(L.var_hi[i])) return 1;
+      return 0;
+    };
+    auto zstep = [&](int t) { return t + 1 < L.T ? L.zoff[t + 1] - L.zoff[t] : L.nx[t] + L.nu[t]; };
+    for (int t = 0; t < L.T;) {
+      dto_stage_run r{};
+      r.kind = L.kind[t]; r.t0 = t; r.bounded = bounded(t);
+      r.z0 = L.zoff[t]; r.cd0 = L.cdoff[t]; r.cc0 = L.ccoff[t]; r.io0 = S.ioff[t]; r.w0 = L.woff[t];
+      r.rec0 = S.recoff[t]; r.fac0 = S.facoff[t];
+      r.zs = zstep(t);
+      int e = t + 1;
+      if (e < L.T && L.kind[e] == r.kind && bounded(e) == r.bounded && zstep(e) == r.zs && L.zoff[e] - L.zoff[t] == r.zs) {
+        r.cds = L.cdoff[e] - L.cdoff[t]; r.ccs = L.ccoff[e] - L.ccoff[t]; r.ios = S.ioff[e] - S.ioff[t]; r.ws = L.woff[e] - L.woff[t];
+        r.recs = S.recoff[e] - S.recoff[t]; r.facs = S.facoff[e] - S.facoff[t];
+        for (;; ++e) {
+          if (e >= L.T || L.kind[e] != r.kind || bounded(e) != r.bounded || zstep(e) != r.zs) break;
+          const int64_t n = e - t;
+          if (L.zoff[e] != r.z0 + n * r.zs || L.cdoff[e] != r.cd0 + n * r.cds || L.ccoff[e] != r.cc0 + n * r.ccs ||
+              S.ioff[e] != r.io0 + n * r.ios || L.woff[e] != r.w0 + n * r.ws || S.recoff[e] != r.rec0 + n * r.recs ||
+              S.facoff[e] != r.fac0 + n * r.facs)
+            break;
+        }
+      }
+      r.t1 = e;
+      runs.push_back(r);
+      t = e;
+    }
+    S.n_runs = (int)runs.size();
+    HIP_TRY(hipMalloc((void**)&S.d_runs, runs.size() * sizeof(dto_stage_run)));
+    HIP_TRY(hipMemcpy(S.d_runs, runs.data(), runs.size() * sizeof(dto_stage_run), hipMemcpyHostToDevice));
   }
   const size_t lanes = (size_t)S.G * 64;
   HIP_TRY(hipMalloc((void**)&S.d_ioff, (L.T + 1) * sizeof(int)));
@@ -627,6 +669,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.ccoff = p->d_ccoff;
   a.ioff = S.d_ioff; a.recoff = S.d_recoff; a.facoff = S.d_facoff;
   a.rec_total = S.rec_total; a.fac_total = S.fac_total;
+  a.runs = S.d_runs; a.n_runs = S.n_runs;
   a.lo = S.d_lo; a.hi = S.d_hi; a.params = p->d_params;
   a.wtile = S.use_wtile ? S.wtile : nullptr; a.Nw = L.Nw;
   a.sigx = (S.opt.newton_only && S.use_sigx) ? S.sigx : nullptr;

