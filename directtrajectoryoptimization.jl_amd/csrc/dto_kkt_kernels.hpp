@@ -48,6 +48,7 @@ enum dto_kkt_op {
   DTO_KKT_FWD = 9, DTO_KKT_SEP = 10, DTO_KKT_BWD = 11, DTO_KKT_POST = 12,  // the four kernels behind FACTOR_SOLVE
   DTO_KKT_RHS = 13,        // linear-solver entry points: caller's right-hand side -> stage records
   DTO_KKT_REARM = 14,      // linear-solver entry points: request one factorisation with the fixed delta_w
+  DTO_KKT_UPDATE_EVAL = 15,  // UPDATE of one iteration and EVAL of the next in one pass (z, lam -> z_next, lam_next)
   DTO_KKT_OP_COUNT
 };
 
@@ -129,6 +130,7 @@ struct dto_kkt_args {
   int64_t Nw;
   // SoA state, doubles
   double* z; double* lam; double* zl; double* zu; double* s; double* zs;
+  double* z_next; double* lam_next;   // DTO_KKT_UPDATE_EVAL: where the updated iterate goes (the host swaps the pairs)
   double* dz; double* dlam; double* ds;
   double* rec; double* fac; double* part; double* lspart; double* scal;
   double* filt;  // [G][2*DTO_FILTER_CAP][64] filter entries (theta, phi)
@@ -747,8 +749,18 @@ static __global__ __launch_bounds__(WAVE) void k_rearm(dto_kkt_args a) {
 // ------------------------------------------------------------------------------------------------
 // per-stage derivative blocks.  grid = G*T waves; wave = (tile, stage); lane = instance.
 // ------------------------------------------------------------------------------------------------
+// With a.z_next set (DTO_KKT_UPDATE_EVAL) the step of the iteration that just ended is taken on the way (k_update's
+// arithmetic, expression for expression): the rows of a stage are read as z + alpha dz, lam + alpha dlam, written to z_next /
+// lam_next (other buffers: a block also reads the rows of its neighbour stages, which another wavefront may be writing) and
+// used from registers.  One pass over 36 rows per stage instead of 27 (k_update) + 22 (k_stage_eval).  Bound multipliers and
+// slacks have no reader outside their own stage and are updated in place.
+// The switch is a run-time (wave-uniform) one on purpose: both modes execute the SAME machine code for the model's cost,
+// residual and Jacobian bodies.  As two template instantiations the compiler contracted a cost body  0.1 u^2 + 0.1 (x3^2 +
+// x4^2)  into different multiply-add pairings, and the objective of the fused pass differed from the two-kernel sequence in
+// the last bit (tests/test_fused_update_gpu.py demands equality).
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
+  const bool upd = a.z_next != nullptr;
   // a wavefront walks DTO_SB consecutive stages: the residual partials are summed in registers in stage order (one row set
   // per block instead of one per stage goes to memory), and E_t' lambda_t is handed to the next stage instead of
   // re-evaluating the previous stage's Jacobian there
@@ -756,13 +768,48 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   const int64_t g = blockIdx.x / nblk;
   const int blk = blockIdx.x % nblk;
   const dto_solver_opts& o = a.opt;
-  if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;  // finished instance: its record stays frozen
+  const int t_begin = blk * DTO_SB;
+  double al = 0.0, ad = 0.0, mu_u = 0.0;
+  if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) {  // finished instance: its record stays frozen
+    if (upd) {
+      // ... and its iterate moves to the other buffer unchanged
+      const int te = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
+      for (int i = uload(a.zoff, t_begin); i < uload(a.zoff, te); ++i) *soa(a.z_next, g, a.Nz, i) = *soa(a.z, g, a.Nz, i);
+      for (int i = uload(a.cdoff, t_begin); i < uload(a.cdoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
+      for (int i = uload(a.ccoff, t_begin); i < uload(a.ccoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
+    }
+    return;
+  }
+  if (upd) {
+    al = *soa(a.scal, g, SC_COUNT, SC_ALPHA);
+    ad = *soa(a.scal, g, SC_COUNT, SC_ALPHA_DMAX);
+    mu_u = *soa(a.scal, g, SC_COUNT, SC_MU);
+    if (blk == 0) *soa(a.scal, g, SC_COUNT, SC_ITER) += 1.0;
+  }
+  // the iterate as this pass sees it
+  // (the updated value passes through an empty asm: the compiler then cannot fuse its multiply-add into the arithmetic that
+  // consumes it -- AMDGPU contracts aggressively, fma(x, y, fma(u, v, z)) for fma(x, y, u v) + z -- and the evaluation sees
+  // exactly the double k_update would have stored: the objective differed in the last bit without it)
+  // (both rows are always requested -- no branch between the loads of a stage --; the step row may hold anything when no
+  // step is taken: it is selected away, not multiplied by zero)
+  auto zrow = [&](int i) -> double {
+    const double v0 = *soa(a.z, g, a.Nz, i), dv = *soa(a.dz, g, a.Nz, i);
+    double v = v0 + al * dv;
+    asm volatile("" : "+v"(v));
+    return upd ? v : v0;
+  };
+  auto lrow = [&](int i) -> double {
+    const double v0 = *soa(a.lam, g, a.Nc, i), dv = *soa(a.dlam, g, a.Nc, i);
+    double v = v0 + al * dv;
+    asm volatile("" : "+v"(v));
+    return upd ? v : v0;
+  };
   double A_f = 0.0, A_th1 = 0.0, A_thinf = 0.0, A_dinf = 0.0, A_szmax = 0.0, A_isz = 0.0, A_sumlam = 0.0, A_sumz = 0.0,
          A_logbar = 0.0, A_xmax = 0.0;
   double ecarry[M::MAX_NX], enext[M::MAX_NX];   // E_{t-1}' lambda_{t-1} from the previous stage / E_t' lambda_t for the next
   bool have_carry = false;
   const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
-  for (int t = blk * DTO_SB; t < t_end; ++t) {
+  for (int t = t_begin; t < t_end; ++t) {
   dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -773,8 +820,56 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     auto put = [&](int e, double v) { rec[(int64_t)e << 6] = v; };
 
     arr<D::NP> p;
+    if (upd) {
+      constexpr double KSIG = 1e10;
+      StageBounds<D::NP> sbu;
+      load_stage_bounds<D::NP>(a, g, z0, sbu);
 #pragma unroll
-    for (int i = 0; i < D::NP; ++i) p[i] = *soa(a.z, g, a.Nz, z0 + i);
+      for (int i = 0; i < D::NP; ++i) {
+        const double pold = *soa(a.z, g, a.Nz, z0 + i);
+        const double dp = *soa(a.dz, g, a.Nz, z0 + i);
+        double pn = pold + al * dp;
+        asm volatile("" : "+v"(pn));
+        if (!o.newton_only) {
+          const double lo = sbu.lo[i], hi = sbu.hi[i];
+          if (lo != hi) {
+            if (finite_lo(lo)) {
+              const double zl = sbu.zl[i];
+              const double gap = pold - lo;
+              const double dzl = mu_u / gap - zl - (zl / gap) * dp;
+              double zn = zl + ad * dzl;
+              const double gn = pn - lo;
+              zn = fmin(fmax(zn, mu_u / (KSIG * gn)), KSIG * mu_u / gn);
+              *soa(a.zl, g, a.Nz, z0 + i) = zn;
+            }
+            if (finite_hi(hi)) {
+              const double zu = sbu.zu[i];
+              const double gap = hi - pold;
+              const double dzu = mu_u / gap - zu + (zu / gap) * dp;
+              double zn = zu + ad * dzu;
+              const double gn = hi - pn;
+              zn = fmin(fmax(zn, mu_u / (KSIG * gn)), KSIG * mu_u / gn);
+              *soa(a.zu, g, a.Nz, z0 + i) = zn;
+            }
+          }
+        }
+        p[i] = pn;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) p[i] = *soa(a.z, g, a.Nz, z0 + i);
+    }
+    // every row of the stage is requested here, before any is used and before anything is stored (the compiler does not move
+    // a load above a store it cannot tell apart): x_{t+1}, lambda_t, nu_t
+    arr<D::NY> y, lam;
+    arr<D::Q> nu;
+#pragma unroll
+    for (int i = 0; i < D::NY; ++i) {
+      y[i] = zrow(uload(a.zoff, t + 1) + i);
+      lam[i] = lrow(uload(a.cdoff, t) + i);
+    }
+#pragma unroll
+    for (int j = 0; j < D::Q; ++j) nu[j] = lrow(uload(a.ccoff, t) + j);
     arr<CO::NW> wc;
     load_params(wc, a, g, t);
 
@@ -792,6 +887,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       double o1[1];
       CO::eval(p.data(), p.data() + CO::NX, wc.data(), o1);
       cost_val = o1[0];
+      asm volatile("" : "+v"(cost_val));   // summed below as a value: not contracted into the sum differently per instantiation
       CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
       if constexpr (CO::SNH > 0 && !D::FUSED) {
         arr<CO::SNH> hv;
@@ -806,14 +902,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
 
     if constexpr (KD::DYN >= 0) {
       using DY = typename M::template Dyn<KD::DYN>;
-      arr<DY::NY> y, lam, d;
+      arr<DY::NY> d;
       arr<DY::NW> w;
       load_params(w, a, g, t);
-#pragma unroll
-      for (int i = 0; i < DY::NY; ++i) {
-        y[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i);
-        lam[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + i);
-      }
       arr<DY::NJ> jv;
       DY::eval_jac(p.data(), p.data() + DY::NX, y.data(), w.data(), d.data(), jv.data());
       DY::jtlam(jv.data(), lam.data(), rp.data());
@@ -845,10 +936,27 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     double dinf = 0.0, szmax = 0.0, iszmax = 0.0, sumz = 0.0, logbar = 0.0, xmax = 0.0;
     if constexpr (KD::CON >= 0) {
       using C = typename M::template Con<KD::CON>;
-      arr<C::NW> w; arr<C::NC> c, nu; arr<C::NJ> jv;
+      arr<C::NW> w; arr<C::NC> c; arr<C::NJ> jv;
       load_params(w, a, g, t);
 #pragma unroll
-      for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j);
+      for (int j = 0; j < C::NC; ++j) {
+        if (upd) {
+          if (!o.newton_only && D::ineq(j)) {
+            constexpr double KSIG = 1e10;
+            const int si = uload(a.ioff, t) + D::slack(j);
+            const double sv = *soa(a.s, g, a.Ni, si);
+            const double zv = *soa(a.zs, g, a.Ni, si);
+            const double dsv = *soa(a.ds, g, a.Ni, si);
+            const double dzs = mu_u / sv - zv - (zv / sv) * dsv;
+            double sn = sv + al * dsv;
+            asm volatile("" : "+v"(sn));
+            double zn = zv + ad * dzs;
+            zn = fmin(fmax(zn, mu_u / (KSIG * sn)), KSIG * mu_u / sn);
+            *soa(a.s, g, a.Ni, si) = sn;
+            *soa(a.zs, g, a.Ni, si) = zn;
+          }
+        }
+      }
       C::eval(p.data(), p.data() + C::NX, w.data(), c.data());
       C::jac(p.data(), p.data() + C::NX, w.data(), jv.data());
       C::jtlam(jv.data(), nu.data(), rp.data());
@@ -894,9 +1002,9 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       arr<DP::NX + DP::NU> pp; arr<DP::NY> lamp; arr<DP::NW> w; arr<DP::NJ> jv;
       load_params(w, a, g, t - 1);
 #pragma unroll
-      for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t - 1) + i);
+      for (int i = 0; i < DP::NX + DP::NU; ++i) pp[i] = zrow(uload(a.zoff, t - 1) + i);
 #pragma unroll
-      for (int i = 0; i < DP::NY; ++i) lamp[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t - 1) + i);
+      for (int i = 0; i < DP::NY; ++i) lamp[i] = lrow(uload(a.cdoff, t - 1) + i);
       DP::jac(pp.data(), pp.data() + DP::NX, p.data(), w.data(), jv.data());
       DP::etlam(jv.data(), lamp.data(), rp.data());
       }
@@ -924,12 +1032,10 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       }
       if constexpr (KD::DYN >= 0) {
         using DY = typename M::template Dyn<KD::DYN>;
-        arr<DY::NY> y, lam; arr<DY::NW> w; arr<DY::NJ> jn, jo;
+        arr<DY::NW> w; arr<DY::NJ> jn, jo;
         load_params(w, a, g, t);
 #pragma unroll
         for (int i = 0; i < DY::NY; ++i) {
-          y[i] = *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i);
-          lam[i] = *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + i);
           sv[D::NP + i] = alpha * *soa(a.dz, g, a.Nz, uload(a.zoff, t + 1) + i);
         }
         DY::jac(p.data(), p.data() + DY::NX, y.data(), w.data(), jn.data());
@@ -942,10 +1048,8 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       }
       if constexpr (KD::CON >= 0) {
         using C = typename M::template Con<KD::CON>;
-        arr<C::NW> w; arr<C::NC> nu; arr<C::NJ> jn, jo;
+        arr<C::NW> w; arr<C::NJ> jn, jo;
         load_params(w, a, g, t);
-#pragma unroll
-        for (int j = 0; j < C::NC; ++j) nu[j] = *soa(a.lam, g, a.Nc, uload(a.ccoff, t) + j);
         C::jac(p.data(), p.data() + C::NX, w.data(), jn.data());
 #pragma unroll
         for (int i = 0; i < C::NJ; ++i) jo[i] = qn_old_kj[i];
@@ -1018,6 +1122,14 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
           logbar += log(hi - p[i]);
         }
       }
+    }
+    if (upd) {
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) *soa(a.z_next, g, a.Nz, z0 + i) = p[i];
+#pragma unroll
+      for (int i = 0; i < D::NY; ++i) *soa(a.lam_next, g, a.Nc, uload(a.cdoff, t) + i) = lam[i];
+#pragma unroll
+      for (int j = 0; j < D::Q; ++j) *soa(a.lam_next, g, a.Nc, uload(a.ccoff, t) + j) = nu[j];
     }
     A_f += cost_val;
     A_th1 += th1;
@@ -1196,6 +1308,23 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
 // ------------------------------------------------------------------------------------------------
 // dense block helpers (all indices are literals after unrolling)
 // ------------------------------------------------------------------------------------------------
+// 1 / x for a pivot: v_rcp_f64 and two Newton steps (5 instructions, a dependent chain of 5) instead of the IEEE division
+// sequence (14 instructions, a chain of 10) -- the reciprocals of the pivots are the longest dependent chains of a stage and,
+// at one wavefront per SIMD, exposed.  Within 1 ulp of the correctly rounded quotient (tools/micro/rcp_accuracy.hip).
+#ifndef DTO_PIVOT_RCP
+#define DTO_PIVOT_RCP 1
+#endif
+__device__ __forceinline__ double pivot_recip(double x) {
+#if DTO_PIVOT_RCP
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 template <int BD>
 __device__ __forceinline__ void ldl_inplace(double* S, double* dinv, double piv_tol, bool& ok, int& nneg) {
   // right-looking LDL^T on the packed lower triangle, static order, no pivoting; L overwrites the strict
@@ -1213,7 +1342,7 @@ __device__ __forceinline__ void ldl_inplace(double* S, double* dinv, double piv_
       dj = (dj < 0.0 ? -1.0 : 1.0) * fmax(fabs(dj), piv_tol);
     }
     if (dj < 0.0) ++nneg;
-    const double inv = 1.0 / dj;
+    const double inv = pivot_recip(dj);
     dinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < BD; ++i) {
@@ -2658,6 +2787,10 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_UPDATE_EVAL:   // the same kernel, a.z_next / a.lam_next set by the host
+        if (!a.z_next || !a.lam_next) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_stage_eval<M>, dim3(gb), dim3(WAVE), 0, st, a);
+        break;
       case DTO_KKT_RHS: hipLaunchKernelGGL(k_rhs_record<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_REARM: hipLaunchKernelGGL(k_rearm, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       default: return -1;

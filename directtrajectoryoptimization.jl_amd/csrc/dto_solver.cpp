@@ -52,6 +52,8 @@ struct SolverState {
   double *d_lo = nullptr, *d_hi = nullptr;
   // SoA state
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
+  double *z_alt = nullptr, *lam_alt = nullptr;   // second iterate / multiplier buffers of the fused UPDATE+EVAL pass (lazy)
+  int fuse_state = 0;                            // 0 not decided, 1 buffers allocated, -1 not available (memory, switch)
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
   double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr, *cpart = nullptr;
@@ -75,10 +77,11 @@ struct SolverState {
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
-                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs})
+                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
+    z_alt = lam_alt = nullptr; fuse_state = 0;
     csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
     d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
@@ -674,6 +677,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.wtile = S.use_wtile ? S.wtile : nullptr; a.Nw = L.Nw;
   a.sigx = (S.opt.newton_only && S.use_sigx) ? S.sigx : nullptr;
   a.sigc = (S.opt.newton_only && S.use_sigc) ? S.sigc : nullptr;
+  a.z_next = nullptr; a.lam_next = nullptr;
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
@@ -683,6 +687,25 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
   a.opt = S.opt;
+}
+
+// The fused UPDATE+EVAL pass needs a second copy of the iterate and the multipliers (0.07 MB per instance at T = 1000):
+// allocated at the first use if the device has the memory to spare; DTO_FUSE_UPDATE=0 switches the pass off (A/B, tests).
+static bool fused_update_available(Problem* p) {
+  SolverState& S = *p->solver;
+  if (const char* e = getenv("DTO_FUSE_UPDATE")) if (atoi(e) == 0) return false;   // read per call: tests flip it
+  if (S.fuse_state != 0) return S.fuse_state > 0;
+  S.fuse_state = -1;
+  const size_t lanes = (size_t)S.G * 64;
+  const size_t need = lanes * (size_t)(p->L.Nz + p->L.Nc) * sizeof(double);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)24 << 30)) return false;
+  if (hipMalloc((void**)&S.z_alt, std::max<size_t>(8, lanes * p->L.Nz * sizeof(double))) != hipSuccess) { S.z_alt = nullptr; return false; }
+  if (hipMalloc((void**)&S.lam_alt, std::max<size_t>(8, lanes * p->L.Nc * sizeof(double))) != hipSuccess) {
+    (void)hipFree(S.z_alt); S.z_alt = nullptr; S.lam_alt = nullptr; return false;
+  }
+  S.fuse_state = 1;
+  return true;
 }
 
 static int kkt_launch(Problem* p, int op, const dto_kkt_args& a, hipStream_t st) {
@@ -1561,13 +1584,26 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   dto::fill_kkt_args(p, a);
   if (p->solver->G_active > 0) a.G = p->solver->G_active;   // tiles behind hold finished instances only (dto_solver_repack)
   int rc;
+  // UPDATE of iteration k and EVAL of iteration k+1 run as one pass (k_stage_eval with a.z_next set: 36 instead of 49 rows per stage) into
+  // the second iterate buffers; an EVEN number of them per call, so that the call ends on the buffers it started on (the
+  // tiles behind G_active, finished instances, are not touched and stay valid there)
+  SolverState& S = *p->solver;
+  const int n_fused = dto::fused_update_available(p) ? ((n - 1) / 2) * 2 : 0;
   for (int it = 0; it < n; ++it) {
-    if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
+    if (it > 0 && it <= n_fused) {
+      a.z_next = S.z_alt; a.lam_next = S.lam_alt;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE_EVAL, a, st))) return rc;
+      std::swap(S.z, S.z_alt); std::swap(S.lam, S.lam_alt);
+      a.z = S.z; a.lam = S.lam; a.z_next = nullptr; a.lam_next = nullptr;
+    } else {
+      if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
+    }
     if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
     if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
     if ((rc = dto::kkt_launch(p, DTO_KKT_LINESEARCH, a, st))) return rc;
     if ((rc = dto::kkt_launch(p, DTO_KKT_LS_REDUCE, a, st))) return rc;
-    if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE, a, st))) return rc;
+    if (!(it + 1 < n && it + 1 <= n_fused))
+      if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE, a, st))) return rc;
   }
   return DTO_OK;
 }
@@ -1629,6 +1665,18 @@ int dto_solver_launch_op(dto_problem* h, int op, void* stream) {
   if (op < DTO_KKT_EVAL || op >= DTO_KKT_OP_COUNT) return set_error(DTO_ERR_INVALID, "op out of range");
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
+  if (p->solver->G_active > 0) a.G = p->solver->G_active;
+  if (op == DTO_KKT_UPDATE_EVAL) {
+    // the fused pass writes the updated iterate into the second buffers and the pairs are swapped: a caller that replays an
+    // iteration kernel by kernel uses it an even number of times between two calls that touch finished tiles (repack, end)
+    SolverState& S = *p->solver;
+    if (!dto::fused_update_available(p)) return set_error(DTO_ERR_UNSUPPORTED, "the fused UPDATE+EVAL pass is not available (memory, DTO_FUSE_UPDATE=0)");
+    a.z_next = S.z_alt; a.lam_next = S.lam_alt;
+    const int rc = dto::kkt_launch(p, op, a, (hipStream_t)stream);
+    if (rc) return rc;
+    std::swap(S.z, S.z_alt); std::swap(S.lam, S.lam_alt);
+    return DTO_OK;
+  }
   return dto::kkt_launch(p, op, a, (hipStream_t)stream);
 }
 

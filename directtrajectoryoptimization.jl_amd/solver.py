@@ -499,7 +499,7 @@ class Solver:
         return dict(status=st, iterations=it, **dict(zip(names, arrs)))
 
     KKT_OPS = dict(eval=3, conv=4, factor_solve=5, linesearch=6, ls_reduce=7, update=8, kkt_fwd=9, kkt_sep=10, kkt_bwd=11,
-                   kkt_post=12)
+                   kkt_post=12, update_eval=15)
 
     def set_partitions(self, partitions: int):
         """Chunks of the time-partitioned factorisation (0 = automatic, 1 = sequential)."""

@@ -44,10 +44,15 @@ for k in range(a.iters):
     nf = s.scalar_batch("nfact")
     att = (nf - prev_nf).astype(np.int64)
     prev_nf = nf.copy()
-    dw = s.stats_batch()["delta_w"]
+    al, am = s.scalar_batch("alpha"), s.scalar_batch("alpha_pmax")
+    kidx = np.where(al > 0, np.round(np.log2(np.maximum(am, 1e-300) / np.maximum(al, 1e-300))), 99).astype(int)
+    ls_hist = np.bincount(np.clip(kidx, 0, 9), minlength=10)
+    kt = np.concatenate([kidx, np.zeros((-len(kidx)) % 64, dtype=int)]).reshape(-1, 64).max(axis=1)
     hist.append(att)
     ident = np.arange(B)
-    r = dict(it=k, mean=float(att.mean()), asis=rounds(att, ident), ideal=rounds(att, np.argsort(att, kind="stable")))
+    r = dict(it=k, mean=float(att.mean()), asis=rounds(att, ident), ideal=rounds(att, np.argsort(att, kind="stable")),
+             ls_trial_hist=ls_hist.tolist(), tiles_needing_more_than_2_trials=float((kt >= 2).mean()),
+             tiles_needing_more_than_1_trial=float((kt >= 1).mean()))
     if k > 0:
         r["prev1"] = rounds(att, np.argsort(hist[-2], kind="stable"))
         r["prevE"] = rounds(att, perm_E)
