@@ -321,12 +321,12 @@ def main():
     kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd",
                  kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd",
                  kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update",
-                 update_eval="k_stage_eval(update+eval)")
+                 update_eval="k_update_eval")
     if not seq_sweep:
         kname["kkt_sep"] = "k_kkt_sep"
     tot = {k: 0.0 for k in kname}
     cnt = {k: 0 for k in kname}
-    # the loop above runs UPDATE of one iteration and EVAL of the next as one pass (k_stage_eval with the step folded in) when the library could
+    # the loop above runs UPDATE of one iteration and EVAL of the next as one pass (k_update_eval) when the library could
     # allocate its second iterate buffers; the replay does the same: the first iteration starts with k_stage_eval, the
     # following (an even number: the pass swaps buffer pairs) with the fused pass, k_update closes the last one
     fused = os.environ.get("DTO_FUSE_UPDATE", "1") != "0"

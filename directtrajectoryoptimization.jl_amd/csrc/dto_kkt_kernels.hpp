@@ -749,18 +749,18 @@ static __global__ __launch_bounds__(WAVE) void k_rearm(dto_kkt_args a) {
 // ------------------------------------------------------------------------------------------------
 // per-stage derivative blocks.  grid = G*T waves; wave = (tile, stage); lane = instance.
 // ------------------------------------------------------------------------------------------------
-// With a.z_next set (DTO_KKT_UPDATE_EVAL) the step of the iteration that just ended is taken on the way (k_update's
+// UPD (k_update_eval, DTO_KKT_UPDATE_EVAL): the step of the iteration that just ended is taken on the way (k_update's
 // arithmetic, expression for expression): the rows of a stage are read as z + alpha dz, lam + alpha dlam, written to z_next /
 // lam_next (other buffers: a block also reads the rows of its neighbour stages, which another wavefront may be writing) and
 // used from registers.  One pass over 36 rows per stage instead of 27 (k_update) + 22 (k_stage_eval).  Bound multipliers and
 // slacks have no reader outside their own stage and are updated in place.
-// The switch is a run-time (wave-uniform) one on purpose: both modes execute the SAME machine code for the model's cost,
-// residual and Jacobian bodies.  As two template instantiations the compiler contracted a cost body  0.1 u^2 + 0.1 (x3^2 +
-// x4^2)  into different multiply-add pairings, and the objective of the fused pass differed from the two-kernel sequence in
-// the last bit (tests/test_fused_update_gpu.py demands equality).
-template <class M>
-__global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
-  const bool upd = a.z_next != nullptr;
+// Two instantiations of one body: every value the model's generated bodies consume passes through an empty asm in BOTH, so
+// that the compiler sees the same expression graph over opaque registers and contracts it the same way (as loads in one
+// and multiply-adds in the other it paired the products of a cost body  0.1 u^2 + 0.1 (x3^2 + x4^2)  differently: the
+// objective of the fused pass differed from the two-kernel sequence in the last bit).  A run-time switch inside one kernel
+// was tried instead: 256 + 162 registers, one wavefront per SIMD, both modes 1.5-2x slower.
+template <class M, bool UPD>
+__device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
   // a wavefront walks DTO_SB consecutive stages: the residual partials are summed in registers in stage order (one row set
   // per block instead of one per stage goes to memory), and E_t' lambda_t is handed to the next stage instead of
   // re-evaluating the previous stage's Jacobian there
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   const int t_begin = blk * DTO_SB;
   double al = 0.0, ad = 0.0, mu_u = 0.0;
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) {  // finished instance: its record stays frozen
-    if (upd) {
+    if constexpr (UPD) {
       // ... and its iterate moves to the other buffer unchanged
       const int te = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
       for (int i = uload(a.zoff, t_begin); i < uload(a.zoff, te); ++i) *soa(a.z_next, g, a.Nz, i) = *soa(a.z, g, a.Nz, i);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     }
     return;
   }
-  if (upd) {
+  if constexpr (UPD) {
     al = *soa(a.scal, g, SC_COUNT, SC_ALPHA);
     ad = *soa(a.scal, g, SC_COUNT, SC_ALPHA_DMAX);
     mu_u = *soa(a.scal, g, SC_COUNT, SC_MU);
@@ -790,19 +790,19 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   // (the updated value passes through an empty asm: the compiler then cannot fuse its multiply-add into the arithmetic that
   // consumes it -- AMDGPU contracts aggressively, fma(x, y, fma(u, v, z)) for fma(x, y, u v) + z -- and the evaluation sees
   // exactly the double k_update would have stored: the objective differed in the last bit without it)
-  // (both rows are always requested -- no branch between the loads of a stage --; the step row may hold anything when no
-  // step is taken: it is selected away, not multiplied by zero)
   auto zrow = [&](int i) -> double {
-    const double v0 = *soa(a.z, g, a.Nz, i), dv = *soa(a.dz, g, a.Nz, i);
-    double v = v0 + al * dv;
-    asm volatile("" : "+v"(v));
-    return upd ? v : v0;
+    double v;
+    if constexpr (UPD) v = *soa(a.z, g, a.Nz, i) + al * *soa(a.dz, g, a.Nz, i);
+    else v = *soa(a.z, g, a.Nz, i);
+    asm("" : "+v"(v));
+    return v;
   };
   auto lrow = [&](int i) -> double {
-    const double v0 = *soa(a.lam, g, a.Nc, i), dv = *soa(a.dlam, g, a.Nc, i);
-    double v = v0 + al * dv;
-    asm volatile("" : "+v"(v));
-    return upd ? v : v0;
+    double v;
+    if constexpr (UPD) v = *soa(a.lam, g, a.Nc, i) + al * *soa(a.dlam, g, a.Nc, i);
+    else v = *soa(a.lam, g, a.Nc, i);
+    asm("" : "+v"(v));
+    return v;
   };
   double A_f = 0.0, A_th1 = 0.0, A_thinf = 0.0, A_dinf = 0.0, A_szmax = 0.0, A_isz = 0.0, A_sumlam = 0.0, A_sumz = 0.0,
          A_logbar = 0.0, A_xmax = 0.0;
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
     auto put = [&](int e, double v) { rec[(int64_t)e << 6] = v; };
 
     arr<D::NP> p;
-    if (upd) {
+    if constexpr (UPD) {
       constexpr double KSIG = 1e10;
       StageBounds<D::NP> sbu;
       load_stage_bounds<D::NP>(a, g, z0, sbu);
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         const double pold = *soa(a.z, g, a.Nz, z0 + i);
         const double dp = *soa(a.dz, g, a.Nz, z0 + i);
         double pn = pold + al * dp;
-        asm volatile("" : "+v"(pn));
+        asm("" : "+v"(pn));
         if (!o.newton_only) {
           const double lo = sbu.lo[i], hi = sbu.hi[i];
           if (lo != hi) {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < D::NP; ++i) p[i] = *soa(a.z, g, a.Nz, z0 + i);
+      for (int i = 0; i < D::NP; ++i) p[i] = zrow(z0 + i);
     }
     // every row of the stage is requested here, before any is used and before anything is stored (the compiler does not move
     // a load above a store it cannot tell apart): x_{t+1}, lambda_t, nu_t
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       double o1[1];
       CO::eval(p.data(), p.data() + CO::NX, wc.data(), o1);
       cost_val = o1[0];
-      asm volatile("" : "+v"(cost_val));   // summed below as a value: not contracted into the sum differently per instantiation
+      asm("" : "+v"(cost_val));   // summed below as a value: not contracted into the sum differently per instantiation
       CO::grad(p.data(), p.data() + CO::NX, wc.data(), rp.data());
       if constexpr (CO::SNH > 0 && !D::FUSED) {
         arr<CO::SNH> hv;
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
       load_params(w, a, g, t);
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
-        if (upd) {
+        if constexpr (UPD) {
           if (!o.newton_only && D::ineq(j)) {
             constexpr double KSIG = 1e10;
             const int si = uload(a.ioff, t) + D::slack(j);
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
             const double dsv = *soa(a.ds, g, a.Ni, si);
             const double dzs = mu_u / sv - zv - (zv / sv) * dsv;
             double sn = sv + al * dsv;
-            asm volatile("" : "+v"(sn));
+            asm("" : "+v"(sn));
             double zn = zv + ad * dzs;
             zn = fmin(fmax(zn, mu_u / (KSIG * sn)), KSIG * mu_u / sn);
             *soa(a.s, g, a.Ni, si) = sn;
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
         }
       }
     }
-    if (upd) {
+    if constexpr (UPD) {
 #pragma unroll
       for (int i = 0; i < D::NP; ++i) *soa(a.z_next, g, a.Nz, z0 + i) = p[i];
 #pragma unroll
@@ -1158,6 +1158,11 @@ __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) {
   part[8 << 6] = A_logbar;
   part[9 << 6] = A_xmax;
 }
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) { stage_eval_body<M, false>(a); }
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_update_eval(dto_kkt_args a) { stage_eval_body<M, true>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // first level of the deterministic reductions: every (tile, chunk) wave folds the per-stage partials of its
@@ -2787,9 +2792,9 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_UPDATE: hipLaunchKernelGGL(k_update<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_UPDATE_EVAL:   // the same kernel, a.z_next / a.lam_next set by the host
+      case DTO_KKT_UPDATE_EVAL:
         if (!a.z_next || !a.lam_next) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_stage_eval<M>, dim3(gb), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_update_eval<M>, dim3(gb), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_RHS: hipLaunchKernelGGL(k_rhs_record<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_REARM: hipLaunchKernelGGL(k_rearm, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;

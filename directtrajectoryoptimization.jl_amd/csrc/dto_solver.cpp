@@ -1584,7 +1584,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   dto::fill_kkt_args(p, a);
   if (p->solver->G_active > 0) a.G = p->solver->G_active;   // tiles behind hold finished instances only (dto_solver_repack)
   int rc;
-  // UPDATE of iteration k and EVAL of iteration k+1 run as one pass (k_stage_eval with a.z_next set: 36 instead of 49 rows per stage) into
+  // UPDATE of iteration k and EVAL of iteration k+1 run as one pass (k_update_eval: 36 instead of 49 rows per stage) into
   // the second iterate buffers; an EVEN number of them per call, so that the call ends on the buffers it started on (the
   // tiles behind G_active, finished instances, are not touched and stay valid there)
   SolverState& S = *p->solver;

@@ -1,4 +1,4 @@
-"""The fused UPDATE+EVAL pass (csrc/dto_kkt_kernels.hpp: k_stage_eval with a.z_next set; csrc/dto_solver.cpp: dto_solver_iterate) takes the
+"""The fused UPDATE+EVAL pass (csrc/dto_kkt_kernels.hpp: k_update_eval; csrc/dto_solver.cpp: dto_solver_iterate) takes the
 step of iteration k while it evaluates iteration k+1 -- one pass over the iterate instead of two.  It must not change a
 bit: the same expressions, the values used from registers instead of being re-read.  DTO_FUSE_UPDATE=0 runs k_update and
 k_stage_eval one after the other (the library reads the switch at every dto_solver_iterate call)."""

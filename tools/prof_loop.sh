@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/loop_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $GRAFT_REPO_ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B > $OUT/run.log 2>&1
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $GRAFT_REPO_ROOT/bench.py --loop-only --steps ${STEPS:-8} --warmup ${WARMUP:-2} --batch $B > $OUT/run.log 2>&1
 echo "exit $?" >> $OUT/run.log
 cd $GRAFT_REPO_ROOT
 F=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)
