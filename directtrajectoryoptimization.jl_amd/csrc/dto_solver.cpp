@@ -1572,6 +1572,7 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   if ((rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
   if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
   S.begun = true;
+  (void)dto::fused_update_available(p);   // the second iterate buffers are allocated here, not inside the first iteration
   return DTO_OK;
 }
 
@@ -1987,6 +1988,7 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
   S.opt.warm = 0;   // the flag only concerns the initialisation kernel
   S.begun = true;
+  (void)dto::fused_update_available(p);
   return DTO_OK;
 }
 

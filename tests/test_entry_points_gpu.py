@@ -68,17 +68,36 @@ def test_linear_solver_entry_points_match_dense_solves(model, T, dw, partitions)
     finally:
         s.set_partitions(0)
     # an indefinite case: no regularisation, large multipliers -> the factorisation reports the wrong inertia
+    # (also with the plain sequential sweep, whose lanes stop storing carries once an attempt is lost -- the
+    # single attempt of these entry points must be swept through: the pivot count is the matrix's inertia whatever the
+    # neighbouring lanes do, and the solve is K^-1 rhs although the inertia is "wrong")
     MU2 = 300.0 * rng.standard_normal((B, nc))
     dMU2 = dev(MU2)
-    s.kkt_assemble(dZ.data_ptr(), B, nz, dMU2.data_ptr(), nc, 0.0, dc)
-    ok2, neg2 = s.kkt_factor()
-    for b in range(B):
-        H, J = dense_blocks(onlp, Z[b], MU2[b])
-        K = np.block([[H, J.T], [J, -dc * np.eye(nc)]])
-        eig = np.linalg.eigvalsh(K)
-        if np.min(np.abs(eig)) > 1e-6:                         # away from singular matrices the counts agree exactly
-            assert int(np.sum(eig < 0)) == neg2[b]
-            assert bool(ok2[b]) == (int(np.sum(eig < 0)) == nc)
+    for part in (0, 1):
+        s.set_partitions(part)
+        try:
+            s.kkt_assemble(dZ.data_ptr(), B, nz, dMU2.data_ptr(), nc, 0.0, dc)
+            ok2, neg2 = s.kkt_factor()
+            RX, RC = rng.standard_normal((B, nz)), rng.standard_normal((B, nc))
+            dRX, dRC = dev(RX), dev(RC)
+            oX = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+            oC = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+            s.kkt_solve(dRX.data_ptr(), nz, dRC.data_ptr(), nc, oX.data_ptr(), nz, oC.data_ptr(), nc)
+            torch.cuda.synchronize()
+            oX, oC = oX.cpu().numpy(), oC.cpu().numpy()
+            for b in range(B):
+                H, J = dense_blocks(onlp, Z[b], MU2[b])
+                K = np.block([[H, J.T], [J, -dc * np.eye(nc)]])
+                eig = np.linalg.eigvalsh(K)
+                if np.min(np.abs(eig)) > 1e-6:                     # away from singular matrices the counts agree exactly
+                    assert int(np.sum(eig < 0)) == neg2[b], (part, b)
+                    assert bool(ok2[b]) == (int(np.sum(eig < 0)) == nc)
+                    sol = np.linalg.solve(K, np.concatenate([RX[b], RC[b]]))
+                    scale = np.max(np.abs(sol))
+                    # an indefinite K without pivoting: 1e-6 of the solution (condition numbers up to 1e10 here)
+                    assert np.max(np.abs(oX[b] - sol[:nz])) <= 1e-6 * scale and np.max(np.abs(oC[b] - sol[nz:])) <= 1e-6 * scale, (part, b)
+        finally:
+            s.set_partitions(0)
 
 
 def test_linear_solver_entry_points_reject_misuse():
@@ -211,6 +230,42 @@ def test_repack_of_running_instances_changes_nothing_but_the_cost():
     assert np.array_equal(st_c, st_a.astype(np.int32)) and np.array_equal(it_c, it_a.astype(np.int32)) and torch.equal(zc, za)
     assert len(set(it_a.tolist())) > 10                         # the instances really finished at different times
 
+
+
+def test_repack_on_a_tiny_model_with_more_than_one_tile():
+    """with a short horizon the widest vector that dto_solver_repack moves is the filter (48 rows per instance),
+    not the iterate: pendulum T = 8 has 23 variables.  130 instances (three tiles) that finish at different iterations,
+    solved through dto_solve_batch (which repacks by itself); every solution is checked with the oracle."""
+    import torch
+    from test_solve_gpu import kkt_report, oracle_for
+    s, p = product_solver("pendulum", 8)
+    B = 130
+    rng = np.random.Generator(np.random.PCG64(21))
+    import dto_amd
+    Z = np.zeros((B, s.nlp.num_variables))
+    for b in range(B):
+        xs, us = p["guess"](rng)
+        # spread the difficulty: instances start at different distances from the solution
+        us = [u * (0.1 + 3.0 * (b % 7)) for u in us]
+        xs = [x + 1.5 * (b % 5) * rng.standard_normal(len(x)) for x in xs]
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, us)
+        Z[b] = s._z0
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    assert nz < 48
+    d = torch.tensor(Z, device="cuda")
+    xo = torch.zeros((B, nz), device="cuda", dtype=torch.float64)
+    mo = torch.zeros((B, nc), device="cuda", dtype=torch.float64)
+    # check_every = 1: a repack opportunity after every iteration
+    st, it = s.solve_batch(d.data_ptr(), B, nz, xo.data_ptr(), nz, mo.data_ptr(), nc, check_every=1)
+    torch.cuda.synchronize()
+    assert np.all(st == 1), np.bincount(st)
+    assert it.max() > it.min()            # a staggered finish
+    X, MU = xo.cpu().numpy(), mo.cpu().numpy()
+    onlp = oracle_for("pendulum", 8)
+    for b in range(0, B, 9):
+        rep = kkt_report(onlp, X[b], MU[b])
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"], (b, rep)
 
 def test_varying_state_dimensions_callbacks_kkt_step_and_solve():
     """Per-stage state / action dimensions on the whole path (dimensions(), src/dynamics.jl:206-211; round-1 verdict: the
