@@ -468,6 +468,9 @@ struct SoaRunIO {
 #ifndef DTO_SEQ_PREFETCH_BWD
 #define DTO_SEQ_PREFETCH_BWD 1
 #endif
+#ifndef DTO_SEQ_PREFETCH_MAX
+#define DTO_SEQ_PREFETCH_MAX 56   // doubles per StageIn up to which the next stage is requested ahead
+#endif
 template <class M, int K, bool BOUNDED, bool BWD>
 struct StageIn {
   using D = KindDims<M, K>;
@@ -1915,10 +1918,13 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
           } else {
             auto sweep = [&](auto bounded) {
               using IO = SoaPreIO<M, K, decltype(bounded)::value, false>;
+              // (stages with long records -- quasi-Newton blocks, stored derivatives -- are not double-buffered: twice their
+              // rows do not fit the register file next to the block algebra)
+              constexpr bool PRE = DTO_SEQ_PREFETCH_FWD && sizeof(typename IO::In) <= DTO_SEQ_PREFETCH_MAX * sizeof(double);
               typename IO::In nxt, cur;
-              if (DTO_SEQ_PREFETCH_FWD) nxt.load(bufs, run, run.t0);
+              if (PRE) nxt.load(bufs, run, run.t0);
               for (int t = run.t0; t < run.t1; ++t) {
-                if (DTO_SEQ_PREFETCH_FWD) {
+                if (PRE) {
                   cur = nxt;
                   nxt.load(bufs, run, min(t + 1, run.t1 - 1));   // in flight while stage t is worked on
                 } else {
@@ -2298,10 +2304,11 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
         } else {
           auto sweep = [&](auto bounded) {
             using IO = SoaPreIO<M, K, decltype(bounded)::value, true>;
+            constexpr bool PRE = DTO_SEQ_PREFETCH_BWD && sizeof(typename IO::In) <= DTO_SEQ_PREFETCH_MAX * sizeof(double);
             typename IO::In nxt, cur;
-            if (DTO_SEQ_PREFETCH_BWD) nxt.load(bufs, run, run.t1 - 1);
+            if (PRE) nxt.load(bufs, run, run.t1 - 1);
             for (int t = run.t1 - 1; t >= run.t0; --t) {
-              if (DTO_SEQ_PREFETCH_BWD) {
+              if (PRE) {
                 cur = nxt;
                 nxt.load(bufs, run, max(t - 1, run.t0));   // in flight while stage t is worked on
               } else {
