@@ -699,7 +699,7 @@ static bool fused_update_available(Problem* p) {
   const size_t lanes = (size_t)S.G * 64;
   const size_t need = lanes * (size_t)(p->L.Nz + p->L.Nc) * sizeof(double);
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)24 << 30)) return false;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)40 << 30)) return false;
   if (hipMalloc((void**)&S.z_alt, std::max<size_t>(8, lanes * p->L.Nz * sizeof(double))) != hipSuccess) { S.z_alt = nullptr; return false; }
   if (hipMalloc((void**)&S.lam_alt, std::max<size_t>(8, lanes * p->L.Nc * sizeof(double))) != hipSuccess) {
     (void)hipFree(S.z_alt); S.z_alt = nullptr; S.lam_alt = nullptr; return false;
