@@ -385,7 +385,12 @@ def main():
             break
         except Exception:
             continue
-    roofline = dict(kernel=kname[dom], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+    # `bound` follows the contract (the kernel is priced against the HBM roofline: it is a streaming sweep whose arithmetic is
+    # FP64 vector, not MFMA); what actually limits k_kkt_fwd_seq is recorded next to it (profiles/r03: SQ counters)
+    limited_by = ("instruction issue at one wavefront per SIMD (FP64 vector unit active 63 % of a wavefront's cycles, 17 % waiting) and "
+                  "lock-step inertia-correction rounds (a tile pays for its slowest lane); not HBM: profiles/r03/"
+                  "sq_counters_soa_sweeps_B131072_final.txt, DESIGN.md section 4.2") if kname[dom].startswith("k_kkt_fwd") else None
+    roofline = dict(kernel=kname[dom], bound="hbm", limited_by=limited_by, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
                     algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
