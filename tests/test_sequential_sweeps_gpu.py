@@ -1,0 +1,59 @@
+"""The plain sequential sweeps (k_kkt_fwd_seq / k_kkt_bwd_seq: run table, buffer resources, next-stage prefetch, one launch
+for every inertia-correction round) are what a large batch runs; a small batch is cut into time chunks instead.  Here the
+sequential form is forced (set_partitions(1)) on the barrier models -- variable bounds, fixed end points given as bounds,
+inequality rows with slacks: the BOUNDED variants of the prefetching IO -- and compared with the time-partitioned form of the
+same solves and with the oracle's KKT conditions."""
+import numpy as np
+import pytest
+
+from conftest import product_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _guesses(s, p, B, seed=0):
+    import dto_amd
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Z = np.zeros((B, s.nlp.num_variables))
+    for b in range(B):
+        xs, us = p["guess"](rng)
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, us)
+        Z[b] = s._z0
+    return Z
+
+
+@pytest.mark.parametrize("model,T,B", [("car", 51, 70), ("cartpole", 200, 3), ("acrobot_bounds", 101, 65), ("pendulum", 50, 64)])
+def test_sequential_and_time_partitioned_sweeps_solve_alike(model, T, B):
+    import torch
+    from test_solve_gpu import kkt_report, oracle_for
+    s, p = product_solver(model, T)
+    Z = _guesses(s, p, B, seed=13)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    res = {}
+    for part in (1, 0):
+        s.set_partitions(part)
+        try:
+            d = torch.tensor(Z, device="cuda")
+            xo = torch.zeros((B, nz), device="cuda", dtype=torch.float64)
+            mo = torch.zeros((B, max(1, nc)), device="cuda", dtype=torch.float64)
+            st, it = s.solve_batch(d.data_ptr(), B, nz, xo.data_ptr(), nz, mo.data_ptr(), max(1, nc))
+            if part == 1:
+                assert s.partitions() == 1
+            torch.cuda.synchronize()
+            res[part] = (st.copy(), it.copy(), xo.cpu().numpy(), mo.cpu().numpy()[:, :nc])
+        finally:
+            s.set_partitions(0)
+    st, it, X, MU = res[1]
+    assert np.all(st == 1), np.bincount(st)
+    assert np.all(res[0][0] == 1)
+    # the two forms round differently (the chunked one eliminates through spikes): same algorithm, iteration counts of the
+    # same size -- medians within 15 %
+    assert abs(np.median(it) - np.median(res[0][1])) <= 0.15 * max(4.0, np.median(res[0][1])), (np.median(it), np.median(res[0][1]))
+    onlp = oracle_for(model, T)
+    barrier = model in ("car", "cartpole", "acrobot_bounds")
+    for b in range(0, B, max(1, B // 8)):
+        rep = kkt_report(onlp, X[b], MU[b])
+        # the bars of tests/test_solve_gpu.py: barrier models to the barrier accuracy compl_inf_tol = 1e-3 of the reference Options
+        assert rep["violation"] <= (1e-5 if barrier else 1e-6) and rep["bound_viol"] <= 1e-12 and rep["sign_ok"], (b, rep)
+        assert rep["stationarity"] <= (1e-3 if barrier else 1e-5) and rep["compl"] <= 1e-3, (b, rep)
