@@ -49,6 +49,8 @@ enum dto_kkt_op {
   DTO_KKT_RHS = 13,        // linear-solver entry points: caller's right-hand side -> stage records
   DTO_KKT_REARM = 14,      // linear-solver entry points: request one factorisation with the fixed delta_w
   DTO_KKT_UPDATE_EVAL = 15,  // UPDATE of one iteration and EVAL of the next in one pass (z, lam -> z_next, lam_next)
+  DTO_KKT_BWD_EARLY = 16,    // back substitution of the tiles whose forward sweep has published its tag (second stream)
+  DTO_KKT_BWD_REST = 17,     // ... and of the tiles DTO_KKT_BWD_EARLY left
   DTO_KKT_OP_COUNT
 };
 
@@ -131,6 +133,9 @@ struct dto_kkt_args {
   // SoA state, doubles
   double* z; double* lam; double* zl; double* zu; double* s; double* zs;
   double* z_next; double* lam_next;   // DTO_KKT_UPDATE_EVAL: where the updated iterate goes (the host swaps the pairs)
+  // sequential sweeps overlapped through a second stream: per tile, the tag (iteration counter of the host) of the last
+  // finished forward sweep / back substitution; NULL = plain launches
+  int* tile_fwd_tag; int* tile_bwd_tag; int sweep_tag;
   double* dz; double* dlam; double* ds;
   double* rec; double* fac; double* part; double* lspart; double* scal;
   double* filt;  // [G][2*DTO_FILTER_CAP][64] filter entries (theta, phi)
@@ -1988,7 +1993,14 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) { kkt_fwd_body
 // the plain sequential sweep is asked to fit two wavefronts per SIMD (256 VGPRs): nothing else hides its memory and
 // dependent-issue latencies
 template <class M>
-__global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_args a) { kkt_fwd_body<M, false>(a); }
+__global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_args a) {
+  kkt_fwd_body<M, false>(a);
+  if (a.tile_fwd_tag) {
+    // this tile's factorisation is complete: tell the early back substitutions (k_kkt_bwd_early, other stream)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(a.tile_fwd_tag + blockIdx.x, a.sweep_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // reduced system over the separators + inertia + retry state machine.  grid = G waves.
 template <class M>
@@ -2348,6 +2360,25 @@ template <class M>
 __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) { kkt_bwd_body<M, true>(a); }
 template <class M>
 __global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
+// A forward launch ends with its wavefront slots draining: the tiles that start late and climb a long regularisation ladder
+// (up to six rounds, 20 ms) run alone at the end -- 105-110 ms for 80 ms of work at 8 192 tiles on 1 024 slots
+// (profiles/r03/sq_counters_soa_sweeps_B524288_final.txt).  k_kkt_bwd_early runs on a second, low-priority stream next to the
+// forward launch: its blocks get the slots the forward launch no longer fills and do the back substitution of every tile
+// whose forward sweep has published this iteration's tag (release / acquire at agent scope).  A block never waits: a tile that
+// is not ready is left to k_kkt_bwd_rest, which the host launches after both.
+template <class M>
+__global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_early(dto_kkt_args a) {
+  if (a.tile_bwd_tag[blockIdx.x] == a.sweep_tag) return;   // done by an earlier pass of this kernel
+  if (__hip_atomic_load(a.tile_fwd_tag + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sweep_tag) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  kkt_bwd_body<M, false>(a);
+  if (threadIdx.x == 0) a.tile_bwd_tag[blockIdx.x] = a.sweep_tag;
+}
+template <class M>
+__global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_rest(dto_kkt_args a) {
+  if (a.tile_bwd_tag[blockIdx.x] == a.sweep_tag) return;
+  kkt_bwd_body<M, false>(a);
+}
 
 __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) {
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
@@ -2790,6 +2821,12 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_BWD:
         if (a.P > 1) hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
         else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_BWD_EARLY:
+      case DTO_KKT_BWD_REST:
+        if (a.P != 1 || !a.tile_fwd_tag || !a.tile_bwd_tag) return (int)hipErrorInvalidValue;
+        if (op == DTO_KKT_BWD_EARLY) hipLaunchKernelGGL(k_kkt_bwd_early<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL(k_kkt_bwd_rest<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gb), dim3(WAVE), 0, st, a); break;

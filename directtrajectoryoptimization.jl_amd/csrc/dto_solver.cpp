@@ -52,6 +52,11 @@ struct SolverState {
   double *d_lo = nullptr, *d_hi = nullptr;
   // SoA state
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
+  // sequential sweeps overlapped through a second stream (k_kkt_bwd_early)
+  int *tile_fwd_tag = nullptr, *tile_bwd_tag = nullptr;
+  int sweep_tag = 0;
+  hipStream_t stream_lo = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *z_alt = nullptr, *lam_alt = nullptr;   // second iterate / multiplier buffers of the fused UPDATE+EVAL pass (lazy)
   int fuse_state = 0;                            // 0 not decided, 1 buffers allocated, -1 not available (memory, switch)
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
@@ -77,11 +82,14 @@ struct SolverState {
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
-                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt})
+                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    z_alt = lam_alt = nullptr; fuse_state = 0;
+    z_alt = lam_alt = nullptr; fuse_state = 0; tile_fwd_tag = tile_bwd_tag = nullptr; sweep_tag = 0;
+    if (stream_lo) { (void)hipStreamDestroy(stream_lo); stream_lo = nullptr; }
+    if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+    if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
     d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
@@ -481,6 +489,28 @@ static int dev_alloc(T** p, size_t count) {
 // switch the number of chunks among those the state was allocated for (dto_solver_repack; back to P0 when a batch is loaded)
 // Inertia-correction rounds the sequential sweep does per launch (0 = all of them in one launch).  DTO_FWD_ROUNDS is a
 // measurement knob (tools/), not part of the interface.
+// Back substitutions next to the draining forward launch (csrc/dto_kkt_kernels.hpp: k_kkt_bwd_early): sequential form with
+// more tiles than wavefront slots, all rounds in one forward launch, the caller's stream not being captured into a graph.
+// DTO_OVERLAP_SWEEPS=0 switches it off (read at every call: tests flip it).
+static bool overlap_sweeps(Problem* p, hipStream_t st) {
+  SolverState& S = *p->solver;
+  if (const char* e = getenv("DTO_OVERLAP_SWEEPS")) if (atoi(e) == 0) return false;
+  const int tiles = S.G_active > 0 ? S.G_active : S.G;
+  if (S.P != 1 || tiles <= 2048 || S.opt.newton_only) return false;   // pays with more than two tiles per wavefront slot
+  static const int per = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
+  if (per > 0) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+  if (!S.stream_lo) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&S.stream_lo, hipStreamNonBlocking, lo) != hipSuccess) { S.stream_lo = nullptr; return false; }
+    if (hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&S.ev_join, hipEventDisableTiming) != hipSuccess)
+      return false;
+  }
+  return S.ev_fork && S.ev_join;
+}
 static int fwd_rounds_per_launch() {
   static const int v = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
   return v;
@@ -635,6 +665,8 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   if ((rc = dev_alloc(&S.part, lanes * nblk * S.info.npart))) return rc;
   if ((rc = dev_alloc(&S.lspart, lanes * nblk * 2 * S.info.ls_trials))) return rc;
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
+  if ((rc = dev_alloc(&S.tile_fwd_tag, (size_t)S.G + 8))) return rc;
+  if ((rc = dev_alloc(&S.tile_bwd_tag, (size_t)S.G + 8))) return rc;
   if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
   {
     // chunk boundaries of every P in [1, P_cap] (or of the one fixed P), back to back: block q holds q + 1 entries
@@ -678,6 +710,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.sigx = (S.opt.newton_only && S.use_sigx) ? S.sigx : nullptr;
   a.sigc = (S.opt.newton_only && S.use_sigc) ? S.sigc : nullptr;
   a.z_next = nullptr; a.lam_next = nullptr;
+  a.tile_fwd_tag = a.tile_bwd_tag = nullptr; a.sweep_tag = 0;
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
@@ -1590,6 +1623,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   // tiles behind G_active, finished instances, are not touched and stay valid there)
   SolverState& S = *p->solver;
   const int n_fused = dto::fused_update_available(p) ? ((n - 1) / 2) * 2 : 0;
+  const bool overlap = dto::overlap_sweeps(p, st);
   for (int it = 0; it < n; ++it) {
     if (it > 0 && it <= n_fused) {
       a.z_next = S.z_alt; a.lam_next = S.lam_alt;
@@ -1600,7 +1634,28 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
       if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
     }
     if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
-    if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+    if (overlap) {
+      // forward sweeps on the caller's stream, early back substitutions on the low-priority one, the rest and the post pass
+      // after both have finished
+      a.tile_fwd_tag = S.tile_fwd_tag; a.tile_bwd_tag = S.tile_bwd_tag; a.sweep_tag = ++S.sweep_tag;
+      HIP_TRY(hipEventRecord(S.ev_fork, st));
+      HIP_TRY(hipStreamWaitEvent(S.stream_lo, S.ev_fork, 0));
+      if ((rc = dto::kkt_launch(p, DTO_KKT_FWD, a, st))) return rc;
+      // (DTO_OVERLAP_PASSES: further passes for the tiles whose block came too early; measured: 1, 3 and 8 passes give the
+      // same 202 ms per iteration at 524 288 instances against 205 without the second stream)
+      {
+        static const int passes = [] { const char* e = getenv("DTO_OVERLAP_PASSES"); return e ? atoi(e) : 1; }();
+        for (int k = 0; k < passes; ++k)
+          if ((rc = dto::kkt_launch(p, DTO_KKT_BWD_EARLY, a, S.stream_lo))) return rc;
+      }
+      HIP_TRY(hipEventRecord(S.ev_join, S.stream_lo));
+      HIP_TRY(hipStreamWaitEvent(st, S.ev_join, 0));
+      if ((rc = dto::kkt_launch(p, DTO_KKT_BWD_REST, a, st))) return rc;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_POST, a, st))) return rc;
+      a.tile_fwd_tag = a.tile_bwd_tag = nullptr;
+    } else {
+      if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+    }
     if ((rc = dto::kkt_launch(p, DTO_KKT_LINESEARCH, a, st))) return rc;
     if ((rc = dto::kkt_launch(p, DTO_KKT_LS_REDUCE, a, st))) return rc;
     if (!(it + 1 < n && it + 1 <= n_fused))

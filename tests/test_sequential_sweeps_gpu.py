@@ -57,3 +57,37 @@ def test_sequential_and_time_partitioned_sweeps_solve_alike(model, T, B):
         # the bars of tests/test_solve_gpu.py: barrier models to the barrier accuracy compl_inf_tol = 1e-3 of the reference Options
         assert rep["violation"] <= (1e-5 if barrier else 1e-6) and rep["bound_viol"] <= 1e-12 and rep["sign_ok"], (b, rep)
         assert rep["stationarity"] <= (1e-3 if barrier else 1e-5) and rep["compl"] <= 1e-3, (b, rep)
+
+
+def test_early_back_substitutions_on_the_second_stream_change_nothing():
+    """With more than two tiles per wavefront slot dto_solver_iterate runs the back substitutions of finished tiles on a
+    low-priority stream next to the draining forward launch (k_kkt_bwd_early); DTO_OVERLAP_SWEEPS=0 is the plain launch
+    sequence.  Same kernels' arithmetic on the same data: bit-identical iterates, multipliers, steps and scalars."""
+    import os
+    import torch
+    s, p = product_solver("acrobot", 101)
+    tiles = 2049 + 3                     # > 2048 tiles: the overlapped path; a ragged last tile
+    B = tiles * 64 - 17
+    Zs = _guesses(s, p, 192, seed=4)
+    Z = np.tile(Zs, (B // 192 + 1, 1))[:B]
+    d = torch.tensor(Z, device="cuda")
+    names = ["z", "multipliers", "dz", "dmultipliers"]
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["DTO_OVERLAP_SWEEPS"] = mode
+        try:
+            s.begin_batch(d.data_ptr(), B, Z.shape[1])
+            assert s.partitions() == 1
+            for n in (4, 3):
+                s.iterate_batch(n)
+            res[mode] = {k: s.peek_batch(k) for k in names}
+            res[mode]["stats"] = s.stats_batch()
+            res[mode]["nfact"] = s.scalar_batch("nfact")
+        finally:
+            del os.environ["DTO_OVERLAP_SWEEPS"]
+    s.release_state()
+    assert np.array_equal(res["0"]["nfact"], res["1"]["nfact"]) and res["0"]["nfact"].sum() > 7 * B
+    for k in ("iterations", "status", "objective", "alpha", "delta_w", "mu"):
+        assert np.array_equal(res["0"]["stats"][k], res["1"]["stats"][k]), k
+    for k in names:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
