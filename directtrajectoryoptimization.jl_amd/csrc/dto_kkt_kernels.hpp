@@ -51,6 +51,7 @@ enum dto_kkt_op {
   DTO_KKT_UPDATE_EVAL = 15,  // UPDATE of one iteration and EVAL of the next in one pass (z, lam -> z_next, lam_next)
   DTO_KKT_BWD_EARLY = 16,    // back substitution of the tiles whose forward sweep has published its tag (second stream)
   DTO_KKT_BWD_REST = 17,     // ... and of the tiles DTO_KKT_BWD_EARLY left
+  DTO_KKT_BWD_GATE = 18,     // one wavefront that returns when every forward block of the launch has started
   DTO_KKT_OP_COUNT
 };
 
@@ -136,6 +137,7 @@ struct dto_kkt_args {
   // sequential sweeps overlapped through a second stream: per tile, the tag (iteration counter of the host) of the last
   // finished forward sweep / back substitution; NULL = plain launches
   int* tile_fwd_tag; int* tile_bwd_tag; int sweep_tag;
+  int* fwd_started;   // forward blocks of this launch that have started (zeroed by the host before the launch)
   double* dz; double* dlam; double* ds;
   double* rec; double* fac; double* part; double* lspart; double* scal;
   double* filt;  // [G][2*DTO_FILTER_CAP][64] filter entries (theta, phi)
@@ -1994,6 +1996,7 @@ __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) { kkt_fwd_body
 // dependent-issue latencies
 template <class M>
 __global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_args a) {
+  if (a.fwd_started && threadIdx.x == 0) atomicAdd(a.fwd_started, 1);
   kkt_fwd_body<M, false>(a);
   if (a.tile_fwd_tag) {
     // this tile's factorisation is complete: tell the early back substitutions (k_kkt_bwd_early, other stream)
@@ -2366,6 +2369,16 @@ __global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_seq(dto_kkt_a
 // forward launch: its blocks get the slots the forward launch no longer fills and do the back substitution of every tile
 // whose forward sweep has published this iteration's tag (release / acquire at agent scope).  A block never waits: a tile that
 // is not ready is left to k_kkt_bwd_rest, which the host launches after both.
+// The early kernel must not take wavefront slots while the forward launch still has blocks to start (stream priorities only
+// weight the arbitration: without the gate the forward launch got 9 ms longer).  One wavefront in front of it on the second
+// stream: returns when every forward block has started -- from then on free slots are slots the forward launch cannot use.
+// Bounded (~0.3 s), one slot of 1 024.
+static __global__ __launch_bounds__(WAVE) void k_kkt_bwd_gate(dto_kkt_args a) {
+  for (int spin = 0; spin < 100000; ++spin) {
+    if (__hip_atomic_load(a.fwd_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.G) return;
+    __builtin_amdgcn_s_sleep(127);
+  }
+}
 template <class M>
 __global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_early(dto_kkt_args a) {
   if (a.tile_bwd_tag[blockIdx.x] == a.sweep_tag) return;   // done by an earlier pass of this kernel
@@ -2821,6 +2834,10 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_BWD:
         if (a.P > 1) hipLaunchKernelGGL(k_kkt_bwd<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
         else hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_BWD_GATE:
+        if (!a.fwd_started) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_kkt_bwd_gate, dim3(1), dim3(WAVE), 0, st, a);
         break;
       case DTO_KKT_BWD_EARLY:
       case DTO_KKT_BWD_REST:

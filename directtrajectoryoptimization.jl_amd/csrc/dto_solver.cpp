@@ -53,7 +53,7 @@ struct SolverState {
   // SoA state
   double *z = nullptr, *lam = nullptr, *zl = nullptr, *zu = nullptr, *s = nullptr, *zs = nullptr;
   // sequential sweeps overlapped through a second stream (k_kkt_bwd_early)
-  int *tile_fwd_tag = nullptr, *tile_bwd_tag = nullptr;
+  int *tile_fwd_tag = nullptr, *tile_bwd_tag = nullptr, *fwd_started = nullptr;
   int sweep_tag = 0;
   hipStream_t stream_lo = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -82,11 +82,11 @@ struct SolverState {
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
-                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag})
+                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag, (void*)fwd_started})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    z_alt = lam_alt = nullptr; fuse_state = 0; tile_fwd_tag = tile_bwd_tag = nullptr; sweep_tag = 0;
+    z_alt = lam_alt = nullptr; fuse_state = 0; tile_fwd_tag = tile_bwd_tag = fwd_started = nullptr; sweep_tag = 0;
     if (stream_lo) { (void)hipStreamDestroy(stream_lo); stream_lo = nullptr; }
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
@@ -667,6 +667,7 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
   if ((rc = dev_alloc(&S.tile_fwd_tag, (size_t)S.G + 8))) return rc;
   if ((rc = dev_alloc(&S.tile_bwd_tag, (size_t)S.G + 8))) return rc;
+  if ((rc = dev_alloc(&S.fwd_started, 16))) return rc;
   if ((rc = dev_alloc(&S.filt, lanes * 2 * S.info.filter_cap))) return rc;
   {
     // chunk boundaries of every P in [1, P_cap] (or of the one fixed P), back to back: block q holds q + 1 entries
@@ -710,7 +711,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.sigx = (S.opt.newton_only && S.use_sigx) ? S.sigx : nullptr;
   a.sigc = (S.opt.newton_only && S.use_sigc) ? S.sigc : nullptr;
   a.z_next = nullptr; a.lam_next = nullptr;
-  a.tile_fwd_tag = a.tile_bwd_tag = nullptr; a.sweep_tag = 0;
+  a.tile_fwd_tag = a.tile_bwd_tag = nullptr; a.sweep_tag = 0; a.fwd_started = nullptr;
   a.z = S.z; a.lam = S.lam; a.zl = S.zl; a.zu = S.zu; a.s = S.s; a.zs = S.zs;
   a.dz = S.dz; a.dlam = S.dlam; a.ds = S.ds;
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
@@ -1624,6 +1625,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   SolverState& S = *p->solver;
   const int n_fused = dto::fused_update_available(p) ? ((n - 1) / 2) * 2 : 0;
   const bool overlap = dto::overlap_sweeps(p, st);
+  static const bool gate = [] { const char* e = getenv("DTO_OVERLAP_GATE"); return !e || atoi(e) != 0; }();
   for (int it = 0; it < n; ++it) {
     if (it > 0 && it <= n_fused) {
       a.z_next = S.z_alt; a.lam_next = S.lam_alt;
@@ -1638,9 +1640,12 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
       // forward sweeps on the caller's stream, early back substitutions on the low-priority one, the rest and the post pass
       // after both have finished
       a.tile_fwd_tag = S.tile_fwd_tag; a.tile_bwd_tag = S.tile_bwd_tag; a.sweep_tag = ++S.sweep_tag;
+      a.fwd_started = gate ? S.fwd_started : nullptr;
+      if (gate) HIP_TRY(hipMemsetAsync(S.fwd_started, 0, sizeof(int), st));
       HIP_TRY(hipEventRecord(S.ev_fork, st));
       HIP_TRY(hipStreamWaitEvent(S.stream_lo, S.ev_fork, 0));
       if ((rc = dto::kkt_launch(p, DTO_KKT_FWD, a, st))) return rc;
+      if (gate && (rc = dto::kkt_launch(p, DTO_KKT_BWD_GATE, a, S.stream_lo))) return rc;
       // (DTO_OVERLAP_PASSES: further passes for the tiles whose block came too early; measured: 1, 3 and 8 passes give the
       // same 202 ms per iteration at 524 288 instances against 205 without the second stream)
       {
@@ -1652,7 +1657,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
       HIP_TRY(hipStreamWaitEvent(st, S.ev_join, 0));
       if ((rc = dto::kkt_launch(p, DTO_KKT_BWD_REST, a, st))) return rc;
       if ((rc = dto::kkt_launch(p, DTO_KKT_POST, a, st))) return rc;
-      a.tile_fwd_tag = a.tile_bwd_tag = nullptr;
+      a.tile_fwd_tag = a.tile_bwd_tag = nullptr; a.fwd_started = nullptr;
     } else {
       if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
     }
