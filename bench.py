@@ -177,8 +177,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--batch", type=int, default=524288,
                     help="instances per GPU (default sized for the 288 GB of an MI355X: ~0.36 MB of solver state per instance, ~70 GB stay free; "
-                         ">= 131072 instances run the plain sequential sweep two wavefronts per SIMD and the larger batch keeps the GPU "
-                         "filled while instances converge and leave, DESIGN.md sections 5, 7)")
+                         "> 65536 instances run the plain sequential sweeps, one wavefront per SIMD = 1024 tiles at a time; the larger batch keeps the "
+                         "GPU filled while instances converge and leave, DESIGN.md sections 4.2, 7)")
     ap.add_argument("--no-full-solves", action="store_true", help="skip the T=101 time-to-solution side measurement")
     ap.add_argument("--loop-only", action="store_true",
                     help="run only the headline loop (warm-up + timed iterations) and print value / ms_per_step: the command "

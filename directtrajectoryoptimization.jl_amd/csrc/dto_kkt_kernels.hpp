@@ -1992,8 +1992,8 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
 
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_kkt_fwd(dto_kkt_args a) { kkt_fwd_body<M, true>(a); }
-// the plain sequential sweep is asked to fit two wavefronts per SIMD (256 VGPRs): nothing else hides its memory and
-// dependent-issue latencies
+// the plain sequential sweep: ONE wavefront per SIMD (512 registers, nothing spilled inside the stage loops; rounds 1-2 ran it
+// at two with spills -- DESIGN.md section 4.2 for what that cost), the next stage's rows in flight during a stage
 template <class M>
 __global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_args a) {
   if (a.fwd_started && threadIdx.x == 0) atomicAdd(a.fwd_started, 1);

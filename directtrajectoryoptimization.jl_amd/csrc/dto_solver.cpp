@@ -867,7 +867,7 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   HIP_TRY(hipMemcpyAsync(S.d_inst_of_slot, S.inst_of_slot.data(), lanes * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));   // src / inst_new are host temporaries of this call
   S.G_active = g_new;
-  // too few tiles left for two wavefronts per SIMD: cut the horizon into chunks again (each chunk wave carries a spike, one
+  // too few tiles left to fill the wavefront slots of the sequential sweeps: cut the horizon into chunks again (each chunk wave carries a spike, one
   // wavefront per SIMD); the chunk arrays were sized for it when the batch was loaded
   if (S.P_cap > S.P0) {
     int P_new = 1;
