@@ -490,13 +490,16 @@ static int dev_alloc(T** p, size_t count) {
 // Inertia-correction rounds the sequential sweep does per launch (0 = all of them in one launch).  DTO_FWD_ROUNDS is a
 // measurement knob (tools/), not part of the interface.
 // Back substitutions next to the draining forward launch (csrc/dto_kkt_kernels.hpp: k_kkt_bwd_early): sequential form with
-// more tiles than wavefront slots, all rounds in one forward launch, the caller's stream not being captured into a graph.
+// more tiles than wavefront slots (1 024 at one wavefront per SIMD), all rounds in one forward launch, the caller's stream not being captured into a graph.
 // DTO_OVERLAP_SWEEPS=0 switches it off (read at every call: tests flip it).
 static bool overlap_sweeps(Problem* p, hipStream_t st) {
   SolverState& S = *p->solver;
   if (const char* e = getenv("DTO_OVERLAP_SWEEPS")) if (atoi(e) == 0) return false;
   const int tiles = S.G_active > 0 ? S.G_active : S.G;
-  if (S.P != 1 || tiles <= 2048 || S.opt.newton_only) return false;   // pays with more than two tiles per wavefront slot
+  // pays as soon as the tiles do not all fit the 1 024 wavefront slots at once (measured with the gate: 66 560 instances 37.1
+  // vs 41.7 ms per iteration, 90 112: 42.1 vs 44.9, 131 072: 53.7 vs 55.9, 524 288: 199.5 vs 206.7; 65 536: 29.9 vs 29.6)
+  static const int min_tiles = [] { const char* e = getenv("DTO_OVERLAP_MIN_TILES"); return e ? atoi(e) : 1024; }();
+  if (S.P != 1 || tiles <= min_tiles || S.opt.newton_only) return false;
   static const int per = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
   if (per > 0) return false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -256,7 +256,7 @@ int dto_solver_stats(dto_problem* p, int32_t* status, int32_t* iterations, doubl
  * 5 FACTOR_SOLVE, 6 LINESEARCH, 7 LS_REDUCE, 8 UPDATE, 9..12 the kernels behind FACTOR_SOLVE, 15 UPDATE_EVAL: UPDATE of one
  * iteration and EVAL of the next in one pass -- it writes into the second iterate buffers and swaps them: use it an even
  * number of times between calls that touch finished tiles) so a caller can time it with events on `stream`.
- * dto_solver_iterate itself runs UPDATE_EVAL wherever it can and, for batches of more than two tiles per wavefront slot, the
+ * dto_solver_iterate itself runs UPDATE_EVAL wherever it can and, for batches of more than 1 024 tiles (65 536 instances), the
  * back substitutions of finished tiles on a second low-priority stream next to the forward launch (joined before it
  * returns to the caller's stream order); both bit-identical to the plain sequence (DTO_FUSE_UPDATE=0, DTO_OVERLAP_SWEEPS=0). */
 int dto_solver_launch_op(dto_problem* p, int op, void* stream);

@@ -60,13 +60,13 @@ def test_sequential_and_time_partitioned_sweeps_solve_alike(model, T, B):
 
 
 def test_early_back_substitutions_on_the_second_stream_change_nothing():
-    """With more than two tiles per wavefront slot dto_solver_iterate runs the back substitutions of finished tiles on a
+    """With more tiles than wavefront slots (1 024) dto_solver_iterate runs the back substitutions of finished tiles on a
     low-priority stream next to the draining forward launch (k_kkt_bwd_early); DTO_OVERLAP_SWEEPS=0 is the plain launch
     sequence.  Same kernels' arithmetic on the same data: bit-identical iterates, multipliers, steps and scalars."""
     import os
     import torch
     s, p = product_solver("acrobot", 101)
-    tiles = 2049 + 3                     # > 2048 tiles: the overlapped path; a ragged last tile
+    tiles = 1024 + 40                    # > 1024 tiles (the wavefront slots of the sweeps): the overlapped path; a ragged last tile
     B = tiles * 64 - 17
     Zs = _guesses(s, p, 192, seed=4)
     Z = np.tile(Zs, (B // 192 + 1, 1))[:B]
