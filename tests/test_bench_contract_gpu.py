@@ -1,0 +1,55 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
+higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the `roofline` and `cpu_baseline` objects.  Run here
+on a small batch (8 192 instances, T = 200, a few iterations) as a child process, the way the driver starts it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _run(["--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "8192", "--horizon", "200", "--no-full-solves",
+              "--no-dense-blocks", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # value = iterations of all instances per second over the timed steps
+    assert abs(d["value"] - 8192 * 4 / (d["ms_per_step"] * 4e-3)) <= 0.02 * d["value"]
+
+
+def test_loop_only_line():
+    d = _run(["--loop-only", "--steps", "3", "--warmup", "1", "--batch", "8192", "--horizon", "200"])
+    assert d["steps"] == 3 and d["instances_per_gpu"] == 8192 and d["value"] > 0 and d["engine"] == "soa"
+
+
+def test_cpu_baseline_object():
+    """The `cpu_baseline` leg (oracle's C port in a child process started before torch / HIP) on a short horizon."""
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4096", "--horizon", "200", "--no-full-solves", "--no-dense-blocks"])
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "value_1core", "scaling_vs_1core", "all_cores", "host"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
+    assert c["host"]["affinity_cpus"] >= c["cores"]
