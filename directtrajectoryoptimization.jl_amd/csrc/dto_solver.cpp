@@ -514,6 +514,12 @@ static bool overlap_sweeps(Problem* p, hipStream_t st) {
   }
   return S.ev_fork && S.ev_join;
 }
+// chunks of the time-partitioned factorisation for `tiles` tiles when the caller leaves the choice to the library: as many as
+// keep every chunk wavefront resident at once, if that is at least three; else the plain sequential sweeps (see ensure_state)
+static int auto_chunks(int64_t tiles, int n_simd) {
+  const int64_t fit = tiles > 0 ? (int64_t)n_simd / tiles : 1;
+  return fit >= 3 ? (int)std::min<int64_t>(fit, 64) : 1;
+}
 static int fwd_rounds_per_launch() {
   static const int v = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
   return v;
@@ -545,7 +551,13 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
       n_simd = 4 * cus;
   }
-  int P_new = S.forced_P > 0 ? S.forced_P : (n_simd + G_new - 1) / G_new;
+  // Round 3 (tools/partition_sweep.py, acrobot T = 1000, ms per iteration): the time-partitioned form pays while ALL its chunk
+  // wavefronts (512 registers: one per SIMD) are resident at once and there are at least three chunks --
+  //   16 384 instances (256 tiles): 4 chunks 12.6, sequential 19.5;   18 432: 3 chunks 15.4, 4 chunks (1 152 waves) 20.1, seq. 20.2;
+  //   20 480: 3 chunks 16.0, seq. 20.5;   22 528: 3 chunks (1 056 waves) 24.3, seq. 20.9;   24 576: 2 chunks 22.6, seq. 21.2;
+  //   32 768: 2 chunks 25.5, seq. 22.5;   49 152: 2 chunks 41.9, seq. 25.9;   57 344: 43.6 / 28.1
+  // -- otherwise the sequential sweeps (one launch for all inertia-correction rounds, next stage in flight) are faster
+  int P_new = S.forced_P > 0 ? S.forced_P : auto_chunks(G_new, n_simd);
   P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / 8))));
   // per-stage state dimensions (dimensions(), src/dynamics.jl:206-211): the sequential sweep takes them as they come; the
   // time-partitioned form assumes one separator size, so such problems run with a single chunk
@@ -877,7 +889,7 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
     // only while the chunk waves (one per SIMD: 512-VGPR kernels) still fit the GPU at once; just above one residency the
     // in-kernel round loop of the sequential form is faster (262 144 instances, full solves: 1.285 M it/s with the switch
     // at 7/8 of the SIMDs, 1.295 M with this rule, 1.304 M without any switch -- the batch never gets that small)
-    while (P_new < S.P_cap && (int64_t)g_new * P_new * 2 <= (int64_t)S.n_simd) P_new *= 2;
+    while (P_new * 2 <= std::min(S.P_cap, auto_chunks(g_new, S.n_simd))) P_new *= 2;
     set_partitions_now(S, std::min(P_new, S.P_cap));
   }
   return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
