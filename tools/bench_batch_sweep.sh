@@ -5,7 +5,7 @@ TAG=${1:-r03}
 OUT=gpurun_out/sweep_$TAG
 mkdir -p $OUT
 : > $OUT/batch_sweep.txt
-for B in 64 1024 8192 32768 65536 66560 98304 131072 196608 262144 393216 524288; do
+for B in 64 1024 8192 12288 18432 24576 32768 49152 65536 66560 98304 131072 196608 262144 393216 524288; do
   timeout -k 5 400 python bench.py --loop-only --steps 20 --warmup 5 --batch $B 2> $OUT/err_$B.log | tail -1 >> $OUT/batch_sweep.txt
 done
 python - "$OUT/batch_sweep.txt" <<'PY'
