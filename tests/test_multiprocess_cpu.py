@@ -89,3 +89,20 @@ def test_chunked_guess_generation_is_the_same_stream():
     for chunk in (1, 7, 23, 100):
         got = make_guesses_device(s, p, 23, 5, torch.device("cpu"), chunk=chunk).numpy()
         assert np.array_equal(got, whole), chunk
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent starts two ranks as child processes
+    (torch.distributed.run, 127.0.0.1) without importing torch itself; rank 0 prints ONE line with n_gpus = 2.  The ranks run
+    the launcher self-test (gloo all-reduce on the CPU) instead of the GPU workload."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DTO_BENCH_PARENT_CHECK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["launcher_selftest"] is True and d["n_gpus"] == 2 and d["rank_sum"] == 1.0
+    assert "parent imported torch: False" in out.stderr
