@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
         "dto_solver_footprint": [vp, c_int64_p, c_int64_p, c_int64_p, C.POINTER(C.c_int)],
         "dto_solver_set_partitions": [vp, C.c_int],
         "dto_solver_partitions": [vp, C.POINTER(C.c_int)],
+        "dto_solver_fused_update": [vp, C.POINTER(C.c_int)],
         "dto_solver_set_engine": [vp, C.c_int],
         "dto_solver_engine": [vp, C.POINTER(C.c_int)],
         "dto_solver_release": [vp],

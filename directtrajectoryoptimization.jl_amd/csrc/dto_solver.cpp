@@ -748,7 +748,12 @@ static bool fused_update_available(Problem* p) {
   const size_t lanes = (size_t)S.G * 64;
   const size_t need = lanes * (size_t)(p->L.Nz + p->L.Nc) * sizeof(double);
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)40 << 30)) return false;
+  // head room left to the caller after the second buffers: an eighth of the device (36 GB of an MI355X's 288; the bench's own
+  // buffers at the default batch need 28 GB), DTO_FUSE_RESERVE_GB overrides; dto_solver_footprint reports whether the pass is on
+  static const double reserve_gb = [] { const char* e = getenv("DTO_FUSE_RESERVE_GB"); return e ? atof(e) : -1.0; }();
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  const size_t reserve = reserve_gb >= 0.0 ? (size_t)(reserve_gb * 1073741824.0) : total_b / 8;
+  if (free_b < need + reserve) return false;
   if (hipMalloc((void**)&S.z_alt, std::max<size_t>(8, lanes * p->L.Nz * sizeof(double))) != hipSuccess) { S.z_alt = nullptr; return false; }
   if (hipMalloc((void**)&S.lam_alt, std::max<size_t>(8, lanes * p->L.Nc * sizeof(double))) != hipSuccess) {
     (void)hipFree(S.z_alt); S.z_alt = nullptr; S.lam_alt = nullptr; return false;
@@ -885,12 +890,13 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   // too few tiles left to fill the wavefront slots of the sequential sweeps: cut the horizon into chunks again (each chunk wave carries a spike, one
   // wavefront per SIMD); the chunk arrays were sized for it when the batch was loaded
   if (S.P_cap > S.P0) {
-    int P_new = 1;
     // only while the chunk waves (one per SIMD: 512-VGPR kernels) still fit the GPU at once; just above one residency the
     // in-kernel round loop of the sequential form is faster (262 144 instances, full solves: 1.285 M it/s with the switch
-    // at 7/8 of the SIMDs, 1.295 M with this rule, 1.304 M without any switch -- the batch never gets that small)
-    while (P_new * 2 <= std::min(S.P_cap, auto_chunks(g_new, S.n_simd))) P_new *= 2;
-    set_partitions_now(S, std::min(P_new, S.P_cap));
+    // at 7/8 of the SIMDs, 1.295 M with this rule, 1.304 M without any switch -- the batch never gets that small).
+    // The same ">= 3 chunks or sequential" rule as when a batch is loaded (auto_chunks returns 1 or >= 3; the cstart tables
+    // hold every P in [1, P_cap]): two chunks were measured slower than the sequential sweeps
+    const int P_new = std::max(1, std::min(S.P_cap, auto_chunks(g_new, S.n_simd)));
+    set_partitions_now(S, P_new);
   }
   return fetch_scalars(p, st);         // the host copy of the scalar block follows the move
 }
@@ -1596,13 +1602,17 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   if (b->ldx < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldx < num_variables");
   int rc = p->ensure_device();
   if (rc) return rc;
-  p->im_active = dto::use_im(p, b->B);
-  if (p->im_active) {
-    if ((rc = dto::ensure_im_state(p, b->B))) return rc;
-    if (p->solver) p->solver->begun = false;
-    return dto::im_begin(p, opt, b, false, 0.0);
-  }
+  // no batch is begun until this call has succeeded: a failed set-up must not leave the previous batch (of either engine)
+  // marked as running, or a caller that ignores the error would silently advance it
+  if (p->solver) p->solver->begun = false;
   if (p->im) p->im->begun = false;
+  p->im_active = false;
+  if (dto::use_im(p, b->B)) {
+    if ((rc = dto::ensure_im_state(p, b->B))) return rc;
+    if ((rc = dto::im_begin(p, opt, b, false, 0.0))) return rc;
+    p->im_active = true;
+    return DTO_OK;
+  }
   rc = dto::ensure_state(p, b->B);
   if (rc) return rc;
   SolverState& S = *p->solver;
@@ -1868,6 +1878,13 @@ int dto_solver_partitions(dto_problem* h, int* partitions) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !p->solver || !partitions) return set_error(DTO_ERR_INVALID, "no solver state");
   *partitions = p->solver->P;
+  return DTO_OK;
+}
+
+int dto_solver_fused_update(dto_problem* h, int* fused) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !fused) return set_error(DTO_ERR_INVALID, "null argument");
+  *fused = (!p->im_active && p->solver && p->solver->begun && dto::fused_update_available(p)) ? 1 : 0;
   return DTO_OK;
 }
 

@@ -528,6 +528,12 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_solver_partitions(self._solve_nlp._h, C.byref(v)))
         return v.value
 
+    def fused_update(self) -> bool:
+        """True if iterate_batch runs UPDATE + EVAL as one pass for the begun batch (include/dto.h: dto_solver_fused_update)."""
+        v = C.c_int(0)
+        capi.check(self._solve_nlp._lib.dto_solver_fused_update(self._solve_nlp._h, C.byref(v)))
+        return bool(v.value)
+
     def launch_op(self, name: str, stream=0):
         """Launch one kernel of the iteration (diagnostic / timing).  `name`: a key of KKT_OPS (SoA engine) or 'im_' + a key of
         IM_OPS (instance-major engine: on the work list its last pass built)."""

@@ -264,6 +264,10 @@ int dto_solver_launch_op(dto_problem* p, int op, void* stream);
  * tiles x chunks fills the GPU's SIMDs; 1 = plain sequential sweep.  Takes effect at the next begin/step. */
 int dto_solver_set_partitions(dto_problem* p, int partitions);
 int dto_solver_partitions(dto_problem* p, int* partitions);
+/* 1 if dto_solver_iterate runs UPDATE of one iteration and EVAL of the next as one pass for the batch begun last (the second
+ * iterate buffers could be allocated: an eighth of the device stays free after them, DTO_FUSE_RESERVE_GB overrides; and
+ * DTO_FUSE_UPDATE is not 0), else 0: the two-kernel sequence, bit-identical */
+int dto_solver_fused_update(dto_problem* p, int* fused);
 /* Engine behind dto_solver_begin / dto_solve_batch: 0 = automatic, 1 = SoA tiles (64 instances share a wavefront for the whole
  * solve; time-partitioned sweeps for small batches), 2 = instance-major (csrc/dto_im_kernels.hpp: per-instance stage records,
  * work lists, one factorisation attempt per instance and pass; exact-Hessian models).  Automatic = SoA tiles (the faster one

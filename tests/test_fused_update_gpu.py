@@ -33,6 +33,7 @@ def _run(s, Z, fused, calls):
     try:
         d = torch.tensor(Z, device="cuda")
         s.begin_batch(d.data_ptr(), Z.shape[0], Z.shape[1])
+        assert s.fused_update() == fused      # a silent fall-back to the two-kernel sequence would compare it with itself
         for n in calls:
             s.iterate_batch(n)
         out = {k: s.peek_batch(k) for k in NAMES}

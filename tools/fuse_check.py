@@ -1,5 +1,5 @@
 import os, sys, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 import dto_amd
 from dto_amd import problems as P

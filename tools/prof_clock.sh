@@ -5,9 +5,11 @@ B=${1:-131072}; TAG=${2:-r03}
 OUT=$PWD/gpurun_out/clock_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+[ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
 cd /tmp
-timeout -k 5 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/raw -- python3 $GRAFT_REPO_ROOT/bench.py --loop-only --steps 6 --warmup 2 --batch $B > $OUT/run.log 2>&1
-cd $GRAFT_REPO_ROOT
+timeout -k 5 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/raw -- python3 $ROOT/bench.py --loop-only --steps 6 --warmup 2 --batch $B > $OUT/run.log 2>&1
+cd $ROOT
 python3 - "$OUT" <<'PY' | tee $OUT/clock.txt
 import csv, glob, sys, collections
 out = sys.argv[1]

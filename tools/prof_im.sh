@@ -7,10 +7,12 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+[ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
 cd /tmp
-timeout -k 5 420 rocprofv3 --kernel-trace --output-format rocpd -d $OUT -o run -- python3 $GRAFT_REPO_ROOT/tools/im_vs_soa.py "$@" > $OUT/run.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --output-format rocpd -d $OUT -o run -- python3 $ROOT/tools/im_vs_soa.py "$@" > $OUT/run.log 2>&1
 echo "rocprofv3 exit: $?" >> $OUT/run.log
-cd $GRAFT_REPO_ROOT
+cd $ROOT
 DB=$(find $OUT -name "*.db" | head -1)
 grep '^{' $OUT/run.log
 [ -n "$DB" ] && python3 tools/rocpd_stats.py $DB $OUT/kernel_stats.csv | head -14

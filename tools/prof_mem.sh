@@ -5,7 +5,9 @@ B=${1:-131072}; TAG=${2:-r03}
 OUT=$PWD/gpurun_out/mem_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="$GRAFT_REPO_ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
+CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+[ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
 cd /tmp
 timeout -k 5 120 rocprofv3 --list-avail > $OUT/avail.txt 2>&1
 grep -o "TCP_[A-Z0-9_]*\|TCC_[A-Z0-9_]*\|TA_[A-Z0-9_]*\|TD_[A-Z0-9_]*" $OUT/avail.txt | sort -u > $OUT/avail_mem_names.txt
@@ -21,7 +23,7 @@ for SET in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANS
   timeout -k 5 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $CMD > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET) exit $?" >> $OUT/passes.log
 done
-cd $GRAFT_REPO_ROOT
+cd $ROOT
 python3 tools/pmc_sq_summary.py $OUT/mem_counters.json $(find $OUT -name "*counter_collection.csv") > $OUT/mem_counters.txt 2>&1
 grep -A30 "k_kkt_fwd_seq\|k_kkt_bwd_seq" $OUT/mem_counters.txt | head -90
 tail -3 $OUT/pass*.log | head -60

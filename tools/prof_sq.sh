@@ -5,7 +5,9 @@ B=${1:-131072}; TAG=${2:-r03}
 OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="$GRAFT_REPO_ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
+CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+[ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
 cd /tmp
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
@@ -15,7 +17,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 5 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $CMD > $OUT/pass$i.log 2>&1
   echo "pass $i exit $?" >> $OUT/passes.log
 done
-cd $GRAFT_REPO_ROOT
+cd $ROOT
 python3 tools/pmc_sq_summary.py $OUT/sq_counters.json $(find $OUT -name "*counter_collection.csv") > $OUT/sq_counters.txt 2>&1
 grep -A26 "k_kkt_fwd_seq\|k_kkt_bwd_seq" $OUT/sq_counters.txt | head -80
 rm -rf $OUT/pass1 $OUT/pass2 $OUT/pass3
