@@ -378,6 +378,13 @@ def generate_wide_source(st: Structure, name: str) -> str:
     return "\n".join(out) + "\n"
 
 
+def with_im_engine() -> bool:
+    """The instance-major engine (csrc/dto_im_kernels.hpp) is an opt-in experiment measured 1.7x slower than the SoA tiles
+    (DESIGN.md section 5): it is compiled into a plugin only when DTO_PLUGIN_IM=1 is set while the plugin is generated (its own
+    cache key).  Default plugins carry no instance-major kernels: dto_solver_set_engine(h, 2) then reports DTO_ERR_UNSUPPORTED."""
+    return os.environ.get("DTO_PLUGIN_IM", "0") == "1"
+
+
 def generate_source(st: Structure, name: str) -> str:
     if st.wide:
         return generate_wide_source(st, name)
@@ -386,7 +393,9 @@ def generate_source(st: Structure, name: str) -> str:
     out.append(f"// generated by directtrajectoryoptimization.jl_amd/plugin.py (v{GENERATOR_VERSION}) -- do not edit")
     out.append('#include "dto_eval_kernels.hpp"')
     out.append('#include "dto_kkt_kernels.hpp"')
-    out.append('#include "dto_im_kernels.hpp"')
+    with_im = with_im_engine()
+    if with_im:
+        out.append('#include "dto_im_kernels.hpp"')
     out.append("namespace {")
     mx = lambda xs: max([0] + [int(x) for x in xs])
     max_nx = mx([d.num_state for d in st.dyn] + [d.num_next_state for d in st.dyn] + [c.num_state for c in st.cost])
@@ -558,11 +567,13 @@ def generate_source(st: Structure, name: str) -> str:
                    f"{g.num_jacobian}, {nh}, gen_jr, gen_jc, gen_hr, gen_hc, {len(g.indices_inequality)}, gen_iq}};")
     out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::launch_eval<Model>(op, a, s); }")
     out.append("static int launch_kkt(int op, const dto_kkt_args* a, void* s) { return dto::launch_kkt<Model>(op, a, s); }")
-    out.append("static int launch_im(int op, const dto_im_args* a, void* s) { return dto::im::launch_im<Model>(op, a, s); }")
+    if with_im:
+        out.append("static int launch_im(int op, const dto_im_args* a, void* s) { return dto::im::launch_im<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, {'&k_general' if g is not None else 'nullptr'}, {1 if h else 0},")
-    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>, nullptr, nullptr, launch_im, dto::im::im_info<Model>")
+    out.append(f"  Model::MAX_KEY, launch, launch_kkt, dto::kkt_info<Model>, nullptr, nullptr, "
+               + ("launch_im, dto::im::im_info<Model>" if with_im else "nullptr, nullptr"))
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')

@@ -18,6 +18,38 @@ from conftest import product_solver
 
 pytestmark = pytest.mark.gpu
 
+IM_MODELS = [("pendulum", 50), ("acrobot", 101), ("cartpole", 200), ("car", 51)]
+_IM_CACHE = {}
+
+
+def im_solver(model, T):
+    """A Solver whose plugin carries the instance-major kernels: they are compiled in only under DTO_PLUGIN_IM=1
+    (plugin.py:with_im_engine; __graft_entry__.build() prebuilds these four variants)."""
+    import os
+    import dto_amd
+    from dto_amd import problems as P
+    if (model, T) not in _IM_CACHE:
+        old = os.environ.get("DTO_PLUGIN_IM")
+        os.environ["DTO_PLUGIN_IM"] = "1"
+        try:
+            p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=True)
+            s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name=model + "_im")
+        finally:
+            if old is None:
+                del os.environ["DTO_PLUGIN_IM"]
+            else:
+                os.environ["DTO_PLUGIN_IM"] = old
+        _IM_CACHE[(model, T)] = (s, p)
+    return _IM_CACHE[(model, T)]
+
+
+def test_default_plugins_carry_no_instance_major_engine():
+    import dto_amd
+    s, p = product_solver("pendulum", 50)
+    with pytest.raises(Exception):
+        s.set_engine("im")
+    s.set_engine("auto")
+
 
 def _guesses(s, p, B, seed=0):
     import dto_amd
@@ -49,7 +81,7 @@ def _run_iterations(s, Z, engine, n_iter, names):
 @pytest.mark.parametrize("model,T,B", [("pendulum", 50, 70), ("acrobot", 101, 130), ("cartpole", 200, 3), ("car", 51, 66)])
 def test_first_iterations_match_the_soa_engine(model, T, B):
     """Same guesses, k iterations on each engine: iterates, multipliers, bound multipliers, slacks and the last step."""
-    s, p = product_solver(model, T)
+    s, p = im_solver(model, T)
     Z = _guesses(s, p, B, seed=11)
     names = ["z", "multipliers", "dz", "dmultipliers", "z_lower", "z_upper", "slack", "slack_multipliers", "dslack"]
     for k in (1, 3):
@@ -83,7 +115,7 @@ def test_full_solves_are_kkt_points(model, T, B):
     engine on the same guesses."""
     import torch
     from test_solve_gpu import kkt_report, oracle_for
-    s, p = product_solver(model, T)
+    s, p = im_solver(model, T)
     Z = _guesses(s, p, B, seed=5)
     nz, nc = s.nlp.num_variables, s.nlp.num_constraint
     res = {}

@@ -27,6 +27,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     T, B = a.horizon, a.batch
+    os.environ["DTO_PLUGIN_IM"] = "1"      # the instance-major kernels are compiled into a plugin only on request
     p = P.build_acrobot(T=T, evaluate_hessian=True)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
     nz, nc = s.nlp.num_variables, s.nlp.num_constraint
