@@ -35,8 +35,15 @@ function _push!(w::_DagWriter, key, json::String)
     return w.index[key]
 end
 
+# The reference pins Symbolics 0.1.29 - 0.1.32 (Project.toml:22; SymbolicUtils 0.11 - 0.13 underneath).  In that series the
+# accessor of the expression inside a `Num` is `Symbolics.value` (`unwrap` was added in a later series and is the name used
+# from Symbolics 1.x on); the tree interface is `SymbolicUtils.istree / operation / arguments` there (`iscall` replaces
+# `istree` from SymbolicUtils 2.x on).  Both spellings are resolved once, at load time, so the walker runs on either.
+const _unwrap = isdefined(Symbolics, :unwrap) ? Symbolics.unwrap : Symbolics.value
+const _istree = isdefined(SymbolicUtils, :istree) ? SymbolicUtils.istree : SymbolicUtils.iscall
+
 function _visit!(w::_DagWriter, ex)
-    ex = Symbolics.unwrap(ex)
+    ex = _unwrap(ex)
     haskey(w.index, ex) && return w.index[ex]
     if ex isa Number
         return _push!(w, ex, "{\"op\":\"const\",\"value\":$(_num(ex))}")
@@ -45,7 +52,7 @@ function _visit!(w::_DagWriter, ex)
         name, i = w.varid[ex]
         return _push!(w, ex, "{\"op\":\"var\",\"name\":\"$name\",\"index\":$i}")
     end
-    SymbolicUtils.istree(ex) || error("unsupported leaf in a model expression: $ex")
+    _istree(ex) || error("unsupported leaf in a model expression: $ex")
     f = SymbolicUtils.operation(ex)
     args = [_visit!(w, a) for a in SymbolicUtils.arguments(ex)]
     list = join(args, ",")
@@ -61,9 +68,9 @@ function _visit!(w::_DagWriter, ex)
         return _push!(w, ex, "{\"op\":\"pow\",\"args\":[$list]}")
     elseif f === ifelse || nameof(f) === :ifelse        # IfElse.ifelse(cond, a, b), cond = (lhs < rhs) or (lhs <= rhs)
         c = SymbolicUtils.arguments(ex)[1]
-        cf = SymbolicUtils.operation(Symbolics.unwrap(c))
+        cf = SymbolicUtils.operation(_unwrap(c))
         cmp = cf === (<) ? "lt" : (cf === (<=) ? "le" : error("ifelse condition must be < or <="))
-        l, r = [_visit!(w, a) for a in SymbolicUtils.arguments(Symbolics.unwrap(c))]
+        l, r = [_visit!(w, a) for a in SymbolicUtils.arguments(_unwrap(c))]
         return _push!(w, ex, "{\"op\":\"ifelse\",\"cmp\":\"$cmp\",\"args\":[$l,$r,$(args[2]),$(args[3])]}")
     elseif haskey(_DTO_FUNCS, f)
         return _push!(w, ex, "{\"op\":\"call\",\"fn\":\"$(_DTO_FUNCS[f])\",\"args\":[$list]}")
@@ -75,7 +82,7 @@ end
 function _class_json(dims::Vector{Pair{String,Int}}, vars::Dict{String,Vector{Num}}, outputs; extra = "")
     w = _DagWriter(String[], Dict{Any,Int}(), Dict{Any,Tuple{String,Int}}())
     for (name, vs) in vars, (i, v) in enumerate(vs)
-        w.varid[Symbolics.unwrap(v)] = (name, i - 1)
+        w.varid[_unwrap(v)] = (name, i - 1)
     end
     outs = [_visit!(w, o) for o in outputs]
     head = join(["\"$k\":$v" for (k, v) in dims], ",")

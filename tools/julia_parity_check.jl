@@ -7,8 +7,8 @@
 #     julia --project=/path/to/DirectTrajectoryOptimization.jl tools/julia_parity_check.jl tests/golden
 #     julia --project=/path/to/DirectTrajectoryOptimization.jl tools/julia_parity_check.jl tests/golden --solve   # + Ipopt
 #
-# For every fixture it rebuilds the same problem with the reference's own constructors (models as in examples/*.jl and
-# test/*.jl), evaluates the five MOI methods of src/moi.jl at the fixture's point (z, mu, sigma) and compares
+# For every fixture it rebuilds the same problem with the reference's own constructors and the reference's own model
+# functions (parsed out of examples/*/*.jl under DTO_REFERENCE, default: the package directory), evaluates the five MOI methods of src/moi.jl at the fixture's point (z, mu, sigma) and compares
 #   * totals and both structures bit for bit            (src/data.jl:61-220)
 #   * f, grad f, c, J, H                                to 1e-8 relative (the tolerance of BASELINE.json's north star).
 # The fixtures were produced by oracle/ (sympy, 30-digit mpmath) -- agreement here pins the oracle, and with it every
@@ -18,70 +18,49 @@ using LinearAlgebra, JSON
 const DTO = DirectTrajectoryOptimization
 const MOI = DTO.MOI
 
-# ---------------------------------------------------------------- models (examples/*/*.jl, test/dynamics.jl)
-function pendulum(x, u, w)
-    mass, length_com, gravity, damping = 1.0, 0.5, 9.81, 0.1
-    [x[2], (u[1] / ((mass * length_com * length_com)) - gravity * sin(x[1]) / length_com - damping * x[2] / (mass * length_com * length_com))]
+# ---------------------------------------------------------------- models: the reference's OWN definitions, read at run time
+# Symbolics' sparsity patterns depend on how an expression is written (`length1 * length1` vs `length1^2`, `[f1; f2] .* v` vs a
+# diagonal matrix product, `0` vs `0.0` in a matrix literal: SURVEY.md App. A.4), so the models are not restated here: the
+# top-level `function` definitions (and the two obstacle constants) are taken verbatim out of the reference's example files,
+# each example into its own module, WITHOUT running the rest of the example (no solve, no plotting).
+const REF = get(ENV, "DTO_REFERENCE", pkgdir(DirectTrajectoryOptimization))
+
+defname(ex) = begin
+    (ex isa Expr && (ex.head == :function || ex.head == :(=))) || return nothing
+    sig = ex.args[1]
+    while sig isa Expr && (sig.head == :where || sig.head == :(::)); sig = sig.args[1]; end
+    if ex.head == :(=) && sig isa Symbol; return sig; end                       # plain assignment  name = value
+    (sig isa Expr && sig.head == :call && sig.args[1] isa Symbol) ? sig.args[1] : nothing
 end
-function cartpole(x, u, w)
-    mc, mp, l, g = 1.0, 0.2, 0.5, 9.81
-    q, qd = x[1:2], x[3:4]
-    s, c = sin(q[2]), cos(q[2])
-    H = [mc+mp mp*l*c; mp*l*c mp*l^2]
-    Cm = [0.0 -mp*qd[2]*l*s; 0.0 0.0]
-    G = [0.0, mp * g * l * s]
-    B = [1.0, 0.0]
-    qdd = -H \ (Cm * qd + G - B * u[1])
-    [qd; qdd]
+
+function load_example(relpath, names)
+    m = Module(gensym(:reference_example))
+    Core.eval(m, :(using LinearAlgebra))
+    src = read(joinpath(REF, relpath), String)
+    pos, found = 1, Symbol[]
+    while pos <= ncodeunits(src)
+        ex, pos = Meta.parse(src, pos; raise=false, greedy=true)
+        n = defname(ex)
+        if n !== nothing && n in names
+            Core.eval(m, ex)
+            push!(found, n)
+        end
+    end
+    all(n -> n in found, names) || error("$relpath: definitions not found: $(setdiff(names, found))")
+    m
 end
-function acrobot(x, u, w)
-    mass1, inertia1, length1, lengthcom1 = 1.0, 0.33, 1.0, 0.5
-    mass2, inertia2, length2, lengthcom2 = 1.0, 0.33, 1.0, 0.5
-    gravity, friction1, friction2 = 9.81, 0.1, 0.1
-    function M(x, w)
-        a = inertia1 + inertia2 + mass2 * length1^2 + 2.0 * mass2 * length1 * lengthcom2 * cos(x[2])
-        b = inertia2 + mass2 * length1 * lengthcom2 * cos(x[2])
-        c = inertia2
-        [a b; b c]
-    end
-    function Mass_inv(x, w)
-        m = M(x, w)
-        1.0 / (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * [m[2, 2] -m[1, 2]; -m[2, 1] m[1, 1]]
-    end
-    function tau(x, w)
-        a = (-1.0 * mass1 * gravity * lengthcom1 * sin(x[1]) - mass2 * gravity * (length1 * sin(x[1]) + lengthcom2 * sin(x[1] + x[2])))
-        b = -1.0 * mass2 * gravity * lengthcom2 * sin(x[1] + x[2])
-        [a, b]
-    end
-    function Cor(x, w)
-        a = -2.0 * mass2 * length1 * lengthcom2 * sin(x[2]) * x[4]
-        b = -1.0 * mass2 * length1 * lengthcom2 * sin(x[2]) * x[4]
-        c = mass2 * length1 * lengthcom2 * sin(x[2]) * x[3]
-        [a b; c 0.0]
-    end
-    Bm(x, w) = [0.0, 1.0]
-    q, v = view(x, 1:2), view(x, 3:4)
-    qdd = Mass_inv(q, w) * (-1.0 * Cor(x, w) * v + tau(q, w) + Bm(q, w) * u[1] - [friction1 0.0; 0.0 friction2] * v)
-    [x[3], x[4], qdd[1], qdd[2]]
-end
-car(x, u, w) = [u[1] * cos(x[3]), u[1] * sin(x[3]), u[2]]
-midpoint(f, h) = (y, x, u, w) -> y - (x + h * f(0.5 * (x + y), u, w))
-function rk3_implicit(f, h)
-    function explicit(x, u, w)
-        k1 = f(x, u, w) * h
-        k2 = f(x + 0.5 * k1, u, w) * h
-        k3 = f(x - k1 + 2.0 * k2, u, w) * h
-        x + (k1 + 4.0 * k2 + k3) / 6.0
-    end
-    (y, x, u, w) -> y - explicit(x, u, w)
-end
+
+const EX_PENDULUM = load_example("examples/pendulum/pendulum.jl", [:pendulum, :midpoint_implicit])
+const EX_CARTPOLE = load_example("examples/cartpole/cartpole.jl", [:cartpole, :rk3_explicit, :rk3_implicit])
+const EX_ACROBOT = load_example("examples/acrobot/acrobot.jl", [:acrobot, :midpoint_implicit])
+const EX_CAR = load_example("examples/car/car.jl", [:car, :midpoint_implicit, :p_obs, :r_obs, :obs])
 
 # ---------------------------------------------------------------- problems of the fixtures (oracle/sympy_models.py:build)
 function build(model, T)
     eh = true
     if model == "pendulum"
         n, m = 2, 1; x1, xT = [0.0, 0.0], [pi, 0.0]
-        d = Dynamics(midpoint(pendulum, 0.05), n, n, m, evaluate_hessian=eh)
+        d = Dynamics(EX_PENDULUM.midpoint_implicit, n, n, m, evaluate_hessian=eh)     # examples/pendulum/pendulum.jl:36-39
         ct = Cost((x, u, w) -> 0.1 * dot(x[1:2], x[1:2]) + 0.1 * dot(u, u), n, m, evaluate_hessian=eh)
         cT = Cost((x, u, w) -> 0.1 * dot(x[1:2], x[1:2]), n, 0, evaluate_hessian=eh)
         cons = [Constraint((x, u, w) -> x - x1, n, m, evaluate_hessian=eh), [Constraint() for t = 2:T-1]...,
@@ -89,7 +68,7 @@ function build(model, T)
         bnds = [[Bound(n, m) for t = 1:T-1]..., Bound(n, 0)]
     elseif model == "cartpole"
         n, m = 4, 1; x1, xT = zeros(4), [0.0, pi, 0.0, 0.0]
-        d = Dynamics(rk3_implicit(cartpole, 0.05), n, n, m, evaluate_hessian=eh)
+        d = Dynamics(EX_CARTPOLE.rk3_implicit, n, n, m, evaluate_hessian=eh)         # examples/cartpole/cartpole.jl:44-56
         ct = Cost((x, u, w) -> 0.5 * 1.0e-2 * dot(x - xT, x - xT) + 0.5 * 1.0e-1 * dot(u, u), n, m, evaluate_hessian=eh)
         cT = Cost((x, u, w) -> 0.5 * 1.0e2 * dot(x - xT, x - xT), n, 0, evaluate_hessian=eh)
         cons = [Constraint((x, u, w) -> x - x1, n, m, evaluate_hessian=eh), [Constraint() for t = 2:T-1]...,
@@ -97,7 +76,7 @@ function build(model, T)
         bnds = [[Bound(n, m, action_lower=[-3.0], action_upper=[3.0]) for t = 1:T-1]..., Bound(n, 0)]
     elseif model == "acrobot" || model == "acrobot_bounds"
         n, m = 4, 1; x1 = zeros(4)
-        d = Dynamics(midpoint(acrobot, 0.05), n, n, m, evaluate_hessian=eh)
+        d = Dynamics(EX_ACROBOT.midpoint_implicit, n, n, m, evaluate_hessian=eh)      # examples/acrobot/acrobot.jl:88-91
         ct = Cost((x, u, w) -> 0.1 * dot(x[3:4], x[3:4]) + 0.1 * dot(u, u), n, m, evaluate_hessian=eh)
         cT = Cost((x, u, w) -> 0.1 * dot(x[3:4], x[3:4]), n, 0, evaluate_hessian=eh)
         if model == "acrobot"
@@ -113,10 +92,10 @@ function build(model, T)
         end
     elseif model == "car"
         n, m = 3, 2; x1, xT = zeros(3), [1.0, 1.0, 0.0]
-        d = Dynamics(midpoint(car, 0.1), n, n, m, evaluate_hessian=eh)
+        d = Dynamics(EX_CAR.midpoint_implicit, n, n, m, evaluate_hessian=eh)          # examples/car/car.jl:23-26
         ct = Cost((x, u, w) -> 0.0 * dot(x - xT, x - xT) + 1.0 * dot(u, u), n, m, evaluate_hessian=eh)
         cT = Cost((x, u, w) -> 0.0 * dot(x - xT, x - xT), n, 0, evaluate_hessian=eh)
-        obs = (x, u, w) -> [0.1^2 - dot(x[1:2] - [0.5, 0.5], x[1:2] - [0.5, 0.5])]
+        obs = EX_CAR.obs                                                               # examples/car/car.jl:51-56
         cons = [[Constraint(obs, n, m, indices_inequality=collect(1:1), evaluate_hessian=eh) for t = 1:T-1]...,
                 Constraint(obs, n, 0, indices_inequality=collect(1:1), evaluate_hessian=eh)]
         lo, hi = [-0.5, -0.5], [0.5, 0.5]
