@@ -203,6 +203,7 @@ struct DirectIO {
   __device__ __forceinline__ double sigc_dyn(int) const { return 0.0; }
   __device__ __forceinline__ double slack(int j) const { return Bp[RC::B_S + D::slack(j)]; }
   __device__ __forceinline__ double slack_mult(int j) const { return Bp[RC::B_ZS + D::slack(j)]; }
+  static constexpr bool PAIR_CARRY = false;
   __device__ __forceinline__ void put_carry(int i, double v) const { Cp[i] = v; }
   __device__ __forceinline__ double carry(int i) const { return Cp[i]; }
   __device__ __forceinline__ void put_dp(int i, double v) const { Dp[i] = v; }
@@ -743,6 +744,7 @@ struct LdsIO {
   __device__ __forceinline__ double sigc_dyn(int) const { return 0.0; }
   __device__ __forceinline__ double slack(int j) const { return Bp[RC::B_S + D::slack(j)]; }
   __device__ __forceinline__ double slack_mult(int j) const { return Bp[RC::B_ZS + D::slack(j)]; }
+  static constexpr bool PAIR_CARRY = false;
   __device__ __forceinline__ void put_carry(int, double) const {}   // the kernel stores the carry-in itself (staged)
   __device__ __forceinline__ double carry(int i) const { return cv[i]; }
   __device__ __forceinline__ void put_dp(int i, double v) const { dstage[i] = v; }

@@ -192,6 +192,7 @@ __device__ __forceinline__ T uload(const T* p, int64_t i) {
 // bytes) reads as 0 and drops writes; the row offset itself travels in the scalar offset, which the hardware's range check
 // does not include -- callers pass valid rows only.
 typedef int dto_v2i __attribute__((ext_vector_type(2)));
+typedef int dto_v4i __attribute__((ext_vector_type(4)));
 struct TileBuf {
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ void bind(const double* base, int64_t tile, int64_t rows) {
@@ -203,6 +204,29 @@ struct TileBuf {
   }
   __device__ __forceinline__ void st(int row, double v) const {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dto_v2i, v), r, threadIdx.x * 8u, row << 9, 0);
+  }
+  // PAIR-INTERLEAVED rows (the carry records, round 4): inside a block of rows that starts at `row0` the logical rows 2k and
+  // 2k + 1 share one 1 KiB line, 16 bytes per lane, so that a wavefront moves two rows with ONE buffer_load/store_dwordx4.
+  // The sweeps at one wavefront per SIMD have nobody to hide their vector-memory issue behind: 14 carry rows per stage are 7
+  // instructions instead of 14 going forward and coming back.  A lane that must not store (its attempt is lost, or it did not
+  // ask for a factorisation) gets an offset beyond the resource -- the hardware drops the write -- so the stores are
+  // straight-line code the scheduler can spread over the arithmetic instead of a branch around a burst.
+  __device__ __forceinline__ void ld2(int row0, int k, double& v0, double& v1) const {
+    const dto_v4i q = __builtin_amdgcn_raw_buffer_load_b128(r, threadIdx.x * 16u, (row0 << 9) + (k << 10), 0);
+    v0 = __builtin_bit_cast(double, dto_v2i{q[0], q[1]});
+    v1 = __builtin_bit_cast(double, dto_v2i{q[2], q[3]});
+  }
+  __device__ __forceinline__ void st2(int row0, int k, double v0, double v1, bool on) const {
+    const dto_v2i a0 = __builtin_bit_cast(dto_v2i, v0), a1 = __builtin_bit_cast(dto_v2i, v1);
+    __builtin_amdgcn_raw_buffer_store_b128(dto_v4i{a0[0], a0[1], a1[0], a1[1]}, r, on ? threadIdx.x * 16u : 0x80000000u,
+                                           (row0 << 9) + (k << 10), 0);
+  }
+  __device__ __forceinline__ double ld1p(int row0, int i) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, threadIdx.x * 16u + (i & 1) * 8u, (row0 << 9) + ((i >> 1) << 10), 0));
+  }
+  __device__ __forceinline__ void st1p(int row0, int i, double v, bool on) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dto_v2i, v), r, on ? threadIdx.x * 16u + (i & 1) * 8u : 0x80000000u,
+                                          (row0 << 9) + ((i >> 1) << 10), 0);
   }
 };
 struct SoaBufs {
@@ -285,8 +309,8 @@ void fill_info(dto_kkt_info* o) {
   if constexpr (K < M::N_KIND) {
     using D = KindDims<M, K>;
     o->rec_size[K] = D::REC;
-    o->fac_size[K] = D::FAC;
-    o->fac_size_seq[K] = D::F_CX;
+    o->fac_size[K] = (D::FAC + 1) & ~1;        // even: the carry rows are stored pair-interleaved (TileBuf::st2)
+    o->fac_size_seq[K] = (D::F_CX + 1) & ~1;
     o->n_ineq[K] = D::QI;
     fill_info<M, K + 1>(o);
   }
@@ -366,7 +390,7 @@ struct SoaIO {
   double* facp;
   __device__ __forceinline__ SoaIO(const dto_kkt_args& a_, int64_t g_, int t_)
       : a(a_), g(g_), t(t_), z0(uload(a_.zoff, t_)), recp(a_.rec + ((g_ * a_.rec_total + uload(a_.recoff, t_)) << 6) + threadIdx.x),
-        facp(a_.fac + ((g_ * a_.fac_total + uload(a_.facoff, t_)) << 6) + threadIdx.x) {}
+        facp(a_.fac + ((g_ * a_.fac_total + uload(a_.facoff, t_)) << 6) + 2 * threadIdx.x) {}
   __device__ __forceinline__ double rec(int e) const { return recp[(int64_t)e << 6]; }
   __device__ __forceinline__ double p(int i) const { return *soa(a.z, g, a.Nz, z0 + i); }
   __device__ __forceinline__ double y(int i) const { return *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i); }
@@ -383,14 +407,30 @@ struct SoaIO {
   __device__ __forceinline__ double slack(int j) const { return *soa(a.s, g, a.Ni, uload(a.ioff, t) + D::slack(j)); }
   __device__ __forceinline__ double slack_mult(int j) const { return *soa(a.zs, g, a.Ni, uload(a.ioff, t) + D::slack(j)); }
   // carry-in record of the stage (written by the forward sweep, read by the backward sweep)
-  __device__ __forceinline__ void put_carry(int i, double v) const { facp[(int64_t)i << 6] = v; }
-  __device__ __forceinline__ double carry(int i) const { return facp[(int64_t)i << 6]; }
+  // carry rows: pair-interleaved inside the stage's block (see TileBuf::st2)
+  static constexpr bool PAIR_CARRY = true;
+  __device__ __forceinline__ void put_carry(int i, double v, bool on = true) const { if (on) facp[((int64_t)(i >> 1) << 7) + (i & 1)] = v; }
+  __device__ __forceinline__ double carry(int i) const { return facp[((int64_t)(i >> 1) << 7) + (i & 1)]; }
+  __device__ __forceinline__ void put_carry2(int i, double v0, double v1, bool on) const {
+    if (on) *reinterpret_cast<double2*>(facp + ((int64_t)(i >> 1) << 7)) = double2{v0, v1};
+  }
+  __device__ __forceinline__ void carry2(int i, double& v0, double& v1) const {
+    const double2 q = *reinterpret_cast<const double2*>(facp + ((int64_t)(i >> 1) << 7));
+    v0 = q.x; v1 = q.y;
+  }
   // the step
   __device__ __forceinline__ void put_dp(int i, double v) const { *soa(a.dz, g, a.Nz, z0 + i) = v; }
   __device__ __forceinline__ void put_dnu(int j, double v) const { *soa(a.dlam, g, a.Nc, uload(a.ccoff, t) + j) = v; }
   __device__ __forceinline__ void put_dlam(int k, double v) const { *soa(a.dlam, g, a.Nc, uload(a.cdoff, t) + k) = v; }
   __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = v; }
-  __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
+  __device__ __forceinline__ long long* prof() const {
+#if DTO_KKT_PROFILE
+    return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr;
+#else
+    return nullptr;   // the cycle stamps are compiled in only with -DDTO_KKT_PROFILE=1 (DTO_PLUGIN_CXXFLAGS, tools/kkt_profile.py):
+                      // even a never-taken stamp is a branch that cuts the stage into basic blocks the scheduler cannot cross
+#endif
+  }
 };
 
 // SoaIO for a stage inside a run (dto_stage_run): every offset is arithmetic -- offset of the run's first stage + stride x
@@ -450,13 +490,23 @@ struct SoaRunIO {
   __device__ __forceinline__ double sigc_dyn(int k) const { return b.sigc.ld(cd0 + k); }
   __device__ __forceinline__ double slack(int j) const { return b.s.ld(io0 + D::slack(j)); }
   __device__ __forceinline__ double slack_mult(int j) const { return b.zs.ld(io0 + D::slack(j)); }
-  __device__ __forceinline__ void put_carry(int i, double v) const { b.fac.st(fac0 + i, v); }
-  __device__ __forceinline__ double carry(int i) const { return b.fac.ld(fac0 + i); }
+  static constexpr bool PAIR_CARRY = true;
+  __device__ __forceinline__ void put_carry(int i, double v, bool on = true) const { b.fac.st1p(fac0, i, v, on); }
+  __device__ __forceinline__ double carry(int i) const { return b.fac.ld1p(fac0, i); }
+  __device__ __forceinline__ void put_carry2(int i, double v0, double v1, bool on) const { b.fac.st2(fac0, i >> 1, v0, v1, on); }
+  __device__ __forceinline__ void carry2(int i, double& v0, double& v1) const { b.fac.ld2(fac0, i >> 1, v0, v1); }
   __device__ __forceinline__ void put_dp(int i, double v) const { b.dz.st(z0 + i, v); }
   __device__ __forceinline__ void put_dnu(int j, double v) const { b.dlam.st(cc0 + j, v); }
   __device__ __forceinline__ void put_dlam(int k, double v) const { b.dlam.st(cd0 + k, v); }
   __device__ __forceinline__ void put_ds(int j, double v) const { b.ds.st(io0 + D::slack(j), v); }
-  __device__ __forceinline__ long long* prof() const { return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr; }
+  __device__ __forceinline__ long long* prof() const {
+#if DTO_KKT_PROFILE
+    return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr;
+#else
+    return nullptr;   // the cycle stamps are compiled in only with -DDTO_KKT_PROFILE=1 (DTO_PLUGIN_CXXFLAGS, tools/kkt_profile.py):
+                      // even a never-taken stamp is a branch that cuts the stage into basic blocks the scheduler cannot cross
+#endif
+  }
 };
 
 // Everything the block algebra reads of one stage, in registers.  The sequential sweeps request the rows of stage t+1
@@ -478,6 +528,9 @@ struct SoaRunIO {
 #ifndef DTO_SEQ_PREFETCH_MAX
 #define DTO_SEQ_PREFETCH_MAX 56   // doubles per StageIn up to which the next stage is requested ahead
 #endif
+#ifndef DTO_KKT_PROFILE
+#define DTO_KKT_PROFILE 0
+#endif
 template <class M, int K, bool BOUNDED, bool BWD>
 struct StageIn {
   using D = KindDims<M, K>;
@@ -491,7 +544,8 @@ struct StageIn {
     const int z0 = r.z0 + n * r.zs, cd0 = r.cd0 + n * r.cds, cc0 = r.cc0 + n * r.ccs, io0 = r.io0 + n * r.ios;
     const int rec0 = (int)r.rec0 + n * (int)r.recs, fac0 = (int)r.fac0 + n * (int)r.facs;
 #pragma unroll
-    for (int i = 0; i < NCAR; ++i) car[i] = b.fac.ld(fac0 + i);
+    for (int i = 0; i + 1 < NCAR; i += 2) b.fac.ld2(fac0, i >> 1, car[i], car[i + 1]);
+    if constexpr (NCAR % 2 == 1) car[NCAR - 1] = b.fac.ld1p(fac0, NCAR - 1);
 #pragma unroll
     for (int i = 0; i < D::REC; ++i) rec[i] = b.rec.ld(rec0 + i);
     if constexpr (HAS_P) {
@@ -539,6 +593,7 @@ struct SoaPreIO : SoaRunIO<M, K, BOUNDED> {
   __device__ __forceinline__ double slack(int j) const { return in.s[j]; }
   __device__ __forceinline__ double slack_mult(int j) const { return in.zs[j]; }
   __device__ __forceinline__ double carry(int i) const { return in.car[i]; }
+  __device__ __forceinline__ void carry2(int i, double& v0, double& v1) const { v0 = in.car[i]; v1 = in.car[i + 1]; }
   __device__ __forceinline__ void bounds(StageBounds<D::NP>& sb) const {
     if constexpr (BOUNDED) {
 #pragma unroll
@@ -1445,6 +1500,7 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
   }
   long long* const prof_ = io.prof();
   long long tq_ = prof_ ? clock64() : 0;
+  if (prof_) prof_[13] = tq_;
 #define DTO_KKT_TICK(slot) do { if (prof_) { const long long n_ = clock64(); prof_[slot] += n_ - tq_; tq_ = n_; } } while (0)
 
 #pragma unroll
@@ -1711,6 +1767,7 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
     }
   }
   DTO_KKT_TICK(5);
+  if (prof_) prof_[14] = tq_;
 }
 
 template <class M, int K, bool SPK, class IO>
@@ -1726,17 +1783,38 @@ __device__ __forceinline__ void stage_forward(const dto_solver_opts& o, const IO
   double Z[SPK ? BD * NX : 1];
   double cx_direct[SPK ? (NY > 0 ? NY : 1) * NX : 1];
   double dinv[BD];
+  // cycle stamps (tools/kkt_profile.py; blockIdx.x == 1, thread 0): 0 = between two stages (loop, prefetch issue, copy of the
+  // prefetched rows), 2 = carry stores, 1 / 4 / 5 = stage_factor (loads + derivative code + scatter / LDL / substitutions),
+  // 6 = Schur complement onto x_{t+1}, 7 = stages stamped
+  long long* const pf_ = io.prof();
+  const long long te_ = pf_ ? clock64() : 0;
+  if (pf_ && pf_[15]) pf_[0] += te_ - pf_[15];
   // --- carry-in of this stage is all the backward sweep needs besides the stage record (not of a lost attempt)
   // `keep_lost`: the last attempt of the ladder (or the single attempt of the linear-solver entry points) is swept through and
   // stored even with the wrong inertia -- it is the factorisation the backward sweep will use
-  if (need && (SPK || ok || keep_lost)) {
+  {
+    const bool on = need && (SPK || ok || keep_lost);
+    constexpr int NT_ = NX * (NX + 1) / 2, NCY = SPK ? D::FAC : D::F_CX;
+    static_assert(D::F_P == 0 && D::F_PY == NT_ && D::F_CX == NT_ + NX, "carry record: P, py, Cx back to back");
+    double cv[NCY > 0 ? NCY : 1];
 #pragma unroll
-    for (int i = 0; i < NX * (NX + 1) / 2; ++i) io.put_carry(D::F_P + i, cy.P[i]);
+    for (int i = 0; i < NT_; ++i) cv[i] = cy.P[i];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) io.put_carry(D::F_PY + i, cy.py[i]);
+    for (int i = 0; i < NX; ++i) cv[NT_ + i] = cy.py[i];
     if constexpr (SPK) {
 #pragma unroll
-      for (int i = 0; i < NX * NX; ++i) io.put_carry(D::F_CX + i, sp.Cx[i]);
+      for (int i = 0; i < NX * NX; ++i) cv[NT_ + NX + i] = sp.Cx[i];
+    }
+    auto elem = [&](int i) { return cv[i]; };
+    if constexpr (IO::PAIR_CARRY) {
+#pragma unroll
+      for (int i = 0; i + 1 < NCY; i += 2) io.put_carry2(i, elem(i), elem(i + 1), on);
+      if constexpr (NCY % 2 == 1) io.put_carry(NCY - 1, elem(NCY - 1), on);
+    } else {
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < NCY; ++i) io.put_carry(i, elem(i));
+      }
     }
   }
   const int nneg_in = nneg;
@@ -1767,6 +1845,13 @@ __device__ __forceinline__ void stage_forward(const dto_solver_opts& o, const IO
 #pragma unroll
     for (int i = 0; i < BD; ++i) acc += XD[i * NY + c] * y[i];
     cy.py[c] = acc;
+  }
+  if (pf_) {
+    const long long now_ = clock64();
+    pf_[6] += now_ - pf_[14];
+    pf_[2] += pf_[13] - te_;
+    pf_[15] = now_;
+    pf_[7] += 1;
   }
   if constexpr (SPK) {
     // separator contributions and the coupling handed to the next stage's x rows
@@ -2163,13 +2248,25 @@ __device__ __forceinline__ void stage_backward(const dto_solver_opts& o, const I
   // --- rebuild this stage's factorisation from its record and the stored carry-in
   Carry<M> cy;
   Spike<M> sp;
+  {
+    constexpr int NT_ = NX * (NX + 1) / 2, NCY = SPK ? D::FAC : D::F_CX;
+    double cv[NCY > 0 ? NCY + 1 : 1];
+    if constexpr (IO::PAIR_CARRY) {
 #pragma unroll
-  for (int i = 0; i < NX * (NX + 1) / 2; ++i) cy.P[i] = io.carry(D::F_P + i);
+      for (int i = 0; i + 1 < NCY; i += 2) io.carry2(i, cv[i], cv[i + 1]);
+      if constexpr (NCY % 2 == 1) cv[NCY - 1] = io.carry(NCY - 1);
+    } else {
 #pragma unroll
-  for (int i = 0; i < NX; ++i) cy.py[i] = io.carry(D::F_PY + i);
-  if constexpr (SPK) {
+      for (int i = 0; i < NCY; ++i) cv[i] = io.carry(i);
+    }
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) sp.Cx[i] = io.carry(D::F_CX + i);
+    for (int i = 0; i < NT_; ++i) cy.P[i] = cv[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) cy.py[i] = cv[NT_ + i];
+    if constexpr (SPK) {
+#pragma unroll
+      for (int i = 0; i < NX * NX; ++i) sp.Cx[i] = cv[NT_ + NX + i];
+    }
   }
   double S[BD * (BD + 1) / 2];
   double w[BD];

@@ -597,6 +597,12 @@ def _kernel_headers_digest() -> str:
     return hsh.hexdigest()
 
 
+def _extra_flags() -> List[str]:
+    """Extra compiler flags of a plugin build (measurement variants: -DDTO_KKT_PROFILE=1, -DDTO_SEQ_FWD_OCC=2, ...); part of the
+    cache key."""
+    return os.environ.get("DTO_PLUGIN_CXXFLAGS", "").split()
+
+
 def _prepare_plugin(st: Structure, name: str):
     """(path of the plugin .so, compile command or None if it is already built).  Not thread-safe (the structural-key
     switch of the code generator is a module global): call it serially, compile in parallel."""
@@ -607,7 +613,7 @@ def _prepare_plugin(st: Structure, name: str):
         key_src = generate_source(st, name)
     finally:
         _cg.STRUCTURAL_KEYS = False
-    digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION).encode()).hexdigest()[:16]
+    digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION + " ".join(_extra_flags())).encode()).hexdigest()[:16]
     os.makedirs(PLUGIN_DIR, exist_ok=True)
     base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")
     so = base + ".so"
@@ -620,7 +626,7 @@ def _prepare_plugin(st: Structure, name: str):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = so + f".tmp{os.getpid()}"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", CSRC,
-           "-Wno-unused-value", "-o", tmp, hip_src]
+           "-Wno-unused-value"] + _extra_flags() + ["-o", tmp, hip_src]
     return so, cmd
 
 
