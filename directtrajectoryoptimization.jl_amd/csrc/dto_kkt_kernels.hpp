@@ -181,6 +181,10 @@ __device__ __forceinline__ T uload(const T* p, int64_t i) {
   return ((const __attribute__((address_space(4))) T*)p)[i];
 }
 
+// Pair-interleaved rows of a stage block (stage records, carry records): logical rows 2k, 2k + 1 share one 1 KiB line, 16 bytes
+// per lane.  `base` points at the block's first row + 2 * lane; the block has an even number of rows (fill_info rounds up).
+__device__ __forceinline__ int64_t pair_at(int e) { return ((int64_t)(e >> 1) << 7) + (e & 1); }
+
 // One SoA array of ONE tile as a buffer resource (rows of 64 doubles).  Every access is
 //     buffer_load/store_dwordx2  v, v_lane, s[rsrc], s_row  offen
 // -- resource and row offset in SGPRs (scalar ALU), ONE VGPR (8 x lane) shared by every array.  Measured reason
@@ -308,7 +312,7 @@ template <class M, int K = 0>
 void fill_info(dto_kkt_info* o) {
   if constexpr (K < M::N_KIND) {
     using D = KindDims<M, K>;
-    o->rec_size[K] = D::REC;
+    o->rec_size[K] = (D::REC + 1) & ~1;        // even: pair-interleaved rows
     o->fac_size[K] = (D::FAC + 1) & ~1;        // even: the carry rows are stored pair-interleaved (TileBuf::st2)
     o->fac_size_seq[K] = (D::F_CX + 1) & ~1;
     o->n_ineq[K] = D::QI;
@@ -389,9 +393,9 @@ struct SoaIO {
   const double* recp;
   double* facp;
   __device__ __forceinline__ SoaIO(const dto_kkt_args& a_, int64_t g_, int t_)
-      : a(a_), g(g_), t(t_), z0(uload(a_.zoff, t_)), recp(a_.rec + ((g_ * a_.rec_total + uload(a_.recoff, t_)) << 6) + threadIdx.x),
+      : a(a_), g(g_), t(t_), z0(uload(a_.zoff, t_)), recp(a_.rec + ((g_ * a_.rec_total + uload(a_.recoff, t_)) << 6) + 2 * threadIdx.x),
         facp(a_.fac + ((g_ * a_.fac_total + uload(a_.facoff, t_)) << 6) + 2 * threadIdx.x) {}
-  __device__ __forceinline__ double rec(int e) const { return recp[(int64_t)e << 6]; }
+  __device__ __forceinline__ double rec(int e) const { return recp[pair_at(e)]; }   // pair-interleaved like the carries
   __device__ __forceinline__ double p(int i) const { return *soa(a.z, g, a.Nz, z0 + i); }
   __device__ __forceinline__ double y(int i) const { return *soa(a.z, g, a.Nz, uload(a.zoff, t + 1) + i); }
   __device__ __forceinline__ double lam(int k) const { return *soa(a.lam, g, a.Nc, uload(a.cdoff, t) + k); }
@@ -448,7 +452,7 @@ struct SoaRunIO {
       : a(a_), b(b_), t(t_), z0(r.z0 + (t_ - r.t0) * r.zs), cd0(r.cd0 + (t_ - r.t0) * r.cds), cc0(r.cc0 + (t_ - r.t0) * r.ccs),
         io0(r.io0 + (t_ - r.t0) * r.ios), w0(r.w0 + (t_ - r.t0) * r.ws), rec0((int)r.rec0 + (t_ - r.t0) * (int)r.recs),
         fac0((int)r.fac0 + (t_ - r.t0) * (int)r.facs) {}
-  __device__ __forceinline__ double rec(int e) const { return b.rec.ld(rec0 + e); }
+  __device__ __forceinline__ double rec(int e) const { return b.rec.ld1p(rec0, e); }
   __device__ __forceinline__ double p(int i) const { return b.z.ld(z0 + i); }
   __device__ __forceinline__ double y(int i) const { return b.z.ld(z0 + D::NP + i); }   // x_{t+1} follows [x_t; u_t]
   __device__ __forceinline__ double lam(int k) const { return b.lam.ld(cd0 + k); }
@@ -547,7 +551,8 @@ struct StageIn {
     for (int i = 0; i + 1 < NCAR; i += 2) b.fac.ld2(fac0, i >> 1, car[i], car[i + 1]);
     if constexpr (NCAR % 2 == 1) car[NCAR - 1] = b.fac.ld1p(fac0, NCAR - 1);
 #pragma unroll
-    for (int i = 0; i < D::REC; ++i) rec[i] = b.rec.ld(rec0 + i);
+    for (int i = 0; i + 1 < D::REC; i += 2) b.rec.ld2(rec0, i >> 1, rec[i], rec[i + 1]);
+    if constexpr (D::REC % 2 == 1) rec[D::REC - 1] = b.rec.ld1p(rec0, D::REC - 1);
     if constexpr (HAS_P) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) p[i] = b.z.ld(z0 + i);
@@ -790,15 +795,15 @@ __global__ __launch_bounds__(WAVE) void k_rhs_record(dto_kkt_args a) {
   dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
-    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + threadIdx.x;
+    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + 2 * threadIdx.x;   // pair-interleaved rows: pair_at()
     const double* rx = a.rhs_x + inst * a.ld_rhs_x;
     const double* rc = a.rhs_c + inst * a.ld_rhs_c;
 #pragma unroll
-    for (int i = 0; i < D::NP; ++i) rec[(int64_t)(D::R_RP + i) << 6] = live ? -rx[uload(a.zoff, t) + i] : 0.0;
+    for (int i = 0; i < D::NP; ++i) rec[pair_at(D::R_RP + i)] = live ? -rx[uload(a.zoff, t) + i] : 0.0;
 #pragma unroll
-    for (int k = 0; k < D::NY; ++k) rec[(int64_t)(D::R_D + k) << 6] = live ? -rc[uload(a.cdoff, t) + k] : 0.0;
+    for (int k = 0; k < D::NY; ++k) rec[pair_at(D::R_D + k)] = live ? -rc[uload(a.cdoff, t) + k] : 0.0;
 #pragma unroll
-    for (int j = 0; j < D::Q; ++j) rec[(int64_t)(D::R_C + j) << 6] = live ? -rc[uload(a.ccoff, t) + j] : 0.0;
+    for (int j = 0; j < D::Q; ++j) rec[pair_at(D::R_C + j)] = live ? -rc[uload(a.ccoff, t) + j] : 0.0;
   });
 }
 
@@ -881,8 +886,11 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
     using KD = typename D::KD;
     using CO = typename M::template Cost<KD::COST>;
     const int z0 = uload(a.zoff, t);
-    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + threadIdx.x;
-    auto put = [&](int e, double v) { rec[(int64_t)e << 6] = v; };
+    double* rec = a.rec + ((g * a.rec_total + uload(a.recoff, t)) << 6) + 2 * threadIdx.x;   // pair-interleaved rows: pair_at()
+    // exact-Hessian models: the record is just the residuals (r_p, d, c) -- collected in registers and stored two rows at a
+    // time (one 16-byte store per lane and pair) after the last of them; quasi-Newton records are written entry by entry
+    double recv[D::FUSED && D::REC > 0 ? D::REC + 1 : 1];
+    auto put = [&](int e, double v) { if constexpr (D::FUSED) recv[e] = v; else rec[pair_at(e)] = v; };
 
     arr<D::NP> p;
     if constexpr (UPD) {
@@ -942,9 +950,9 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
     double qn_old_dj[D::QN && D::N_DJ > 0 ? D::N_DJ : 1], qn_old_kj[D::QN && D::N_KJ > 0 ? D::N_KJ : 1];
     if constexpr (D::QN) {
 #pragma unroll
-      for (int i = 0; i < D::N_DJ; ++i) qn_old_dj[i] = rec[(int64_t)(D::R_DJ + i) << 6];
+      for (int i = 0; i < D::N_DJ; ++i) qn_old_dj[i] = rec[pair_at(D::R_DJ + i)];
 #pragma unroll
-      for (int i = 0; i < D::N_KJ; ++i) qn_old_kj[i] = rec[(int64_t)(D::R_KJ + i) << 6];
+      for (int i = 0; i < D::N_KJ; ++i) qn_old_kj[i] = rec[pair_at(D::R_KJ + i)];
     }
     arr<D::NP> rp;
     double cost_val;
@@ -1090,7 +1098,7 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
 #pragma unroll
         for (int i = 0; i < D::NP; ++i) {
           gn[i] = gc[i];
-          go[i] = rec[(int64_t)(D::R_GC + i) << 6];
+          go[i] = rec[pair_at(D::R_GC + i)];
           put(D::R_GC + i, gc[i]);
           sv[i] = alpha * *soa(a.dz, g, a.Nz, z0 + i);
         }
@@ -1135,7 +1143,7 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
         for (int i = 0; i < NE; ++i) B[tri(i, i)] += 1e-8;
       } else {
 #pragma unroll
-        for (int i = 0; i < NBQ; ++i) B[i] = rec[(int64_t)(D::R_B + i) << 6];
+        for (int i = 0; i < NBQ; ++i) B[i] = rec[pair_at(D::R_B + i)];
         // symmetric rank-one update: element Hessians of lam'd are indefinite, which SR1 can represent (BFGS cannot);
         // the inertia ladder of the factorization takes care of the resulting indefinite reduced Hessians
         double v[NE > 0 ? NE : 1];
@@ -1165,8 +1173,14 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
     StageBounds<D::NP> sb;
     load_stage_bounds<D::NP>(a, g, z0, sb);
 #pragma unroll
+    for (int i = 0; i < D::NP; ++i) put(D::R_RP + i, rp[i]);
+    if constexpr (D::FUSED) {
+#pragma unroll
+      for (int i = 0; i + 1 < D::REC; i += 2) *reinterpret_cast<double2*>(rec + ((int64_t)(i >> 1) << 7)) = double2{recv[i], recv[i + 1]};
+      if constexpr (D::REC % 2 == 1) rec[pair_at(D::REC - 1)] = recv[D::REC - 1];
+    }
+#pragma unroll
     for (int i = 0; i < D::NP; ++i) {
-      put(D::R_RP + i, rp[i]);
       xmax = fmax(xmax, fabs(p[i]));
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (o.newton_only) {
