@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "dto_model_plugin.h"
 
@@ -63,6 +64,12 @@ namespace wide {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifndef DTO_WIDE_LDL_RANK1
+#define DTO_WIDE_LDL_RANK1 1   // 0: the blocked LDL^T with one-wavefront diagonal tiles (rounds 1-3), kept for A/B runs
+#endif
+#ifndef DTO_WIDE_LDL_INLINE
+#define DTO_WIDE_LDL_INLINE __attribute__((noinline))
+#endif
 constexpr int WG = 256;  // 4 wavefronts
 constexpr int TB = 16;   // MFMA tile edge
 
@@ -223,6 +230,10 @@ __device__ __forceinline__ void diag_tile(double* Mx, int ld, int o, double* d, 
   if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[26] += t_ - tq_; tq_ = t_; }
 }
 
+// barrier for phases that exchange data through LDS only: __syncthreads() also waits for every outstanding global STORE of the
+// wavefront (the factor records streaming to HBM) -- a full memory round trip at each of the barriers that follow a copy
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
 //      On exit: strict lower part = L, d/dinv = pivots, LI = inverses of the unit-lower diagonal tiles.
 template <int N>
@@ -263,6 +274,168 @@ __device__ __forceinline__ void ldl_blocked(double* Mx, double* d, double* dinv,
     __syncthreads();
     if (prof && threadIdx.x == 0) { const long long t1_ = clock64(); prof[23] += t1_ - t0_; t0_ = t1_; }
   }
+}
+
+// ---- right-looking LDL^T of the N x N matrix in LDS with the matrix held in REGISTERS (round 4).
+//      The blocked form above spends its time in the eight 16 x 16 diagonal tiles of a stage, each factorised by ONE wavefront
+//      through v_readlane broadcasts while the other three wait at a barrier (profiles/r04/wide_phase_cycles_*: 15.6 k cycles per
+//      tile, 125 k of the 363 k cycles of a stage).  Here all 256 threads hold a 4 x 4 comb of the symmetric matrix
+//      (rows ti + 16 a, columns tj + 16 b: 16 doubles per thread) for the whole factorisation; step k costs one exchange of
+//      column k through a 64-double LDS buffer (ping-pong: one barrier per step), nine LDS reads and at most sixteen
+//      multiply-adds per thread -- the chain is 64 short steps instead of 8 long tiles plus 24 barriers.  L (strict lower part),
+//      the pivots and the inverses of the unit-lower diagonal tiles (for the MFMA triangular solves that follow) are written back
+//      at the end; negative / tiny pivots are counted like in ldl_blocked (same test, same order of pivots).
+// (out of line, LDS pointers by address space: the caller's kernel is already at 256 + 182 registers, inlined three times the
+// comb pushed it into scratch)
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) int lds_int;
+template <int N>
+__device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds_double* dinv, lds_double* LI, lds_double* colb,
+                                                    lds_double* dg0, double piv_tol, lds_int* cnt, long long* prof = nullptr) {
+  long long tq_ = prof ? clock64() : 0;
+#define DTO_LDL_TICK(slot) do { if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[slot] += t_ - tq_; tq_ = t_; } } while (0)
+  using D = Dims<N>;
+  constexpr int LD = D::LD;
+  static_assert(N == 64 && WG == 256, "thread comb: 16 x 16 threads, 4 x 4 elements each");
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double r[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r[a][b] = Mx[(ti + 16 * a) * LD + tj + 16 * b];
+  }
+  if (tid < N) dg0[tid] = fabs(Mx[tid * LD + tid]);
+  DTO_LDL_TICK(20);
+  int nneg = 0, tiny = 0;
+  // four columns per exchange: the owners publish the raw columns k0 .. k0+3 (updated by all earlier blocks), every thread
+  // factorises the 4 x 4 pivot block itself (redundantly: 10 values, four short reciprocal chains), forward-substitutes its four
+  // rows and its four columns against it (y_p = L_ip d_p) and applies the rank-4 update to its comb: 16 barriers per
+  // factorisation instead of 64.
+  // (the comb is indexed with the block column kb: it must be a compile-time constant or the comb lands in scratch memory)
+  auto block_col = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+#pragma unroll 1
+    for (int kq = 0; kq < 4; ++kq) {
+      const int kk = kq * 4, k0 = kb * 16 + kk;
+      lds_double* cb = colb + (kq & 1) * 4 * N;
+      if ((tj >> 2) == kq) {
+        const int q = tj & 3;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cb[q * N + ti + 16 * a] = r[a][kb];
+      }
+      lds_barrier();
+      // pivot block: P[q][p] = column k0+q at row k0+p (symmetric)
+      double L4[4][4], dd[4], di[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int p2 = 0; p2 <= q; ++p2) L4[q][p2] = cb[p2 * N + k0 + q];   // A[k0+q][k0+p2] = column k0+p2 at row k0+q
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double pv = L4[j][j];
+#pragma unroll
+        for (int p2 = 0; p2 < j; ++p2) pv = fma(-L4[j][p2] * dd[p2], L4[j][p2], pv);
+        double rc = __builtin_amdgcn_rcp(pv);
+        rc = fma(fma(-pv, rc, 1.0), rc, rc);
+        rc = fma(fma(-pv, rc, 1.0), rc, rc);
+        dd[j] = pv; di[j] = rc;
+        if (!(fabs(pv) > piv_tol * fmax(1.0, dg0[k0 + j]))) tiny = 1;
+        if (pv < 0.0) ++nneg;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+          double v = L4[i][j];
+#pragma unroll
+          for (int p2 = 0; p2 < j; ++p2) v = fma(-L4[i][p2] * dd[p2], L4[j][p2], v);
+          L4[i][j] = v * rc;
+        }
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[k0 + j] = dd[j]; dinv[k0 + j] = di[j]; }
+      }
+      // y (rows) and u (columns): y_p = A[i][k0+p] - sum_{s<p} y_s L4[p][s]; columns that are not beyond this block get u = 0
+      // (their entries are final or handled below), so the rank-4 update itself is unconditional
+      double yr[4][4], lr[4][4], yc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const bool later = tj + 16 * a > k0 + 3;
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          double v = cb[p2 * N + ti + 16 * a], u = cb[p2 * N + tj + 16 * a];
+#pragma unroll
+          for (int s2 = 0; s2 < p2; ++s2) { v = fma(-yr[a][s2], L4[p2][s2], v); u = fma(-yc[a][s2], L4[p2][s2], u); }
+          yr[a][p2] = v; yc[a][p2] = u;
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) { lr[a][p2] = yr[a][p2] * di[p2]; yc[a][p2] = later ? yc[a][p2] : 0.0; }
+      }
+      // only the lower blocks of the comb (a >= b) are ever written back
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int a = b; a < 4; ++a) {
+          double upd = r[a][b];
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) upd = fma(-lr[a][p2], yc[b][p2], upd);
+          r[a][b] = upd;
+        }
+      }
+      // the four columns of this block keep y (their L D): comb block column kb, threads tj in [kk, kk + 3]
+      if ((tj >> 2) == kq) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          // (selects kept apart by empty asm: as a chain of ifs the compiler turns them into yr[a][tj & 3], i.e. the array goes to
+          // scratch memory and every step pays scratch round trips)
+          double own = yr[a][0];
+          own = ((tj & 3) == 1) ? yr[a][1] : own; asm("" : "+v"(own));
+          own = ((tj & 3) == 2) ? yr[a][2] : own; asm("" : "+v"(own));
+          own = ((tj & 3) == 3) ? yr[a][3] : own; asm("" : "+v"(own));
+          r[a][kb] = own;
+        }
+      }
+    }
+  };
+  block_col(std::integral_constant<int, 0>{});
+  block_col(std::integral_constant<int, 1>{});
+  block_col(std::integral_constant<int, 2>{});
+  block_col(std::integral_constant<int, 3>{});
+  lds_barrier();
+  DTO_LDL_TICK(21);
+  // L[i][j] = A_j[i][j] / d_j for i > j (column j of the thread's comb stopped changing after step j)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti + 16 * a, j = tj + 16 * b;
+      if (i > j) Mx[i * LD + j] = r[a][b] * dinv[j];
+    }
+  }
+  if (tid == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
+  lds_barrier();
+  DTO_LDL_TICK(22);
+  // inverses of the four unit-lower diagonal tiles, one wavefront each: lane c (< 16) builds column c of X = L_kk^-1 row by row
+  {
+    const int w = wave_id(), l = lane_id(), o = w * TB;
+    lds_double* LIk = LI + w * TB * D::LI_LD;
+    double X[TB];
+    X[0] = (l == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j + 1 < TB; ++j) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k <= j; ++k) sacc += Mx[(o + j + 1) * LD + o + k] * X[k];
+      X[j + 1] = (l == j + 1) ? 1.0 : (l < j + 1 ? -sacc : 0.0);
+      __builtin_amdgcn_sched_barrier(0);   // one row at a time: without it all 136 LDS reads are hoisted to the top (272 registers)
+    }
+    if (l < TB) {
+#pragma unroll
+      for (int rr = 0; rr < TB; ++rr) LIk[rr * D::LI_LD + l] = X[rr];
+    }
+  }
+  lds_barrier();
+  DTO_LDL_TICK(23);
+#undef DTO_LDL_TICK
 }
 
 // X <- X * L^-T for row-tile `ib` of X (one wavefront; tiles of one row depend only on each other)
@@ -325,6 +498,9 @@ __device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
 template <int MAT>
 __device__ __forceinline__ void copy_mat(double* dst, const double* src) {
   static_assert(MAT % 2 == 0, "matrix size must be even for 16-byte copies");
+  // (left to the compiler's own pipelining: all nine pieces of a thread in registers at once made this kernel spill, three at a
+  // time with the loop kept rolled was slower than this plain form -- 65 k against 38 k cycles for the four loads of a stage of
+  // the backward sweep, profiles/r04/wide_phase_cycles.txt)
   const double2* s2 = reinterpret_cast<const double2*>(src);
   double2* d2 = reinterpret_cast<double2*>(dst);
   for (int i = threadIdx.x; i < MAT / 2; i += WG) d2[i] = s2[i];
@@ -442,6 +618,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   const double gam = a.gam_inst ? a.gam_inst[b] : 1.0;
   double* stat = vec + 20 * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4;  // f, th1, thinf, dinf (LDS scalars)
   double* fxm = stat + 8;   // [N] 1.0 where x_t is fixed by equal bounds
+  double* colb = fxm + N;   // [2][4][N] column exchange of ldl_rank1 (four columns per step, ping-pong)
+  double* dg0 = colb + 8 * N;  // [N] |diagonal| before the factorisation (tiny-pivot test)
   if (tid < 8) stat[tid] = 0.0;
 
   long long tick_ = clock64();
@@ -483,7 +661,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
           for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(0);
         // ---- phase 1: model code (wave-uniform values, one wavefront per function)
         if (w == 0) {
@@ -504,14 +682,14 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             if (l == 0) stat[0] += stat[6];
           }
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(1);
         // ---- phase 2: residual from the constant part (variable Jacobian entries are still zero in MF/ME/fu)
         if (tid < N) {
           const double acc = nlf[tid] + fu[tid] * sc[0] + dot_rr<N>(MF + tid * LD, xv) + dot_rr<N>(ME + tid * LD, yv);
           bd[tid] = -acc;
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(2);
         // ---- phase 3: variable Jacobian entries, Hessian blocks
         if (a.stats && w == 2) {
@@ -542,7 +720,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             else if (r >= N && c >= N) sc[1] += v;
           }
         }
-        __syncthreads();
+        lds_barrier();
         if constexpr (DY::NH > 0) {
           if (tid < DY::NH) {
             const int r = DY::h_row(tid), c = DY::h_col(tid);
@@ -557,7 +735,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             }
           }
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(3);
         // ---- phase 4: gradient of the Lagrangian -> right-hand sides
         if (w == 0) {
@@ -571,7 +749,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             sc[3] = sc[1] + dw;
           }
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(4);
         // ---- solver use: dual infeasibility of the free variables; variables fixed by equal bounds become identity rows
         if (a.stats && w == 3) {
@@ -582,7 +760,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if (l == 0) stat[3] = fmax(stat[3], v);
         }
         if (a.fixed_lo) {
-          __syncthreads();
+          lds_barrier();
           for (int i = tid; i < N * N; i += WG) {
             const int r = i >> 6, c = i & 63;
             if (fxm[r] != 0.0 || fxm[c] != 0.0) MA[r * LD + c] = (r == c) ? 1.0 : 0.0;
@@ -590,7 +768,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             if (fxm[r] != 0.0) MV[r * LD + c] = 0.0;
           }
           if (tid < N && fxm[tid] != 0.0) { au[tid] = 0.0; bx[tid] = 0.0; }
-          __syncthreads();
+          lds_barrier();
         }
         // ---- phase 5: eliminate u
         const double piv = sc[3], ip = 1.0 / piv, bu = sc[2];
@@ -610,16 +788,17 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if (piv < 0.0) cnt[0] += 1;
           if (!(fabs(piv) > a.piv_tol)) cnt[1] |= 1;
         }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(5);
         // ---- phase 6: A = L_A D_A L_A'
-        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt, blockIdx.x == 0 ? a.prof : nullptr);
+        if (DTO_WIDE_LDL_RANK1) ldl_rank1<N>((lds_double*)MA, (lds_double*)dA, (lds_double*)dAi, (lds_double*)LI, (lds_double*)colb, (lds_double*)dg0, a.piv_tol, (lds_int*)cnt, blockIdx.x == 0 ? a.prof : nullptr);
+        else ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt, blockIdx.x == 0 ? a.prof : nullptr);
         DTO_WIDE_TICK(6);
         // ---- phase 7: F~ = F L_A^-T (row tiles), V~ = L_A^-1 V (column tiles), bx~ = L_A^-1 bx
         if (w == 0) trsv_lower<N>(MA, bx);
         trsm_right_rowtile<N>(MF, MA, LI, w);
         trsm_left_coltile<N>(MV, MA, LI, w);
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(7);
         // ---- phase 8: M = D + F~ D_A^-1 F~' (registers), E'' = E - F~ D_A^-1 V~ (in place), bd~
         d4 macc[NT];
@@ -645,27 +824,28 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
         }
         copy_mat<MAT>(fac + D::F_LA, MA);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
         if (tid < N) bd[tid] = tmp[tid];
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(8);
         // ---- phase 9: M = L_M D_M L_M'   (the KKT pivots of this block are -D_M)
         if (tid == 0) cnt[0] += N;  // N negative pivots if every D_M entry is positive; corrected below
-        __syncthreads();
+        lds_barrier();
         {
           int* cm = cnt + 2;  // scratch counters for M
           if (tid == 0) { cm[0] = 0; cm[1] = 0; }
-          __syncthreads();
-          ldl_blocked<N>(MA, dM, dMi, LI, a.piv_tol, cm);
+          lds_barrier();
+          if (DTO_WIDE_LDL_RANK1) ldl_rank1<N>((lds_double*)MA, (lds_double*)dM, (lds_double*)dMi, (lds_double*)LI, (lds_double*)colb, (lds_double*)dg0, a.piv_tol, (lds_int*)cm);
+          else ldl_blocked<N>(MA, dM, dMi, LI, a.piv_tol, cm);
           if (tid == 0) { cnt[0] -= cm[0]; cnt[1] |= cm[1]; }
         }
         DTO_WIDE_TICK(9);
         // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
         if (w == 0) trsv_lower<N>(MA, bd);
         trsm_left_coltile<N>(ME, MA, LI, w);
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(10);
         // ---- phase 11: P' = -V~' D_A^-1 V~ + E~' D_M^-1 E~ (registers), carried right-hand side
 #pragma unroll
@@ -692,25 +872,25 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         if (tid == 0) fac[D::F_VEC + D::V_GC + N] = gc[N];
         if (tid == 0) { fac[D::F_VEC + D::V_SC + 0] = ip; fac[D::F_VEC + D::V_SC + 1] = bu; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
         if (tid < N) { byc[tid] = tmp[tid]; gyp[tid] = gyn[tid]; }
-        __syncthreads();
+        lds_barrier();
         DTO_WIDE_TICK(11);
         // the y-y part of this stage's Hessian and the u rank-one term complete P'
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
           MA[r * LD + c] -= vu[r] * vu[c] * ip;
         }
-        __syncthreads();
+        lds_barrier();
         if constexpr (DY::NH > 0) {
           if (tid < DY::NH) {
             const int r = DY::h_row(tid), c = DY::h_col(tid);
             if (r >= N + NU && c >= N + NU) MA[(r - N - NU) * LD + c - N - NU] += hv[tid];
           }
         }
-        __syncthreads();
+        lds_barrier();
       }
     });
   }
@@ -762,7 +942,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           if (tid < N && fxm[tid] != 0.0) bx[tid] = 0.0;
           __syncthreads();
         }
-        ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
+        if (DTO_WIDE_LDL_RANK1) ldl_rank1<N>((lds_double*)MA, (lds_double*)dA, (lds_double*)dAi, (lds_double*)LI, (lds_double*)colb, (lds_double*)dg0, a.piv_tol, (lds_int*)cnt);
+        else ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt);
         if (w == 0) {
           trsv_lower<N>(MA, bx);
           if (l < N) bx[l] *= dAi[l];
@@ -1112,7 +1293,7 @@ int wide_info(dto_wide_info* out) {
   out->n = M::WIDE_N;
   out->nu = M::WIDE_NU;
   out->fac_stage = D::FAC;
-  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 8 + M::WIDE_N);
+  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 8 + M::WIDE_N + 9 * M::WIDE_N);
   return 0;
 }
 
