@@ -50,7 +50,8 @@ class Options:
     skip_finalize_solution_call: str = "no"
     # not a reference field: what the GPU solver uses for the Hessian of the Lagrangian when the problem was built with
     # evaluate_hessian=false (where the reference leaves Ipopt on its limited-memory Hessian).  "auto": exact second
-    # derivatives derived from the traced expressions (they cost nothing here); "sr1": per-stage SR1 blocks.
+    # derivatives derived from the traced expressions (they cost nothing here) with a one-time HessianModeNotice, "exact": the
+    # same without the notice; "sr1": per-stage SR1 blocks, no second derivatives evaluated (Solver.hessian_mode reports it).
     hessian_approximation: str = "auto"
 
 
@@ -348,6 +349,29 @@ def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
     return c
 
 
+class HessianModeNotice(UserWarning):
+    """Issued once per process when a problem built with evaluate_hessian=false is solved with second derivatives anyway."""
+
+
+_NOTICED = False
+
+
+def _notice_default_mode():
+    """The reference's default (evaluate_hessian=false, src/solver.jl:7) leaves Ipopt on its limited-memory quasi-Newton Hessian.
+    Here the traced expressions are differentiated twice and the exact Hessian of the Lagrangian is used instead -- said out
+    loud, once, because it is NOT what the reference does: Options(hessian_approximation="sr1") gives a mode that evaluates no
+    second derivatives (per-stage SR1 blocks; 13 against 9 iterations on pendulum T=50, 48 of 64 acrobot T=101 seeds within 1000
+    iterations against 64 of 64: profiles/r04/quasi_newton_modes_reference_configs.txt)."""
+    global _NOTICED
+    if not _NOTICED:
+        _NOTICED = True
+        import warnings
+        warnings.warn("evaluate_hessian=false: the GPU solver differentiates the traced expressions twice and iterates with the exact "
+                      "Hessian of the Lagrangian (the reference leaves Ipopt on its limited-memory quasi-Newton Hessian here); "
+                      "Options(hessian_approximation='sr1') selects the quasi-Newton mode, 'exact' silences this notice",
+                      HessianModeNotice, stacklevel=3)
+
+
 class Solver:
     """Solver(dynamics, objective, constraints, bounds; evaluate_hessian=false,
     general_constraint=GeneralConstraint(), options=Options(), parameters=...) -- src/solver.jl:6-21."""
@@ -367,6 +391,12 @@ class Solver:
         self._solve_nlp = self.nlp
         self._mu_to_reference = None
         s_dyn, s_obj, s_con, s_eh, changed = list(dynamics), list(objective), list(constraints), bool(evaluate_hessian), False
+        if self.options.hessian_approximation not in ("auto", "exact", "sr1"):
+            raise ValueError("Options.hessian_approximation must be 'auto', 'exact' or 'sr1'")
+        # how the solver gets its Hessian of the Lagrangian (reported: Solver.hessian_mode)
+        self.hessian_mode = "exact" if s_eh else ("sr1" if self.options.hessian_approximation == "sr1" else "exact-from-trace")
+        if self.hessian_mode == "exact-from-trace" and self.options.hessian_approximation == "auto":
+            _notice_default_mode()
         if not s_eh and self.options.hessian_approximation != "sr1":
             # Default mode: the expressions are there, so the solver differentiates them twice itself; the MOI surface of
             # self.nlp still reports [:Grad, :Jac] exactly like the reference (src/moi.jl:122).
