@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "dto_math.hpp"
 #include "dto_model_plugin.h"
 
 namespace dto {

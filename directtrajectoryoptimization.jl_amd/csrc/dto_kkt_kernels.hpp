@@ -2592,8 +2592,8 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
       DY::trig_args(pm.data(), pm.data() + DY::NX, ym.data(), w.data(), a1);
 #pragma unroll
       for (int j = 0; j < NTRIG; ++j) {
-        sincos(a0[j], &tS0[j], &tC0[j]);
-        sincos(a1[j] - a0[j], &ts[j], &tc[j]);
+        DTO_SINCOS(a0[j], &tS0[j], &tC0[j]);
+        DTO_SINCOS(a1[j] - a0[j], &ts[j], &tc[j]);
       }
     }
     double alpha = amin;

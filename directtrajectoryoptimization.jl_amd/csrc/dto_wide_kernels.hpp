@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "dto_math.hpp"
 #include "dto_model_plugin.h"
 
 enum dto_wide_op { DTO_WIDE_STEP = 0, DTO_WIDE_MERIT = 1 };

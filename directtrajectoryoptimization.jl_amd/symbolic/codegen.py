@@ -7,7 +7,7 @@ function body that the hand-written stage kernels in csrc/ inline, not a Julia c
 The emitted body is pure straight-line code over `double` temporaries: every DAG node is
 computed once (the DAG is interned, so this is global CSE across *all* outputs of the
 function -- the reference's generated closures recompute shared sub-expressions per entry),
-sin/cos of one argument are paired into a single `sincos`, integer powers are expanded into
+sin/cos of one argument are paired into a single `DTO_SINCOS` (csrc/dto_math.hpp: straight-line f64 sin + cos), integer powers are expanded into
 multiplications.  No indexing is dynamic, so after inlining everything lives in VGPRs.
 """
 from __future__ import annotations
@@ -148,7 +148,7 @@ def emit_body(outputs: Sequence[Expr], out_name, var_arrays: Dict[str, str],
         s, c = f"{tmp_prefix}{sin_of[a.id].id}", f"{tmp_prefix}{cos_of[a.id].id}"
         if a.id not in done_pairs:
             done_pairs.add(a.id)
-            lines.append(f"{indent}double {s}, {c}; sincos({ref(a)}, &{s}, &{c});")
+            lines.append(f"{indent}double {s}, {c}; DTO_SINCOS({ref(a)}, &{s}, &{c});")
         return s, c
 
     for n in order:

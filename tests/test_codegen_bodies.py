@@ -18,7 +18,8 @@ from dto_amd.symbolic.codegen import emit_body, is_affine, trig_arguments
 
 
 def _compile(tmp_path, name, funcs):
-    src = ["#define _GNU_SOURCE", "#include <math.h>"]
+    # the bodies call DTO_SINCOS: the same straight-line sin + cos the device code uses (csrc/dto_math.hpp compiles as C++ and C)
+    src = ["#define _GNU_SOURCE", "#include <math.h>", "#define DTO_SINCOS(x, s, c) sincos((x), (s), (c))"]
     for fn, params, body in funcs:
         src.append(f"void {fn}({params}) {{\n{body}\n}}")
     c = tmp_path / f"{name}.c"

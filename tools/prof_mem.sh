@@ -5,9 +5,9 @@ B=${1:-131072}; TAG=${2:-r03}
 OUT=$PWD/gpurun_out/mem_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 [ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
+CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
 cd /tmp
 timeout -k 5 120 rocprofv3 --list-avail > $OUT/avail.txt 2>&1
 grep -o "TCP_[A-Z0-9_]*\|TCC_[A-Z0-9_]*\|TA_[A-Z0-9_]*\|TD_[A-Z0-9_]*" $OUT/avail.txt | sort -u > $OUT/avail_mem_names.txt

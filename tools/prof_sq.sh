@@ -5,9 +5,9 @@ B=${1:-131072}; TAG=${2:-r03}
 OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 [ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
+CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
 cd /tmp
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
