@@ -433,7 +433,7 @@ def main():
     # HBM bytes per launch: NOT measured in this run (PMC counters need a profiler pass) -- taken from the committed
     # rocprofv3 --pmc passes of this same command and batch size if there are any, with the file named; else null
     traffic, traffic_source = None, None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         fn = os.path.join("profiles", rnd, f"pmc_traffic_acrobot_T{T}_B{B}.json")
         try:
             with open(os.path.join(ROOT, fn)) as f:

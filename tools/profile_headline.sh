@@ -1,8 +1,8 @@
 #!/bin/bash
-# Profile (rounds 2 and 3) of the headline loop ALONE (acrobot T=1000, default batch): kernel statistics and the two HBM traffic
-# passes.  Run on the GPU box from the repo root: bash tools/profile_headline.sh [batch] ; results under gpurun_out/prof_r03/
+# Profile (rounds 2 to 4) of the headline loop ALONE (acrobot T=1000, default batch): kernel statistics and the two HBM traffic
+# passes.  Run on the GPU box from the repo root: bash tools/profile_headline.sh [batch] ; results under gpurun_out/prof_$TAG/ (TAG defaults to r04)
 B=${1:-524288}
-OUT=gpurun_out/prof_r03
+OUT=gpurun_out/prof_${TAG:-r04}
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="bench.py --loop-only --steps ${STEPS:-40} --warmup ${WARMUP:-5} --batch $B"
