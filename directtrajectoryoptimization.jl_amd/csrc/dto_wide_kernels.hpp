@@ -512,9 +512,11 @@ template <int N>
 __device__ __forceinline__ double dot_rr(const double* a, const double* v) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-  for (int c = 0; c < N; c += 4) {
+  for (int c = 0; c + 3 < N; c += 4) {
     s0 += a[c] * v[c]; s1 += a[c + 1] * v[c + 1]; s2 += a[c + 2] * v[c + 2]; s3 += a[c + 3] * v[c + 3];
   }
+#pragma unroll
+  for (int c = N & ~3; c < N; ++c) s0 += a[c] * v[c];   // (evaluator plugins of 17 .. 63 states: any N)
   return (s0 + s1) + (s2 + s3);
 }
 template <int N>
@@ -1084,28 +1086,32 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
       using CO = typename M::template Cost<KD::COST>;
       constexpr bool HAS_DYN = KD::DYN >= 0;
       constexpr int NUK = HAS_DYN ? NU : 0;
-      xv[l] = z[a.zoff[t] + l];
+      // lane = state index; evaluator plugins exist for any uniform N <= 64 (the KKT kernels for N == 64 only)
+      const bool ln = l < N;
+      if (ln) xv[l] = z[a.zoff[t] + l];
       if (l < NUK) uv[l] = z[a.zoff[t] + N + l];
-      if constexpr (HAS_DYN) yv[l] = z[a.zoff[t + 1] + l];
+      if constexpr (HAS_DYN) { if (ln) yv[l] = z[a.zoff[t + 1] + l]; }
       if constexpr (OP == DTO_OP_OBJ) {
         CO::eval(xv, uv, wp, ov);
         if (l == 0) a.scratch[b * a.T + t] = ov[0];
       } else if constexpr (OP == DTO_OP_GRAD) {
         CO::grad(xv, uv, wp, ov);
         double* g = a.out + b * a.ldout + a.zoff[t];
-        g[l] = ov[l];
+        if (ln) g[l] = ov[l];
         if (l < NUK) g[N + l] = ov[N + l];
       } else if constexpr (OP == DTO_OP_CON) {
         if constexpr (HAS_DYN) {
           using DY = typename M::template Dyn<KD::DYN>;
-          ov[l] = 0.0;
+          if (ln) ov[l] = 0.0;
           DY::eval_nl(xv, uv, yv, wp, hv);
           if (l < DY::NNL) ov[DY::nl_row(l)] = hv[l];
-          const double* row = fe_s + l * NC;
-          double acc = ov[l] + dot_rr<N>(row, xv) + dot_rr<N>(row + N + NU, yv);
+          if (ln) {
+            const double* row = fe_s + l * NC;
+            double acc = ov[l] + dot_rr<N>(row, xv) + dot_rr<N>(row + N + NU, yv);
 #pragma unroll
-          for (int j = 0; j < NU; ++j) acc += row[N + j] * uv[j];
-          a.out[b * a.ldout + a.cdoff[t] + l] = acc;
+            for (int j = 0; j < NU; ++j) acc += row[N + j] * uv[j];
+            a.out[b * a.ldout + a.cdoff[t] + l] = acc;
+          }
         }
       } else if constexpr (OP == DTO_OP_JAC) {
         if constexpr (HAS_DYN) {
@@ -1138,7 +1144,7 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
         if constexpr (HAS_DYN) {
           using DY = typename M::template Dyn<KD::DYN>;
           if constexpr (DY::NH > 0) {
-            lamv[l] = mu[a.cdoff[t] + l];
+            if (ln) lamv[l] = mu[a.cdoff[t] + l];
             DY::hess(xv, uv, yv, wp, lamv, hv);
             const int* mrow = a.hmap_dyn_own + kind * a.hmap_stride;
             for (int i = l; i < DY::NH; i += 64) {
@@ -1156,10 +1162,12 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
               using DP = typename M::template Dyn<KP::DYN>;
               if constexpr (DP::NH > 0) {
                 // previous point: x_{t-1}, u_{t-1}, y = x_t
-                yv[l] = xv[l];
-                xv[l] = z[a.zoff[t - 1] + l];
+                if (ln) {
+                  yv[l] = xv[l];
+                  xv[l] = z[a.zoff[t - 1] + l];
+                  lamv[l] = mu[a.cdoff[t - 1] + l];
+                }
                 if (l < NU) uv[l] = z[a.zoff[t - 1] + N + l];
-                lamv[l] = mu[a.cdoff[t - 1] + l];
                 DP::hess(xv, uv, yv, a.w + b * a.ldw + a.woff[t - 1], lamv, hv);
                 const int* mrow = a.hmap_dyn_next + kind * a.hmap_stride;
                 for (int i = l; i < DP::NH; i += 64) {

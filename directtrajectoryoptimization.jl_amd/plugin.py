@@ -82,13 +82,22 @@ class Structure:
                 raise ValueError(f"stage {t + 1}: constraint dims != {(nx, nu)}")
         max_nx = max([d.num_state for d in self.dyn] + [c.num_state for c in self.cost])
         self.wide = max_nx >= WIDE_MIN_STATE
+        self.wide_n = WIDE_STATE
         if self.wide:
-            ok = (all(d.num_state == WIDE_STATE and d.num_next_state == WIDE_STATE and d.num_action == 1 for d in self.dyn)
+            # the tile (MFMA) KKT kernels are built for exactly WIDE_STATE states; the evaluator callbacks of the same family
+            # take any uniform dimension up to it: a problem with 17 .. 63 states gets its callbacks from a plugin of its own
+            # size and its solves from the 64-state embedding (solver.py: pad_to_wide)
+            n0 = self.dyn[0].num_state if self.dyn else max_nx
+            ok = (WIDE_MIN_STATE <= n0 <= WIDE_STATE
+                  and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == 1 for d in self.dyn)
+                  and all(c.num_state == n0 for c in self.cost)
                   and not self.con and self.general is None
                   and all(d.num_parameter == 0 for d in self.dyn))
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
-                                 f"{WIDE_STATE} states, one action and bound-only stage constraints")
+                                 f"one uniform state dimension up to {WIDE_STATE}, one action and bound-only stage constraints")
+            self.wide_n = n0
+        self.wide_solver = self.wide and self.wide_n == WIDE_STATE
         if self.evaluate_hessian:
             # all objects must agree on the flag
             for o in list(self.dyn) + list(self.cost) + list(self.con):
@@ -339,7 +348,7 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     out.append("struct Model {")
-    out.append(f"  static constexpr int WIDE_N = {WIDE_STATE}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
+    out.append(f"  static constexpr int WIDE_N = {st.wide_n}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
     max_key = max([1] + [st.key_slots(k) for k in st.kinds])
     out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = {1 if st.evaluate_hessian else 0}, MAX_KEY = {max_key};")
     out.append("  template <int K> struct WKind;")
@@ -367,11 +376,13 @@ def generate_wide_source(st: Structure, name: str) -> str:
     rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
     out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
     out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::wide::launch_wide_eval<Model>(op, a, s); }")
-    out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
+    if st.wide_solver:
+        out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, nullptr, {1 if st.evaluate_hessian else 0},")
-    out.append(f"  {max_key}, launch, nullptr, nullptr, launch_wide, dto::wide::wide_info<Model>, nullptr, nullptr")
+    out.append(f"  {max_key}, launch, nullptr, nullptr, "
+               + ("launch_wide, dto::wide::wide_info<Model>" if st.wide_solver else "nullptr, nullptr") + ", nullptr, nullptr")
     out.append("};")
     out.append("}  // namespace")
     out.append('extern "C" const dto_model_vtable* dto_model_get(void) { return &k_vtable; }')

@@ -405,13 +405,23 @@ class Solver:
                 s_dyn, s_obj, s_con = up
                 s_eh, changed = True, True
         gen = general_constraint if (general_constraint is not None and general_constraint.num_constraint > 0) else None
+        # 17 .. 63 states: embedded in the 64 states of the tile kernels (padding states fixed at zero); solve() /
+        # get_trajectory() map between the two layouts, the batched entry points take the solver's (pad_batch / unpad_batch)
+        self._pad = None
+        s_bounds = bounds
+        if gen is None and parameters is None and s_eh:
+            padded = pad_to_wide(s_dyn, s_obj, s_con, bounds, s_eh)
+            if padded is not None:
+                s_dyn, s_obj, s_con, s_bounds, zmap, mumap = padded
+                self._pad = (zmap, mumap)
+                changed = True
         if gen is not None:
             folded = fold_general_constraint(s_dyn, s_obj, s_con, gen, s_eh)
             if folded is not None:
                 s_con, self._mu_to_reference = folded
                 gen, changed = None, True
         if changed:
-            self._solve_nlp = NLPData(s_dyn, s_obj, s_con, bounds, evaluate_hessian=s_eh, general_constraint=gen,
+            self._solve_nlp = NLPData(s_dyn, s_obj, s_con, s_bounds, evaluate_hessian=s_eh, general_constraint=gen,
                                       parameters=parameters, name=name if gen is None and self._mu_to_reference is None else name + "_folded")
 
     @property
@@ -433,6 +443,22 @@ class Solver:
         capi.check(self._solve_nlp._lib.dto_kkt_step_batch(self._solve_nlp._h, C.byref(b), mu_ptr, ldmu, float(delta_w), float(delta_c),
                                                     dx_ptr, lddx, dmu_ptr, lddmu, C.byref(ok)))
         return bool(ok.value)
+
+    def pad_batch(self, Z):
+        """Host array [..., num_variables] in the problem's layout -> the solver's layout (identity unless the problem was embedded
+        in the 64 states of the tile kernels: the padding states are zero)."""
+        Z = np.asarray(Z, dtype=float)
+        if self._pad is None:
+            return Z
+        out = np.zeros(Z.shape[:-1] + (self._solve_nlp.num_variables,))
+        out[..., self._pad[0]] = Z
+        return out
+
+    def unpad_batch(self, Z, multipliers=False):
+        Z = np.asarray(Z)
+        if self._pad is None:
+            return Z
+        return Z[..., self._pad[1 if multipliers else 0]]
 
     def multipliers_to_reference(self, mu):
         """Multipliers of the batched entry points come back in the SOLVER's row order; when a stage-local GeneralConstraint
@@ -627,6 +653,50 @@ def _with_exact_hessians(dynamics, objective, constraints):
     return out
 
 
+def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
+    """Stage objects of a problem with 17 .. 63 states embedded in the 64 states the tile (MFMA) kernels are built for
+    (csrc/dto_wide_kernels.hpp; the reference allows any dimensions, src/dynamics.jl:206-211): the padding states follow
+    y_k - x_k = 0, cost nothing and are fixed at zero by equal bounds at every knot, so the kernels treat them as identity
+    rows.  Returns (dynamics, objective, constraints, bounds, zmap, mumap) -- zmap / mumap: positions of the padded problem's
+    variables / constraint rows that belong to the original problem, in the original order -- or None if the problem does not
+    fit the tile path either way (several actions, stage constraints, parameters, varying dimensions, user Jacobians)."""
+    from .plugin import WIDE_MIN_STATE, WIDE_STATE
+    from .symbolic import expr as E
+    T = len(objective)
+    n = dynamics[0].num_state
+    if not (WIDE_MIN_STATE <= n < WIDE_STATE):
+        return None
+    if any(d.num_state != n or d.num_next_state != n or d.num_action != 1 or d.num_parameter != 0 or d.user_jacobian for d in dynamics):
+        return None
+    if any(c.num_constraint > 0 for c in constraints) or any(c.num_parameter != 0 for c in objective):
+        return None
+    N = WIDE_STATE
+    x, y = E.variables("x", N), E.variables("y", N)
+    cache = {}
+
+    def pad(o):
+        if id(o) not in cache:
+            if isinstance(o, Dynamics):
+                cache[id(o)] = Dynamics(list(o.evaluate_expr) + [y[k] - x[k] for k in range(n, N)], N, N, 1,
+                                        evaluate_hessian=evaluate_hessian)
+            else:
+                cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, evaluate_hessian=evaluate_hessian)
+        return cache[id(o)]
+
+    dyn2 = [pad(d) for d in dynamics]
+    obj2 = [pad(c) for c in objective]
+    z0 = np.zeros(N - n)
+    bnd2 = [Bound(N, len(b.action_lower), state_lower=np.concatenate([b.state_lower, z0]), state_upper=np.concatenate([b.state_upper, z0]),
+                  action_lower=b.action_lower, action_upper=b.action_upper) for b in bounds]
+    zmap, mumap = [], []
+    for t in range(T):
+        base = t * (N + 1)
+        zmap += list(range(base, base + n)) + ([base + N] if t < T - 1 else [])
+        if t < T - 1:
+            mumap += list(range(t * N, t * N + n))
+    return dyn2, obj2, [Constraint() for _ in range(T)], bnd2, np.asarray(zmap, dtype=np.int64), np.asarray(mumap, dtype=np.int64)
+
+
 def fold_general_constraint(dynamics, objective, constraints, general, evaluate_hessian):
     """Stage constraints equivalent to `constraints` + `general` when every general row depends on one knot only.
 
@@ -683,10 +753,10 @@ def solve(solver: Solver):
     mu = np.zeros(max(1, n.num_constraint))
     status, iters = C.c_int32(0), C.c_int32(0)
     co = _c_options(solver.options)
-    capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver._z0)), capi.dptr(x), capi.dptr(mu),
+    capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver.pad_batch(solver._z0))), capi.dptr(x), capi.dptr(mu),
                                 C.byref(status), C.byref(iters)))
-    solver._solution = x
-    solver._duals = mu[:n.num_constraint]
+    solver._solution = solver.unpad_batch(x)
+    solver._duals = solver.unpad_batch(mu[:n.num_constraint], multipliers=True)
     if solver._mu_to_reference is not None:
         ref = np.zeros(solver.nlp.num_constraint)
         ref[solver._mu_to_reference] = mu[:n.num_constraint]
@@ -696,7 +766,7 @@ def solve(solver: Solver):
         # the reference prints Ipopt's iteration log at this level (src/options.jl:23); here: one summary line
         names = {0: "cut off (max_cpu_time)", 1: "converged", 2: "maximum iterations reached", 3: "failed (non-finite iterate)"}
         try:
-            f = solver.nlp.eval_objective(x)
+            f = solver.nlp.eval_objective(solver._solution)
         except Exception:
             f = float("nan")
         print(f"dto_amd: {names.get(solver.status, solver.status)} after {solver.iterations} iterations, objective {f:.10e}")

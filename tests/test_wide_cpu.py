@@ -89,3 +89,35 @@ def test_full_horizon_layout_totals():
     assert s.nlp.num_jacobian == (T - 1) * n * (2 * n + m)
     lo, hi = s.nlp.variable_bounds
     assert np.all(lo[:n] == hi[:n]) and np.all(lo[-n:] == hi[-n:]) and hi[-n] == pytest.approx(np.pi)
+
+
+def test_embedding_of_a_24_state_problem_in_the_64_state_kernels():
+    """solver.py: pad_to_wide -- the padded dynamics reproduce the original residuals in their first 24 rows and y_k - x_k in
+    the padding rows, the cost is unchanged, the padding states are fixed at zero, and zmap / mumap pick the original
+    variables / rows out of the padded layout in the original order."""
+    from dto_amd.solver import pad_to_wide
+    n, T = 24, 5
+    p = P.build_acrobot_padded(T=T, n=n, terminal="physical")
+    out = pad_to_wide(p["dynamics"], p["objective"], p["constraints"], p["bounds"], True)
+    assert out is not None
+    dyn, obj, cons, bnds, zmap, mumap = out
+    assert dyn[0] is dyn[1] and obj[0] is obj[1] and obj[-1] is not obj[0]           # object sharing preserved (stage classes)
+    assert (dyn[0].num_state, dyn[0].num_next_state, dyn[0].num_action) == (64, 64, 1) and obj[-1].num_state == 64
+    rng = np.random.default_rng(2)
+    x, u, y = rng.random(64), rng.random(1), rng.random(64)
+    env = {("x", i): float(v) for i, v in enumerate(x)}
+    env.update({("y", i): float(v) for i, v in enumerate(y)}); env[("u", 0)] = float(u[0])
+    r_pad = np.array(evaluate(dyn[0].evaluate_expr, env))
+    r_org = np.array(evaluate(p["dynamics"][0].evaluate_expr, env))
+    assert np.max(np.abs(r_pad[:n] - r_org)) == 0.0 and np.max(np.abs(r_pad[n:] - (y[n:] - x[n:]))) == 0.0
+    assert evaluate(obj[0].evaluate_expr, env) == evaluate(p["objective"][0].evaluate_expr, env)
+    for b in bnds:
+        assert np.all(b.state_lower[n:] == 0.0) and np.all(b.state_upper[n:] == 0.0)
+    nz_pad = (T - 1) * 65 + 64
+    z_pad = np.arange(nz_pad, dtype=float)
+    z = z_pad[zmap]
+    assert len(zmap) == (T - 1) * (n + 1) + n and len(mumap) == (T - 1) * n
+    assert np.array_equal(z[:n], np.arange(n)) and z[n] == 64 and np.array_equal(z[n + 1:2 * n + 1], 65 + np.arange(n))
+    assert np.array_equal(mumap[:n], np.arange(n)) and mumap[n] == 64
+    # not eligible: several actions, stage constraints, or already 64 states
+    assert pad_to_wide(P.build_acrobot_padded(T=3)["dynamics"], *[P.build_acrobot_padded(T=3)[k] for k in ("objective", "constraints", "bounds")], True) is None

@@ -224,3 +224,55 @@ def test_wide_default_mode_solve_and_callbacks():
     se = dto_amd.Solver(pe["dynamics"], pe["objective"], pe["constraints"], pe["bounds"], evaluate_hessian=True, name="acrobot_padded")
     se._z0[:] = s._z0
     assert dto_amd.solve(se) == 1 and se.iterations == its_default
+
+
+def test_24_state_problem_callbacks_and_solve_through_the_64_state_embedding():
+    """State dimensions between 17 and 63 (the reference allows any, src/dynamics.jl:206-211; VERDICT r3: "n in 17-63 has no
+    kernel at all"): the evaluator callbacks come from a tile-family plugin of the problem's own size (structures in the
+    reference layout of the 24-state problem), solve! embeds the problem in the 64 states of the MFMA kernels with the padding
+    states fixed at zero (solver.py: pad_to_wide) and maps the trajectory back.  Oracle: oracle/padded_model.py at n = 24."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives
+    n_, T = 24, 30
+    p = P.build_acrobot_padded(T=T, n=n_, target=0.4, terminal="physical")
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot24")
+    n = s.nlp
+    nz, nc = n.num_variables, n.num_constraint
+    assert (nz, nc) == ((T - 1) * (n_ + 1) + n_, (T - 1) * n_)                     # the PROBLEM's own layout
+    assert s._solve_nlp is not n and s._solve_nlp.num_variables == (T - 1) * 65 + 64  # the solver's: 64 states per knot
+    om = PaddedAcrobot(n_)
+    rng = np.random.default_rng(24)
+    z, mu, sigma = rng.random(nz), rng.random(nc), 0.6
+    f, g, c, J, H = dense_derivatives(om, T, z, mu, sigma)
+    gv = np.zeros(nz); n.eval_objective_gradient(gv, z)
+    cv = np.zeros(nc); n.eval_constraint(cv, z)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    Hv = np.zeros(int(n.sizes.nnz_hess_key)); n.eval_hessian_lagrangian(Hv, z, sigma, mu)
+    assert abs(n.eval_objective(z) - f) <= 1e-8 * max(1.0, abs(f))
+    assert np.max(np.abs(gv - g)) <= 1e-8 * max(1.0, np.max(np.abs(g)))
+    assert np.max(np.abs(cv - c)) <= 1e-8 * max(1.0, np.max(np.abs(c)))
+    jr, jc = np.array(n.jacobian_structure()).T - 1
+    Jd = np.zeros_like(J); Jd[jr, jc] = Jv
+    assert np.max(np.abs(Jd - J)) <= 1e-8 * np.max(np.abs(J))
+    hr, hc = np.array(n.hessian_lagrangian_structure()).T - 1
+    Hd = np.zeros_like(H); Hd[hr, hc] = Hv
+    assert np.max(np.abs(Hd - H)) <= 1e-8 * max(1.0, np.max(np.abs(H)))
+    # solve! from the reference-style guess; result in the problem's layout, a KKT point of the ORACLE's 24-state problem
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    zs, ls = s._solution, s._duals
+    assert zs.shape == (nz,) and ls.shape == (nc,)
+    f, g, c, J, _ = dense_derivatives(om, T, zs, ls, 1.0)
+    vlo, vhi = n.variable_bounds
+    fixed = vlo == vhi
+    assert np.max(np.abs(zs[fixed] - vlo[fixed])) < 1e-12 and np.max(np.abs(c)) <= 1e-6
+    r = g + J.T @ ls
+    assert np.max(np.abs(r[~fixed])) <= 1e-5 * max(1.0, np.max(np.abs(ls)))
+    x_sol, u_sol = dto_amd.get_trajectory(s)
+    assert len(x_sol) == T and x_sol[0].shape == (n_,) and np.linalg.norm(x_sol[-1][:4] - p["xT"][:4]) < 1e-3
+    # batched entry points take the solver's layout: pad_batch / unpad_batch are the maps
+    Zp = s.pad_batch(s._z0[None, :])
+    assert Zp.shape == (1, (T - 1) * 65 + 64) and np.array_equal(s.unpad_batch(Zp)[0], s._z0)
