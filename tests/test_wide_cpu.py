@@ -71,12 +71,20 @@ def test_wide_plugin_source_and_structure_rules(padded):
     src = generate_source(st, "acrobot_padded")
     assert '#include "dto_wide_kernels.hpp"' in src and "dto_kkt_kernels.hpp" not in src
     assert "NJV = 18" in src and "NNL = 2" in src and "WIDE_N = 64" in src
-    # the tile kernels are built for 64 states / one action / exact Hessians: anything else in the wide range is refused
-    bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 1, evaluate_hessian=True)
+    # 17 .. 63 states (round 4): a callbacks-only plugin of the problem's own size (the KKT kernels are built for 64 states: the
+    # solver embeds such a problem, solver.py: pad_to_wide) -- no k_wide_step instantiation in it
+    d20 = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 1, evaluate_hessian=True)
     cost = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 1, evaluate_hessian=True)
     costT = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 0, evaluate_hessian=True)
+    st20 = Structure([d20], [cost, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+    assert st20.wide and st20.wide_n == 20 and not st20.wide_solver
+    src20 = generate_source(st20, "m20")
+    assert "WIDE_N = 20" in src20 and "launch_wide<Model>" not in src20 and "launch_wide_eval<Model>" in src20
+    # several actions or stage constraints in the wide range are still refused
+    bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 2, evaluate_hessian=True)
+    cost2 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 2, evaluate_hessian=True)
     with pytest.raises(ValueError):
-        Structure([bad], [cost, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+        Structure([bad], [cost2, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
 
 
 def test_full_horizon_layout_totals():
