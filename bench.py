@@ -275,12 +275,13 @@ def main():
 
     T, B = a.horizon, a.batch
     # Safety net for the memory-sized default: solver state (~0.36 MB per instance at T = 1000, 0.49 MB when the batch may
-    # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 20 GB to spare; shrink by whole
+    # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 5 GB to spare (the estimate is the measured high-water mark); shrink by whole
     # residencies of the sequential sweep (131 072 instances) if another process holds part of the HBM.
     free_b = torch.cuda.mem_get_info(dev)[0]
     # (+ 0.072 MB per instance for the second iterate / multiplier buffers of the fused UPDATE+EVAL pass: 8 (N_z + N_c) bytes)
-    per_inst_of = lambda b: (0.37e6 if b > 131072 else 0.50e6) * (T / 1000.0) + 2 * 8.0 * 5 * T + 8.0 * 9 * T
-    while B > 131072 and B * per_inst_of(B) + 7e9 > free_b - 20e9:
+    # measured at the default batch: 301.6 GB in use at the high-water mark (hbm_free_min_gb 7.4 of 309) = this estimate
+    per_inst_of = lambda b: (0.41e6 if b > 131072 else 0.54e6) * (T / 1000.0) + 2 * 8.0 * 5 * T + 8.0 * 9 * T
+    while B > 131072 and B * per_inst_of(B) + 7e9 > free_b - 5e9:
         B -= 131072
     if dist is not None:   # every rank runs the same shard size: the smallest any of them could take
         bt = torch.tensor([B], device=dev, dtype=torch.int64)
