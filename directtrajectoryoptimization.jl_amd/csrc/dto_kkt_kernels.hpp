@@ -428,7 +428,9 @@ struct SoaIO {
   __device__ __forceinline__ void put_dlam(int k, double v) const { *soa(a.dlam, g, a.Nc, uload(a.cdoff, t) + k) = v; }
   __device__ __forceinline__ void put_ds(int j, double v) const { *soa(a.ds, g, a.Ni, uload(a.ioff, t) + D::slack(j)) = v; }
   __device__ __forceinline__ long long* prof() const {
-#if DTO_KKT_PROFILE
+#if DTO_KKT_PROFILE == 2   // (tools/micro/fused_sweeps_check.py: the same stamps behind a wave-UNIFORM condition)
+    return a.prof;
+#elif DTO_KKT_PROFILE
     return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr;
 #else
     return nullptr;   // the cycle stamps are compiled in only with -DDTO_KKT_PROFILE=1 (DTO_PLUGIN_CXXFLAGS, tools/kkt_profile.py):
@@ -504,7 +506,9 @@ struct SoaRunIO {
   __device__ __forceinline__ void put_dlam(int k, double v) const { b.dlam.st(cd0 + k, v); }
   __device__ __forceinline__ void put_ds(int j, double v) const { b.ds.st(io0 + D::slack(j), v); }
   __device__ __forceinline__ long long* prof() const {
-#if DTO_KKT_PROFILE
+#if DTO_KKT_PROFILE == 2   // (tools/micro/fused_sweeps_check.py: the same stamps behind a wave-UNIFORM condition)
+    return a.prof;
+#elif DTO_KKT_PROFILE
     return (a.prof && blockIdx.x == 1 && threadIdx.x == 0) ? a.prof : nullptr;
 #else
     return nullptr;   // the cycle stamps are compiled in only with -DDTO_KKT_PROFILE=1 (DTO_PLUGIN_CXXFLAGS, tools/kkt_profile.py):
@@ -2474,6 +2478,19 @@ template <class M>
 __global__ __launch_bounds__(WAVE) void k_kkt_bwd(dto_kkt_args a) { kkt_bwd_body<M, true>(a); }
 template <class M>
 __global__ __launch_bounds__(WAVE, DTO_SEQ_BWD_OCC) void k_kkt_bwd_seq(dto_kkt_args a) { kkt_bwd_body<M, false>(a); }
+#ifndef DTO_FUSE_SWEEPS
+#define DTO_FUSE_SWEEPS 0
+#endif
+#if DTO_FUSE_SWEEPS
+// EXPERIMENT (tools/micro/fused_sweeps_check.py, -DDTO_FUSE_SWEEPS=1): both sweeps of a tile in one wavefront -- the form that gave
+// deterministic wrong results in round 3 when both bodies were inline and the forward prefetch was on.  Not used by the product.
+template <class M>
+__global__ __launch_bounds__(WAVE, 1) void k_kkt_fwdbwd_seq(dto_kkt_args a) {
+  kkt_fwd_body<M, false>(a);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  kkt_bwd_body<M, false>(a);
+}
+#endif
 // A forward launch ends with its wavefront slots draining: the tiles that start late and climb a long regularisation ladder
 // (up to six rounds, 20 ms) run alone at the end -- 105-110 ms for 80 ms of work at 8 192 tiles on 1 024 slots
 // (profiles/r03/sq_counters_soa_sweeps_B524288_final.txt).  k_kkt_bwd_early runs on a second, low-priority stream next to the
@@ -2931,8 +2948,13 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         } else {
           // the sequential sweep loops over its rounds inside the launch, a.fwd_rounds at most per launch (0: all of them)
           const int per = a.fwd_rounds > 0 ? a.fwd_rounds : rounds;
+#if DTO_FUSE_SWEEPS
+          if (per == rounds) { hipLaunchKernelGGL(k_kkt_fwdbwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a); } else
+#endif
+          {
           for (int r = 0; r < rounds; r += per) hipLaunchKernelGGL(k_kkt_fwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
           hipLaunchKernelGGL(k_kkt_bwd_seq<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          }
         }
         hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
