@@ -213,6 +213,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
   a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
   a.fac = p->wide_fac; a.flags = p->wide_flags; a.Nc = L.Nc;
   a.fixed_lo = a.fixed_hi = nullptr; a.dw_inst = nullptr; a.gam_inst = nullptr; a.active = nullptr; a.stats = nullptr; a.merit = nullptr;
+  a.zl = a.zu = nullptr; a.mu_inst = nullptr; a.tau_min = 0.99;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_WIDE_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   const int lrc = p->vt->launch_wide(DTO_WIDE_STEP, &a, (void*)st);
@@ -245,15 +246,64 @@ static __global__ void k_rows_axpy(double* y, const double* x, const double* alp
     y[b * ldy + i] += al * x[b * ldx + i];
 }
 
+// ---- finite variable bounds on the wide path (round 4): the barrier bookkeeping around k_wide_step, instance-major ----------
+// push the guess into the bounds and put the bound multipliers on the central path of mu (Waechter & Biegler 2006, section 3.6;
+// the same rule as k_init of the lane-per-instance path)
+static __global__ void k_wide_init_bounds(double* z, double* zl, double* zu, const double* lo, const double* hi, double mu,
+                                          double bound_push, double bound_frac, int64_t n) {
+  const int64_t b = blockIdx.x / AXPY_BLOCKS_PER_ROW, blk = blockIdx.x % AXPY_BLOCKS_PER_ROW;
+  for (int64_t i = blk * blockDim.x + threadIdx.x; i < n; i += (int64_t)AXPY_BLOCKS_PER_ROW * blockDim.x) {
+    double v = z[b * n + i], l = 0.0, u = 0.0;
+    const double a = lo[i], c = hi[i];
+    if (a == c) v = a;
+    else {
+      const bool fl = a > -1e300, fh = c < 1e300;
+      if (fl && fh) {
+        const double pl = fmin(bound_push * fmax(1.0, fabs(a)), bound_frac * (c - a));
+        const double pu = fmin(bound_push * fmax(1.0, fabs(c)), bound_frac * (c - a));
+        v = fmin(fmax(v, a + pl), c - pu);
+      } else if (fl) v = fmax(v, a + bound_push * fmax(1.0, fabs(a)));
+      else if (fh) v = fmin(v, c - bound_push * fmax(1.0, fabs(c)));
+      if (fl) l = mu / (v - a);
+      if (fh) u = mu / (c - v);
+    }
+    z[b * n + i] = v; zl[b * n + i] = l; zu[b * n + i] = u;
+  }
+}
+// bound multipliers after a step: z_L + alpha_d dz_L with dz_L = mu/(x-lo) - z_L - z_L/(x-lo) dx at the OLD point, kept within
+// [mu / (kappa gap'), kappa mu / gap'] of the NEW gap (Ipopt's kappa_Sigma = 1e10 safeguard); runs before z is updated
+static __global__ void k_wide_update_bounds(const double* z, const double* dz, double* zl, double* zu, const double* lo, const double* hi,
+                                            const double* alpha_p, const double* alpha_d, const double* mu, int64_t n) {
+  const int64_t b = blockIdx.x / AXPY_BLOCKS_PER_ROW, blk = blockIdx.x % AXPY_BLOCKS_PER_ROW;
+  const double ap = alpha_p[b], ad = alpha_d[b], m = mu[b];
+  if (ap == 0.0 && ad == 0.0) return;
+  constexpr double KSIG = 1e10;
+  for (int64_t i = blk * blockDim.x + threadIdx.x; i < n; i += (int64_t)AXPY_BLOCKS_PER_ROW * blockDim.x) {
+    const double a = lo[i], c = hi[i];
+    if (a == c) continue;
+    const double x = z[b * n + i], dx = dz[b * n + i], xn = x + ap * dx;
+    if (a > -1e300) {
+      const double g = x - a, gn = xn - a, l = zl[b * n + i];
+      zl[b * n + i] = fmin(fmax(l + ad * (m / g - l - (l / g) * dx), m / (KSIG * gn)), KSIG * m / gn);
+    }
+    if (c < 1e300) {
+      const double g = c - x, gn = c - xn, u = zu[b * n + i];
+      zu[b * n + i] = fmin(fmax(u + ad * (m / g - u + (u / g) * dx), m / (KSIG * gn)), KSIG * m / gn);
+    }
+  }
+}
+
 static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                             double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
   int rc = p->ensure_device();
   if (rc) return rc;
   const Layout& L = p->L;
   if (L.Nstage != 0 || L.Ngen != 0) return set_error(DTO_ERR_UNSUPPORTED, "wide-stage models: dynamics rows and bounds only");
+  // finite bounds (lo < hi, one side finite): primal-dual barrier, round 4; n_bnd = number of bound multipliers
+  int64_t n_bnd = 0;
   for (int64_t i = 0; i < L.Nz; ++i)
-    if (L.var_lo[i] != L.var_hi[i] && (std::isfinite(L.var_lo[i]) || std::isfinite(L.var_hi[i])))
-      return set_error(DTO_ERR_UNSUPPORTED, "wide-stage solver: variables may be free or fixed (lo == hi), not bounded");
+    if (L.var_lo[i] != L.var_hi[i]) n_bnd += (std::isfinite(L.var_lo[i]) ? 1 : 0) + (std::isfinite(L.var_hi[i]) ? 1 : 0);
+  const bool barrier = n_bnd > 0;
   if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
   dto_options u;
   if (opt) u = *opt; else dto_options_default(&u);
@@ -272,11 +322,13 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     p->wide_fac_len = need_fac;
   }
   double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_dw = nullptr,
-         *d_stats = nullptr, *d_merit = nullptr, *d_alpha = nullptr, *d_gam = nullptr;
+         *d_stats = nullptr, *d_merit = nullptr, *d_alpha = nullptr, *d_gam = nullptr, *d_zl = nullptr, *d_zu = nullptr, *d_mu = nullptr,
+         *d_alphad = nullptr;
   int *d_flags = nullptr, *d_active = nullptr;
   auto cleanup = [&]() {
     for (void* q : {(void*)z, (void*)lam, (void*)dz, (void*)dlam, (void*)d_lo, (void*)d_hi, (void*)d_dw, (void*)d_stats,
-                    (void*)d_merit, (void*)d_alpha, (void*)d_gam, (void*)d_flags, (void*)d_active})
+                    (void*)d_merit, (void*)d_alpha, (void*)d_gam, (void*)d_flags, (void*)d_active, (void*)d_zl, (void*)d_zu, (void*)d_mu,
+                    (void*)d_alphad})
       if (q) (void)hipFree(q);
   };
 #define WTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
@@ -299,10 +351,18 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   WTRY(hipMemsetAsync(lam, 0, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double), st));
   WTRY(hipMemsetAsync(dz, 0, (size_t)B * Nz * sizeof(double), st));
   WTRY(hipMemsetAsync(dlam, 0, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double), st));
+  if (barrier) {
+    WTRY(hipMalloc((void**)&d_zl, (size_t)B * Nz * sizeof(double)));
+    WTRY(hipMalloc((void**)&d_zu, (size_t)B * Nz * sizeof(double)));
+    WTRY(hipMalloc((void**)&d_mu, B * sizeof(double)));
+    WTRY(hipMalloc((void**)&d_alphad, B * sizeof(double)));
+    hipLaunchKernelGGL(k_wide_init_bounds, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, d_zl, d_zu, (const double*)d_lo,
+                       (const double*)d_hi, o.mu_init, o.bound_push, o.bound_frac, Nz);
+  }
 
   struct Inst {
     int status = 0, iter = 0, ls_fail = 0, full_streak = 0, attempt = 0, acc_count = 0;
-    double f_last = 1e300;
+    double f_last = 1e300, mu = 0.0;
     double dw = 0.0, dlast = 0.0, theta_max = -1.0, theta_min = -1.0, alpha = 0.0, gam = 1.0, gamma_acc = 1.0;
     std::vector<double> filt;  // (theta, phi) pairs, ring of DTO_FILTER_CAP
     int filter_n = 0;
@@ -311,6 +371,9 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   std::vector<int> h_active((size_t)B), h_flags((size_t)B);
   std::vector<double> h_gam((size_t)B, 1.0);
   std::vector<double> h_dw((size_t)B), h_stats((size_t)B * DTO_WIDE_NSTAT), h_merit((size_t)B * 2 * DTO_WIDE_TRIALS), h_alpha((size_t)B);
+  std::vector<double> h_mu((size_t)B, barrier ? o.mu_init : 0.0), h_alphad((size_t)B, 0.0);
+  for (auto& s : I) s.mu = barrier ? o.mu_init : 0.0;
+  if (barrier) WTRY(hipMemcpyAsync(d_mu, h_mu.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
   dto_wide_args a;
   a.T = L.T; a.B = B;
   a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.params = p->d_params;
@@ -319,6 +382,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   a.dz = dz; a.lddz = Nz; a.dmu = dlam; a.lddmu = Nc;
   a.fac = p->wide_fac; a.flags = d_flags; a.Nc = Nc; a.prof = nullptr;
   a.fixed_lo = d_lo; a.fixed_hi = d_hi; a.dw_inst = d_dw; a.gam_inst = d_gam; a.active = d_active; a.stats = d_stats; a.merit = d_merit;
+  a.zl = d_zl; a.zu = d_zu; a.mu_inst = d_mu; a.tau_min = o.tau_min;
   auto launch = [&](int op) -> int {
     const int lrc = p->vt->launch_wide(op, &a, (void*)st);
     return lrc;
@@ -349,7 +413,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       WTRY(hipMemcpyAsync(h_flags.data(), d_flags, B * sizeof(int), hipMemcpyDeviceToHost, st));
       WTRY(hipMemcpyAsync(h_stats.data(), d_stats, h_stats.size() * sizeof(double), hipMemcpyDeviceToHost, st));
       WTRY(hipStreamSynchronize(st));
-      bool again = false;
+      bool again = false, mu_moved = false;
       for (int64_t i = 0; i < B; ++i) {
         if (!h_active[(size_t)i]) continue;
         Inst& s = I[(size_t)i];
@@ -357,21 +421,54 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
         if (first_pass) {
           // ---- B: convergence test at the current iterate (Ipopt's scaled error, reference Options tolerances)
           const double f = sv[DTO_WIDE_F], th1 = sv[DTO_WIDE_TH1], thinf = sv[DTO_WIDE_THINF], dinf = sv[DTO_WIDE_DINF];
-          const double sd = std::max(o.s_max, sv[DTO_WIDE_SUMLAM] / (double)std::max<int64_t>(1, Nc)) / o.s_max;
-          const double e0 = std::max(dinf / sd, thinf);
-          // Ipopt's acceptable level over consecutive iterations (no bounds on this path: no complementarity term)
+          // Ipopt's scaling with the bound multipliers included; complementarity measured against mu_target (as k_conv does)
+          const double sumz = barrier ? sv[DTO_WIDE_SUMZ] : 0.0;
+          const double sd = std::max(o.s_max, (sv[DTO_WIDE_SUMLAM] + sumz) / (double)std::max<int64_t>(1, Nc + n_bnd)) / o.s_max;
+          const double scn = std::max(o.s_max, sumz / (double)std::max<int64_t>(1, n_bnd)) / o.s_max;
+          auto compl_at = [&](double m) {
+            if (!barrier) return 0.0;
+            const double szmin = sv[DTO_WIDE_ISZMAX] > 0.0 ? 1.0 / sv[DTO_WIDE_ISZMAX] : 1e300;
+            return std::max(sv[DTO_WIDE_SZMAX] - m, m - szmin);
+          };
+          const double c0 = compl_at(o.mu_target);
+          const double e0 = std::max(std::max(dinf / sd, thinf), c0 / scn);
           const bool acceptable = o.acceptable_iter > 0 && e0 <= o.acceptable_tol && dinf <= o.acceptable_dual_inf_tol &&
-                                  thinf <= o.acceptable_constr_viol_tol &&
+                                  thinf <= o.acceptable_constr_viol_tol && c0 <= o.acceptable_compl_inf_tol &&
                                   std::fabs(f - s.f_last) / std::max(1.0, std::fabs(f)) <= o.acceptable_obj_change_tol;
           s.acc_count = acceptable ? s.acc_count + 1 : 0;
           s.f_last = f;
           if (!(f == f) || !(th1 == th1) || !(dinf == dinf)) s.status = 3;
-          else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol) s.status = 1;
+          else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) s.status = 1;
           else if (o.acceptable_iter > 0 && s.acc_count >= o.acceptable_iter) s.status = 4;
           else if (s.iter >= o.max_iter) s.status = 2;
+          else if (barrier) {
+            // monotone barrier update (Waechter & Biegler (7)) with mu_target as the floor; the step just computed belongs to
+            // the old mu: instances whose mu moved are evaluated again before anything is decided about their factorisation
+            const double mu_floor = std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
+            double m = s.mu;
+            bool changed = false;
+            for (int k = 0; k < 8; ++k) {
+              const double emu = std::max(std::max(dinf / sd, thinf), compl_at(m) / scn);
+              if (!(emu <= o.kappa_eps * m) || m <= mu_floor) break;
+              m = std::max(mu_floor, std::min(o.kappa_mu * m, std::pow(m, o.theta_mu)));
+              changed = true;
+            }
+            if (changed) { s.mu = m; h_mu[(size_t)i] = m; s.filter_n = 0; mu_moved = true; }
+          }
           if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
           if (s.status != 0) { h_active[(size_t)i] = 0; continue; }
         }
+      }
+      if (first_pass && mu_moved) {
+        // the barrier parameter of some instance moved: its step (and statistics) are re-evaluated with the new mu before the
+        // inertia of that factorisation is judged; nothing of the ladder advances in this pass
+        WTRY(hipMemcpyAsync(d_mu, h_mu.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+        first_pass = false;
+        continue;
+      }
+      for (int64_t i = 0; i < B; ++i) {
+        if (!h_active[(size_t)i]) continue;
+        Inst& s = I[(size_t)i];
         // ---- C: inertia (Algorithm IC, ladder on the exact Hessian)
         if (h_flags[(size_t)i] || s.attempt >= o.max_refactor) {
           if (s.dw > 0.0 && s.gam != 0.0) s.dlast = s.dw;
@@ -415,9 +512,12 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       Inst& s = I[(size_t)i];
       const double* sv = &h_stats[(size_t)i * DTO_WIDE_NSTAT];
       const double* mv = &h_merit[(size_t)i * 2 * DTO_WIDE_TRIALS];
-      const double th0 = sv[DTO_WIDE_TH1], phi0 = sv[DTO_WIDE_F], dphi = sv[DTO_WIDE_GPHID];
+      // with finite bounds: phi = f - mu sum log(gaps) (the merit kernel adds the same terms at the trial points), trial steps
+      // alpha_pmax 2^-k (fraction to the boundary), dual step alpha_dmax for the bound multipliers
+      const double amax = barrier ? sv[DTO_WIDE_APMAX] : 1.0;
+      const double th0 = sv[DTO_WIDE_TH1], phi0 = sv[DTO_WIDE_F] - (barrier ? s.mu * sv[DTO_WIDE_LOGBAR] : 0.0), dphi = sv[DTO_WIDE_GPHID];
       const int nf = std::min(s.filter_n, DTO_FILTER_CAP);
-      double alpha = 1.0, chosen = -1.0;
+      double alpha = amax, chosen = -1.0;
       bool ftype = false;
       int best = 0;
       for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
@@ -439,7 +539,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       }
       bool augment;
       if (chosen < 0.0) {
-        double ab = 1.0;
+        double ab = amax;
         for (int k = 0; k < best; ++k) ab *= 0.5;
         chosen = (mv[2 * best + 1] == mv[2 * best + 1] && mv[2 * best + 1] < th0) ? ab : alpha * 2.0;
         s.ls_fail = 1; augment = true;
@@ -452,15 +552,23 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
         s.filter_n++;
       }
       s.alpha = chosen;
-      s.full_streak = (chosen >= 1.0) ? s.full_streak + 1 : 0;
+      s.full_streak = (chosen >= amax) ? s.full_streak + 1 : 0;
+      h_alphad[(size_t)i] = barrier ? sv[DTO_WIDE_ADMAX] : 0.0;
       if (i == 0 && getenv("DTO_WIDE_VERBOSE"))
         fprintf(stderr, "it %3d f %.6e th1 %.3e thinf %.3e dinf %.3e dphi %.3e dw %.2e att %d alpha %.4g lsfail %d | f(1) %.6e th(1) %.3e f(.5) %.6e th(.5) %.3e\n",
                 s.iter, phi0, th0, sv[DTO_WIDE_THINF], sv[DTO_WIDE_DINF], dphi, s.dw, s.attempt, chosen, s.ls_fail, mv[0], mv[1], mv[2], mv[3]);
       s.iter++;
       h_alpha[(size_t)i] = chosen;
     }
-    // ---- E: take the steps
+    // ---- E: take the steps (bound multipliers first: their update reads the old point)
     WTRY(hipMemcpyAsync(d_alpha, h_alpha.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+    if (barrier) {
+      for (int64_t i = 0; i < B; ++i) if (h_alpha[(size_t)i] == 0.0) h_alphad[(size_t)i] = 0.0;
+      WTRY(hipMemcpyAsync(d_alphad, h_alphad.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_wide_update_bounds, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, (const double*)z, (const double*)dz,
+                         d_zl, d_zu, (const double*)d_lo, (const double*)d_hi, (const double*)d_alpha, (const double*)d_alphad,
+                         (const double*)d_mu, Nz);
+    }
     hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, (const double*)dz, (const double*)d_alpha, Nz, Nz, Nz);
     if (Nc > 0)
       hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, lam, (const double*)dlam, (const double*)d_alpha, Nc, Nc, Nc);

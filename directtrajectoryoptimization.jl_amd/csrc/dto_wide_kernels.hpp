@@ -55,9 +55,18 @@ struct dto_wide_args {
   const double* gam_inst;  // [B] 1: exact Hessian of the Lagrangian, 0: Gauss-Newton (constraint curvature lam' d'' dropped)
   const int* active;       // [B] 0 = skip this instance
   double* stats;           // [B][DTO_WIDE_NSTAT]: f, theta_1, theta_inf, dual infeasibility, grad f' dz, sum |lam|
-  double* merit;           // [B][2 * DTO_WIDE_TRIALS]: (f, theta_1) at z + 2^-k dz, k = 0..TRIALS-1 (DTO_WIDE_MERIT)
+  double* merit;           // [B][2 * DTO_WIDE_TRIALS]: (phi, theta_1) at z + alpha_pmax 2^-k dz, k = 0..TRIALS-1 (DTO_WIDE_MERIT)
+  // ---- finite variable bounds (round 4; NULL: variables are free or fixed): primal-dual barrier terms of the components
+  //      with lo < hi, one of them finite -- Sigma = z_L / (x - lo) + z_U / (hi - x) on the diagonal, mu / (x - lo) - mu / (hi - x)
+  //      in the right-hand side (the bound multipliers are eliminated, as in the lane-per-instance path: dto_kkt_kernels.hpp)
+  const double* zl; const double* zu;   // [B][Nz] bound multipliers
+  const double* mu_inst;                // [B] barrier parameter
+  double tau_min;                       // fraction-to-the-boundary parameter floor (0.99)
 };
-enum { DTO_WIDE_F = 0, DTO_WIDE_TH1, DTO_WIDE_THINF, DTO_WIDE_DINF, DTO_WIDE_GPHID, DTO_WIDE_SUMLAM, DTO_WIDE_NSTAT = 8 };
+// stats: 0 f (barrier terms excluded), 1 theta_1, 2 theta_inf, 3 dual infeasibility, 4 grad phi' dz, 5 sum |lam|, 6/7 scratch,
+// 8 alpha_pmax, 9 alpha_dmax, 10 max s z, 11 max 1 / (s z), 12 sum z, 13 sum log s  (8..13 only with bounds)
+enum { DTO_WIDE_F = 0, DTO_WIDE_TH1, DTO_WIDE_THINF, DTO_WIDE_DINF, DTO_WIDE_GPHID, DTO_WIDE_SUMLAM, DTO_WIDE_APMAX = 8, DTO_WIDE_ADMAX,
+       DTO_WIDE_SZMAX, DTO_WIDE_ISZMAX, DTO_WIDE_SUMZ, DTO_WIDE_LOGBAR, DTO_WIDE_NSTAT = 16 };
 #define DTO_WIDE_TRIALS 8
 
 namespace dto {
@@ -564,6 +573,51 @@ __device__ __forceinline__ double wave_sum(double v) {
     }                                                                              \
   } while (0)
 
+// barrier terms of one variable with bounds lo < hi (at least one finite): sig = z_L/(x-lo) + z_U/(hi-x),
+// br = mu/(x-lo) - mu/(hi-x); dz_L = mu/(x-lo) - z_L - z_L/(x-lo) dx and likewise for the upper bound are formed from the same
+// pieces after the back substitution (wide_bar_step)
+struct WideBar { double sig, br, sz_max, isz_max, sum_z, logb, zdiff; };
+__device__ __forceinline__ WideBar wide_bar(double x, double lo, double hi, double zl, double zu, double mu) {
+  WideBar o{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (lo == hi) return o;
+  if (lo > -1e300) {
+    const double g = x - lo;
+    o.sig += zl / g; o.br += mu / g; o.sz_max = fmax(o.sz_max, g * zl); o.isz_max = fmax(o.isz_max, 1.0 / (g * zl));
+    o.sum_z += fabs(zl); o.logb += log(g); o.zdiff -= zl;
+  }
+  if (hi < 1e300) {
+    const double g = hi - x;
+    o.sig += zu / g; o.br -= mu / g; o.sz_max = fmax(o.sz_max, g * zu); o.isz_max = fmax(o.isz_max, 1.0 / (g * zu));
+    o.sum_z += fabs(zu); o.logb += log(g); o.zdiff += zu;
+  }
+  return o;
+}
+// step-length bounds of one variable given its primal step dx: ap <= tau (x-lo)/(-dx) ..., ad from z + ad dz >= (1 - tau) z
+__device__ __forceinline__ void wide_bar_step(double x, double dx, double lo, double hi, double zl, double zu, double mu, double tau,
+                                              double& ap, double& ad) {
+  if (lo == hi) return;
+  if (lo > -1e300) {
+    const double g = x - lo, dzl = mu / g - zl - (zl / g) * dx;
+    if (dx < 0.0) ap = fmin(ap, -tau * g / dx);
+    if (dzl < 0.0) ad = fmin(ad, -tau * zl / dzl);
+  }
+  if (hi < 1e300) {
+    const double g = hi - x, dzu = mu / g - zu + (zu / g) * dx;
+    if (dx > 0.0) ap = fmin(ap, tau * g / dx);
+    if (dzu < 0.0) ad = fmin(ad, -tau * zu / dzu);
+  }
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) v = fmin(v, __shfl_xor(v, sft));
+  return v;
+}
+
 template <class M, int WKI>
 struct WK {
   using KD = typename M::template WKind<WKI>;
@@ -620,10 +674,16 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   const double dw = a.dw_inst ? a.dw_inst[b] : a.delta_w, dc = a.delta_c;
   const double gam = a.gam_inst ? a.gam_inst[b] : 1.0;
   double* stat = vec + 20 * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4;  // f, th1, thinf, dinf (LDS scalars)
-  double* fxm = stat + 8;   // [N] 1.0 where x_t is fixed by equal bounds
+  double* fxm = stat + 16;  // [N] 1.0 where x_t is fixed by equal bounds
   double* colb = fxm + N;   // [2][4][N] column exchange of ldl_rank1 (four columns per step, ping-pong)
   double* dg0 = colb + 8 * N;  // [N] |diagonal| before the factorisation (tiny-pivot test)
-  if (tid < 8) stat[tid] = 0.0;
+  double* brx = dg0 + N;       // [N + 1] barrier part of the right-hand side of x (and of u at [N]); 0 without finite bounds
+  if (tid < 16) stat[tid] = (tid == DTO_WIDE_APMAX || tid == DTO_WIDE_ADMAX) ? 1.0 : 0.0;
+  const bool barrier = a.zl != nullptr;
+  const double mub = (barrier && a.mu_inst) ? a.mu_inst[b] : 0.0;
+  const double* zlb = barrier ? a.zl + b * a.ldz : nullptr;
+  const double* zub = barrier ? a.zu + b * a.ldz : nullptr;
+  const double taub = fmax(a.tau_min, 1.0 - mub);
 
   long long tick_ = clock64();
   for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
@@ -648,10 +708,33 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           yv[tid] = z[a.zoff[t + 1] + tid];
           lamv[tid] = mu[a.cdoff[t] + tid];
           au[tid] = 0.0; vu[tid] = 0.0; nlf[tid] = 0.0;
-          MA[tid * LD + tid] += dw;
           fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
+          double sig = 0.0;
+          brx[tid] = 0.0;
+          if (barrier) {
+            const int gi = a.zoff[t] + tid;
+            const WideBar wb = wide_bar(xv[tid], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub);
+            sig = wb.sig; brx[tid] = wb.br;
+            if (a.stats) {   // tid < N is exactly wavefront 0: complementarity / barrier statistics of this knot's states
+              const double m1 = wave_max(wb.sz_max), m2 = wave_max(wb.isz_max), s1 = wave_sum(wb.sum_z), s2 = wave_sum(wb.logb);
+              if (tid == 0) {
+                stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], m1); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], m2);
+                stat[DTO_WIDE_SUMZ] += s1; stat[DTO_WIDE_LOGBAR] += s2;
+              }
+            }
+          }
+          MA[tid * LD + tid] += dw + sig;
         }
         if (tid == 0) { sc[0] = z[a.zoff[t] + N]; sc[1] = 0.0; }
+        if (tid == 64) {   // the action of this knot (one lane of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
+          double* ubar = brx + N;
+          WideBar wb{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          if (barrier) {
+            const int gi = a.zoff[t] + N;
+            wb = wide_bar(z[gi], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub);
+          }
+          ubar[0] = wb.br; ubar[1] = wb.sig; ubar[2] = wb.zdiff; ubar[3] = wb.sz_max; ubar[4] = wb.isz_max; ubar[5] = wb.sum_z; ubar[6] = wb.logb;
+        }
         {
           constexpr int NC = 2 * N + NU;
           const double* fe = DY::fe_const();
@@ -742,22 +825,35 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         DTO_WIDE_TICK(3);
         // ---- phase 4: gradient of the Lagrangian -> right-hand sides
         if (w == 0) {
-          bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l];
+          bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l] + brx[l];
         } else if (w == 1) {
           gyn[l] = dot_cr<N>(ME + l, LD, lamv);
         } else if (w == 2) {
           const double part = wave_sum(fu[l] * lamv[l]);
           if (l == 0) {
-            sc[2] = -(gc[N] + part);
-            sc[3] = sc[1] + dw;
+            const double* ubar = brx + N;
+            sc[2] = -(gc[N] + part) + ubar[0];
+            sc[3] = sc[1] + dw + ubar[1];
+            if (barrier && a.stats) {
+              stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], ubar[3]); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], ubar[4]);
+              stat[DTO_WIDE_SUMZ] += ubar[5]; stat[DTO_WIDE_LOGBAR] += ubar[6];
+            }
           }
         }
         lds_barrier();
         DTO_WIDE_TICK(4);
-        // ---- solver use: dual infeasibility of the free variables; variables fixed by equal bounds become identity rows
+        // ---- solver use: dual infeasibility of the free variables (grad L - z_L + z_U with bounds); variables fixed by equal
+        //      bounds become identity rows
         if (a.stats && w == 3) {
-          double v = (fxm[l] != 0.0) ? 0.0 : fabs(bx[l] - byc[l]);
-          if (l == 0) v = fmax(v, fabs(sc[2]));
+          double zd = 0.0;
+          if (barrier) {
+            const int gi = a.zoff[t] + l;
+            const double lo = a.fixed_lo[gi], hi = a.fixed_hi[gi];
+            if (lo != hi) zd = (hi < 1e300 ? zub[gi] : 0.0) - (lo > -1e300 ? zlb[gi] : 0.0);
+          }
+          // bx = -grad L + byc + brx
+          double v = (fxm[l] != 0.0) ? 0.0 : fabs(-(bx[l] - byc[l] - brx[l]) + zd);
+          if (l == 0) v = fmax(v, fabs(-(sc[2] - brx[N]) + brx[N + 2]));
 #pragma unroll
           for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
           if (l == 0) stat[3] = fmax(stat[3], v);
@@ -927,16 +1023,30 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         __syncthreads();
         if (tid < N) {
-          MA[tid * LD + tid] += dw;
-          bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid];
+          double sig = 0.0;
+          brx[tid] = 0.0;
+          double zd = 0.0;
+          if (barrier) {
+            const int gi = a.zoff[t] + tid;
+            const WideBar wb = wide_bar(xv[tid], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub);
+            sig = wb.sig; brx[tid] = wb.br; zd = wb.zdiff;
+            if (a.stats) {
+              const double m1 = wave_max(wb.sz_max), m2 = wave_max(wb.isz_max), s1 = wave_sum(wb.sum_z), s2 = wave_sum(wb.logb);
+              if (tid == 0) {
+                stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], m1); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], m2);
+                stat[DTO_WIDE_SUMZ] += s1; stat[DTO_WIDE_LOGBAR] += s2;
+              }
+            }
+          }
+          MA[tid * LD + tid] += dw + sig;
+          bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid] + brx[tid];
+          if (a.stats) {
+            double v = (fxm[tid] != 0.0) ? 0.0 : fabs(gc[tid] + gyp[tid] + zd);
+            v = wave_max(v);
+            if (tid == 0) stat[3] = fmax(stat[3], v);
+          }
         }
         __syncthreads();
-        if (a.stats && w == 3) {
-          double v = (fxm[l] != 0.0) ? 0.0 : fabs(gc[l] + gyp[l]);
-#pragma unroll
-          for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
-          if (l == 0) stat[3] = fmax(stat[3], v);
-        }
         if (a.fixed_lo) {
           for (int i = tid; i < N * N; i += WG) {
             const int r = i >> 6, c = i & 63;
@@ -956,8 +1066,15 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             a.dz[b * a.lddz + a.zoff[t] + l] = bx[l];
           }
           if (a.stats) {
-            const double part = wave_sum(gc[l] * bx[l]);
+            const double part = wave_sum((gc[l] - brx[l]) * bx[l]);     // gradient of the barrier objective along the step
             if (l == 0) stat[4] += part;
+            if (barrier) {
+              const int gi = a.zoff[t] + l;
+              double ap = 1.0, ad = 1.0;
+              wide_bar_step(xv[l], bx[l], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub, taub, ap, ad);
+              ap = wave_min(ap); ad = wave_min(ad);
+              if (l == 0) { stat[DTO_WIDE_APMAX] = fmin(stat[DTO_WIDE_APMAX], ap); stat[DTO_WIDE_ADMAX] = fmin(stat[DTO_WIDE_ADMAX], ad); }
+            }
           }
         }
         __syncthreads();
@@ -1014,8 +1131,30 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       const double du = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
       if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = du;
       if (a.stats) {
-        const double gpart = wave_sum(fv[D::V_GC + l] * xv[l]);
-        if (l == 0) stat[4] += gpart + fv[D::V_GC + N] * du;
+        // gradient of the barrier objective along the step, fraction-to-the-boundary limits of this knot (x: lane, u: lane 0)
+        double brl = 0.0, ap = 1.0, ad = 1.0;
+        if (barrier) {
+          const int gi = a.zoff[t] + l;
+          const double xo = z[gi], lo = a.fixed_lo[gi], hi = a.fixed_hi[gi];
+          brl = wide_bar(xo, lo, hi, zlb[gi], zub[gi], mub).br;
+          wide_bar_step(xo, xv[l], lo, hi, zlb[gi], zub[gi], mub, taub, ap, ad);
+          if (l == 0) {
+            const int gu = a.zoff[t] + N;
+            const double uo = z[gu], ulo = a.fixed_lo[gu], uhi = a.fixed_hi[gu];
+            wide_bar_step(uo, du, ulo, uhi, zlb[gu], zub[gu], mub, taub, ap, ad);
+          }
+          ap = wave_min(ap); ad = wave_min(ad);
+        }
+        const double gpart = wave_sum((fv[D::V_GC + l] - brl) * xv[l]);
+        if (l == 0) {
+          double bru = 0.0;
+          if (barrier) {
+            const int gu = a.zoff[t] + N;
+            bru = wide_bar(z[gu], a.fixed_lo[gu], a.fixed_hi[gu], zlb[gu], zub[gu], mub).br;
+            stat[DTO_WIDE_APMAX] = fmin(stat[DTO_WIDE_APMAX], ap); stat[DTO_WIDE_ADMAX] = fmin(stat[DTO_WIDE_ADMAX], ad);
+          }
+          stat[4] += gpart + (fv[D::V_GC + N] - bru) * du;
+        }
       }
     }
     __syncthreads();
@@ -1023,7 +1162,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     __syncthreads();
     DTO_WIDE_TICK(16);
   }
-  if (a.stats && tid < 6) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
+  if (a.stats && tid < DTO_WIDE_NSTAT) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
 }
 
 // one wavefront per instance: out[b] = sum_t rows[b][t] in a fixed order (lane-strided partials, then a tree)
@@ -1261,13 +1400,36 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) { lin0 += row[N + j] * pv[N + j]; lind += row[N + j] * dp[N + j]; }
       }
-      double alpha = 1.0;
+      // trial steps alpha_pmax 2^-k (alpha_pmax = 1 without finite bounds); with bounds phi is the barrier objective
+      const bool barrier = a.zl != nullptr;
+      const double mub = (barrier && a.mu_inst) ? a.mu_inst[b] : 0.0;
+      double alpha = barrier ? a.stats[b * DTO_WIDE_NSTAT + DTO_WIDE_APMAX] : 1.0;
+      double lo_l = 0.0, hi_l = 0.0, lo_u = 0.0, hi_u = 0.0;
+      if (barrier) {
+        lo_l = a.fixed_lo[a.zoff[t] + l]; hi_l = a.fixed_hi[a.zoff[t] + l];
+        if (NUK > 0) { lo_u = a.fixed_lo[a.zoff[t] + N]; hi_u = a.fixed_hi[a.zoff[t] + N]; }
+      }
 #pragma unroll 1
       for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
         pk[l] = pv[l] + alpha * dp[l];
         if (l < NUK) pk[N + l] = pv[N + l] + alpha * dp[N + l];
         CO::eval(pk, pk + N, wp, nl + 8);
         if (l == 0) facc[k] += nl[8];
+        if (barrier) {
+          double lb = 0.0;
+          const double xk = pv[l] + alpha * dp[l];
+          if (lo_l != hi_l) {
+            if (lo_l > -1e300) lb += log(xk - lo_l);
+            if (hi_l < 1e300) lb += log(hi_l - xk);
+          }
+          if (NUK > 0 && l == 0 && lo_u != hi_u) {
+            const double uk = pv[N] + alpha * dp[N];
+            if (lo_u > -1e300) lb += log(uk - lo_u);
+            if (hi_u < 1e300) lb += log(hi_u - uk);
+          }
+          lb = wave_sum(lb);
+          if (l == 0) facc[k] -= mub * lb;
+        }
         if constexpr (HAS_DYN) {
           using DY = typename M::template Dyn<KD::DYN>;
           yk[l] = yv[l] + alpha * dy[l];
@@ -1302,7 +1464,7 @@ int wide_info(dto_wide_info* out) {
   out->n = M::WIDE_N;
   out->nu = M::WIDE_NU;
   out->fac_stage = D::FAC;
-  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 8 + M::WIDE_N + 9 * M::WIDE_N);
+  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 16 + M::WIDE_N + 10 * M::WIDE_N + 8);
   return 0;
 }
 

@@ -238,7 +238,7 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
     )
 
 
-def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full"):
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
     blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
     terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
@@ -250,8 +250,10 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
     dt = Dynamics(acrobot_padded_midpoint(n), n, n, m, evaluate_hessian=evaluate_hessian)
     ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
     cT = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]), n, 0, evaluate_hessian=evaluate_hessian)
-    b1 = Bound(n, m, state_lower=x1, state_upper=x1)
-    bt = Bound(n, m)
+    # u_max: action bounds -u_max <= u <= u_max at every knot (examples/cartpole/cartpole.jl:81-89 style)
+    ub = {} if u_max is None else dict(action_lower=-u_max * np.ones(m), action_upper=u_max * np.ones(m))
+    b1 = Bound(n, m, state_lower=x1, state_upper=x1, **ub)
+    bt = Bound(n, m, **ub)
     if terminal == "physical":
         lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
         lo[:4] = hi[:4] = xT[:4]

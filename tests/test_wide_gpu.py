@@ -276,3 +276,58 @@ def test_24_state_problem_callbacks_and_solve_through_the_64_state_embedding():
     # batched entry points take the solver's layout: pad_batch / unpad_batch are the maps
     Zp = s.pad_batch(s._z0[None, :])
     assert Zp.shape == (1, (T - 1) * 65 + 64) and np.array_equal(s.unpad_batch(Zp)[0], s._z0)
+
+
+def test_wide_solve_with_action_bounds():
+    """Finite variable bounds on the tile path (round 4; VERDICT r3: "a bounded 64-state test, examples/cartpole/cartpole.jl:81-89
+    style"): the 64-state model with -u_max <= u <= u_max at every knot, u_max chosen so that the bound is active along part of
+    the solution.  The primal-dual barrier terms live in k_wide_step / k_wide_merit, mu follows Ipopt's monotone rule down to
+    mu_target.  Checked with the ORACLE's derivatives: dynamics satisfied, bounds respected, the Lagrangian stationary in the
+    free variables where no bound is active and pushed the right way where one is, complementarity at compl_inf_tol."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives
+    T, B = 40, 3
+    # the unbounded solve first: how large the action gets
+    pu = P.build_acrobot_padded(T=T, target=0.5, terminal="physical")
+    su = dto_amd.Solver(pu["dynamics"], pu["objective"], pu["constraints"], pu["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    xs, us = pu["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(su, xs); dto_amd.initialize_controls(su, [0.1 * u for u in us])
+    assert dto_amd.solve(su) == 1
+    u_free = np.array([u[0] for u in dto_amd.get_trajectory(su)[1]])
+    u_max = 0.6 * float(np.max(np.abs(u_free)))
+    p = P.build_acrobot_padded(T=T, target=0.5, terminal="physical", u_max=u_max)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+        dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo_ = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo_.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert np.all(status == 1) and np.all(iters < 300), (status, iters)
+    zo, lam = zo.cpu().numpy(), lo_.cpu().numpy()
+    om = PaddedAcrobot(64)
+    vlo, vhi = s.nlp.variable_bounds
+    fixed = vlo == vhi
+    bounded = ~fixed & (np.isfinite(vlo) | np.isfinite(vhi))
+    assert bounded.sum() == T - 1
+    for b in range(B):
+        z = zo[b]
+        f, g, c, J, _ = dense_derivatives(om, T, z, lam[b], 1.0)
+        assert np.max(np.abs(c)) <= 1e-6
+        assert np.all(z[bounded] >= vlo[bounded]) and np.all(z[bounded] <= vhi[bounded])
+        r = g + J.T @ lam[b]
+        free = ~fixed & ~bounded
+        assert np.max(np.abs(r[free])) <= 1e-5 * max(1.0, np.max(np.abs(lam[b])))
+        # bounded components: r = z_L - z_U with z_L, z_U >= 0 complementary to the gaps (mu_target = 1e-4, compl_inf_tol = 1e-3)
+        zl, zu = np.maximum(r[bounded], 0.0), np.maximum(-r[bounded], 0.0)
+        compl = np.maximum(zl * (z[bounded] - vlo[bounded]), zu * (vhi[bounded] - z[bounded]))
+        assert np.max(compl) <= 1e-3, np.max(compl)
+        assert np.sum(np.abs(np.abs(z[bounded]) - u_max) < 1e-3) >= 2          # the bound is active somewhere
+    assert abs(np.max(np.abs(zo[0][bounded])) - u_max) < 1e-3
