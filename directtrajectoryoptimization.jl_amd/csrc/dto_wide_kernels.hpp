@@ -626,7 +626,9 @@ struct WK {
 // ---------------------------------------------------------------------------------------------------
 // the kernel: forward factor/solve sweep, terminal solve, backward sweep.  grid = B, block = 256.
 // ---------------------------------------------------------------------------------------------------
-template <class M>
+// BAR: instantiation with the barrier terms of finite variable bounds (launch_wide picks it when the caller passes bound
+// multipliers); the plain KKT step carries none of that code
+template <class M, bool BAR>
 __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
   static_assert(N == 64, "wide path is built for 64 states (one wavefront of rows, 4 x 4 tiles)");
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   double* dg0 = colb + 8 * N;  // [N] |diagonal| before the factorisation (tiny-pivot test)
   double* brx = dg0 + N;       // [N + 1] barrier part of the right-hand side of x (and of u at [N]); 0 without finite bounds
   if (tid < 16) stat[tid] = (tid == DTO_WIDE_APMAX || tid == DTO_WIDE_ADMAX) ? 1.0 : 0.0;
-  const bool barrier = a.zl != nullptr;
+  const bool barrier = BAR && a.zl != nullptr;
   const double mub = (barrier && a.mu_inst) ? a.mu_inst[b] : 0.0;
   const double* zlb = barrier ? a.zl + b * a.ldz : nullptr;
   const double* zub = barrier ? a.zu + b * a.ldz : nullptr;
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           au[tid] = 0.0; vu[tid] = 0.0; nlf[tid] = 0.0;
           fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
           double sig = 0.0;
-          brx[tid] = 0.0;
+          if (BAR) brx[tid] = 0.0;
           if (barrier) {
             const int gi = a.zoff[t] + tid;
             const WideBar wb = wide_bar(xv[tid], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub);
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           MA[tid * LD + tid] += dw + sig;
         }
         if (tid == 0) { sc[0] = z[a.zoff[t] + N]; sc[1] = 0.0; }
-        if (tid == 64) {   // the action of this knot (one lane of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
+        if (BAR && tid == 64) {   // the action of this knot (one lane of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
           double* ubar = brx + N;
           WideBar wb{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
           if (barrier) {
@@ -825,15 +827,15 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         DTO_WIDE_TICK(3);
         // ---- phase 4: gradient of the Lagrangian -> right-hand sides
         if (w == 0) {
-          bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l] + brx[l];
+          bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l] + (BAR ? brx[l] : 0.0);
         } else if (w == 1) {
           gyn[l] = dot_cr<N>(ME + l, LD, lamv);
         } else if (w == 2) {
           const double part = wave_sum(fu[l] * lamv[l]);
           if (l == 0) {
             const double* ubar = brx + N;
-            sc[2] = -(gc[N] + part) + ubar[0];
-            sc[3] = sc[1] + dw + ubar[1];
+            sc[2] = -(gc[N] + part) + (BAR ? ubar[0] : 0.0);
+            sc[3] = sc[1] + dw + (BAR ? ubar[1] : 0.0);
             if (barrier && a.stats) {
               stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], ubar[3]); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], ubar[4]);
               stat[DTO_WIDE_SUMZ] += ubar[5]; stat[DTO_WIDE_LOGBAR] += ubar[6];
@@ -852,8 +854,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             if (lo != hi) zd = (hi < 1e300 ? zub[gi] : 0.0) - (lo > -1e300 ? zlb[gi] : 0.0);
           }
           // bx = -grad L + byc + brx
-          double v = (fxm[l] != 0.0) ? 0.0 : fabs(-(bx[l] - byc[l] - brx[l]) + zd);
-          if (l == 0) v = fmax(v, fabs(-(sc[2] - brx[N]) + brx[N + 2]));
+          double v = (fxm[l] != 0.0) ? 0.0 : fabs(-(bx[l] - byc[l] - (BAR ? brx[l] : 0.0)) + zd);
+          if (l == 0) v = fmax(v, fabs(-(sc[2] - (BAR ? brx[N] : 0.0)) + (BAR ? brx[N + 2] : 0.0)));
 #pragma unroll
           for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
           if (l == 0) stat[3] = fmax(stat[3], v);
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         __syncthreads();
         if (tid < N) {
           double sig = 0.0;
-          brx[tid] = 0.0;
+          if (BAR) brx[tid] = 0.0;
           double zd = 0.0;
           if (barrier) {
             const int gi = a.zoff[t] + tid;
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             }
           }
           MA[tid * LD + tid] += dw + sig;
-          bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid] + brx[tid];
+          bx[tid] = -(gc[tid] + gyp[tid]) + byc[tid] + (BAR ? brx[tid] : 0.0);
           if (a.stats) {
             double v = (fxm[tid] != 0.0) ? 0.0 : fabs(gc[tid] + gyp[tid] + zd);
             v = wave_max(v);
@@ -1066,7 +1068,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             a.dz[b * a.lddz + a.zoff[t] + l] = bx[l];
           }
           if (a.stats) {
-            const double part = wave_sum((gc[l] - brx[l]) * bx[l]);     // gradient of the barrier objective along the step
+            const double part = wave_sum((gc[l] - (BAR ? brx[l] : 0.0)) * bx[l]);     // gradient of the barrier objective along the step
             if (l == 0) stat[4] += part;
             if (barrier) {
               const int gi = a.zoff[t] + l;
@@ -1481,9 +1483,15 @@ int launch_wide(int op, const dto_wide_args* a, void* stream) {
   if (op != DTO_WIDE_STEP) return (int)hipErrorInvalidValue;
   dto_wide_info info;
   wide_info<M>(&info);
-  hipError_t e = hipFuncSetAttribute((const void*)k_wide_step<M>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
+  if (a->zl) {
+    hipError_t eb = hipFuncSetAttribute((const void*)k_wide_step<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
+    if (eb != hipSuccess) return (int)eb;
+    hipLaunchKernelGGL((k_wide_step<M, true>), dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute((const void*)k_wide_step<M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_wide_step<M>, dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL((k_wide_step<M, false>), dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
 }
 
