@@ -83,7 +83,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int WG = 256;  // 4 wavefronts
 constexpr int TB = 16;   // MFMA tile edge
 
-template <int N>
+template <int N, int NU = 1>
 struct Dims {
   static constexpr int LD = N + 1;             // row stride of the LDS matrices (odd: column walks are conflict free)
   static constexpr int MAT = N * LD;           // doubles per matrix
@@ -92,8 +92,11 @@ struct Dims {
   static constexpr int LI = NT * TB * LI_LD;   // inverses of the unit-lower diagonal tiles
   // factor record of one stage in HBM
   static constexpr int F_LA = 0, F_FT = MAT, F_VT = 2 * MAT, F_LM = 3 * MAT, F_ET = 4 * MAT, F_VEC = 5 * MAT;
-  static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = 5 * N, V_VU = 6 * N, V_GC = 7 * N, V_SC = 8 * N + 8;
-  static constexpr int FAC = F_VEC + 8 * N + 16;
+  // vectors: D_A^-1, D_M^-1, bx~, bd^, the NU action rows (A_xu, F_u, V_u after the elimination inside the action block), cost
+  // gradient [N + 8], scalars of the action block (V_SC: 1 / pivot [NU], reduced right-hand side [NU], unit-lower factor [NU][NU])
+  static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = V_AU + NU * N, V_VU = V_FU + NU * N,
+                       V_GC = V_VU + NU * N, V_SC = V_GC + N + 8;
+  static constexpr int FAC = F_VEC + V_SC + ((NU * (NU + 2) + 7) & ~7);
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -618,6 +621,17 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
+// LDS of k_wide_step in doubles: four matrices, tile inverses, 15 + 3 NU vectors, gradient pad, model outputs, the action
+// block, counters, statistics, fixed mask, column exchange (8 N), dg0, barrier terms
+template <class M>
+struct StepLds {
+  static constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+  static constexpr int SC = (3 * NU + NU * NU + 7) & ~7;
+  static constexpr int DOUBLES = 4 * Dims<N>::MAT + Dims<N>::LI + (15 + 3 * NU) * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + SC + 4 + 16
+                                 + N + 8 * N + N + N + 8 * NU;
+  static constexpr int BYTES = DOUBLES * (int)sizeof(double);
+};
+
 template <class M, int WKI>
 struct WK {
   using KD = typename M::template WKind<WKI>;
@@ -632,8 +646,10 @@ template <class M, bool BAR>
 __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
   static_assert(N == 64, "wide path is built for 64 states (one wavefront of rows, 4 x 4 tiles)");
-  static_assert(NU == 1, "wide path eliminates one action per stage");
-  using D = Dims<N>;
+  static_assert(NU >= 1 && NU <= 4, "wide path: one to four actions per stage");
+  using D = Dims<N, NU>;
+  using SL = StepLds<M>;
+  static_assert(SL::BYTES <= 160 * 1024, "wide path: this model's stage data does not fit the 160 KB of LDS of one workgroup");
   constexpr int LD = D::LD, MAT = D::MAT, NT = D::NT;
   extern __shared__ double sm[];
   double* MA = sm;
@@ -645,10 +661,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   double* xv = vec;            // [N]
   double* yv = xv + N;         // [N]
   double* lamv = yv + N;       // [N]
-  double* au = lamv + N;       // A_xu
-  double* fu = au + N;         // F_u
-  double* vu = fu + N;         // V_u (u-y coupling)
-  double* bx = vu + N;
+  double* au = lamv + N;       // A_xu   [NU][N]: row j = coupling of action j
+  double* fu = au + NU * N;    // F_u    [NU][N]
+  double* vu = fu + NU * N;    // V_u    [NU][N] (u-y coupling)
+  double* bx = vu + NU * N;
   double* bd = bx + N;
   double* byc = bd + N;        // carried right-hand side for the next x
   double* byn = byc + N;
@@ -658,14 +674,16 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   double* dAi = dA + N;
   double* dM = dAi + N;
   double* dMi = dM + N;
-  double* nlf = dMi + N;       // nonlinear remainder of the residual, scattered to rows
-  double* gc = nlf + N;        // cost gradient [N + NU]
+  double* gc = dMi + N;        // cost gradient [N + NU]
   double* tmp = gc + N + 8;    // [N]
   double* hv = tmp + N;        // dynamics Hessian values [MAX_NH]
   double* chv = hv + M::MAX_NH;  // cost Hessian values [MAX_SNH]
   double* jvv = chv + M::MAX_SNH;  // variable Jacobian entries [MAX_NJV]
-  double* sc = jvv + M::MAX_NJV;   // scalars: 0 uv, 1 auu, 2 bu, 3 piv
-  int* cnt = (int*)(sc + 8);       // 0 nneg, 1 tiny
+  double* sc = jvv + M::MAX_NJV;   // the action block: u [NU], W_uu [NU][NU] (LDL^T in place), right-hand side [NU], 1 / pivot [NU]
+  double* auu = sc + NU;
+  double* buv = auu + NU * NU;
+  double* ipv = buv + NU;
+  int* cnt = (int*)(sc + SL::SC);  // 0 nneg, 1 tiny
 
   const int tid = threadIdx.x, w = wave_id(), l = lane_id();
   const int64_t b = blockIdx.x;
@@ -675,11 +693,12 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   if (a.active && !a.active[b]) return;
   const double dw = a.dw_inst ? a.dw_inst[b] : a.delta_w, dc = a.delta_c;
   const double gam = a.gam_inst ? a.gam_inst[b] : 1.0;
-  double* stat = vec + 20 * N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4;  // f, th1, thinf, dinf (LDS scalars)
+  double* stat = sc + SL::SC + 4;  // f, th1, thinf, dinf (LDS scalars)
   double* fxm = stat + 16;  // [N] 1.0 where x_t is fixed by equal bounds
   double* colb = fxm + N;   // [2][4][N] column exchange of ldl_rank1 (four columns per step, ping-pong)
   double* dg0 = colb + 8 * N;  // [N] |diagonal| before the factorisation (tiny-pivot test)
-  double* brx = dg0 + N;       // [N + 1] barrier part of the right-hand side of x (and of u at [N]); 0 without finite bounds
+  double* nlf = dg0;           // nonlinear remainder of the residual, scattered to rows (phases 0-2 only: shares dg0, phases 6 and 9)
+  double* brx = dg0 + N;       // [N + 8 NU] barrier part of the right-hand side of x, then 8 numbers per action; 0 without finite bounds
   if (tid < 16) stat[tid] = (tid == DTO_WIDE_APMAX || tid == DTO_WIDE_ADMAX) ? 1.0 : 0.0;
   const bool barrier = BAR && a.zl != nullptr;
   const double mub = (barrier && a.mu_inst) ? a.mu_inst[b] : 0.0;
@@ -709,7 +728,9 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           xv[tid] = z[a.zoff[t] + tid];
           yv[tid] = z[a.zoff[t + 1] + tid];
           lamv[tid] = mu[a.cdoff[t] + tid];
-          au[tid] = 0.0; vu[tid] = 0.0; nlf[tid] = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { au[j * N + tid] = 0.0; vu[j * N + tid] = 0.0; }
+          nlf[tid] = 0.0;
           fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
           double sig = 0.0;
           if (BAR) brx[tid] = 0.0;
@@ -727,12 +748,13 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
           MA[tid * LD + tid] += dw + sig;
         }
-        if (tid == 0) { sc[0] = z[a.zoff[t] + N]; sc[1] = 0.0; }
-        if (BAR && tid == 64) {   // the action of this knot (one lane of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
-          double* ubar = brx + N;
+        if (tid < NU) sc[tid] = z[a.zoff[t] + N + tid];
+        if (tid < NU * NU) auu[tid] = 0.0;
+        if (BAR && tid >= 64 && tid < 64 + NU) {   // the actions of this knot (lanes of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
+          double* ubar = brx + N + 8 * (tid - 64);
           WideBar wb{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
           if (barrier) {
-            const int gi = a.zoff[t] + N;
+            const int gi = a.zoff[t] + N + (tid - 64);
             wb = wide_bar(z[gi], a.fixed_lo[gi], a.fixed_hi[gi], zlb[gi], zub[gi], mub);
           }
           ubar[0] = wb.br; ubar[1] = wb.sig; ubar[2] = wb.zdiff; ubar[3] = wb.sz_max; ubar[4] = wb.isz_max; ubar[5] = wb.sum_z; ubar[6] = wb.logb;
@@ -745,7 +767,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             const double* row = fe + r * NC;
             MF[r * LD + l] = row[l];
             ME[r * LD + l] = row[N + NU + l];
-            if (l < NU) fu[r] = row[N + l];
+            if (l < NU) fu[l * N + r] = row[N + l];
           }
           for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
         }
@@ -774,7 +796,9 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         DTO_WIDE_TICK(1);
         // ---- phase 2: residual from the constant part (variable Jacobian entries are still zero in MF/ME/fu)
         if (tid < N) {
-          const double acc = nlf[tid] + fu[tid] * sc[0] + dot_rr<N>(MF + tid * LD, xv) + dot_rr<N>(ME + tid * LD, yv);
+          double acc = nlf[tid] + fu[tid] * sc[0] + dot_rr<N>(MF + tid * LD, xv) + dot_rr<N>(ME + tid * LD, yv);
+#pragma unroll
+          for (int j = 1; j < NU; ++j) acc += fu[j * N + tid] * sc[j];
           bd[tid] = -acc;
         }
         lds_barrier();
@@ -796,7 +820,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           const int r = DY::jv_row(tid), c = DY::jv_col(tid);
           const double v = jvv[tid];
           if (c < N) MF[r * LD + c] = v;
-          else if (c < N + NU) fu[r] = v;
+          else if (c < N + NU) fu[(c - N) * N + r] = v;
           else ME[r * LD + c - N - NU] = v;
         }
         if constexpr (CO::SNH > 0) {
@@ -804,8 +828,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             const int r = CO::sh_row(tid), c = CO::sh_col(tid);
             const double v = chv[tid];
             if (r < N && c < N) MA[r * LD + c] += v;
-            else if (r < N && c >= N) au[r] += v;
-            else if (r >= N && c >= N) sc[1] += v;
+            else if (r < N && c >= N) au[(c - N) * N + r] += v;
+            else if (r >= N && c >= N) auu[(r - N) * NU + c - N] += v;
           }
         }
         lds_barrier();
@@ -815,11 +839,11 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             const double v = hv[tid];
             if (r < N) {
               if (c < N) MA[r * LD + c] += v;
-              else if (c < N + NU) au[r] += v;
+              else if (c < N + NU) au[(c - N) * N + r] += v;
               else MV[r * LD + c - N - NU] += v;
             } else if (r < N + NU) {
-              if (c >= N && c < N + NU) sc[1] += v;
-              else if (c >= N + NU) vu[c - N - NU] += v;
+              if (c >= N && c < N + NU) auu[(r - N) * NU + c - N] += v;
+              else if (c >= N + NU) vu[(r - N) * N + c - N - NU] += v;
             }
           }
         }
@@ -831,14 +855,17 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         } else if (w == 1) {
           gyn[l] = dot_cr<N>(ME + l, LD, lamv);
         } else if (w == 2) {
-          const double part = wave_sum(fu[l] * lamv[l]);
-          if (l == 0) {
-            const double* ubar = brx + N;
-            sc[2] = -(gc[N] + part) + (BAR ? ubar[0] : 0.0);
-            sc[3] = sc[1] + dw + (BAR ? ubar[1] : 0.0);
-            if (barrier && a.stats) {
-              stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], ubar[3]); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], ubar[4]);
-              stat[DTO_WIDE_SUMZ] += ubar[5]; stat[DTO_WIDE_LOGBAR] += ubar[6];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            const double part = wave_sum(fu[j * N + l] * lamv[l]);
+            if (l == 0) {
+              const double* ubar = brx + N + 8 * j;
+              buv[j] = -(gc[N + j] + part) + (BAR ? ubar[0] : 0.0);
+              auu[j * NU + j] += dw + (BAR ? ubar[1] : 0.0);
+              if (barrier && a.stats) {
+                stat[DTO_WIDE_SZMAX] = fmax(stat[DTO_WIDE_SZMAX], ubar[3]); stat[DTO_WIDE_ISZMAX] = fmax(stat[DTO_WIDE_ISZMAX], ubar[4]);
+                stat[DTO_WIDE_SUMZ] += ubar[5]; stat[DTO_WIDE_LOGBAR] += ubar[6];
+              }
             }
           }
         }
@@ -855,7 +882,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
           // bx = -grad L + byc + brx
           double v = (fxm[l] != 0.0) ? 0.0 : fabs(-(bx[l] - byc[l] - (BAR ? brx[l] : 0.0)) + zd);
-          if (l == 0) v = fmax(v, fabs(-(sc[2] - (BAR ? brx[N] : 0.0)) + (BAR ? brx[N + 2] : 0.0)));
+          if (l < NU) v = fmax(v, fabs(-(buv[l] - (BAR ? brx[N + 8 * l] : 0.0)) + (BAR ? brx[N + 8 * l + 2] : 0.0)));
 #pragma unroll
           for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
           if (l == 0) stat[3] = fmax(stat[3], v);
@@ -868,26 +895,85 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             if (fxm[c] != 0.0) MF[r * LD + c] = 0.0;
             if (fxm[r] != 0.0) MV[r * LD + c] = 0.0;
           }
-          if (tid < N && fxm[tid] != 0.0) { au[tid] = 0.0; bx[tid] = 0.0; }
+          if (tid < N && fxm[tid] != 0.0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) au[j * N + tid] = 0.0;
+            bx[tid] = 0.0;
+          }
           lds_barrier();
         }
-        // ---- phase 5: eliminate u
-        const double piv = sc[3], ip = 1.0 / piv, bu = sc[2];
+        // ---- phase 5: eliminate u.  Several actions: W_uu = L_u D_u L_u' in place (one thread, NU <= 4), the coupling rows
+        //      and the right-hand side go through L_u^-1, after which every action is a rank-one term of its own
+        if constexpr (NU > 1) {
+          if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+              const double d = auu[j * NU + j], id = 1.0 / d;
+              double tcol[NU];
+#pragma unroll
+              for (int k = j + 1; k < NU; ++k) tcol[k] = auu[k * NU + j];
+#pragma unroll
+              for (int k = j + 1; k < NU; ++k) {
+#pragma unroll
+                for (int k2 = j + 1; k2 <= k; ++k2) auu[k * NU + k2] -= tcol[k] * tcol[k2] * id;
+                auu[k * NU + j] = tcol[k] * id;
+                buv[k] -= tcol[k] * id * buv[j];
+              }
+              ipv[j] = id;
+            }
+          }
+          lds_barrier();
+          if (tid < 3 * N) {
+            double* arr = tid < N ? au + tid : (tid < 2 * N ? fu + tid - N : vu + tid - 2 * N);
+            double cj[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) cj[j] = arr[j * N];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+#pragma unroll
+              for (int k = j + 1; k < NU; ++k) cj[k] -= auu[k * NU + j] * cj[j];
+            }
+#pragma unroll
+            for (int j = 1; j < NU; ++j) arr[j * N] = cj[j];
+          }
+          lds_barrier();
+        }
+        double ip[NU], bu[NU];
+        if constexpr (NU == 1) { ip[0] = 1.0 / auu[0]; bu[0] = buv[0]; }
+        else {
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { ip[j] = ipv[j]; bu[j] = buv[j]; }
+        }
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
-          MA[r * LD + c] -= au[r] * au[c] * ip;
-          MF[r * LD + c] -= fu[r] * au[c] * ip;
-          MV[r * LD + c] -= au[r] * vu[c] * ip;
-          ME[r * LD + c] -= fu[r] * vu[c] * ip;
+          double da = 0.0, df = 0.0, dv = 0.0, de = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            const double ar = au[j * N + r] * ip[j], fr = fu[j * N + r] * ip[j], ac = au[j * N + c], vc = vu[j * N + c];
+            da += ar * ac; df += fr * ac; dv += ar * vc; de += fr * vc;
+          }
+          MA[r * LD + c] -= da;
+          MF[r * LD + c] -= df;
+          MV[r * LD + c] -= dv;
+          ME[r * LD + c] -= de;
         }
         if (tid < N) {
-          bx[tid] -= au[tid] * bu * ip;
-          bd[tid] -= fu[tid] * bu * ip;
-          byn[tid] = -vu[tid] * bu * ip;
+          double sx = 0.0, sd = 0.0, sy = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            const double bj = bu[j] * ip[j];
+            sx += au[j * N + tid] * bj; sd += fu[j * N + tid] * bj; sy += vu[j * N + tid] * bj;
+          }
+          bx[tid] -= sx;
+          bd[tid] -= sd;
+          byn[tid] = -sy;
         }
         if (tid == 0) {
-          if (piv < 0.0) cnt[0] += 1;
-          if (!(fabs(piv) > a.piv_tol)) cnt[1] |= 1;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            if (ip[j] < 0.0) cnt[0] += 1;
+            if (!(fabs(1.0 / ip[j]) > a.piv_tol)) cnt[1] |= 1;
+          }
         }
         lds_barrier();
         DTO_WIDE_TICK(5);
@@ -909,7 +995,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int row = w * TB + q + 4 * j, col = jb * TB + r;
-            macc[jb][j] = (row == col ? dc : 0.0) + fu[row] * fu[col] * ip;
+            double fuu = 0.0;
+#pragma unroll
+            for (int ju = 0; ju < NU; ++ju) fuu += fu[ju * N + row] * fu[ju * N + col] * ip[ju];
+            macc[jb][j] = (row == col ? dc : 0.0) + fuu;
           }
         }
         mm_row4<0, N>(macc, MF, w * TB, MF, dAi, 1.0);
@@ -966,13 +1055,21 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           fv[D::V_DM + tid] = dMi[tid];
           fv[D::V_BX + tid] = bx[tid];
           fv[D::V_BD + tid] = bd[tid];
-          fv[D::V_AU + tid] = au[tid];
-          fv[D::V_FU + tid] = fu[tid];
-          fv[D::V_VU + tid] = vu[tid];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) {
+            fv[D::V_AU + j * N + tid] = au[j * N + tid];
+            fv[D::V_FU + j * N + tid] = fu[j * N + tid];
+            fv[D::V_VU + j * N + tid] = vu[j * N + tid];
+          }
           fv[D::V_GC + tid] = gc[tid];
         }
-        if (tid == 0) fac[D::F_VEC + D::V_GC + N] = gc[N];
-        if (tid == 0) { fac[D::F_VEC + D::V_SC + 0] = ip; fac[D::F_VEC + D::V_SC + 1] = bu; }
+        if (tid < NU) {
+          double* fs = fac + D::F_VEC;
+          fs[D::V_GC + N + tid] = gc[N + tid];
+          fs[D::V_SC + tid] = (NU == 1) ? ip[0] : ipv[tid];
+          fs[D::V_SC + NU + tid] = buv[tid];
+        }
+        if (NU > 1 && tid < NU * NU) fac[D::F_VEC + D::V_SC + 2 * NU + tid] = auu[tid];
         lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
@@ -982,7 +1079,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         // the y-y part of this stage's Hessian and the u rank-one term complete P'
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
-          MA[r * LD + c] -= vu[r] * vu[c] * ip;
+          double dvv = 0.0;
+#pragma unroll
+          for (int j = 0; j < NU; ++j) dvv += vu[j * N + r] * vu[j * N + c] * ip[j];
+          MA[r * LD + c] -= dvv;
         }
         lds_barrier();
         if constexpr (DY::NH > 0) {
@@ -1100,9 +1200,12 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       dMi[tid] = fv[D::V_DM + tid];
       bx[tid] = fv[D::V_BX + tid];
       bd[tid] = fv[D::V_BD + tid];
-      au[tid] = fv[D::V_AU + tid];
-      fu[tid] = fv[D::V_FU + tid];
-      vu[tid] = fv[D::V_VU + tid];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        au[j * N + tid] = fv[D::V_AU + j * N + tid];
+        fu[j * N + tid] = fv[D::V_FU + j * N + tid];
+        vu[j * N + tid] = fv[D::V_VU + j * N + tid];
+      }
     }
     __syncthreads();
     DTO_WIDE_TICK(14);
@@ -1128,10 +1231,20 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       a.dmu[b * a.lddmu + a.cdoff[t] + tid] = lamv[tid];
     }
     if (w == 1) {
-      // u = (bu - au'x - fu'lam - vu'y) / piv
-      const double part = wave_sum(au[l] * xv[l] + fu[l] * lamv[l] + vu[l] * yv[l]);
-      const double du = (fv[D::V_SC + 1] - part) * fv[D::V_SC + 0];
-      if (l == 0) a.dz[b * a.lddz + a.zoff[t] + N] = du;
+      // u_j = (bu_j - au_j'x - fu_j'lam - vu_j'y) / piv_j - sum_{k > j} L_u[k][j] u_k, last action first
+      double duv[NU];
+#pragma unroll
+      for (int j = NU - 1; j >= 0; --j) {
+        const double part = wave_sum(au[j * N + l] * xv[l] + fu[j * N + l] * lamv[l] + vu[j * N + l] * yv[l]);
+        double uj = (fv[D::V_SC + NU + j] - part) * fv[D::V_SC + j];
+#pragma unroll
+        for (int k = j + 1; k < NU; ++k) uj -= fv[D::V_SC + 2 * NU + k * NU + j] * duv[k];
+        duv[j] = uj;
+      }
+      double du = duv[0];   // lane j < NU: its own action
+#pragma unroll
+      for (int j = 1; j < NU; ++j) du = (l == j) ? duv[j] : du;
+      if (l < NU) a.dz[b * a.lddz + a.zoff[t] + N + l] = du;
       if (a.stats) {
         // gradient of the barrier objective along the step, fraction-to-the-boundary limits of this knot (x: lane, u: lane 0)
         double brl = 0.0, ap = 1.0, ad = 1.0;
@@ -1140,22 +1253,26 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           const double xo = z[gi], lo = a.fixed_lo[gi], hi = a.fixed_hi[gi];
           brl = wide_bar(xo, lo, hi, zlb[gi], zub[gi], mub).br;
           wide_bar_step(xo, xv[l], lo, hi, zlb[gi], zub[gi], mub, taub, ap, ad);
-          if (l == 0) {
-            const int gu = a.zoff[t] + N;
+          if (l < NU) {
+            const int gu = a.zoff[t] + N + l;
             const double uo = z[gu], ulo = a.fixed_lo[gu], uhi = a.fixed_hi[gu];
             wide_bar_step(uo, du, ulo, uhi, zlb[gu], zub[gu], mub, taub, ap, ad);
           }
           ap = wave_min(ap); ad = wave_min(ad);
         }
-        const double gpart = wave_sum((fv[D::V_GC + l] - brl) * xv[l]);
-        if (l == 0) {
+        double gl = (fv[D::V_GC + l] - brl) * xv[l];
+        if (l < NU) {
           double bru = 0.0;
           if (barrier) {
-            const int gu = a.zoff[t] + N;
+            const int gu = a.zoff[t] + N + l;
             bru = wide_bar(z[gu], a.fixed_lo[gu], a.fixed_hi[gu], zlb[gu], zub[gu], mub).br;
-            stat[DTO_WIDE_APMAX] = fmin(stat[DTO_WIDE_APMAX], ap); stat[DTO_WIDE_ADMAX] = fmin(stat[DTO_WIDE_ADMAX], ad);
           }
-          stat[4] += gpart + (fv[D::V_GC + N] - bru) * du;
+          gl += (fv[D::V_GC + N + l] - bru) * du;
+        }
+        const double gpart = wave_sum(gl);
+        if (l == 0) {
+          if (barrier) { stat[DTO_WIDE_APMAX] = fmin(stat[DTO_WIDE_APMAX], ap); stat[DTO_WIDE_ADMAX] = fmin(stat[DTO_WIDE_ADMAX], ad); }
+          stat[4] += gpart;
         }
       }
     }
@@ -1409,7 +1526,7 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
       double lo_l = 0.0, hi_l = 0.0, lo_u = 0.0, hi_u = 0.0;
       if (barrier) {
         lo_l = a.fixed_lo[a.zoff[t] + l]; hi_l = a.fixed_hi[a.zoff[t] + l];
-        if (NUK > 0) { lo_u = a.fixed_lo[a.zoff[t] + N]; hi_u = a.fixed_hi[a.zoff[t] + N]; }
+        if (l < NUK) { lo_u = a.fixed_lo[a.zoff[t] + N + l]; hi_u = a.fixed_hi[a.zoff[t] + N + l]; }
       }
 #pragma unroll 1
       for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
@@ -1424,8 +1541,8 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
             if (lo_l > -1e300) lb += log(xk - lo_l);
             if (hi_l < 1e300) lb += log(hi_l - xk);
           }
-          if (NUK > 0 && l == 0 && lo_u != hi_u) {
-            const double uk = pv[N] + alpha * dp[N];
+          if (l < NUK && lo_u != hi_u) {
+            const double uk = pv[N + l] + alpha * dp[N + l];
             if (lo_u > -1e300) lb += log(uk - lo_u);
             if (hi_u < 1e300) lb += log(hi_u - uk);
           }
@@ -1461,12 +1578,12 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
 
 template <class M>
 int wide_info(dto_wide_info* out) {
-  using D = Dims<M::WIDE_N>;
+  using D = Dims<M::WIDE_N, M::WIDE_NU>;
   out->supported = 1;
   out->n = M::WIDE_N;
   out->nu = M::WIDE_NU;
   out->fac_stage = D::FAC;
-  out->lds_bytes = (int)sizeof(double) * (4 * D::MAT + D::LI + 20 * M::WIDE_N + 8 + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 4 + 16 + M::WIDE_N + 10 * M::WIDE_N + 8);
+  out->lds_bytes = StepLds<M>::BYTES;
   return 0;
 }
 

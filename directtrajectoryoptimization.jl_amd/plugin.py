@@ -31,6 +31,7 @@ PLUGIN_DIR = os.path.join(_HERE, "_plugins")
 GENERATOR_VERSION = "8"
 WIDE_MIN_STATE = 17   # above this the lane-per-instance register kernels give way to the tile (MFMA) kernels
 WIDE_STATE = 64       # the state dimension the tile kernels are built for
+WIDE_MAX_ACTION = 4   # actions per knot on the tile path (LDS budget of one workgroup)
 
 
 class Structure:
@@ -83,20 +84,25 @@ class Structure:
         max_nx = max([d.num_state for d in self.dyn] + [c.num_state for c in self.cost])
         self.wide = max_nx >= WIDE_MIN_STATE
         self.wide_n = WIDE_STATE
+        self.wide_nu = 1
         if self.wide:
             # the tile (MFMA) KKT kernels are built for exactly WIDE_STATE states; the evaluator callbacks of the same family
             # take any uniform dimension up to it: a problem with 17 .. 63 states gets its callbacks from a plugin of its own
             # size and its solves from the 64-state embedding (solver.py: pad_to_wide)
             n0 = self.dyn[0].num_state if self.dyn else max_nx
+            nu0 = self.dyn[0].num_action if self.dyn else 1
             ok = (WIDE_MIN_STATE <= n0 <= WIDE_STATE
-                  and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == 1 for d in self.dyn)
+                  and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == nu0 for d in self.dyn)
+                  and 1 <= nu0 <= WIDE_MAX_ACTION
                   and all(c.num_state == n0 for c in self.cost)
                   and not self.con and self.general is None
                   and all(d.num_parameter == 0 for d in self.dyn))
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
-                                 f"one uniform state dimension up to {WIDE_STATE}, one action and bound-only stage constraints")
+                                 f"one uniform state dimension up to {WIDE_STATE}, one to {WIDE_MAX_ACTION} actions (the same number at "
+                                 f"every knot) and bound-only stage constraints")
             self.wide_n = n0
+            self.wide_nu = nu0
         self.wide_solver = self.wide and self.wide_n == WIDE_STATE
         if self.evaluate_hessian:
             # all objects must agree on the flag
@@ -348,8 +354,16 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     out.append("struct Model {")
-    out.append(f"  static constexpr int WIDE_N = {st.wide_n}, WIDE_NU = 1, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
+    out.append(f"  static constexpr int WIDE_N = {st.wide_n}, WIDE_NU = {st.wide_nu}, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
     max_key = max([1] + [st.key_slots(k) for k in st.kinds])
+    if st.wide_solver:
+        # csrc/dto_wide_kernels.hpp: StepLds -- the stage data of one instance must fit the LDS of one workgroup
+        n, nu = st.wide_n, st.wide_nu
+        lds = 8 * (4 * n * (n + 1) + (n // 16) * 16 * 17 + (15 + 3 * nu) * n + 8 + max_nh + max_snh + max_njv
+                   + ((3 * nu + nu * nu + 7) & ~7) + 4 + 16 + 11 * n + 8 * nu)
+        if lds > 160 * 1024:
+            raise ValueError(f"wide stages: {lds} bytes of stage data per instance exceed the 160 KB of LDS of one workgroup "
+                             f"({nu} actions, {max_nh} dynamics-Hessian / {max_snh} cost-Hessian / {max_njv} variable Jacobian entries)")
     out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = {1 if st.evaluate_hessian else 0}, MAX_KEY = {max_key};")
     out.append("  template <int K> struct WKind;")
     out.append("  template <int C> struct Dyn;")

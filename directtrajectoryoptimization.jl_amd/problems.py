@@ -118,15 +118,27 @@ def padded_mixing(n=64, m=1, seed=64):
     return rng.standard_normal((n, n + m)) / np.sqrt(n + m)
 
 
-def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64):
+def padded_torque(u):
+    """Elbow torque of the padded acrobot with m actions: u[0] for m = 1 (cfg5 as BASELINE.json states it); for m > 1 the
+    actions enter with weights 2^-j plus a bilinear term, so that the action block of the stage Hessian is dense."""
+    m = len(u)
+    tau = u[0]
+    for j in range(1, m):
+        tau = tau + 0.5 ** j * u[j]
+    if m > 1:
+        tau = tau + 0.1 * u[0] * u[m - 1]
+    return tau
+
+
+def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64, m=1):
     """y - x - h*f(0.5(x+y), u) with f = [acrobot(x[0:4], u); 0] + eps * M [xm; u]: the four physical states keep the
     acrobot dynamics, the padding states are a stable-ish dense linear system, and every residual row depends on every
     column of [x; u], so the stage Jacobian block is structurally dense (blocks of n + m + n = 129 for n = 64)."""
-    M = padded_mixing(n, 1, seed)
+    M = padded_mixing(n, m, seed)
 
     def f(y, x, u, w):
         xm = 0.5 * (x + y)
-        phys = acrobot(xm[0:4], u, w)
+        phys = acrobot(xm[0:4], [padded_torque(u)], w)
         lin = M @ np.concatenate([xm, u])
         rhs = np.array([(phys[i] if i < 4 else 0.0) + eps * lin[i] for i in range(n)], dtype=object)
         return y - (x + h * rhs)
@@ -238,17 +250,28 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
     )
 
 
-def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None):
+def padded_action_cost(x, u):
+    """0.1 |u|^2 for one action; several actions are coupled to each other and to one padding state."""
+    m = len(u)
+    c = 0.1 * dot(u, u)
+    for j in range(m - 1):
+        c = c + 0.05 * u[j] * u[j + 1]
+    if m > 1:
+        c = c + 0.02 * u[m - 1] * x[5]
+    return c
+
+
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
     blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
     terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
-    64-dimensional terminal state is reachable only for horizons of more than 64 knots."""
-    m = 1
+    64-dimensional terminal state is reachable only for horizons of more than 64 knots.
+    m > 1: several actions (padded_torque, padded_action_cost) -- not a BASELINE.json configuration, a test of the action block."""
     x1 = np.zeros(n)
     xT = np.zeros(n)
     xT[0] = target
-    dt = Dynamics(acrobot_padded_midpoint(n), n, n, m, evaluate_hessian=evaluate_hessian)
-    ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + 0.1 * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+    dt = Dynamics(acrobot_padded_midpoint(n, m=m), n, n, m, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + padded_action_cost(x, u), n, m, evaluate_hessian=evaluate_hessian)
     cT = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]), n, 0, evaluate_hessian=evaluate_hessian)
     # u_max: action bounds -u_max <= u <= u_max at every knot (examples/cartpole/cartpole.jl:81-89 style)
     ub = {} if u_max is None else dict(action_lower=-u_max * np.ones(m), action_upper=u_max * np.ones(m))

@@ -659,14 +659,17 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
     y_k - x_k = 0, cost nothing and are fixed at zero by equal bounds at every knot, so the kernels treat them as identity
     rows.  Returns (dynamics, objective, constraints, bounds, zmap, mumap) -- zmap / mumap: positions of the padded problem's
     variables / constraint rows that belong to the original problem, in the original order -- or None if the problem does not
-    fit the tile path either way (several actions, stage constraints, parameters, varying dimensions, user Jacobians)."""
-    from .plugin import WIDE_MIN_STATE, WIDE_STATE
+    fit the tile path either way (more than four actions, stage constraints, parameters, varying dimensions, user Jacobians)."""
+    from .plugin import WIDE_MAX_ACTION, WIDE_MIN_STATE, WIDE_STATE
     from .symbolic import expr as E
     T = len(objective)
     n = dynamics[0].num_state
     if not (WIDE_MIN_STATE <= n < WIDE_STATE):
         return None
-    if any(d.num_state != n or d.num_next_state != n or d.num_action != 1 or d.num_parameter != 0 or d.user_jacobian for d in dynamics):
+    nu = dynamics[0].num_action
+    if not (1 <= nu <= WIDE_MAX_ACTION):
+        return None
+    if any(d.num_state != n or d.num_next_state != n or d.num_action != nu or d.num_parameter != 0 or d.user_jacobian for d in dynamics):
         return None
     if any(c.num_constraint > 0 for c in constraints) or any(c.num_parameter != 0 for c in objective):
         return None
@@ -677,7 +680,7 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
     def pad(o):
         if id(o) not in cache:
             if isinstance(o, Dynamics):
-                cache[id(o)] = Dynamics(list(o.evaluate_expr) + [y[k] - x[k] for k in range(n, N)], N, N, 1,
+                cache[id(o)] = Dynamics(list(o.evaluate_expr) + [y[k] - x[k] for k in range(n, N)], N, N, nu,
                                         evaluate_hessian=evaluate_hessian)
             else:
                 cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, evaluate_hessian=evaluate_hessian)
@@ -690,8 +693,8 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
                   action_lower=b.action_lower, action_upper=b.action_upper) for b in bounds]
     zmap, mumap = [], []
     for t in range(T):
-        base = t * (N + 1)
-        zmap += list(range(base, base + n)) + ([base + N] if t < T - 1 else [])
+        base = t * (N + nu)
+        zmap += list(range(base, base + n)) + (list(range(base + N, base + N + nu)) if t < T - 1 else [])
         if t < T - 1:
             mumap += list(range(t * N, t * N + n))
     return dyn2, obj2, [Constraint() for _ in range(T)], bnd2, np.asarray(zmap, dtype=np.int64), np.asarray(mumap, dtype=np.int64)

@@ -28,13 +28,24 @@ def mixing(n=64, m=1):
     return rng.standard_normal((n, n + m)) / np.sqrt(n + m)
 
 
+def torque(u):
+    """m = 1: u[0] (cfg5).  m > 1 (tests of the action block only): sum_j 2^-j u_j + 0.1 u_0 u_{m-1}"""
+    m = len(u)
+    tau = u[0]
+    for j in range(1, m):
+        tau = tau + S.fl(0.5 ** j) * u[j]
+    if m > 1:
+        tau = tau + S.fl(0.1) * u[0] * u[m - 1]
+    return tau
+
+
 class PaddedAcrobot:
-    def __init__(self, n=64):
-        self.n, self.m = n, 1
-        self.M = mixing(n, 1)
-        self.phys = S.Dynamics(S.acrobot_midpoint, 4, 4, 1, evaluate_hessian=True)
-        # local variable order of the small object: [x(4); u(1); y(4)] -> positions in [x(n); u; y(n)]
-        self.emb = np.array([0, 1, 2, 3, n, n + 1, n + 2, n + 3, n + 4])
+    def __init__(self, n=64, m=1):
+        self.n, self.m = n, m
+        self.M = mixing(n, m)
+        self.phys = S.Dynamics(lambda y, x, u, w: S.acrobot_midpoint(y, x, [torque(u)], w), 4, 4, m, evaluate_hessian=True)
+        # local variable order of the small object: [x(4); u(m); y(4)] -> positions in [x(n); u; y(n)]
+        self.emb = np.array([0, 1, 2, 3] + [n + j for j in range(m)] + [n + m + k for k in range(4)])
 
     def _lin_blocks(self):
         n, M = self.n, self.M
@@ -58,20 +69,21 @@ class PaddedAcrobot:
         Fx, Fu, E = self._lin_blocks()
         J = np.hstack([Fx, Fu, E])
         vals = self.phys.jacobian(list(y[:4]), list(x[:4]), list(u), [])
-        Js = np.zeros((4, 9))
+        m = self.m
+        Js = np.zeros((4, 8 + m))
         for r, c, v in zip(self.phys.jacobian_sparsity[0], self.phys.jacobian_sparsity[1], vals):
             Js[r - 1, c - 1] = v
         # remove the y - x part of the small object (already in the linear blocks), keep -h d acrobot
         Js[:, 0:4] += np.eye(4)
-        Js[:, 5:9] -= np.eye(4)
+        Js[:, 4 + m:8 + m] -= np.eye(4)
         J[:4][:, self.emb] += Js
         return J
 
     def hessian(self, x, u, y, lam):
-        """dense (2n+1) x (2n+1) Hessian of lam' d over [x; u; y]"""
+        """dense (2n+m) x (2n+m) Hessian of lam' d over [x; u; y]"""
         n = self.n
         vals = self.phys.hessian(list(y[:4]), list(x[:4]), list(u), [], list(lam[:4]))
-        H = np.zeros((2 * n + 1, 2 * n + 1))
+        H = np.zeros((2 * n + self.m, 2 * n + self.m))
         for r, c, v in zip(self.phys.hessian_sparsity[0], self.phys.hessian_sparsity[1], vals):
             H[self.emb[r - 1], self.emb[c - 1]] += v
         return H
@@ -82,9 +94,16 @@ class PaddedAcrobot:
         g[2:n] = 0.2 * x[2:n]
         W = np.zeros((n + len(u), n + len(u)))
         W[np.arange(2, n), np.arange(2, n)] = 0.2
-        if len(u):
-            g[n] = 0.2 * u[0]
-            W[n, n] = 0.2
+        m = len(u)
+        for j in range(m):
+            g[n + j] = 0.2 * u[j]
+            W[n + j, n + j] = 0.2
+        for j in range(m - 1):   # several actions: 0.05 u_j u_{j+1} + 0.02 u_{m-1} x_5
+            g[n + j] += 0.05 * u[j + 1]; g[n + j + 1] += 0.05 * u[j]
+            W[n + j, n + j + 1] += 0.05; W[n + j + 1, n + j] += 0.05
+        if m > 1:
+            g[n + m - 1] += 0.02 * x[5]; g[5] += 0.02 * u[m - 1]
+            W[n + m - 1, 5] += 0.02; W[5, n + m - 1] += 0.02
         return g, W
 
 
@@ -125,6 +144,8 @@ def dense_derivatives(model: PaddedAcrobot, T: int, z, mu, sigma=1.0):
         gt, Wt = model.cost_grad_hess(x, u)
         npv = n + len(u)
         f += 0.1 * float(x[2:n] @ x[2:n]) + 0.1 * float(u @ u)
+        if len(u) > 1:
+            f += 0.05 * float(u[:-1] @ u[1:]) + 0.02 * float(u[-1] * x[5])
         g[o:o + npv] += gt
         H[o:o + npv, o:o + npv] += sigma * Wt
         if t < T - 1:

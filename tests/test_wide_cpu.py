@@ -80,11 +80,19 @@ def test_wide_plugin_source_and_structure_rules(padded):
     assert st20.wide and st20.wide_n == 20 and not st20.wide_solver
     src20 = generate_source(st20, "m20")
     assert "WIDE_N = 20" in src20 and "launch_wide<Model>" not in src20 and "launch_wide_eval<Model>" in src20
-    # several actions or stage constraints in the wide range are still refused
-    bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 2, evaluate_hessian=True)
+    # up to four actions per knot (round 4: the action block is factored in place, csrc/dto_wide_kernels.hpp phase 5) ...
+    d2 = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 2, evaluate_hessian=True)
     cost2 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 2, evaluate_hessian=True)
+    st2 = Structure([d2], [cost2, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+    assert st2.wide_nu == 2 and "WIDE_NU = 2" in generate_source(st2, "m20u2")
+    # ... more than that, or stage constraints in the wide range, are still refused
+    bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 5, evaluate_hessian=True)
+    cost5 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 5, evaluate_hessian=True)
     with pytest.raises(ValueError):
-        Structure([bad], [cost2, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+        Structure([bad], [cost5, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
+    con = dto_amd.Constraint(lambda x, u, w: [x[0] - 1.0], 20, 1, evaluate_hessian=True)
+    with pytest.raises(ValueError):
+        Structure([d20], [cost, costT], [con, dto_amd.Constraint()], None, True)
 
 
 def test_full_horizon_layout_totals():
@@ -127,5 +135,42 @@ def test_embedding_of_a_24_state_problem_in_the_64_state_kernels():
     assert len(zmap) == (T - 1) * (n + 1) + n and len(mumap) == (T - 1) * n
     assert np.array_equal(z[:n], np.arange(n)) and z[n] == 64 and np.array_equal(z[n + 1:2 * n + 1], 65 + np.arange(n))
     assert np.array_equal(mumap[:n], np.arange(n)) and mumap[n] == 64
-    # not eligible: several actions, stage constraints, or already 64 states
+    # two actions keep their places behind the 64 padded states
+    d2 = dto_amd.Dynamics(lambda y, x, u, w: y - x - 0.1 * u[0] * x - 0.2 * u[1], 20, 20, 2, evaluate_hessian=True)
+    c2 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x) + dto_amd.dot(u, u), 20, 2, evaluate_hessian=True)
+    cT = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 0, evaluate_hessian=True)
+    out2 = pad_to_wide([d2, d2], [c2, c2, cT], [dto_amd.Constraint() for _ in range(3)],
+                       [dto_amd.Bound(20, 2), dto_amd.Bound(20, 2), dto_amd.Bound(20, 0)], True)
+    assert out2 is not None and out2[0][0].num_action == 2
+    assert np.array_equal(out2[4][20:22], [64, 65]) and out2[4][22] == 66 and len(out2[4]) == 2 * 22 + 20
+    # not eligible: more than four actions, stage constraints, or already 64 states
     assert pad_to_wide(P.build_acrobot_padded(T=3)["dynamics"], *[P.build_acrobot_padded(T=3)[k] for k in ("objective", "constraints", "bounds")], True) is None
+
+
+def test_three_action_model_matches_oracle_restatement():
+    """The several-action variant of the padded model (problems.py: padded_torque / padded_action_cost; a test model of the action
+    block, not a BASELINE.json configuration) against the oracle's own restatement of it (oracle/padded_model.py: torque)."""
+    from oracle.padded_model import PaddedAcrobot
+    m = 3
+    p = P.build_acrobot_padded(T=3, m=m)
+    d, c = p["dynamics"][0], p["objective"][0]
+    om = PaddedAcrobot(64, m)
+    rng = np.random.default_rng(0)
+    x, u, y, lam = rng.random(64), rng.random(m), rng.random(64), rng.random(64)
+    env = {}
+    for nm, v in (("x", x), ("u", u), ("y", y), ("lam", lam)):
+        for i, val in enumerate(v):
+            env[(nm, i)] = float(val)
+    assert np.max(np.abs(np.array(evaluate(d.evaluate_expr, env)) - om.residual(x, u, y))) < 1e-13
+    J = np.zeros((64, 128 + m))
+    J[np.array(d.jacobian_sparsity[0]) - 1, np.array(d.jacobian_sparsity[1]) - 1] = evaluate(d.jacobian_expr, env)
+    assert np.max(np.abs(J - om.jacobian(x, u, y))) < 1e-13
+    H = np.zeros((128 + m, 128 + m))
+    H[np.array(d.hessian_sparsity[0]) - 1, np.array(d.hessian_sparsity[1]) - 1] = evaluate(d.hessian_expr, env)
+    assert np.max(np.abs(H - om.hessian(x, u, y, lam))) < 1e-13
+    assert np.count_nonzero(H[64:64 + m, 64:64 + m]) >= 2          # the action block of the dynamics Hessian is not empty
+    g, W = om.cost_grad_hess(x, u)
+    assert np.max(np.abs(np.array(evaluate(c.gradient_expr, env)) - g)) < 1e-15
+    Hc = np.zeros((64 + m, 64 + m))
+    Hc[np.array(c.solver_sparsity[0]) - 1, np.array(c.solver_sparsity[1]) - 1] = evaluate(c.solver_hessian_expr, env)
+    assert np.max(np.abs(Hc - W)) < 1e-15
