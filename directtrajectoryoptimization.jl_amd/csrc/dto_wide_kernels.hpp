@@ -77,6 +77,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef DTO_WIDE_LDL_RANK1
 #define DTO_WIDE_LDL_RANK1 1   // 0: the blocked LDL^T with one-wavefront diagonal tiles (rounds 1-3), kept for A/B runs
 #endif
+#ifndef DTO_WIDE_SPLIT_BWD
+#define DTO_WIDE_SPLIT_BWD 1   // 1: the backward sweep is its own kernel (k_wide_bwd) that prefetches the next stage's factor record
+#endif                         //    into registers while it works on the current one; 0: the tail of k_wide_step (rounds 1-4)
 #ifndef DTO_WIDE_LDL_INLINE
 #define DTO_WIDE_LDL_INLINE __attribute__((noinline))
 #endif
@@ -481,29 +484,51 @@ __device__ __forceinline__ void trsm_left_coltile(double* X, const double* Lm, c
   }
 }
 
-// v <- L^-1 v (unit lower, strict lower part of Lm), one wavefront, lanes = rows
+// broadcast of one lane's double through the scalar registers (lane is a compile-time constant after unrolling): two
+// v_readlane_b32 instead of the ds_bpermute pair __shfl costs
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// v <- L^-1 v (unit lower, strict lower part of Lm), one wavefront, lanes = rows.  Sixteen columns of the lane's row are loaded
+// (masked to the strict lower part) ahead of the sixteen dependent steps that use them: a step is two v_readlane and one fma
+// (rounds 1-4: one LDS load, a ds_bpermute broadcast and a predicated fma per step, ~190 cycles each at one wavefront per SIMD).
 template <int N>
 __device__ __forceinline__ void trsv_lower(const double* Lm, double* v) {
+  static_assert(N == 64, "one wavefront of rows");
   constexpr int LD = Dims<N>::LD;
   const int l = lane_id();
-  double mine = (l < N) ? v[l] : 0.0;
-  for (int k = 0; k < N - 1; ++k) {
-    const double vk = __shfl(mine, k);
-    if (l > k && l < N) mine -= Lm[l * LD + k] * vk;
+  double mine = v[l];
+#pragma unroll
+  for (int kb = 0; kb < N; kb += 16) {
+    double col[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) col[j] = (l > kb + j) ? Lm[l * LD + kb + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (kb + j < N - 1) mine = __builtin_fma(-col[j], readlane_f64(mine, kb + j), mine);
+    }
   }
-  if (l < N) v[l] = mine;
+  v[l] = mine;
 }
 // v <- L^-T v, one wavefront
 template <int N>
 __device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
+  static_assert(N == 64, "one wavefront of rows");
   constexpr int LD = Dims<N>::LD;
   const int l = lane_id();
-  double mine = (l < N) ? v[l] : 0.0;
-  for (int k = N - 1; k >= 1; --k) {
-    const double vk = __shfl(mine, k);
-    if (l < k) mine -= Lm[k * LD + l] * vk;
+  double mine = v[l];
+#pragma unroll
+  for (int kb = N - 16; kb >= 0; kb -= 16) {
+    double row[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) row[j] = (l < kb + j) ? Lm[(kb + j) * LD + l] : 0.0;
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+      if (kb + j >= 1) mine = __builtin_fma(-row[j], readlane_f64(mine, kb + j), mine);
+    }
   }
-  if (l < N) v[l] = mine;
+  v[l] = mine;
 }
 
 // whole-matrix copies between LDS and the factor record in HBM, 16 bytes per lane (MAT is even and every matrix starts
@@ -1185,6 +1210,11 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   }
   DTO_WIDE_TICK(13);
   if (tid == 0) a.flags[b] = (cnt[0] == (int)a.Nc && cnt[1] == 0) ? 1 : 0;
+#if DTO_WIDE_SPLIT_BWD
+  // the backward sweep is k_wide_bwd (next launch on the same stream): it picks up the statistics from here
+  if (a.stats && tid < DTO_WIDE_NSTAT) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
+  return;
+#endif
   // ---- backward sweep: y = x_{t+1} is in yv.  The factor records were written by all threads of this workgroup.
   __threadfence_block();
   __syncthreads();
@@ -1281,6 +1311,186 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     __syncthreads();
     DTO_WIDE_TICK(16);
   }
+  if (a.stats && tid < DTO_WIDE_NSTAT) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward sweep as a kernel of its own (DTO_WIDE_SPLIT_BWD): same arithmetic as the tail of k_wide_step, but the factor
+// record of stage t-1 travels from HBM into REGISTERS while stage t is worked on from LDS (45 x 16 bytes per thread: five
+// matrices; inside k_wide_step there were no registers for that -- 256 + 240 in use -- and no LDS for a second stage).
+// grid = B, block = 256.
+// ---------------------------------------------------------------------------------------------------
+template <class M>
+struct BwdLds {
+  static constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+  static constexpr int DOUBLES = 4 * Dims<N>::MAT + (9 + 3 * NU) * N + 8 + 32 + 16;
+  static constexpr int BYTES = DOUBLES * (int)sizeof(double);
+};
+
+template <class M, bool BAR>
+__global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
+  constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
+  using D = Dims<N, NU>;
+  constexpr int LD = D::LD, MAT = D::MAT;
+  constexpr int NP = (MAT / 2 + WG - 1) / WG;   // 16-byte pieces of one matrix per thread
+  extern __shared__ double sm[];
+  double* MA = sm;
+  double* MF = MA + MAT;
+  double* MV = MF + MAT;
+  double* ME = MV + MAT;
+  double* xv = ME + MAT;
+  double* yv = xv + N;
+  double* lamv = yv + N;
+  double* au = lamv + N;
+  double* fu = au + NU * N;
+  double* vu = fu + NU * N;
+  double* bx = vu + NU * N;
+  double* bd = bx + N;
+  double* dAi = bd + N;
+  double* dMi = dAi + N;
+  double* gcv = dMi + N;       // cost gradient [N + 8]
+  double* scv = gcv + N + 8;   // scalars of the action block [32]
+  double* stat = scv + 32;     // [16]
+  const int tid = threadIdx.x, w = wave_id(), l = lane_id();
+  const int64_t b = blockIdx.x;
+  if (a.active && !a.active[b]) return;
+  const double* z = a.z + b * a.ldz;
+  const double* facb = a.fac + b * (int64_t)a.T * D::FAC;
+  const bool barrier = BAR && a.zl != nullptr;
+  const double mub = (barrier && a.mu_inst) ? a.mu_inst[b] : 0.0;
+  const double* zlb = barrier ? a.zl + b * a.ldz : nullptr;
+  const double* zub = barrier ? a.zu + b * a.ldz : nullptr;
+  const double taub = fmax(a.tau_min, 1.0 - mub);
+  long long tick_ = clock64();
+  if (tid < N) yv[tid] = a.dz[b * a.lddz + a.zoff[a.T - 1] + tid];
+  if (tid < DTO_WIDE_NSTAT) stat[tid] = a.stats ? a.stats[b * DTO_WIDE_NSTAT + tid] : 0.0;
+
+  typedef double v2d __attribute__((ext_vector_type(2)));   // (HIP's double2 is a class: arrays of it stay in scratch)
+  v2d pe[NP], pm[NP], pf[NP], pv[NP], pa[NP];
+  double pvec[5 + 3 * NU], psc = 0.0;
+  auto load_mat = [&](v2d (&r)[NP], const double* src) {
+    const v2d* s2 = reinterpret_cast<const v2d*>(src);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * WG;
+      if (i < MAT / 2) r[k] = s2[i];
+    }
+  };
+  auto store_mat = [&](double* dst, const v2d (&r)[NP]) {
+    v2d* d2 = reinterpret_cast<v2d*>(dst);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * WG;
+      if (i < MAT / 2) d2[i] = r[k];
+    }
+  };
+  auto issue = [&](int t) {
+    const double* fac = facb + (int64_t)t * D::FAC;
+    const double* fv = fac + D::F_VEC;
+    load_mat(pe, fac + D::F_ET);
+    load_mat(pm, fac + D::F_LM);
+    load_mat(pf, fac + D::F_FT);
+    load_mat(pv, fac + D::F_VT);
+    if (tid < N) {
+      pvec[0] = fv[D::V_DA + tid]; pvec[1] = fv[D::V_DM + tid]; pvec[2] = fv[D::V_BX + tid]; pvec[3] = fv[D::V_BD + tid];
+      pvec[4] = fv[D::V_GC + tid];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        pvec[5 + 3 * j] = fv[D::V_AU + j * N + tid]; pvec[6 + 3 * j] = fv[D::V_FU + j * N + tid]; pvec[7 + 3 * j] = fv[D::V_VU + j * N + tid];
+      }
+    } else if (tid < N + 32) {
+      // [0, 8): cost gradient of the actions; [8, 8 + NU (NU + 2)): 1 / pivots, reduced right-hand sides, L_u
+      const int q = tid - N;
+      psc = (q < 8) ? fv[D::V_GC + N + q] : (q - 8 < ((NU * (NU + 2) + 7) & ~7) ? fv[D::V_SC + q - 8] : 0.0);
+    }
+  };
+  issue(a.T - 2);
+  load_mat(pa, facb + (int64_t)(a.T - 2) * D::FAC + D::F_LA);
+  for (int t = a.T - 2; t >= 0; --t) {
+    __syncthreads();
+    store_mat(ME, pe);
+    store_mat(MA, pm);
+    store_mat(MF, pf);
+    store_mat(MV, pv);
+    if (tid < N) {
+      dAi[tid] = pvec[0]; dMi[tid] = pvec[1]; bx[tid] = pvec[2]; bd[tid] = pvec[3]; gcv[tid] = pvec[4];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) { au[j * N + tid] = pvec[5 + 3 * j]; fu[j * N + tid] = pvec[6 + 3 * j]; vu[j * N + tid] = pvec[7 + 3 * j]; }
+    } else if (tid < N + 32) {
+      const int q = tid - N;
+      if (q < 8) gcv[N + q] = psc; else scv[q - 8] = psc;
+    }
+    __syncthreads();
+    if (t > 0) issue(t - 1);
+    DTO_WIDE_TICK(14);
+    // lam = L_M^-T D_M^-1 (E~ y - bd^)
+    if (tid < N) lamv[tid] = (dot_rr<N>(ME + tid * LD, yv) - bd[tid]) * dMi[tid];
+    __syncthreads();
+    if (w == 0) trsv_lower_t<N>(MA, lamv);
+    __syncthreads();
+    DTO_WIDE_TICK(15);
+    // x = L_A^-T D_A^-1 (bx~ - F~' lam - V~ y)
+    if (tid < N) xv[tid] = (bx[tid] - dot_cr<N>(MF + tid, LD, lamv) - dot_rr<N>(MV + tid * LD, yv)) * dAi[tid];
+    store_mat(MA, pa);   // L_M is done with (the trsv above ended at the last barrier)
+    if (t > 0) load_mat(pa, facb + (int64_t)(t - 1) * D::FAC + D::F_LA);
+    __syncthreads();
+    if (w == 0) trsv_lower_t<N>(MA, xv);
+    __syncthreads();
+    if (tid < N) {
+      a.dz[b * a.lddz + a.zoff[t] + tid] = xv[tid];
+      a.dmu[b * a.lddmu + a.cdoff[t] + tid] = lamv[tid];
+    }
+    if (w == 1) {
+      // u_j = (bu_j - au_j'x - fu_j'lam - vu_j'y) / piv_j - sum_{k > j} L_u[k][j] u_k, last action first
+      double duv[NU];
+#pragma unroll
+      for (int j = NU - 1; j >= 0; --j) {
+        const double part = wave_sum(au[j * N + l] * xv[l] + fu[j * N + l] * lamv[l] + vu[j * N + l] * yv[l]);
+        double uj = (scv[NU + j] - part) * scv[j];
+#pragma unroll
+        for (int k = j + 1; k < NU; ++k) uj -= scv[2 * NU + k * NU + j] * duv[k];
+        duv[j] = uj;
+      }
+      double du = duv[0];   // lane j < NU: its own action
+#pragma unroll
+      for (int j = 1; j < NU; ++j) du = (l == j) ? duv[j] : du;
+      if (l < NU) a.dz[b * a.lddz + a.zoff[t] + N + l] = du;
+      if (a.stats) {
+        // gradient of the barrier objective along the step, fraction-to-the-boundary limits of this knot (x: lane, u: lanes < NU)
+        double brl = 0.0, ap = 1.0, ad = 1.0;
+        if (barrier) {
+          const int gi = a.zoff[t] + l;
+          const double xo = z[gi], lo = a.fixed_lo[gi], hi = a.fixed_hi[gi];
+          brl = wide_bar(xo, lo, hi, zlb[gi], zub[gi], mub).br;
+          wide_bar_step(xo, xv[l], lo, hi, zlb[gi], zub[gi], mub, taub, ap, ad);
+          if (l < NU) {
+            const int gu = a.zoff[t] + N + l;
+            const double uo = z[gu], ulo = a.fixed_lo[gu], uhi = a.fixed_hi[gu];
+            wide_bar_step(uo, du, ulo, uhi, zlb[gu], zub[gu], mub, taub, ap, ad);
+          }
+          ap = wave_min(ap); ad = wave_min(ad);
+        }
+        double gl = (gcv[l] - brl) * xv[l];
+        if (l < NU) {
+          double bru = 0.0;
+          if (barrier) {
+            const int gu = a.zoff[t] + N + l;
+            bru = wide_bar(z[gu], a.fixed_lo[gu], a.fixed_hi[gu], zlb[gu], zub[gu], mub).br;
+          }
+          gl += (gcv[N + l] - bru) * du;
+        }
+        const double gpart = wave_sum(gl);
+        if (l == 0) {
+          if (barrier) { stat[DTO_WIDE_APMAX] = fmin(stat[DTO_WIDE_APMAX], ap); stat[DTO_WIDE_ADMAX] = fmin(stat[DTO_WIDE_ADMAX], ad); }
+          stat[4] += gpart;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < N) yv[tid] = xv[tid];
+    DTO_WIDE_TICK(16);
+  }
+  __syncthreads();
   if (a.stats && tid < DTO_WIDE_NSTAT) a.stats[b * DTO_WIDE_NSTAT + tid] = stat[tid];
 }
 
@@ -1604,11 +1814,21 @@ int launch_wide(int op, const dto_wide_args* a, void* stream) {
     hipError_t eb = hipFuncSetAttribute((const void*)k_wide_step<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
     if (eb != hipSuccess) return (int)eb;
     hipLaunchKernelGGL((k_wide_step<M, true>), dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
+#if DTO_WIDE_SPLIT_BWD
+    eb = hipFuncSetAttribute((const void*)k_wide_bwd<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdLds<M>::BYTES);
+    if (eb != hipSuccess) return (int)eb;
+    hipLaunchKernelGGL((k_wide_bwd<M, true>), dim3((unsigned)a->B), dim3(WG), BwdLds<M>::BYTES, (hipStream_t)stream, *a);
+#endif
     return (int)hipGetLastError();
   }
   hipError_t e = hipFuncSetAttribute((const void*)k_wide_step<M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, info.lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((k_wide_step<M, false>), dim3((unsigned)a->B), dim3(WG), info.lds_bytes, (hipStream_t)stream, *a);
+#if DTO_WIDE_SPLIT_BWD
+  e = hipFuncSetAttribute((const void*)k_wide_bwd<M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BwdLds<M>::BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((k_wide_bwd<M, false>), dim3((unsigned)a->B), dim3(WG), BwdLds<M>::BYTES, (hipStream_t)stream, *a);
+#endif
   return (int)hipGetLastError();
 }
 
