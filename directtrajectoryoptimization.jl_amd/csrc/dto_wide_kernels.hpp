@@ -592,6 +592,66 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- 64-term dot products spread over the whole workgroup: thread = (row or column tid >> 2, quarter tid & 3), sixteen
+//      interleaved terms per thread, the quarters summed across the four lanes by DPP.  (As `if (tid < N) dot_rr<N>(...)` a
+//      product kept ONE wavefront busy for ~5 k cycles -- 64 dependent-latency LDS round trips -- while three waited.)
+__device__ __forceinline__ double quad_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  double o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true));
+  v += o;
+  lo = __double2loint(v); hi = __double2hiint(v);
+  o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));
+  return v + o;
+}
+#ifndef DTO_WIDE_DOTQ
+#define DTO_WIDE_DOTQ 15   // bit per site of the forward sweep (phases 2, 4, 8, 11) that uses the workgroup-wide dot products
+#endif
+#ifndef DTO_DOTQ_UNROLL
+#define DTO_DOTQ_UNROLL 2
+#endif
+// quarter of sum_c A[row][c] v[c] (row-major A, row = tid >> 2): call quad_sum on the result (or on a sum of several quarters)
+template <int N>
+__device__ __forceinline__ double dotq_r(const double* A, int ld, const double* v) {
+  const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const double* ar = A + row * ld + q;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll DTO_DOTQ_UNROLL
+  for (int j = 0; j < N / 4; j += 2) { s0 += ar[4 * j] * v[q + 4 * j]; s1 += ar[4 * j + 4] * v[q + 4 * j + 4]; }
+  return s0 + s1;
+}
+template <int N>
+__device__ __forceinline__ double dotq_rs(const double* A, int ld, const double* v, const double* sc) {
+  const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const double* ar = A + row * ld + q;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll DTO_DOTQ_UNROLL
+  for (int j = 0; j < N / 4; j += 2) {
+    s0 += ar[4 * j] * v[q + 4 * j] * sc[q + 4 * j]; s1 += ar[4 * j + 4] * v[q + 4 * j + 4] * sc[q + 4 * j + 4];
+  }
+  return s0 + s1;
+}
+// quarter of sum_r A[r][col] v[r] (col = tid >> 2)
+template <int N>
+__device__ __forceinline__ double dotq_c(const double* A, int ld, const double* v) {
+  const int col = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const double* ac = A + q * ld + col;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll DTO_DOTQ_UNROLL
+  for (int j = 0; j < N / 4; j += 2) { s0 += ac[4 * j * ld] * v[q + 4 * j]; s1 += ac[(4 * j + 4) * ld] * v[q + 4 * j + 4]; }
+  return s0 + s1;
+}
+template <int N>
+__device__ __forceinline__ double dotq_cs(const double* A, int ld, const double* v, const double* sc) {
+  const int col = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const double* ac = A + q * ld + col;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll DTO_DOTQ_UNROLL
+  for (int j = 0; j < N / 4; j += 2) {
+    s0 += ac[4 * j * ld] * v[q + 4 * j] * sc[q + 4 * j]; s1 += ac[(4 * j + 4) * ld] * v[q + 4 * j + 4] * sc[q + 4 * j + 4];
+  }
+  return s0 + s1;
+}
+
 #define DTO_WIDE_TICK(slot)                                                       \
   do {                                                                             \
     if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {                           \
@@ -785,15 +845,20 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           ubar[0] = wb.br; ubar[1] = wb.sig; ubar[2] = wb.zdiff; ubar[3] = wb.sz_max; ubar[4] = wb.isz_max; ubar[5] = wb.sum_z; ubar[6] = wb.logb;
         }
         {
+          // (sixteen rows per wavefront.  Written as `for (r = w; r < N; r += 4)` the loop stayed rolled -- its trip count
+          //  depends on w -- with a vmcnt(0) after every load: 21 k cycles per stage for 66 KB out of the L2.  Fully unrolled
+          //  with eight or sixteen loads in flight it was faster still but pushed this kernel into 30-60 spilled registers,
+          //  and the SOLVER's use of it -- statistics, fixed components -- then returned NaN steps while the plain KKT step
+          //  stayed correct: not understood, not kept)
           constexpr int NC = 2 * N + NU;
           const double* fe = DY::fe_const();
-#pragma unroll
-          for (int r = w; r < N; r += 4) {
-            const double* row = fe + r * NC;
-            MF[r * LD + l] = row[l];
-            ME[r * LD + l] = row[N + NU + l];
-            if (l < NU) fu[l * N + r] = row[N + l];
+#pragma unroll 1
+          for (int part = 0; part < N / 8; ++part) {   // two rows of both matrices per pass: four loads in flight
+            const int r0 = w + 8 * part, r1 = r0 + 4;
+            const double f0 = fe[r0 * NC + l], e0 = fe[r0 * NC + N + NU + l], f1 = fe[r1 * NC + l], e1 = fe[r1 * NC + N + NU + l];
+            MF[r0 * LD + l] = f0; ME[r0 * LD + l] = e0; MF[r1 * LD + l] = f1; ME[r1 * LD + l] = e1;
           }
+          for (int i = tid; i < N * NU; i += WG) fu[i] = fe[(i % N) * NC + N + i / N];
           for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
         }
         lds_barrier();
@@ -820,12 +885,25 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(1);
         // ---- phase 2: residual from the constant part (variable Jacobian entries are still zero in MF/ME/fu)
+#if DTO_WIDE_DOTQ & 1
+        {
+          const double part = quad_sum(dotq_r<N>(MF, LD, xv) + dotq_r<N>(ME, LD, yv));
+          if ((tid & 3) == 0) {
+            const int row = tid >> 2;
+            double acc = nlf[row] + fu[row] * sc[0] + part;
+#pragma unroll
+            for (int j = 1; j < NU; ++j) acc += fu[j * N + row] * sc[j];
+            bd[row] = -acc;
+          }
+        }
+#else
         if (tid < N) {
           double acc = nlf[tid] + fu[tid] * sc[0] + dot_rr<N>(MF + tid * LD, xv) + dot_rr<N>(ME + tid * LD, yv);
 #pragma unroll
           for (int j = 1; j < NU; ++j) acc += fu[j * N + tid] * sc[j];
           bd[tid] = -acc;
         }
+#endif
         lds_barrier();
         DTO_WIDE_TICK(2);
         // ---- phase 3: variable Jacobian entries, Hessian blocks
@@ -875,11 +953,23 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(3);
         // ---- phase 4: gradient of the Lagrangian -> right-hand sides
+#if DTO_WIDE_DOTQ & 2
+        {
+          const double pf_ = quad_sum(dotq_c<N>(MF, LD, lamv)), pe_ = quad_sum(dotq_c<N>(ME, LD, lamv));
+          if ((tid & 3) == 0) {
+            const int col = tid >> 2;
+            bx[col] = -(gc[col] + gyp[col] + pf_) + byc[col] + (BAR ? brx[col] : 0.0);
+            gyn[col] = pe_;
+          }
+        }
+#else
         if (w == 0) {
           bx[l] = -(gc[l] + gyp[l] + dot_cr<N>(MF + l, LD, lamv)) + byc[l] + (BAR ? brx[l] : 0.0);
         } else if (w == 1) {
           gyn[l] = dot_cr<N>(ME + l, LD, lamv);
-        } else if (w == 2) {
+        }
+#endif
+        if (w == 2) {
 #pragma unroll
           for (int j = 0; j < NU; ++j) {
             const double part = wave_sum(fu[j * N + l] * lamv[l]);
@@ -1013,6 +1103,12 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(7);
         // ---- phase 8: M = D + F~ D_A^-1 F~' (registers), E'' = E - F~ D_A^-1 V~ (in place), bd~
+        // (the factor record leaves as soon as its pieces are final -- L_A, F~, V~ here, L_M before phase 10, E~ before
+        //  phase 11 -- so that the stores drain behind the matrix products: issued together at the end of the stage, the 170 KB
+        //  of all 256 workgroups hit HBM at once and the first loads of the next stage waited ~25 k cycles behind them)
+        copy_mat<MAT>(fac + D::F_LA, MA);
+        copy_mat<MAT>(fac + D::F_FT, MF);
+        copy_mat<MAT>(fac + D::F_VT, MV);
         d4 macc[NT];
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) {
@@ -1035,10 +1131,14 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int jb = 0; jb < NT; ++jb) tile_store(ME, LD, w * TB, jb * TB, eacc[jb]);
         }
-        if (tid < N) {
-          tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
+#if DTO_WIDE_DOTQ & 4
+        {
+          const double part = quad_sum(dotq_rs<N>(MF, LD, bx, dAi));
+          if ((tid & 3) == 0) tmp[tid >> 2] = bd[tid >> 2] - part;
         }
-        copy_mat<MAT>(fac + D::F_LA, MA);
+#else
+        if (tid < N) tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
+#endif
         lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
@@ -1058,21 +1158,12 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         DTO_WIDE_TICK(9);
         // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
+        copy_mat<MAT>(fac + D::F_LM, MA);
         if (w == 0) trsv_lower<N>(MA, bd);
         trsm_left_coltile<N>(ME, MA, LI, w);
         lds_barrier();
         DTO_WIDE_TICK(10);
         // ---- phase 11: P' = -V~' D_A^-1 V~ + E~' D_M^-1 E~ (registers), carried right-hand side
-#pragma unroll
-        for (int jb = 0; jb < NT; ++jb) macc[jb] = d4{0.0, 0.0, 0.0, 0.0};
-        mm_row4<2, N>(macc, MV, w * TB, MV, dAi, -1.0);
-        mm_row4<2, N>(macc, ME, w * TB, ME, dMi, 1.0);
-        if (tid < N) {
-          tmp[tid] = byn[tid] - dot_crs<N>(MV + tid, LD, bx, dAi) + dot_crs<N>(ME + tid, LD, bd, dMi);
-        }
-        copy_mat<MAT>(fac + D::F_LM, MA);
-        copy_mat<MAT>(fac + D::F_FT, MF);
-        copy_mat<MAT>(fac + D::F_VT, MV);
         copy_mat<MAT>(fac + D::F_ET, ME);
         if (tid < N) {
           double* fv = fac + D::F_VEC;
@@ -1095,6 +1186,18 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           fs[D::V_SC + NU + tid] = buv[tid];
         }
         if (NU > 1 && tid < NU * NU) fac[D::F_VEC + D::V_SC + 2 * NU + tid] = auu[tid];
+#pragma unroll
+        for (int jb = 0; jb < NT; ++jb) macc[jb] = d4{0.0, 0.0, 0.0, 0.0};
+        mm_row4<2, N>(macc, MV, w * TB, MV, dAi, -1.0);
+        mm_row4<2, N>(macc, ME, w * TB, ME, dMi, 1.0);
+#if DTO_WIDE_DOTQ & 8
+        {
+          const double part = quad_sum(dotq_cs<N>(ME, LD, bd, dMi) - dotq_cs<N>(MV, LD, bx, dAi));
+          if ((tid & 3) == 0) tmp[tid >> 2] = byn[tid >> 2] + part;
+        }
+#else
+        if (tid < N) tmp[tid] = byn[tid] - dot_crs<N>(MV + tid, LD, bx, dAi) + dot_crs<N>(ME + tid, LD, bd, dMi);
+#endif
         lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
@@ -1424,13 +1527,19 @@ __global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
     if (t > 0) issue(t - 1);
     DTO_WIDE_TICK(14);
     // lam = L_M^-T D_M^-1 (E~ y - bd^)
-    if (tid < N) lamv[tid] = (dot_rr<N>(ME + tid * LD, yv) - bd[tid]) * dMi[tid];
+    {
+      const double part = quad_sum(dotq_r<N>(ME, LD, yv));
+      if ((tid & 3) == 0) lamv[tid >> 2] = (part - bd[tid >> 2]) * dMi[tid >> 2];
+    }
     __syncthreads();
     if (w == 0) trsv_lower_t<N>(MA, lamv);
     __syncthreads();
     DTO_WIDE_TICK(15);
     // x = L_A^-T D_A^-1 (bx~ - F~' lam - V~ y)
-    if (tid < N) xv[tid] = (bx[tid] - dot_cr<N>(MF + tid, LD, lamv) - dot_rr<N>(MV + tid * LD, yv)) * dAi[tid];
+    {
+      const double part = quad_sum(dotq_c<N>(MF, LD, lamv) + dotq_r<N>(MV, LD, yv));
+      if ((tid & 3) == 0) xv[tid >> 2] = (bx[tid >> 2] - part) * dAi[tid >> 2];
+    }
     store_mat(MA, pa);   // L_M is done with (the trsv above ended at the last barrier)
     if (t > 0) load_mat(pa, facb + (int64_t)(t - 1) * D::FAC + D::F_LA);
     __syncthreads();
