@@ -160,7 +160,7 @@ def dense_block_measurement(dev, T=2000, B=256):
     jms = event_time_ms(jfn, 10)
     jbytes = Bj * 8 * (nj + nz)
     return dict(workload=f"acrobot embedded in 64 states, T={T}, {B} instances (BASELINE.json configs[4])",
-                kernel="k_wide_step", inertia_ok=bool(ok), avg_launch_ms=round(ms, 3), block=129, stages=B * (T - 1),
+                kernel="k_wide_step + k_wide_bwd (forward and backward sweep of one KKT step)", inertia_ok=bool(ok), avg_launch_ms=round(ms, 3), block=129, stages=B * (T - 1),
                 kkt_steps_per_sec=round(B / (ms * 1e-3), 1),
                 sqp_iterations_per_sec=round(sqp_its / sqp_dt, 1), sqp_sample=f"{sqp_its} iterations in {sqp_dt:.2f} s (first 3 iterations from the straight-line guess)",
                 roofline=dict(bound="mfma", achieved=round(tflops, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",

@@ -544,6 +544,24 @@ __device__ __forceinline__ void copy_mat(double* dst, const double* src) {
   for (int i = threadIdx.x; i < MAT / 2; i += WG) d2[i] = s2[i];
 }
 
+// LDS -> factor record: three pieces per thread in flight (an LDS round trip per piece otherwise: ~130 cycles x 9 x 5 matrices)
+template <int MAT>
+__device__ __forceinline__ void store_fac(double* dst, const double* src) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d* s2 = reinterpret_cast<const v2d*>(src);
+  v2d* d2 = reinterpret_cast<v2d*>(dst);
+  constexpr int NP = (MAT / 2 + WG - 1) / WG;
+  static_assert(NP % 3 == 0, "pieces per thread");
+#pragma unroll 1
+  for (int k = 0; k < NP; k += 3) {
+    const int i0 = threadIdx.x + k * WG, i1 = i0 + WG, i2 = i1 + WG;
+    const v2d a0 = s2[i0 < MAT / 2 ? i0 : 0], a1 = s2[i1 < MAT / 2 ? i1 : 0], a2 = s2[i2 < MAT / 2 ? i2 : 0];
+    if (i0 < MAT / 2) d2[i0] = a0;
+    if (i1 < MAT / 2) d2[i1] = a1;
+    if (i2 < MAT / 2) d2[i2] = a2;
+  }
+}
+
 // dot products over N terms, fully unrolled with four independent accumulators (LDS loads all in flight)
 template <int N>
 __device__ __forceinline__ double dot_rr(const double* a, const double* v) {
@@ -603,6 +621,9 @@ __device__ __forceinline__ double quad_sum(double v) {
   o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));
   return v + o;
 }
+#ifndef DTO_WIDE_RMW_UNROLL
+#define DTO_WIDE_RMW_UNROLL 2   // element-wise passes over the LDS matrices (rank-one terms of the actions): iterations in flight
+#endif
 #ifndef DTO_WIDE_DOTQ
 #define DTO_WIDE_DOTQ 15   // bit per site of the forward sweep (phases 2, 4, 8, 11) that uses the workgroup-wide dot products
 #endif
@@ -1059,6 +1080,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int j = 0; j < NU; ++j) { ip[j] = ipv[j]; bu[j] = buv[j]; }
         }
+#pragma unroll DTO_WIDE_RMW_UNROLL
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
           double da = 0.0, df = 0.0, dv = 0.0, de = 0.0;
@@ -1106,9 +1128,9 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         // (the factor record leaves as soon as its pieces are final -- L_A, F~, V~ here, L_M before phase 10, E~ before
         //  phase 11 -- so that the stores drain behind the matrix products: issued together at the end of the stage, the 170 KB
         //  of all 256 workgroups hit HBM at once and the first loads of the next stage waited ~25 k cycles behind them)
-        copy_mat<MAT>(fac + D::F_LA, MA);
-        copy_mat<MAT>(fac + D::F_FT, MF);
-        copy_mat<MAT>(fac + D::F_VT, MV);
+        store_fac<MAT>(fac + D::F_LA, MA);
+        store_fac<MAT>(fac + D::F_FT, MF);
+        store_fac<MAT>(fac + D::F_VT, MV);
         d4 macc[NT];
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) {
@@ -1158,13 +1180,13 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         DTO_WIDE_TICK(9);
         // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
-        copy_mat<MAT>(fac + D::F_LM, MA);
+        store_fac<MAT>(fac + D::F_LM, MA);
         if (w == 0) trsv_lower<N>(MA, bd);
         trsm_left_coltile<N>(ME, MA, LI, w);
         lds_barrier();
         DTO_WIDE_TICK(10);
         // ---- phase 11: P' = -V~' D_A^-1 V~ + E~' D_M^-1 E~ (registers), carried right-hand side
-        copy_mat<MAT>(fac + D::F_ET, ME);
+        store_fac<MAT>(fac + D::F_ET, ME);
         if (tid < N) {
           double* fv = fac + D::F_VEC;
           fv[D::V_DA + tid] = dAi[tid];
@@ -1205,6 +1227,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(11);
         // the y-y part of this stage's Hessian and the u rank-one term complete P'
+#pragma unroll DTO_WIDE_RMW_UNROLL
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
           double dvv = 0.0;

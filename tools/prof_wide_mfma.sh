@@ -16,13 +16,18 @@ python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
 d = collections.defaultdict(list)
+per = collections.defaultdict(list)
 for f in glob.glob(out + "/raw/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_wide_step" in r["Kernel_Name"]:
+        # the KKT step is two launches since round 4: forward sweep (k_wide_step) and backward sweep (k_wide_bwd) -- summed here
+        if "k_wide_step" in r["Kernel_Name"] or "k_wide_bwd" in r["Kernel_Name"]:
             d[r["Counter_Name"]].append(float(r["Counter_Value"]))
-m = {k: sum(v) / len(v) for k, v in d.items()}
-res = dict(kernel="dto::wide::k_wide_step (acrobot embedded in 64 states, T=2000, 256 instances = one workgroup per CU)",
-           launches=len(next(iter(d.values()))) if d else 0, counters_mean_per_launch=m)
+            per[("fwd" if "k_wide_step" in r["Kernel_Name"] else "bwd", r["Counter_Name"])].append(float(r["Counter_Value"]))
+nl = max(1, len(per.get(("fwd", "SQ_WAVE_CYCLES"), [])))
+m = {k: sum(v) / nl for k, v in d.items()}
+res = dict(kernel="dto::wide::k_wide_step + k_wide_bwd = one KKT step (acrobot embedded in 64 states, T=2000, 256 instances = one workgroup per CU)",
+           steps=nl, counters_mean_per_step=m,
+           per_kernel_mean={f"{a}:{c}": sum(v) / len(v) for (a, c), v in per.items()})
 if m:
     mf = m.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / 4.0        # MOPS counts 512-flop units, 4 per v_mfma_f64_16x16x4_f64
     cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                   # summed over the 8 XCDs
