@@ -165,15 +165,27 @@ template <int MODE, int N>
 __device__ __forceinline__ void mm_row4(d4 (&c)[4], const double* A, int m0, const double* Bm, const double* s, double sgn) {
   constexpr int LD = Dims<N>::LD;
   const int r = lane_id() & 15, q = lane_id() >> 4;
+  // operands of step k + 4 are requested before the four MFMAs of step k are issued (left to the compiler, the B operands of
+  // MODE 1 / 2 were read one at a time, each behind its own lgkmcnt(0))
+  const double* Ap = (MODE == 2) ? A + q * LD + m0 + r : A + (m0 + r) * LD + q;
+  const double* Bp = (MODE == 0) ? Bm + r * LD + q : Bm + q * LD + r;
+  constexpr int AS = (MODE == 2) ? LD : 1, BK = (MODE == 0) ? 1 : LD, BJ = (MODE == 0) ? TB * LD : TB;
+  double an = Ap[0], sn = s[q], bn[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) bn[jb] = Bp[jb * BJ];
 #pragma unroll 4
   for (int k = 0; k < N; k += 4) {
-    double a = (MODE == 2) ? A[(k + q) * LD + m0 + r] : A[(m0 + r) * LD + k + q];
-    a *= sgn * s[k + q];
+    const double a = an * (sgn * sn);
+    double b[4];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      const double bv = (MODE == 0) ? Bm[(jb * TB + r) * LD + k + q] : Bm[(k + q) * LD + jb * TB + r];
-      c[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, c[jb], 0, 0, 0);
+    for (int jb = 0; jb < 4; ++jb) b[jb] = bn[jb];
+    if (k + 4 < N) {
+      an = Ap[(k + 4) * AS]; sn = s[k + 4 + q];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) bn[jb] = Bp[(k + 4) * BK + jb * BJ];
     }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) c[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[jb], c[jb], 0, 0, 0);
   }
 }
 
@@ -1131,6 +1143,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         store_fac<MAT>(fac + D::F_LA, MA);
         store_fac<MAT>(fac + D::F_FT, MF);
         store_fac<MAT>(fac + D::F_VT, MV);
+        DTO_WIDE_TICK(24);
         d4 macc[NT];
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) {
@@ -1145,6 +1158,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
         }
         mm_row4<0, N>(macc, MF, w * TB, MF, dAi, 1.0);
+        DTO_WIDE_TICK(25);
         {
           d4 eacc[NT];
 #pragma unroll
@@ -1153,6 +1167,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int jb = 0; jb < NT; ++jb) tile_store(ME, LD, w * TB, jb * TB, eacc[jb]);
         }
+        DTO_WIDE_TICK(26);
 #if DTO_WIDE_DOTQ & 4
         {
           const double part = quad_sum(dotq_rs<N>(MF, LD, bx, dAi));

@@ -628,6 +628,12 @@ def _extra_flags() -> List[str]:
     return os.environ.get("DTO_PLUGIN_CXXFLAGS", "").split()
 
 
+# tile (MFMA) plugins: keep the f64 MFMA accumulators in VGPRs.  In AGPR form (the compiler's choice at this register pressure)
+# the 32 accumulator registers of a product loop were copied VGPR -> AGPR at the top and AGPR -> VGPR at the bottom of every
+# pass behind an `s_nop 15` that drains the matrix pipe (csrc/dto_wide_kernels.hpp: mm_row4)
+WIDE_CXXFLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
 def _prepare_plugin(st: Structure, name: str):
     """(path of the plugin .so, compile command or None if it is already built).  Not thread-safe (the structural-key
     switch of the code generator is a module global): call it serially, compile in parallel."""
@@ -638,7 +644,8 @@ def _prepare_plugin(st: Structure, name: str):
         key_src = generate_source(st, name)
     finally:
         _cg.STRUCTURAL_KEYS = False
-    digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+    flags = (WIDE_CXXFLAGS if st.wide else []) + _extra_flags()
+    digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION + " ".join(flags)).encode()).hexdigest()[:16]
     os.makedirs(PLUGIN_DIR, exist_ok=True)
     base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")
     so = base + ".so"
@@ -651,7 +658,7 @@ def _prepare_plugin(st: Structure, name: str):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = so + f".tmp{os.getpid()}"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", CSRC,
-           "-Wno-unused-value"] + _extra_flags() + ["-o", tmp, hip_src]
+           "-Wno-unused-value"] + flags + ["-o", tmp, hip_src]
     return so, cmd
 
 

@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 out = f"/tmp/kres_{os.getpid()}.so"
 res = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I",
-                      os.path.join(root, "directtrajectoryoptimization.jl_amd", "csrc"), "-Wno-unused-value",
+                      os.path.join(root, "directtrajectoryoptimization.jl_amd", "csrc"), "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form",
                       "-Rpass-analysis=kernel-resource-usage", "-o", out, src], capture_output=True, text=True)
 if os.path.exists(out):
     os.remove(out)
