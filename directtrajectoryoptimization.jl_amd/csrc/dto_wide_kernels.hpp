@@ -349,9 +349,18 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
       if ((tj >> 2) == kq) {
         const int q = tj & 3;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) cb[q * N + ti + 16 * a] = r[a][kb];
+        for (int a = kb; a < 4; ++a) cb[q * N + ti + 16 * a] = r[a][kb];
       }
       lds_barrier();
+      // the thread's own rows / columns of the four published columns: requested before the (long, dependent) pivot-block
+      // chain below so that their LDS latency hides behind it
+      // (rows and columns above block column kb are final: nothing of them is read, substituted or updated any more)
+      double cv[4][4], cu[4][4];
+#pragma unroll
+      for (int a = kb; a < 4; ++a) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) { cv[a][p2] = cb[p2 * N + ti + 16 * a]; cu[a][p2] = cb[p2 * N + tj + 16 * a]; }
+      }
       // pivot block: P[q][p] = column k0+q at row k0+p (symmetric)
       double L4[4][4], dd[4], di[4];
 #pragma unroll
@@ -386,11 +395,11 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
       // (their entries are final or handled below), so the rank-4 update itself is unconditional
       double yr[4][4], lr[4][4], yc[4][4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = kb; a < 4; ++a) {
         const bool later = tj + 16 * a > k0 + 3;
 #pragma unroll
         for (int p2 = 0; p2 < 4; ++p2) {
-          double v = cb[p2 * N + ti + 16 * a], u = cb[p2 * N + tj + 16 * a];
+          double v = cv[a][p2], u = cu[a][p2];
 #pragma unroll
           for (int s2 = 0; s2 < p2; ++s2) { v = fma(-yr[a][s2], L4[p2][s2], v); u = fma(-yc[a][s2], L4[p2][s2], u); }
           yr[a][p2] = v; yc[a][p2] = u;
@@ -400,7 +409,7 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
       }
       // only the lower blocks of the comb (a >= b) are ever written back
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = kb; b < 4; ++b) {
 #pragma unroll
         for (int a = b; a < 4; ++a) {
           double upd = r[a][b];
@@ -412,7 +421,7 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
       // the four columns of this block keep y (their L D): comb block column kb, threads tj in [kk, kk + 3]
       if ((tj >> 2) == kq) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = kb; a < 4; ++a) {
           // (selects kept apart by empty asm: as a chain of ifs the compiler turns them into yr[a][tj & 3], i.e. the array goes to
           // scratch memory and every step pays scratch round trips)
           double own = yr[a][0];
