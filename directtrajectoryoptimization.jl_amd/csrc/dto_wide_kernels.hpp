@@ -475,34 +475,113 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
 #undef DTO_LDL_TICK
 }
 
+// chain of KS MFMA k-steps on one accumulator with the operands of the next four steps requested while the current four are
+// issued (fa(step), fb(step) read LDS); KS is a compile-time constant: everything unrolls
+template <int KS, class FA, class FB>
+__device__ __forceinline__ d4 mm_steps(d4 c, FA fa, FB fb) {
+  static_assert(KS % 4 == 0 && KS >= 4, "chunks of four k-steps");
+  double an[4], bn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { an[i] = fa(i); bn[i] = fb(i); }
+#pragma unroll
+  for (int c0 = 0; c0 < KS; c0 += 4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+    if (c0 + 4 < KS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { an[i] = fa(c0 + 4 + i); bn[i] = fb(c0 + 4 + i); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], c, 0, 0, 0);
+  }
+  return c;
+}
+
 // X <- X * L^-T for row-tile `ib` of X (one wavefront; tiles of one row depend only on each other)
 template <int N>
 __device__ __forceinline__ void trsm_right_rowtile(double* X, const double* Lm, const double* LI, int ib) {
   using D = Dims<N>;
-  constexpr int LD = D::LD;
-  for (int jb = 0; jb < D::NT; ++jb) {
+  constexpr int LD = D::LD, LL = D::LI_LD;
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  const double* xr = X + (ib * TB + r) * LD + q;     // A operand: X[ib rows][k]
+  auto tile = [&](auto jbc) {
+    constexpr int jb = decltype(jbc)::value;
     d4 c = tile_load(X, LD, ib * TB, jb * TB);
-    if (jb > 0) c = mm_nt(c, X, LD, ib * TB, Lm, LD, jb * TB, 0, jb * TB, nullptr, -1.0);
+    if constexpr (jb > 0) {
+      const double* lr = Lm + (jb * TB + r) * LD + q;  // B operand ("NT"): L[jb rows][k]
+      c = mm_steps<4 * jb>(c, [&](int st) { return -xr[4 * st]; }, [&](int st) { return lr[4 * st]; });
+    }
     tile_store(X, LD, ib * TB, jb * TB, c);
+    const double* li = LI + (jb * TB + r) * LL + q;
     d4 c2 = {0.0, 0.0, 0.0, 0.0};
-    c2 = mm_nt(c2, X + jb * TB, LD, ib * TB, LI + jb * TB * D::LI_LD, D::LI_LD, 0, 0, TB, nullptr, 1.0);
+    c2 = mm_steps<4>(c2, [&](int st) { return xr[jb * TB + 4 * st]; }, [&](int st) { return li[4 * st]; });
     tile_store(X, LD, ib * TB, jb * TB, c2);
-  }
+  };
+  tile(std::integral_constant<int, 0>{});
+  tile(std::integral_constant<int, 1>{});
+  tile(std::integral_constant<int, 2>{});
+  tile(std::integral_constant<int, 3>{});
 }
 
 // X <- L^-1 X for column-tile `jb` of X (one wavefront)
 template <int N>
 __device__ __forceinline__ void trsm_left_coltile(double* X, const double* Lm, const double* LI, int jb) {
   using D = Dims<N>;
-  constexpr int LD = D::LD;
-  for (int ib = 0; ib < D::NT; ++ib) {
+  constexpr int LD = D::LD, LL = D::LI_LD;
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  const double* xc = X + q * LD + jb * TB + r;       // B operand ("NN"): X[k][jb columns]
+  auto tile = [&](auto ibc) {
+    constexpr int ib = decltype(ibc)::value;
     d4 c = tile_load(X, LD, ib * TB, jb * TB);
-    if (ib > 0) c = mm_nn(c, Lm, LD, ib * TB, X, LD, jb * TB, 0, ib * TB, nullptr, -1.0);
+    if constexpr (ib > 0) {
+      const double* lr = Lm + (ib * TB + r) * LD + q;  // A operand: L[ib rows][k]
+      c = mm_steps<4 * ib>(c, [&](int st) { return -lr[4 * st]; }, [&](int st) { return xc[4 * st * LD]; });
+    }
     tile_store(X, LD, ib * TB, jb * TB, c);
+    const double* li = LI + (ib * TB + r) * LL + q;
     d4 c2 = {0.0, 0.0, 0.0, 0.0};
-    c2 = mm_nn(c2, LI + ib * TB * D::LI_LD, D::LI_LD, 0, X, LD, jb * TB, ib * TB, ib * TB + TB, nullptr, 1.0, 0);
+    c2 = mm_steps<4>(c2, [&](int st) { return li[4 * st]; }, [&](int st) { return xc[(ib * TB + 4 * st) * LD]; });
     tile_store(X, LD, ib * TB, jb * TB, c2);
-  }
+  };
+  tile(std::integral_constant<int, 0>{});
+  tile(std::integral_constant<int, 1>{});
+  tile(std::integral_constant<int, 2>{});
+  tile(std::integral_constant<int, 3>{});
+}
+
+// both triangular solves of phase 7 for one wavefront, tile by tile in turn: two independent chains in one instruction stream
+// (the LDS round trips between the tiles of one hide behind the MFMAs of the other)
+template <int N>
+__device__ __forceinline__ void trsm_pair(double* __restrict__ XF, double* __restrict__ XV, const double* __restrict__ Lm,
+                                          const double* __restrict__ LI, int wv) {
+  using D = Dims<N>;
+  constexpr int LD = D::LD, LL = D::LI_LD;
+  const int r = lane_id() & 15, q = lane_id() >> 4;
+  const double* xr = XF + (wv * TB + r) * LD + q;
+  const double* xc = XV + q * LD + wv * TB + r;
+  auto tile = [&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    d4 cf = tile_load(XF, LD, wv * TB, t * TB);
+    d4 cv = tile_load(XV, LD, t * TB, wv * TB);
+    const double* lr = Lm + (t * TB + r) * LD + q;
+    if constexpr (t > 0) {
+      cf = mm_steps<4 * t>(cf, [&](int st) { return -xr[4 * st]; }, [&](int st) { return lr[4 * st]; });
+      cv = mm_steps<4 * t>(cv, [&](int st) { return -lr[4 * st]; }, [&](int st) { return xc[4 * st * LD]; });
+    }
+    tile_store(XF, LD, wv * TB, t * TB, cf);
+    tile_store(XV, LD, t * TB, wv * TB, cv);
+    const double* li = LI + (t * TB + r) * LL + q;
+    d4 c2 = {0.0, 0.0, 0.0, 0.0}, c3 = {0.0, 0.0, 0.0, 0.0};
+    c2 = mm_steps<4>(c2, [&](int st) { return xr[t * TB + 4 * st]; }, [&](int st) { return li[4 * st]; });
+    c3 = mm_steps<4>(c3, [&](int st) { return li[4 * st]; }, [&](int st) { return xc[(t * TB + 4 * st) * LD]; });
+    tile_store(XF, LD, wv * TB, t * TB, c2);
+    tile_store(XV, LD, t * TB, wv * TB, c3);
+  };
+  tile(std::integral_constant<int, 0>{});
+  tile(std::integral_constant<int, 1>{});
+  tile(std::integral_constant<int, 2>{});
+  tile(std::integral_constant<int, 3>{});
 }
 
 // broadcast of one lane's double through the scalar registers (lane is a compile-time constant after unrolling): two
@@ -852,13 +931,15 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         const double* wp = a.params + a.woff[t];
         // ---- phase 0: the point, constant Jacobian part
         if (tid < N) {
-          xv[tid] = z[a.zoff[t] + tid];
-          yv[tid] = z[a.zoff[t + 1] + tid];
-          lamv[tid] = mu[a.cdoff[t] + tid];
+          if (t == 0) {   // later stages: requested during phase 8 of the stage before, in LDS since its end
+            xv[tid] = z[a.zoff[t] + tid];
+            yv[tid] = z[a.zoff[t + 1] + tid];
+            lamv[tid] = mu[a.cdoff[t] + tid];
+            fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
+          }
 #pragma unroll
           for (int j = 0; j < NU; ++j) { au[j * N + tid] = 0.0; vu[j * N + tid] = 0.0; }
           nlf[tid] = 0.0;
-          fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
           double sig = 0.0;
           if (BAR) brx[tid] = 0.0;
           if (barrier) {
@@ -875,7 +956,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           }
           MA[tid * LD + tid] += dw + sig;
         }
-        if (tid < NU) sc[tid] = z[a.zoff[t] + N + tid];
+        if (t == 0 && tid < NU) sc[tid] = z[a.zoff[t] + N + tid];
         if (tid < NU * NU) auu[tid] = 0.0;
         if (BAR && tid >= 64 && tid < 64 + NU) {   // the actions of this knot (lanes of wavefront 1): ubar = {br, sig, z_U - z_L, max s z, max 1/(s z), sum z, sum log s}
           double* ubar = brx + N + 8 * (tid - 64);
@@ -895,10 +976,13 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           constexpr int NC = 2 * N + NU;
           const double* fe = DY::fe_const();
 #pragma unroll 1
-          for (int part = 0; part < N / 8; ++part) {   // two rows of both matrices per pass: four loads in flight
-            const int r0 = w + 8 * part, r1 = r0 + 4;
-            const double f0 = fe[r0 * NC + l], e0 = fe[r0 * NC + N + NU + l], f1 = fe[r1 * NC + l], e1 = fe[r1 * NC + N + NU + l];
-            MF[r0 * LD + l] = f0; ME[r0 * LD + l] = e0; MF[r1 * LD + l] = f1; ME[r1 * LD + l] = e1;
+          for (int part = 0; part < N / 16; ++part) {   // four rows of both matrices per pass: eight loads in flight
+            const int r0 = w + 16 * part;
+            double fr[4], er[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fr[i] = fe[(r0 + 4 * i) * NC + l]; er[i] = fe[(r0 + 4 * i) * NC + N + NU + l]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { MF[(r0 + 4 * i) * LD + l] = fr[i]; ME[(r0 + 4 * i) * LD + l] = er[i]; }
           }
           for (int i = tid; i < N * NU; i += WG) fu[i] = fe[(i % N) * NC + N + i / N];
           for (int i = tid; i < MAT; i += WG) MV[i] = 0.0;
@@ -1141,14 +1225,24 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         DTO_WIDE_TICK(6);
         // ---- phase 7: F~ = F L_A^-T (row tiles), V~ = L_A^-1 V (column tiles), bx~ = L_A^-1 bx
         if (w == 0) trsv_lower<N>(MA, bx);
-        trsm_right_rowtile<N>(MF, MA, LI, w);
-        trsm_left_coltile<N>(MV, MA, LI, w);
+        trsm_pair<N>(MF, MV, MA, LI, w);
         lds_barrier();
         DTO_WIDE_TICK(7);
         // ---- phase 8: M = D + F~ D_A^-1 F~' (registers), E'' = E - F~ D_A^-1 V~ (in place), bd~
         // (the factor record leaves as soon as its pieces are final -- L_A, F~, V~ here, L_M before phase 10, E~ before
         //  phase 11 -- so that the stores drain behind the matrix products: issued together at the end of the stage, the 170 KB
         //  of all 256 workgroups hit HBM at once and the first loads of the next stage waited ~25 k cycles behind them)
+        // the point of the next stage (x, y, lam, fixed mask, u -- all dead here since phase 5): requested now, written to LDS
+        // at the end of this phase, so that phase 0 of the next stage does not start with a round trip to HBM
+        double nx_ = 0.0, ny_ = 0.0, nl_ = 0.0, nf_ = 0.0, nu_ = 0.0;
+        const bool pre_ = t + 1 < a.T - 1;
+        if (pre_ && tid < N) {
+          nx_ = z[a.zoff[t + 1] + tid];
+          ny_ = z[a.zoff[t + 2] + tid];
+          nl_ = mu[a.cdoff[t + 1] + tid];
+          nf_ = (a.fixed_lo && a.fixed_lo[a.zoff[t + 1] + tid] == a.fixed_hi[a.zoff[t + 1] + tid]) ? 1.0 : 0.0;
+          if (tid < NU) nu_ = z[a.zoff[t + 1] + N + tid];
+        }
         store_fac<MAT>(fac + D::F_LA, MA);
         store_fac<MAT>(fac + D::F_FT, MF);
         store_fac<MAT>(fac + D::F_VT, MV);
@@ -1185,6 +1279,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #else
         if (tid < N) tmp[tid] = bd[tid] - dot_rrs<N>(MF + tid * LD, bx, dAi);
 #endif
+        if (pre_ && tid < N) {
+          xv[tid] = nx_; yv[tid] = ny_; lamv[tid] = nl_; fxm[tid] = nf_;
+          if (tid < NU) sc[tid] = nu_;
+        }
         lds_barrier();
 #pragma unroll
         for (int jb = 0; jb < NT; ++jb) tile_store(MA, LD, w * TB, jb * TB, macc[jb]);
