@@ -154,3 +154,22 @@ def dense_derivatives(model: PaddedAcrobot, T: int, z, mu, sigma=1.0):
             J[t * n:(t + 1) * n, o:o + 2 * n + m] = model.jacobian(x, u, y)
             H[o:o + 2 * n + m, o:o + 2 * n + m] += model.hessian(x, u, y, mu[t * n:(t + 1) * n])
     return f, g, c, J, H
+
+
+def kkt_residual_blockwise(model: PaddedAcrobot, T: int, z, lam):
+    """(c, grad f + J' lam) assembled stage by stage (no dense Jacobian: usable at the full horizon T = 2000 of configs[4])."""
+    n, m = model.n, model.m
+    nz, nc = (T - 1) * (n + m) + n, (T - 1) * n
+    r = np.zeros(nz); c = np.zeros(nc)
+    for t in range(T):
+        o = t * (n + m)
+        x = z[o:o + n]
+        u = z[o + n:o + n + m] if t < T - 1 else np.zeros(0)
+        gt, _ = model.cost_grad_hess(x, u)
+        r[o:o + n + len(u)] += gt
+        if t < T - 1:
+            y = z[o + n + m:o + 2 * n + m]
+            lt = lam[t * n:(t + 1) * n]
+            c[t * n:(t + 1) * n] = model.residual(x, u, y)
+            r[o:o + 2 * n + m] += model.jacobian(x, u, y).T @ lt
+    return c, r

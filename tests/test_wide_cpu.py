@@ -174,3 +174,15 @@ def test_three_action_model_matches_oracle_restatement():
     Hc = np.zeros((64 + m, 64 + m))
     Hc[np.array(c.solver_sparsity[0]) - 1, np.array(c.solver_sparsity[1]) - 1] = evaluate(c.solver_hessian_expr, env)
     assert np.max(np.abs(Hc - W)) < 1e-15
+
+
+def test_blockwise_kkt_residual_matches_dense_assembly():
+    """oracle/padded_model.py: kkt_residual_blockwise (the full-horizon check of tests/test_wide_gpu.py) against the dense
+    assembly of the same oracle on a small case."""
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives, kkt_residual_blockwise
+    om, T = PaddedAcrobot(64, 2), 4
+    rng = np.random.default_rng(0)
+    z, lam = rng.random((T - 1) * 66 + 64), rng.random((T - 1) * 64)
+    _, g, c, J, _ = dense_derivatives(om, T, z, lam, 1.0)
+    c2, r2 = kkt_residual_blockwise(om, T, z, lam)
+    assert np.max(np.abs(c - c2)) == 0.0 and np.max(np.abs(g + J.T @ lam - r2)) < 1e-14

@@ -415,3 +415,42 @@ def test_wide_solve_with_three_bounded_actions():
         compl = np.maximum(zl * (z[bounded] - vlo[bounded]), zu * (vhi[bounded] - z[bounded]))
         assert np.max(compl) <= 1e-3, np.max(compl)
         assert np.sum(np.abs(np.abs(z[bounded]) - u_max) < 1e-3) >= 1          # a bound is active somewhere
+
+
+def test_wide_solve_converges_at_the_full_horizon():
+    """BASELINE configs[4] at its own horizon, T = 2000 ("a converged cfg5 solve at T=2000 with the oracle KKT check"):
+    a swing to 1 rad with the four physical states pinned at the last knot, from the straight-line guess with small random actions.
+    The dense Jacobian (127 936 x 129 999) is out of reach, so the ORACLE's residuals are assembled stage by stage
+    (oracle/padded_model.py: kkt_residual_blockwise): dynamics satisfied, Lagrangian stationary in every free variable, fixed
+    components in place.  (The full swing-up to pi from standard-normal actions does not converge within 500 iterations at this
+    horizon -- tools/wide_solve_demo.py -- like 15 % of the seeds of the 4-state acrobot at T = 1000.)"""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, kkt_residual_blockwise
+    T, B = 2000, 2
+    p = P.build_acrobot_padded(T=T, target=1.0, terminal="physical")
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    assert (nz, nc) == (1999 * 65 + 64, 1999 * 64)
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+        dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.01 * u for u in us])
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert np.all(status == 1) and np.all(iters < 100), (status, iters)
+    zo, lam = zo.cpu().numpy(), lo.cpu().numpy()
+    om = PaddedAcrobot(64)
+    vlo, vhi = s.nlp.variable_bounds
+    fixed = vlo == vhi
+    for b in range(B):
+        c, r = kkt_residual_blockwise(om, T, zo[b], lam[b])
+        assert np.max(np.abs(c)) <= 1e-6, np.max(np.abs(c))
+        assert np.max(np.abs(r[~fixed])) <= 1e-5 * max(1.0, np.max(np.abs(lam[b]))), np.max(np.abs(r[~fixed]))
+        assert np.max(np.abs(zo[b][fixed] - vlo[fixed])) <= 1e-12
+        assert abs(zo[b][(T - 1) * 65] - 1.0) <= 1e-12 and np.max(np.abs(zo[b][:64])) <= 1e-12
