@@ -445,7 +445,8 @@ __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int i = ti + 16 * a, j = tj + 16 * b;
-      if (i > j) Mx[i * LD + j] = r[a][b] * dinv[j];
+      // (diagonal and upper part zeroed: the single-right-hand-side solves then need no masks, trsv_lower / trsv_lower_t)
+      Mx[i * LD + j] = (i > j) ? r[a][b] * dinv[j] : 0.0;
     }
   }
   if (tid == 0) { cnt[0] += nneg; cnt[1] |= tiny; }
@@ -591,7 +592,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 // v <- L^-1 v (unit lower, strict lower part of Lm), one wavefront, lanes = rows.  Sixteen columns of the lane's row are loaded
-// (masked to the strict lower part) ahead of the sixteen dependent steps that use them: a step is two v_readlane and one fma
+// (ldl_rank1 leaves zeros on and above the diagonal; with the blocked factorisation they are masked to the strict lower part:
+// 126 lane masks that the compiler hoists out of the stage loop and spills from the scalar registers) ahead of the sixteen dependent steps that use them: a step is two v_readlane and one fma
 // (rounds 1-4: one LDS load, a ds_bpermute broadcast and a predicated fma per step, ~190 cycles each at one wavefront per SIMD).
 template <int N>
 __device__ __forceinline__ void trsv_lower(const double* Lm, double* v) {
@@ -603,7 +605,7 @@ __device__ __forceinline__ void trsv_lower(const double* Lm, double* v) {
   for (int kb = 0; kb < N; kb += 16) {
     double col[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) col[j] = (l > kb + j) ? Lm[l * LD + kb + j] : 0.0;
+    for (int j = 0; j < 16; ++j) col[j] = (DTO_WIDE_LDL_RANK1 || l > kb + j) ? Lm[l * LD + kb + j] : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (kb + j < N - 1) mine = __builtin_fma(-col[j], readlane_f64(mine, kb + j), mine);
@@ -622,7 +624,7 @@ __device__ __forceinline__ void trsv_lower_t(const double* Lm, double* v) {
   for (int kb = N - 16; kb >= 0; kb -= 16) {
     double row[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) row[j] = (l < kb + j) ? Lm[(kb + j) * LD + l] : 0.0;
+    for (int j = 0; j < 16; ++j) row[j] = (DTO_WIDE_LDL_RANK1 || l < kb + j) ? Lm[(kb + j) * LD + l] : 0.0;
 #pragma unroll
     for (int j = 15; j >= 0; --j) {
       if (kb + j >= 1) mine = __builtin_fma(-row[j], readlane_f64(mine, kb + j), mine);
