@@ -207,7 +207,7 @@ static int wide_step(Problem* p, const dto_batch* b, const double* mu, int64_t l
   dto_wide_args a;
   a.T = L.T; a.B = b->B;
   a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff;
-  a.params = p->d_params;
+  a.params = b->params ? b->params : p->d_params; a.ldw = b->params ? b->ldp : 0;
   a.z = b->x; a.ldz = b->ldx; a.mu = mu; a.ldmu = ldmu;
   a.delta_w = delta_w; a.delta_c = delta_c; a.piv_tol = 1e-9;
   a.dz = dx; a.lddz = lddx; a.dmu = dmu; a.lddmu = lddmu;
@@ -304,7 +304,6 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   for (int64_t i = 0; i < L.Nz; ++i)
     if (L.var_lo[i] != L.var_hi[i]) n_bnd += (std::isfinite(L.var_lo[i]) ? 1 : 0) + (std::isfinite(L.var_hi[i]) ? 1 : 0);
   const bool barrier = n_bnd > 0;
-  if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
   dto_options u;
   if (opt) u = *opt; else dto_options_default(&u);
   dto_solver_opts o;
@@ -376,7 +375,8 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   if (barrier) WTRY(hipMemcpyAsync(d_mu, h_mu.data(), B * sizeof(double), hipMemcpyHostToDevice, st));
   dto_wide_args a;
   a.T = L.T; a.B = B;
-  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff; a.params = p->d_params;
+  a.kind = p->d_kind; a.zoff = p->d_zoff; a.woff = p->d_woff; a.cdoff = p->d_cdoff;
+  a.params = b->params ? b->params : p->d_params; a.ldw = b->params ? b->ldp : 0;
   a.z = z; a.ldz = Nz; a.mu = lam; a.ldmu = Nc;
   a.delta_w = 0.0; a.delta_c = o.delta_c; a.piv_tol = o.piv_tol;
   a.dz = dz; a.lddz = Nz; a.dmu = dlam; a.lddmu = Nc;
@@ -1656,7 +1656,6 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   if (!p || !b || !b->x || !mu || !dx || !dmu) return set_error(DTO_ERR_INVALID, "null argument");
   if (b->ldx < p->L.Nz || ldmu < p->L.Nc || lddx < p->L.Nz || lddmu < p->L.Nc) return set_error(DTO_ERR_INVALID, "leading dimension too small");
   if (p->vt->launch_wide) {
-    if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "per-instance parameters are not supported for wide-stage models");
     return dto::wide_step(p, b, mu, ldmu, delta_w, delta_c, dx, lddx, dmu, lddmu, inertia_ok);
   }
   if (p->L.Ngen > 0) {   // GeneralConstraint rows coupling several knots: bordered system, Schur complement on the border

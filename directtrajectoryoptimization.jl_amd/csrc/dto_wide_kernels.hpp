@@ -39,7 +39,7 @@ struct dto_wide_args {
   const int* zoff;   // [T+1]
   const int* woff;   // [T+1]
   const int* cdoff;  // [T+1]
-  const double* params;
+  const double* params; int64_t ldw;   // stage parameters w_t at params[b * ldw + woff[t]] (ldw = 0: one set shared by all instances)
   const double* z; int64_t ldz;
   const double* mu; int64_t ldmu;
   double delta_w, delta_c, piv_tol;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         using DY = typename M::template Dyn<KD::DYN>;
         using CO = typename M::template Cost<KD::COST>;
         static_assert(DY::NX == N && DY::NY == N && DY::NU == NU, "uniform wide stages expected");
-        const double* wp = a.params + a.woff[t];
+        const double* wp = a.params + b * a.ldw + a.woff[t];
         // ---- phase 0: the point, constant Jacobian part
         if (tid < N) {
           if (t == 0) {   // later stages: requested during phase 8 of the stage before, in LDS since its end
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
       using KD = typename M::template WKind<WKI>;
       if constexpr (KD::DYN < 0) {
         using CO = typename M::template Cost<KD::COST>;
-        const double* wp = a.params + a.woff[t];
+        const double* wp = a.params + b * a.ldw + a.woff[t];
         if (tid < N) {
           xv[tid] = z[a.zoff[t] + tid];
           fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
@@ -1968,7 +1968,7 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
   for (int k = 0; k < DTO_WIDE_TRIALS; ++k) facc[k] = tacc[k] = 0.0;
   for (int t = w; t < a.T; t += 4) {
     const int wk = M::wk_of_kind(a.kind[t]);
-    const double* wp = a.params + a.woff[t];
+    const double* wp = a.params + b * a.ldw + a.woff[t];
     M::dispatch_wk(wk, [&](auto wkc) {
       using KD = typename M::template WKind<decltype(wkc)::value>;
       using CO = typename M::template Cost<KD::COST>;

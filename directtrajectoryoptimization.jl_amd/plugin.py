@@ -95,8 +95,7 @@ class Structure:
                   and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == nu0 for d in self.dyn)
                   and 1 <= nu0 <= WIDE_MAX_ACTION
                   and all(c.num_state == n0 for c in self.cost)
-                  and not self.con and self.general is None
-                  and all(d.num_parameter == 0 for d in self.dyn))
+                  and not self.con and self.general is None)
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
                                  f"one uniform state dimension up to {WIDE_STATE}, one to {WIDE_MAX_ACTION} actions (the same number at "

@@ -130,7 +130,7 @@ def padded_torque(u):
     return tau
 
 
-def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64, m=1):
+def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64, m=1, parametric=False):
     """y - x - h*f(0.5(x+y), u) with f = [acrobot(x[0:4], u); 0] + eps * M [xm; u]: the four physical states keep the
     acrobot dynamics, the padding states are a stable-ish dense linear system, and every residual row depends on every
     column of [x; u], so the stage Jacobian block is structurally dense (blocks of n + m + n = 129 for n = 64)."""
@@ -138,7 +138,8 @@ def acrobot_padded_midpoint(n=64, h=0.05, eps=0.05, seed=64, m=1):
 
     def f(y, x, u, w):
         xm = 0.5 * (x + y)
-        phys = acrobot(xm[0:4], [padded_torque(u)], w)
+        # parametric: the torque is scaled by the stage parameter w[0] (a test of parameters on the tile path)
+        phys = acrobot(xm[0:4], [padded_torque(u) * w[0] if parametric else padded_torque(u)], w)
         lin = M @ np.concatenate([xm, u])
         rhs = np.array([(phys[i] if i < 4 else 0.0) + eps * lin[i] for i in range(n)], dtype=object)
         return y - (x + h * rhs)
@@ -187,6 +188,7 @@ def build_pendulum(T=50, evaluate_hessian=True):
         constraints=[con1] + [Constraint() for _ in range(T - 2)] + [conT],
         bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 
@@ -246,6 +248,7 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
         objective=[ct] * (T - 1) + [cT],
         constraints=constraints, bounds=bounds,
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 
@@ -261,7 +264,7 @@ def padded_action_cost(x, u):
     return c
 
 
-def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1):
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1, parameters=None):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
     blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
     terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
@@ -270,9 +273,14 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
     x1 = np.zeros(n)
     xT = np.zeros(n)
     xT[0] = target
-    dt = Dynamics(acrobot_padded_midpoint(n, m=m), n, n, m, evaluate_hessian=evaluate_hessian)
-    ct = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]) + padded_action_cost(x, u), n, m, evaluate_hessian=evaluate_hessian)
-    cT = Cost(lambda x, u, w: 0.1 * dot(x[2:n], x[2:n]), n, 0, evaluate_hessian=evaluate_hessian)
+    # parameters = (gain, weight): stage parameters w_t = [torque gain, weight of the state cost] (src/solver.jl:10 `parameters`;
+    # not a BASELINE.json configuration: a test of shared / per-instance parameters on the tile path)
+    par = parameters is not None
+    nw = 2 if par else 0
+    dt = Dynamics(acrobot_padded_midpoint(n, m=m, parametric=par), n, n, m, num_parameter=nw, evaluate_hessian=evaluate_hessian)
+    ct = Cost(lambda x, u, w: (w[1] if par else 1.0) * 0.1 * dot(x[2:n], x[2:n]) + padded_action_cost(x, u), n, m,
+              num_parameter=nw, evaluate_hessian=evaluate_hessian)
+    cT = Cost(lambda x, u, w: (w[1] if par else 1.0) * 0.1 * dot(x[2:n], x[2:n]), n, 0, num_parameter=nw, evaluate_hessian=evaluate_hessian)
     # u_max: action bounds -u_max <= u <= u_max at every knot (examples/cartpole/cartpole.jl:81-89 style)
     ub = {} if u_max is None else dict(action_lower=-u_max * np.ones(m), action_upper=u_max * np.ones(m))
     b1 = Bound(n, m, state_lower=x1, state_upper=x1, **ub)
@@ -289,6 +297,7 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
         constraints=[Constraint() for _ in range(T)],
         bounds=[b1] + [bt] * (T - 2) + [bT],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
+        parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 

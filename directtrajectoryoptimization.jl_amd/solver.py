@@ -659,7 +659,7 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
     y_k - x_k = 0, cost nothing and are fixed at zero by equal bounds at every knot, so the kernels treat them as identity
     rows.  Returns (dynamics, objective, constraints, bounds, zmap, mumap) -- zmap / mumap: positions of the padded problem's
     variables / constraint rows that belong to the original problem, in the original order -- or None if the problem does not
-    fit the tile path either way (more than four actions, stage constraints, parameters, varying dimensions, user Jacobians)."""
+    fit the tile path either way (more than four actions, stage constraints, varying dimensions, user Jacobians)."""
     from .plugin import WIDE_MAX_ACTION, WIDE_MIN_STATE, WIDE_STATE
     from .symbolic import expr as E
     T = len(objective)
@@ -669,9 +669,9 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
     nu = dynamics[0].num_action
     if not (1 <= nu <= WIDE_MAX_ACTION):
         return None
-    if any(d.num_state != n or d.num_next_state != n or d.num_action != nu or d.num_parameter != 0 or d.user_jacobian for d in dynamics):
+    if any(d.num_state != n or d.num_next_state != n or d.num_action != nu or d.user_jacobian for d in dynamics):
         return None
-    if any(c.num_constraint > 0 for c in constraints) or any(c.num_parameter != 0 for c in objective):
+    if any(c.num_constraint > 0 for c in constraints):
         return None
     N = WIDE_STATE
     x, y = E.variables("x", N), E.variables("y", N)
@@ -681,9 +681,10 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
         if id(o) not in cache:
             if isinstance(o, Dynamics):
                 cache[id(o)] = Dynamics(list(o.evaluate_expr) + [y[k] - x[k] for k in range(n, N)], N, N, nu,
-                                        evaluate_hessian=evaluate_hessian)
+                                        num_parameter=o.num_parameter, evaluate_hessian=evaluate_hessian)
             else:
-                cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, evaluate_hessian=evaluate_hessian)
+                cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, num_parameter=o.num_parameter,
+                                    evaluate_hessian=evaluate_hessian)
         return cache[id(o)]
 
     dyn2 = [pad(d) for d in dynamics]

@@ -224,7 +224,7 @@ int dto_kkt_solve(dto_problem* p, const double* rhs_x, int64_t ldrx, const doubl
  * status/iterations: HOST [B] (0 running/cut off, 1 converged, 2 max_iter, 3 failed: non-finite iterate,
  * 4 converged to the acceptable level, 5 diverging iterates).
  * Paths by model: lane-per-instance tiles (states <= 16; bounds, inequality rows, per-instance parameters); the tile (MFMA)
- * kernels for 64-state models (variables free, fixed or bounded; no stage constraints, one to four actions, shared parameters); a
+ * kernels for 64-state models (variables free, fixed or bounded; no stage constraints, one to four actions, shared or per-instance parameters); a
  * GeneralConstraint whose rows couple several knots is solved through a HOST-side border (equality rows, variables free or
  * fixed): every step moves the Jacobian and n_g + 1 solutions per instance over PCIe -- a correctness path for tens of
  * instances, not a throughput path. */

@@ -40,10 +40,15 @@ def torque(u):
 
 
 class PaddedAcrobot:
-    def __init__(self, n=64, m=1):
+    def __init__(self, n=64, m=1, parameters=None):
+        """parameters = (gain, weight) (tests of parameters on the tile path only): the torque is scaled by gain, the state cost by
+        weight; None: cfg5 as BASELINE.json states it."""
         self.n, self.m = n, m
         self.M = mixing(n, m)
-        self.phys = S.Dynamics(lambda y, x, u, w: S.acrobot_midpoint(y, x, [torque(u)], w), 4, 4, m, evaluate_hessian=True)
+        self.gain, self.weight = (1.0, 1.0) if parameters is None else (float(parameters[0]), float(parameters[1]))
+        g = S.fl(self.gain)
+        tq = (lambda u: torque(u)) if parameters is None else (lambda u: torque(u) * g)
+        self.phys = S.Dynamics(lambda y, x, u, w: S.acrobot_midpoint(y, x, [tq(u)], w), 4, 4, m, evaluate_hessian=True)
         # local variable order of the small object: [x(4); u(m); y(4)] -> positions in [x(n); u; y(n)]
         self.emb = np.array([0, 1, 2, 3] + [n + j for j in range(m)] + [n + m + k for k in range(4)])
 
@@ -91,9 +96,9 @@ class PaddedAcrobot:
     def cost_grad_hess(self, x, u):
         n = self.n
         g = np.zeros(n + len(u))
-        g[2:n] = 0.2 * x[2:n]
+        g[2:n] = self.weight * 0.2 * x[2:n]
         W = np.zeros((n + len(u), n + len(u)))
-        W[np.arange(2, n), np.arange(2, n)] = 0.2
+        W[np.arange(2, n), np.arange(2, n)] = self.weight * 0.2
         m = len(u)
         for j in range(m):
             g[n + j] = 0.2 * u[j]
@@ -143,7 +148,7 @@ def dense_derivatives(model: PaddedAcrobot, T: int, z, mu, sigma=1.0):
         u = z[o + n:o + n + m] if t < T - 1 else np.zeros(0)
         gt, Wt = model.cost_grad_hess(x, u)
         npv = n + len(u)
-        f += 0.1 * float(x[2:n] @ x[2:n]) + 0.1 * float(u @ u)
+        f += model.weight * 0.1 * float(x[2:n] @ x[2:n]) + 0.1 * float(u @ u)
         if len(u) > 1:
             f += 0.05 * float(u[:-1] @ u[1:]) + 0.02 * float(u[-1] * x[5])
         g[o:o + npv] += gt

@@ -186,3 +186,30 @@ def test_blockwise_kkt_residual_matches_dense_assembly():
     _, g, c, J, _ = dense_derivatives(om, T, z, lam, 1.0)
     c2, r2 = kkt_residual_blockwise(om, T, z, lam)
     assert np.max(np.abs(c - c2)) == 0.0 and np.max(np.abs(g + J.T @ lam - r2)) < 1e-14
+
+
+def test_parametric_model_matches_oracle_restatement():
+    """Stage parameters w_t = [torque gain, state-cost weight] of the 64-state test model (problems.py: build_acrobot_padded(parameters=...))
+    against the oracle's restatement with the same numbers (oracle/padded_model.py: PaddedAcrobot(parameters=...))."""
+    from oracle.padded_model import PaddedAcrobot
+    par = (1.3, 0.7)
+    p = P.build_acrobot_padded(T=3, parameters=par)
+    d, c = p["dynamics"][0], p["objective"][0]
+    assert d.num_parameter == 2 and c.num_parameter == 2 and len(p["parameters"]) == 3
+    om = PaddedAcrobot(64, 1, par)
+    rng = np.random.default_rng(0)
+    x, u, y, lam = rng.random(64), rng.random(1), rng.random(64), rng.random(64)
+    env = {}
+    for nm, v in (("x", x), ("u", u), ("y", y), ("lam", lam), ("w", np.array(par))):
+        for i, val in enumerate(v):
+            env[(nm, i)] = float(val)
+    assert np.max(np.abs(np.array(evaluate(d.evaluate_expr, env)) - om.residual(x, u, y))) < 1e-13
+    J = np.zeros((64, 129))
+    J[np.array(d.jacobian_sparsity[0]) - 1, np.array(d.jacobian_sparsity[1]) - 1] = evaluate(d.jacobian_expr, env)
+    assert np.max(np.abs(J - om.jacobian(x, u, y))) < 1e-13
+    g, _ = om.cost_grad_hess(x, u)
+    assert np.max(np.abs(np.array(evaluate(c.gradient_expr, env)) - g)) < 1e-15
+    # the generator accepts parameters on the tile path (the rule that refused them is gone) and passes them to the model code
+    st = Structure(p["dynamics"], p["objective"], p["constraints"], None, True)
+    src = generate_source(st, "acrobot_padded_par")
+    assert st.wide and "NW = 2" in src
