@@ -409,7 +409,7 @@ class Solver:
         # get_trajectory() map between the two layouts, the batched entry points take the solver's (pad_batch / unpad_batch)
         self._pad = None
         s_bounds = bounds
-        if gen is None and parameters is None and s_eh:
+        if gen is None and s_eh:
             padded = pad_to_wide(s_dyn, s_obj, s_con, bounds, s_eh)
             if padded is not None:
                 s_dyn, s_obj, s_con, s_bounds, zmap, mumap = padded

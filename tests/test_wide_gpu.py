@@ -524,3 +524,54 @@ def test_wide_parameters_shared_and_per_instance():
         r = g + J.T @ lam[b]
         assert np.max(np.abs(r[~fixed])) <= 1e-5 * max(1.0, np.max(np.abs(lam[b])))
     assert np.max(np.abs(zo[0] - zo[2])) > 1e-3
+
+
+def test_24_state_two_action_parametric_problem_through_the_embedding():
+    """The embedding of 17 .. 63-state problems with everything the tile path learnt in round 4 at once: 24 states, two bounded
+    actions, stage parameters -- callbacks in the problem's own layout against the oracle, solve! through the 64-state kernels,
+    the solution a KKT point of the ORACLE's 24-state problem with the bounds respected."""
+    import dto_amd
+    from dto_amd import problems as P
+    from oracle.padded_model import PaddedAcrobot, dense_derivatives
+    n_, T, m, par = 24, 25, 2, (1.2, 0.8)
+    pu = P.build_acrobot_padded(T=T, n=n_, m=m, target=0.4, terminal="physical", parameters=par)
+    su = dto_amd.Solver(pu["dynamics"], pu["objective"], pu["constraints"], pu["bounds"], evaluate_hessian=True,
+                        parameters=pu["parameters"], name="acrobot24u2")
+    n = su.nlp
+    nz, nc = n.num_variables, n.num_constraint
+    assert (nz, nc) == ((T - 1) * (n_ + m) + n_, (T - 1) * n_)
+    assert su._solve_nlp.num_variables == (T - 1) * (64 + m) + 64
+    om = PaddedAcrobot(n_, m, par)
+    rng = np.random.default_rng(5)
+    z, mu = rng.random(nz), rng.random(nc)
+    f, g, c, J, H = dense_derivatives(om, T, z, mu, 0.6)
+    cv = np.zeros(nc); n.eval_constraint(cv, z)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    Hv = np.zeros(int(n.sizes.nnz_hess_key)); n.eval_hessian_lagrangian(Hv, z, 0.6, mu)
+    assert abs(n.eval_objective(z) - f) <= 1e-8 * max(1.0, abs(f)) and np.max(np.abs(cv - c)) <= 1e-8 * max(1.0, np.max(np.abs(c)))
+    jr, jc = np.array(n.jacobian_structure()).T - 1
+    Jd = np.zeros_like(J); Jd[jr, jc] = Jv
+    assert np.max(np.abs(Jd - J)) <= 1e-8 * np.max(np.abs(J))
+    hr, hc = np.array(n.hessian_lagrangian_structure()).T - 1
+    Hd = np.zeros_like(H); Hd[hr, hc] = Hv
+    assert np.max(np.abs(Hd - H)) <= 1e-8 * max(1.0, np.max(np.abs(H)))
+    xs, us = pu["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(su, xs); dto_amd.initialize_controls(su, [0.1 * u for u in us])
+    assert dto_amd.solve(su) == 1, (su.status, su.iterations)
+    u_max = 0.7 * float(np.max(np.abs(np.array(dto_amd.get_trajectory(su)[1]))))
+    p = P.build_acrobot_padded(T=T, n=n_, m=m, target=0.4, terminal="physical", parameters=par, u_max=u_max)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       parameters=p["parameters"], name="acrobot24u2")
+    dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    zs, ls = s._solution, s._duals
+    f, g, c, J, _ = dense_derivatives(om, T, zs, ls, 1.0)
+    vlo, vhi = s.nlp.variable_bounds
+    fixed = vlo == vhi
+    bounded = ~fixed & (np.isfinite(vlo) | np.isfinite(vhi))
+    assert bounded.sum() == (T - 1) * m and np.max(np.abs(c)) <= 1e-6
+    assert np.all(zs[bounded] >= vlo[bounded]) and np.all(zs[bounded] <= vhi[bounded])
+    r = g + J.T @ ls
+    assert np.max(np.abs(r[~fixed & ~bounded])) <= 1e-5 * max(1.0, np.max(np.abs(ls)))
+    zl, zu = np.maximum(r[bounded], 0.0), np.maximum(-r[bounded], 0.0)
+    assert np.max(np.maximum(zl * (zs[bounded] - vlo[bounded]), zu * (vhi[bounded] - zs[bounded]))) <= 1e-3
