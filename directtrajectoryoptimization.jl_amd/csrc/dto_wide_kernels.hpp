@@ -1980,8 +1980,16 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
       if constexpr (HAS_DYN) {
         yv[l] = z[a.zoff[t + 1] + l]; dy[l] = dz[a.zoff[t + 1] + l];
         const double* row = fe_s + l * NC;
-        lin0 = dot_rr<N>(row, pv) + dot_rr<N>(row + N + NU, yv);
-        lind = dot_rr<N>(row, dp) + dot_rr<N>(row + N + NU, dy);
+        // (the four 64-term products in one pass over the row, eight terms in flight: as four fully unrolled dot_rr calls this
+        //  kernel spilled 360 registers)
+        double l0a = 0.0, l0b = 0.0, lda_ = 0.0, ldb_ = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < N; ++c) {
+          const double rx = row[c], ry = row[N + NU + c];
+          l0a += rx * pv[c]; l0b += ry * yv[c]; lda_ += rx * dp[c]; ldb_ += ry * dy[c];
+        }
+        lin0 = l0a + l0b;
+        lind = lda_ + ldb_;
 #pragma unroll
         for (int j = 0; j < NU; ++j) { lin0 += row[N + j] * pv[N + j]; lind += row[N + j] * dp[N + j]; }
       }
