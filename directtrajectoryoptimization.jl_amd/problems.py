@@ -188,7 +188,6 @@ def build_pendulum(T=50, evaluate_hessian=True):
         constraints=[con1] + [Constraint() for _ in range(T - 2)] + [conT],
         bounds=[Bound(n, m)] * (T - 1) + [Bound(n, 0)],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
-        parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 
@@ -248,7 +247,6 @@ def build_acrobot(T=1000, evaluate_hessian=True, endpoint="constraints"):
         objective=[ct] * (T - 1) + [cT],
         constraints=constraints, bounds=bounds,
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
-        parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 
