@@ -193,7 +193,7 @@ Problem::~Problem() {
   for (int* p : {d_kind, d_zoff, d_woff, d_cdoff, d_ccoff, d_jdoff, d_jcoff, d_hoff, d_hmap_cost, d_hmap_dyn_own,
                  d_hmap_dyn_next, d_hmap_con})
     if (p) (void)hipFree(p);
-  for (double* p : {d_params, d_x1, d_mu1, d_out1, d_scratch, wide_fac})
+  for (double* p : {d_params, d_x1, d_mu1, d_out1, d_scratch, wide_fac, border_ws})
     if (p) (void)hipFree(p);
   if (wide_flags) (void)hipFree(wide_flags);
   free_solver();

@@ -41,6 +41,10 @@ struct Problem {
   size_t wide_fac_len = 0;
   int* wide_flags = nullptr;
   size_t wide_flags_len = 0;
+  // device workspace of the bordered (multi-knot GeneralConstraint) step, kept between steps (eight hipMalloc /
+  // hipFree per Newton step -- every hipFree is a device synchronisation)
+  double* border_ws = nullptr;
+  size_t border_ws_len = 0;
 
   // CSR pattern of the KKT matrix in the reference ordering (dto_kkt_csr_structure / dto_kkt_csr_values_batch), built on first use
   std::vector<int64_t> csr_rowptr, csr_col;   // 1-based

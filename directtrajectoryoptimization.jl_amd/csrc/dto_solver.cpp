@@ -1301,20 +1301,25 @@ static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64
   hipStream_t st = (hipStream_t)b->stream;
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
   int rc;
-  double *dJ = nullptr, *dC = nullptr, *dG = nullptr, *dSig = nullptr, *dRx = nullptr, *dRc = nullptr, *dSx = nullptr, *dSc = nullptr;
-  auto cleanup = [&]() {
-    for (double* q : {dJ, dC, dG, dSig, dRx, dRc, dSx, dSc}) if (q) (void)hipFree(q);
-  };
+  // one workspace kept in the problem (grown when a larger batch comes): J | c | grad | sigma | rhs_x | rhs_c | sol_x | sol_c
+  auto cleanup = [&]() {};
 #define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
 #define BRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
-  BTRY(hipMalloc((void**)&dJ, (size_t)B * nnzJ * sizeof(double)));
-  BTRY(hipMalloc((void**)&dC, (size_t)B * Nc * sizeof(double)));
-  BTRY(hipMalloc((void**)&dG, (size_t)B * Nz * sizeof(double)));
-  BTRY(hipMalloc((void**)&dSig, (size_t)B * Nz * sizeof(double)));
-  BTRY(hipMalloc((void**)&dRx, (size_t)B * Nz * sizeof(double)));
-  BTRY(hipMalloc((void**)&dRc, (size_t)B * Nc * sizeof(double)));
-  BTRY(hipMalloc((void**)&dSx, (size_t)B * Nz * sizeof(double)));
-  BTRY(hipMalloc((void**)&dSc, (size_t)B * Nc * sizeof(double)));
+  const size_t ws_need = (size_t)B * ((size_t)nnzJ + 4 * (size_t)Nz + 3 * (size_t)Nc);
+  if (p->border_ws_len < ws_need) {
+    if (p->border_ws) (void)hipFree(p->border_ws);
+    p->border_ws = nullptr; p->border_ws_len = 0;
+    BTRY(hipMalloc((void**)&p->border_ws, ws_need * sizeof(double)));
+    p->border_ws_len = ws_need;
+  }
+  double* dJ = p->border_ws;
+  double* dC = dJ + (size_t)B * nnzJ;
+  double* dG = dC + (size_t)B * Nc;
+  double* dSig = dG + (size_t)B * Nz;
+  double* dRx = dSig + (size_t)B * Nz;
+  double* dRc = dRx + (size_t)B * Nz;
+  double* dSx = dRc + (size_t)B * Nc;
+  double* dSc = dSx + (size_t)B * Nz;
   // ---- derivatives at (x, mu): callbacks on the device, the small vectors come to the host
   BRC(dto_eval_jac_g_batch(h, b, dJ, nnzJ));
   BRC(dto_eval_g_batch(h, b, dC, Nc));
