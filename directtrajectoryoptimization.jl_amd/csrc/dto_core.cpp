@@ -191,7 +191,7 @@ Problem::~Problem() {
   if (d_csr_j) (void)hipFree(d_csr_j);
   if (d_csr_diag) (void)hipFree(d_csr_diag);
   for (int* p : {d_kind, d_zoff, d_woff, d_cdoff, d_ccoff, d_jdoff, d_jcoff, d_hoff, d_hmap_cost, d_hmap_dyn_own,
-                 d_hmap_dyn_next, d_hmap_con})
+                 d_hmap_dyn_next, d_hmap_con, d_csc_ptr, d_csc_k, d_csc_row, d_var_fixed})
     if (p) (void)hipFree(p);
   for (double* p : {d_params, d_x1, d_mu1, d_out1, d_scratch, wide_fac, border_ws})
     if (p) (void)hipFree(p);

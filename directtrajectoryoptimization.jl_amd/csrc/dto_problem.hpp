@@ -45,6 +45,9 @@ struct Problem {
   // hipFree per Newton step -- every hipFree is a device synchronisation)
   double* border_ws = nullptr;
   size_t border_ws_len = 0;
+  // Jacobian pattern by columns (entries of a column in COO order) for the device-side products of the bordered step
+  int *d_csc_ptr = nullptr, *d_csc_k = nullptr, *d_csc_row = nullptr;
+  int* d_var_fixed = nullptr;   // [Nz] 1 where lo == hi
 
   // CSR pattern of the KKT matrix in the reference ordering (dto_kkt_csr_structure / dto_kkt_csr_values_batch), built on first use
   std::vector<int64_t> csr_rowptr, csr_col;   // 1-based

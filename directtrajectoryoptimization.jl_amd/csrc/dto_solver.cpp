@@ -1292,12 +1292,222 @@ static int im_run(Problem* p, double* x_out, int64_t ldxo, double* mu_out, int64
 // ------------------------------------------------------------------------------------------------
 struct BorderStats {
   std::vector<double> grad, c, rx, dz, dmu;   // [B][Nz], [B][Nc], [B][Nz], [B][Nz], [B][Nc]
+  // device border: where grad f, c and r_x of the point lie in the problem's workspace (valid until the next step); the caller
+  // fetches them -- and the step from its own buffers -- once per iteration instead of once per inertia-correction attempt
+  const double *d_grad = nullptr, *d_c = nullptr, *d_rx = nullptr;
 };
+
+// ---- device side of the bordered step (round 4; DTO_BORDER_HOST=1 selects the host algebra of round 3 instead).  Only the
+//      per-instance vectors the host-driven solve loop reads (grad f, c, r_x, the step) and B flags cross PCIe any more; the
+//      Jacobian, the n_g + 1 right-hand sides and solutions and the border algebra stay on the device.
+constexpr int BORDER_MAX_NG = 16;
+// r_x = grad f + J' mu column by column (entries of a column in COO order: the same sums as the host loop of round 3), the
+// general rows of J as dense vectors, the first right-hand side
+static __global__ void k_border_rx(int64_t B, int64_t Nz, int64_t Ns, int64_t nnzJ, const double* J, const double* g, const double* mu,
+                                   int64_t ldmu, const int* cptr, const int* ck, const int* crow, double* rx, double* rhsx, double* Grow) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * Nz) return;
+  const int64_t b = idx / Nz, col = idx - b * Nz;
+  double acc = g[idx];
+  for (int e = cptr[col]; e < cptr[col + 1]; ++e) {
+    const double v = J[b * nnzJ + ck[e]];
+    const int row = crow[e];
+    acc += v * mu[b * ldmu + row];
+    if (row >= Ns) Grow[((int64_t)(row - Ns) * B + b) * Nz + col] += v;   // (this thread owns column col of instance b)
+  }
+  rx[idx] = acc;
+  rhsx[idx] = -acc;
+}
+// per-instance delta_w on the primal diagonal; a variable with lo == hi gets a huge entry instead (its step is ~1e-16 r)
+static __global__ void k_border_sig(int64_t B, int64_t Nz, const double* dw, const int* fixed, int pin_fixed, double* sig) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * Nz) return;
+  sig[idx] = (pin_fixed && fixed[idx % Nz]) ? 1e16 : dw[idx / Nz];
+}
+static __global__ void k_border_rhsc(int64_t B, int64_t Nc, int64_t Ns, const double* c, double* rhsc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * Nc) return;
+  rhsc[idx] = (idx % Nc) < Ns ? -c[idx] : 0.0;
+}
+// one wavefront per instance: S = -(G Y_x + dc I), r_g = -c_g - G v0_x (lane-strided partial sums, fixed tree), then lane 0: S
+// negative definite? (Cholesky of -S, symmetrised) and S drho = r_g by Gaussian elimination with partial pivoting
+static __global__ __launch_bounds__(64) void k_border_solve(int64_t B, int64_t Nz, int64_t Nc, int64_t Ns, int ng, double delta_c,
+                                                            const double* Grow, const double* Yx, const double* v0x, const double* c,
+                                                            double* rho, int* negdef_out) {
+  const int64_t b = blockIdx.x;
+  const int l = threadIdx.x;
+  __shared__ double Sm[BORDER_MAX_NG * BORDER_MAX_NG], rg[BORDER_MAX_NG], Lc[BORDER_MAX_NG * BORDER_MAX_NG];
+  auto gdot = [&](int row, const double* v) {
+    const double* gr = Grow + ((int64_t)row * B + b) * Nz;
+    double acc = 0.0;
+    for (int64_t k = l; k < Nz; k += 64) acc += gr[k] * v[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    return acc;   // lane 0
+  };
+  for (int a = 0; a < ng; ++a) {
+    for (int q = 0; q < ng; ++q) {
+      const double d = gdot(a, Yx + ((int64_t)q * B + b) * Nz);
+      if (l == 0) Sm[a * ng + q] = -d - (a == q ? delta_c : 0.0);
+    }
+    const double d = gdot(a, v0x + b * Nz);
+    if (l == 0) rg[a] = -c[b * Nc + Ns + a] - d;
+  }
+  if (l != 0) return;
+  bool negdef = true;
+  for (int a = 0; a < ng && negdef; ++a)
+    for (int q = 0; q <= a; ++q) {
+      double acc = -0.5 * (Sm[a * ng + q] + Sm[q * ng + a]);
+      for (int k = 0; k < q; ++k) acc -= Lc[a * ng + k] * Lc[q * ng + k];
+      if (a == q) { if (!(acc > 0.0)) { negdef = false; break; } Lc[a * ng + a] = sqrt(acc); }
+      else Lc[a * ng + q] = acc / Lc[q * ng + q];
+    }
+  for (int k = 0; k < ng; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < ng; ++r) if (fabs(Sm[r * ng + k]) > fabs(Sm[piv * ng + k])) piv = r;
+    if (piv != k) {
+      for (int q = 0; q < ng; ++q) { const double t = Sm[k * ng + q]; Sm[k * ng + q] = Sm[piv * ng + q]; Sm[piv * ng + q] = t; }
+      const double t = rg[k]; rg[k] = rg[piv]; rg[piv] = t;
+    }
+    const double d = Sm[k * ng + k];
+    if (d == 0.0) { negdef = false; continue; }
+    for (int r = k + 1; r < ng; ++r) {
+      const double f = Sm[r * ng + k] / d;
+      for (int q = k; q < ng; ++q) Sm[r * ng + q] -= f * Sm[k * ng + q];
+      rg[r] -= f * rg[k];
+    }
+  }
+  for (int k = ng - 1; k >= 0; --k) {
+    double acc = rg[k];
+    for (int q = k + 1; q < ng; ++q) acc -= Sm[k * ng + q] * rg[q];
+    rg[k] = Sm[k * ng + k] != 0.0 ? acc / Sm[k * ng + k] : 0.0;
+  }
+  for (int q = 0; q < ng; ++q) rho[b * ng + q] = rg[q];
+  negdef_out[b] = negdef ? 1 : 0;
+}
+// v = v0 - Y drho; the multipliers of the general rows are drho
+static __global__ void k_border_apply(int64_t B, int64_t Nz, int64_t Nc, int64_t Ns, int ng, const double* v0x, const double* v0c,
+                                      const double* Yx, const double* Yc, const double* rho, double* dx, int64_t lddx, double* dmu,
+                                      int64_t lddmu, double* hdx, double* hdm) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * (Nz + Nc)) return;
+  const int64_t b = idx / (Nz + Nc), k = idx - b * (Nz + Nc);
+  if (k < Nz) {
+    double v = v0x[b * Nz + k];
+    for (int q = 0; q < ng; ++q) v -= Yx[((int64_t)q * B + b) * Nz + k] * rho[b * ng + q];
+    dx[b * lddx + k] = v;
+    hdx[b * Nz + k] = v;
+  } else {
+    const int64_t r = k - Nz;
+    double v;
+    if (r < Ns) {
+      v = v0c[b * Nc + r];
+      for (int q = 0; q < ng; ++q) v -= Yc[((int64_t)q * B + b) * Nc + r] * rho[b * ng + q];
+    } else {
+      v = rho[b * ng + (r - Ns)];
+    }
+    dmu[b * lddmu + r] = v;
+    hdm[b * Nc + r] = v;
+  }
+}
+
+static int ensure_border_csc(Problem* p) {
+  if (p->d_csc_ptr) return DTO_OK;
+  const Layout& L = p->L;
+  std::vector<int> ptr((size_t)L.Nz + 1, 0), ck((size_t)L.nnzJ), crow((size_t)L.nnzJ);
+  for (int64_t k = 0; k < L.nnzJ; ++k) ptr[(size_t)L.jac_cols[(size_t)k]] += 1;   // 1-based column -> slot col + 1 - 1 + 1
+  for (int64_t cidx = 0; cidx < L.Nz; ++cidx) ptr[(size_t)cidx + 1] += ptr[(size_t)cidx];
+  std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t k = 0; k < L.nnzJ; ++k) {   // increasing k inside every column
+    const int64_t col = L.jac_cols[(size_t)k] - 1;
+    const int e = fill[(size_t)col]++;
+    ck[(size_t)e] = (int)k;
+    crow[(size_t)e] = (int)(L.jac_rows[(size_t)k] - 1);
+  }
+  HIP_TRY(hipMalloc((void**)&p->d_csc_ptr, ptr.size() * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&p->d_csc_k, std::max<size_t>(1, ck.size()) * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&p->d_csc_row, std::max<size_t>(1, crow.size()) * sizeof(int)));
+  HIP_TRY(hipMemcpy(p->d_csc_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_csc_k, ck.data(), ck.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_csc_row, crow.data(), crow.size() * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<int> fx((size_t)L.Nz);
+  for (int64_t k = 0; k < L.Nz; ++k) fx[(size_t)k] = (L.var_lo[(size_t)k] == L.var_hi[(size_t)k]) ? 1 : 0;
+  HIP_TRY(hipMalloc((void**)&p->d_var_fixed, std::max<size_t>(1, fx.size()) * sizeof(int)));
+  HIP_TRY(hipMemcpy(p->d_var_fixed, fx.data(), fx.size() * sizeof(int), hipMemcpyHostToDevice));
+  return DTO_OK;
+}
+
+static int bordered_step_device(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
+                                double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed) {
+  const Layout& L = p->L;
+  const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc, ng = L.Ngen, Ns = Nc - ng, nnzJ = L.nnzJ;
+  hipStream_t st = (hipStream_t)b->stream;
+  dto_problem* h = reinterpret_cast<dto_problem*>(p);
+  int rc = ensure_border_csc(p);
+  if (rc) return rc;
+  // workspace: J | c | g | sig | rx | rhsx | rhsc | zero_c | v0x | v0c | Grow[ng] | Yx[ng] | Yc[ng] | hdx | hdm | rho | flags
+  const size_t nBz = (size_t)B * Nz, nBc = (size_t)B * Nc;
+  const size_t ws_need = (size_t)B * nnzJ + nBc + nBz * 6 + nBc * 4 + (size_t)ng * (2 * nBz + nBc) + (size_t)B * ng + 2 * (size_t)B + 8;
+  if (p->border_ws_len < ws_need) {
+    if (p->border_ws) (void)hipFree(p->border_ws);
+    p->border_ws = nullptr; p->border_ws_len = 0;
+    HIP_TRY(hipMalloc((void**)&p->border_ws, ws_need * sizeof(double)));
+    p->border_ws_len = ws_need;
+  }
+  double* w = p->border_ws;
+  auto take = [&](size_t n) { double* q = w; w += n; return q; };
+  double *dJ = take((size_t)B * nnzJ), *dC = take(nBc), *dG = take(nBz), *dSig = take(nBz), *dRxv = take(nBz), *dRhsx = take(nBz),
+         *dRhsc = take(nBc), *dZeroC = take(nBc), *dV0x = take(nBz), *dV0c = take(nBc), *dGrow = take((size_t)ng * nBz),
+         *dYx = take((size_t)ng * nBz), *dYc = take((size_t)ng * nBc), *dHdx = take(nBz), *dHdm = take(nBc), *dRho = take((size_t)B * ng);
+  int* dFlag = reinterpret_cast<int*>(take((size_t)B / 2 + 4));
+  double* dDw = take((size_t)B);
+#define DRC(expr) do { rc = (expr); if (rc) return rc; } while (0)
+  DRC(dto_eval_jac_g_batch(h, b, dJ, nnzJ));
+  DRC(dto_eval_g_batch(h, b, dC, Nc));
+  DRC(dto_eval_grad_f_batch(h, b, dG, Nz));
+  HIP_TRY(hipMemsetAsync(dGrow, 0, (size_t)ng * nBz * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(dZeroC, 0, nBc * sizeof(double), st));
+  hipLaunchKernelGGL(k_border_rx, dim3((unsigned)((nBz + 255) / 256)), dim3(256), 0, st, B, Nz, Ns, nnzJ, (const double*)dJ, (const double*)dG,
+                     mu, ldmu, (const int*)p->d_csc_ptr, (const int*)p->d_csc_k, (const int*)p->d_csc_row, dRxv, dRhsx, dGrow);
+  hipLaunchKernelGGL(k_border_rhsc, dim3((unsigned)((nBc + 255) / 256)), dim3(256), 0, st, B, Nc, Ns, (const double*)dC, dRhsc);
+  // per-instance delta_w through the sigma_x diagonal (pin_fixed: a variable with lo == hi keeps its value)
+  HIP_TRY(hipMemcpyAsync(dDw, dw, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_border_sig, dim3((unsigned)((nBz + 255) / 256)), dim3(256), 0, st, B, Nz, (const double*)dDw, (const int*)p->d_var_fixed,
+                     pin_fixed ? 1 : 0, dSig);
+  dto_kkt_system sys;
+  sys.mu = mu; sys.ldmu = ldmu; sys.sigma_x = dSig; sys.ldsx = Nz; sys.sigma_c = nullptr; sys.ldsc = 0;
+  sys.delta_w = 0.0; sys.delta_c = delta_c;
+  DRC(dto_kkt_assemble(h, b, &sys));
+  std::vector<int32_t> iok((size_t)B, 1);
+  DRC(dto_kkt_factor(h, iok.data(), nullptr, (void*)st));
+  DRC(dto_kkt_solve(h, dRhsx, Nz, dRhsc, Nc, dV0x, Nz, dV0c, Nc, (void*)st));
+  for (int64_t j = 0; j < ng; ++j)
+    DRC(dto_kkt_solve(h, dGrow + (size_t)j * nBz, Nz, dZeroC, Nc, dYx + (size_t)j * nBz, Nz, dYc + (size_t)j * nBc, Nc, (void*)st));
+  hipLaunchKernelGGL(k_border_solve, dim3((unsigned)B), dim3(64), 0, st, B, Nz, Nc, Ns, (int)ng, delta_c, (const double*)dGrow,
+                     (const double*)dYx, (const double*)dV0x, (const double*)dC, dRho, dFlag);
+  hipLaunchKernelGGL(k_border_apply, dim3((unsigned)(((size_t)B * (Nz + Nc) + 255) / 256)), dim3(256), 0, st, B, Nz, Nc, Ns, (int)ng,
+                     (const double*)dV0x, (const double*)dV0c, (const double*)dYx, (const double*)dYc, (const double*)dRho, dx, lddx, dmu,
+                     lddmu, dHdx, dHdm);
+  HIP_TRY(hipGetLastError());
+  std::vector<int> flag((size_t)B);
+  HIP_TRY(hipMemcpyAsync(flag.data(), dFlag, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (stats) { stats->d_grad = dG; stats->d_c = dC; stats->d_rx = dRxv; }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (ok_out)
+    for (int64_t i = 0; i < B; ++i) ok_out[i] = (iok[(size_t)i] != 0 && flag[(size_t)i] != 0) ? 1 : 0;
+#undef DRC
+  return DTO_OK;
+}
 
 static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
                          double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed) {
   const Layout& L = p->L;
   const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc, ng = L.Ngen, Ns = Nc - ng, nnzJ = L.nnzJ;
+  {
+    const char* e = getenv("DTO_BORDER_HOST");
+    if (!(e && atoi(e) != 0) && ng <= BORDER_MAX_NG)
+      return bordered_step_device(p, b, mu, ldmu, dw, delta_c, dx, lddx, dmu, lddmu, ok_out, stats, pin_fixed);
+  }
   hipStream_t st = (hipStream_t)b->stream;
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
   int rc;
@@ -1446,6 +1656,16 @@ static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64
 // from the host like the wide-stage solver, with bordered_step as its linear solver.  Scope: equality rows (dynamics, stage,
 // general) and variables that are free or fixed by equal bounds -- no barrier.
 // ------------------------------------------------------------------------------------------------
+// out[b] = sum_k |rows[b][k]| in a fixed order (lane-strided partial sums, then a tree): the l1 constraint violation of a trial point
+static __global__ __launch_bounds__(64) void k_rows_abs_sum(const double* rows, int64_t ld, int64_t n, double* out) {
+  const int64_t b = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 64) acc += fabs(rows[b * ld + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) out[b] = acc;
+}
+
 static int general_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                                double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
   int rc = p->ensure_device();
@@ -1464,8 +1684,8 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   default_opts(o, u);
   hipStream_t st = (hipStream_t)b->stream;
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
-  double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *zt = nullptr, *df = nullptr, *dc = nullptr, *dal = nullptr;
-  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal}) if (q) (void)hipFree(q); };
+  double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *zt = nullptr, *df = nullptr, *dc = nullptr, *dal = nullptr, *dth = nullptr;
+  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal, dth}) if (q) (void)hipFree(q); };
 #define GTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
 #define GRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
   GTRY(hipMalloc((void**)&z, (size_t)B * Nz * sizeof(double)));
@@ -1476,6 +1696,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   GTRY(hipMalloc((void**)&df, (size_t)B * sizeof(double)));
   GTRY(hipMalloc((void**)&dc, (size_t)B * Nc * sizeof(double)));
   GTRY(hipMalloc((void**)&dal, (size_t)B * sizeof(double)));
+  GTRY(hipMalloc((void**)&dth, (size_t)B * sizeof(double)));
   // the guess, with the fixed variables put on their values
   std::vector<double> hz((size_t)B * Nz);
   GTRY(hipMemcpy2DAsync(hz.data(), Nz * sizeof(double), b->x, b->ldx * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
@@ -1491,7 +1712,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     std::vector<double> filt;
   };
   std::vector<Inst> I((size_t)B);
-  std::vector<double> dwv((size_t)B), hf((size_t)B), hc((size_t)B * Nc), hal((size_t)B);
+  std::vector<double> dwv((size_t)B), hf((size_t)B), hth((size_t)B), hal((size_t)B), hphi0((size_t)B);
   std::vector<int> okv((size_t)B);
   constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
   constexpr int TRIALS = DTO_LS_TRIALS;
@@ -1518,12 +1739,21 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       }
       if (!again) break;
     }
+    if (bs.d_grad) {   // device border: the point's vectors and the final step, once per iteration
+      bs.grad.resize((size_t)B * Nz); bs.c.resize((size_t)B * Nc); bs.rx.resize((size_t)B * Nz); bs.dz.resize((size_t)B * Nz); bs.dmu.resize((size_t)B * Nc);
+      GTRY(hipMemcpyAsync(bs.grad.data(), bs.d_grad, bs.grad.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(bs.c.data(), bs.d_c, bs.c.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(bs.rx.data(), bs.d_rx, bs.rx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(bs.dz.data(), dz, bs.dz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(bs.dmu.data(), dlam, bs.dmu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     // ---- convergence test (Ipopt's scaled error, reference Options), at the point the step was computed at
     GRC(dto_eval_f_batch(h, &bz, df));
     GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
     std::vector<double> hm((size_t)B * Nc);
     GTRY(hipMemcpyAsync(hm.data(), lam, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     GTRY(hipStreamSynchronize(st));
+    hphi0 = hf;   // objective at the current point: the line search's phi_0
     bool any = false;
     std::vector<double> th0((size_t)B), gphid((size_t)B);
     for (int64_t i = 0; i < B; ++i) {
@@ -1550,11 +1780,20 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       }
     }
     if (!any) break;
-    // ---- filter line search over alpha = 2^-k: objective and violation of the trial points from the callbacks
-    std::vector<double> phi((size_t)B * TRIALS), th((size_t)B * TRIALS);
+    // ---- filter line search over alpha = 2^-k: objective and l1 violation of a trial point from the callbacks (the violation
+    //      summed on the device).  Trial k is evaluated only while some running instance has not accepted a shorter-numbered
+    //      one (round 4: all eight trials of every iteration, each with its constraint vector over PCIe, were most of the
+    //      8.7 ms an iteration of a 512-instance batch took; a Newton step near the solution is accepted at alpha = 1)
+    std::vector<double> phi((size_t)B * TRIALS, 0.0), th((size_t)B * TRIALS, 0.0), chosen_a((size_t)B, -1.0);
+    std::vector<char> ftype_a((size_t)B, 0);
+    std::vector<int> best_a((size_t)B, 0);
+    int k_done = 0;
     for (int k = 0; k < TRIALS; ++k) {
+      bool undecided = false;
+      for (int64_t i = 0; i < B; ++i) undecided = undecided || (I[(size_t)i].status == 0 && chosen_a[(size_t)i] < 0.0);
+      if (!undecided) break;
       const double alpha = std::ldexp(1.0, -k);
-      for (int64_t i = 0; i < B; ++i) hal[(size_t)i] = I[(size_t)i].status == 0 ? alpha : 0.0;
+      for (int64_t i = 0; i < B; ++i) hal[(size_t)i] = (I[(size_t)i].status == 0 && chosen_a[(size_t)i] < 0.0) ? alpha : 0.0;
       GTRY(hipMemcpyAsync(zt, z, (size_t)B * Nz * sizeof(double), hipMemcpyDeviceToDevice, st));
       GTRY(hipMemcpyAsync(dal, hal.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, zt, (const double*)dz, (const double*)dal, Nz, Nz, Nz);
@@ -1562,31 +1801,21 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       bt.x = zt;
       GRC(dto_eval_f_batch(h, &bt, df));
       GRC(dto_eval_g_batch(h, &bt, dc, Nc));
+      hipLaunchKernelGGL(k_rows_abs_sum, dim3((unsigned)B), dim3(64), 0, st, (const double*)dc, Nc, Nc, dth);
       GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
-      GTRY(hipMemcpyAsync(hc.data(), dc, hc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      GTRY(hipMemcpyAsync(hth.data(), dth, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
       GTRY(hipStreamSynchronize(st));
+      k_done = k + 1;
       for (int64_t i = 0; i < B; ++i) {
-        double t1 = 0.0;
-        for (int64_t q = 0; q < Nc; ++q) t1 += std::fabs(hc[(size_t)i * Nc + q]);
-        phi[(size_t)i * TRIALS + k] = hf[(size_t)i];
-        th[(size_t)i * TRIALS + k] = t1;
-      }
-    }
-    GRC(dto_eval_f_batch(h, &bz, df));
-    GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
-    GTRY(hipStreamSynchronize(st));
-    for (int64_t i = 0; i < B; ++i) {
-      hal[(size_t)i] = 0.0;
-      Inst& s = I[(size_t)i];
-      if (s.status != 0) continue;
-      const double t0 = th0[(size_t)i], phi0 = hf[(size_t)i], dphi = gphid[(size_t)i];
-      const int nf = std::min(s.filter_n, DTO_FILTER_CAP);
-      double alpha = 1.0, chosen = -1.0;
-      bool ftype = false;
-      int best = 0;
-      for (int k = 0; k < TRIALS; ++k) {
-        const double pk = phi[(size_t)i * TRIALS + k], tk = th[(size_t)i * TRIALS + k];
+        Inst& s = I[(size_t)i];
+        if (s.status != 0 || chosen_a[(size_t)i] >= 0.0) continue;
+        const double pk = hf[(size_t)i], tk = hth[(size_t)i];
+        phi[(size_t)i * TRIALS + k] = pk;
+        th[(size_t)i * TRIALS + k] = tk;
+        int& best = best_a[(size_t)i];
         if (tk < th[(size_t)i * TRIALS + best] || !(th[(size_t)i * TRIALS + best] == th[(size_t)i * TRIALS + best])) best = k;
+        const double t0 = th0[(size_t)i], phi0 = hphi0[(size_t)i], dphi = gphid[(size_t)i];
+        const int nf = std::min(s.filter_n, DTO_FILTER_CAP);
         bool ok = (tk == tk) && (pk == pk) && tk <= s.theta_max;
         const bool sw = dphi < 0.0 && alpha * std::pow(-dphi, S_PHI) > std::pow(t0, S_TH);
         if (ok) {
@@ -1598,12 +1827,21 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
             const double tf = s.filt[2 * q], pf = s.filt[2 * q + 1];
             if (!(tk <= (1.0 - G_TH) * tf || pk <= pf - G_PHI * tf)) { ok = false; break; }
           }
-        if (ok) { chosen = alpha; ftype = sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0)); break; }
-        alpha *= 0.5;
+        if (ok) { chosen_a[(size_t)i] = alpha; ftype_a[(size_t)i] = (sw && (pk <= phi0 + ETA * alpha * dphi + 1e-13 * std::fabs(phi0))) ? 1 : 0; }
       }
+    }
+    (void)k_done;
+    for (int64_t i = 0; i < B; ++i) {
+      hal[(size_t)i] = 0.0;
+      Inst& s = I[(size_t)i];
+      if (s.status != 0) continue;
+      const double t0 = th0[(size_t)i], phi0 = hphi0[(size_t)i];
+      double chosen = chosen_a[(size_t)i];
+      const bool ftype = ftype_a[(size_t)i] != 0;
+      const int best = best_a[(size_t)i];
       bool augment;
-      if (chosen < 0.0) {
-        chosen = (th[(size_t)i * TRIALS + best] < t0) ? std::ldexp(1.0, -best) : alpha * 2.0;
+      if (chosen < 0.0) {   // every trial rejected (all TRIALS were evaluated for this instance): the most feasible one, or the shortest
+        chosen = (th[(size_t)i * TRIALS + best] < t0) ? std::ldexp(1.0, -best) : std::ldexp(1.0, -(TRIALS - 1));
         s.ls_fail = 1; augment = true;
       } else { s.ls_fail = okv[(size_t)i] ? 0 : 1; augment = !ftype; }
       if (augment) {

@@ -610,7 +610,8 @@ def _kernel_headers_digest() -> str:
     emitted would otherwise keep serving stale plugins)."""
     hsh = hashlib.sha256()
     for fn in sorted(os.listdir(CSRC)):
-        if fn.endswith((".hpp", ".h")):
+        # (dto_problem.hpp / dto_layout.hpp belong to the runtime library only: no plugin includes them)
+        if fn.endswith((".hpp", ".h")) and fn not in ("dto_problem.hpp", "dto_layout.hpp"):
             with open(os.path.join(CSRC, fn), "rb") as f:
                 hsh.update(f.read())
     here = os.path.dirname(os.path.abspath(__file__))

@@ -95,3 +95,31 @@ def test_reference_general_constraint_solve_with_a_row_coupling_two_knots():
     assert np.max(np.abs(r[free])) < 1e-5
     # a convex QP with linear constraints: Newton's method needs a handful of iterations
     assert s.iterations <= 10
+
+
+def test_device_border_agrees_with_the_host_border(monkeypatch):
+    """Round 4: the border algebra (r_x = grad f + J' mu, the general rows of J, the n_g x n_g Schur complement, v = v0 - Y drho)
+    runs on the device; DTO_BORDER_HOST=1 keeps round 3's host algebra.  Same step from both (different summation order in the
+    n_g x n_g products only: 1e-10 relative), in a batch large enough that every kernel sees several instances."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    T, B = 8, 40
+    p = P.build_acrobot_coupled(T=T)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       general_constraint=p["general_constraint"], name="acrobot_coupled")
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(3)
+    z = torch.tensor(0.5 * rng.standard_normal((B, nz)), device="cuda")
+    mu = torch.tensor(rng.standard_normal((B, nc)), device="cuda")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DTO_BORDER_HOST", mode)
+        dx = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+        dl = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+        ok = s.kkt_step_batch(z.data_ptr(), B, nz, mu.data_ptr(), nc, 0.8, 1e-6, dx.data_ptr(), nz, dl.data_ptr(), nc)
+        torch.cuda.synchronize()
+        out[mode] = (dx.cpu().numpy(), dl.cpu().numpy(), ok)
+    scale = max(np.max(np.abs(out["1"][0])), np.max(np.abs(out["1"][1])))
+    assert np.all(np.isfinite(out["0"][0])) and out["0"][2] == out["1"][2]
+    assert np.max(np.abs(out["0"][0] - out["1"][0])) <= 1e-10 * scale and np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-10 * scale
