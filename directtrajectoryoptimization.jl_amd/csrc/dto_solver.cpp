@@ -177,7 +177,8 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
 
 struct BorderStats;
 static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
-                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed = false);
+                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed = false,
+                         const double* gdiag = nullptr, const double* gshift = nullptr);
 static int general_solve_batch(Problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                                double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations);
 
@@ -1333,7 +1334,7 @@ static __global__ void k_border_rhsc(int64_t B, int64_t Nc, int64_t Ns, const do
 // negative definite? (Cholesky of -S, symmetrised) and S drho = r_g by Gaussian elimination with partial pivoting
 static __global__ __launch_bounds__(64) void k_border_solve(int64_t B, int64_t Nz, int64_t Nc, int64_t Ns, int ng, double delta_c,
                                                             const double* Grow, const double* Yx, const double* v0x, const double* c,
-                                                            double* rho, int* negdef_out) {
+                                                            const double* gdiag, const double* gshift, double* rho, int* negdef_out) {
   const int64_t b = blockIdx.x;
   const int l = threadIdx.x;
   __shared__ double Sm[BORDER_MAX_NG * BORDER_MAX_NG], rg[BORDER_MAX_NG], Lc[BORDER_MAX_NG * BORDER_MAX_NG];
@@ -1348,10 +1349,11 @@ static __global__ __launch_bounds__(64) void k_border_solve(int64_t B, int64_t N
   for (int a = 0; a < ng; ++a) {
     for (int q = 0; q < ng; ++q) {
       const double d = gdot(a, Yx + ((int64_t)q * B + b) * Nz);
-      if (l == 0) Sm[a * ng + q] = -d - (a == q ? delta_c : 0.0);
+      // slack-eliminated inequality rows (general_solve_batch): s / nu on the diagonal, mu / nu in the right-hand side
+      if (l == 0) Sm[a * ng + q] = -d - (a == q ? delta_c + (gdiag ? gdiag[b * ng + a] : 0.0) : 0.0);
     }
     const double d = gdot(a, v0x + b * Nz);
-    if (l == 0) rg[a] = -c[b * Nc + Ns + a] - d;
+    if (l == 0) rg[a] = -c[b * Nc + Ns + a] - (gshift ? gshift[b * ng + a] : 0.0) - d;
   }
   if (l != 0) return;
   bool negdef = true;
@@ -1438,7 +1440,8 @@ static int ensure_border_csc(Problem* p) {
 }
 
 static int bordered_step_device(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
-                                double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed) {
+                                double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed,
+                                const double* gdiag, const double* gshift) {
   const Layout& L = p->L;
   const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc, ng = L.Ngen, Ns = Nc - ng, nnzJ = L.nnzJ;
   hipStream_t st = (hipStream_t)b->stream;
@@ -1484,7 +1487,7 @@ static int bordered_step_device(Problem* p, const dto_batch* b, const double* mu
   for (int64_t j = 0; j < ng; ++j)
     DRC(dto_kkt_solve(h, dGrow + (size_t)j * nBz, Nz, dZeroC, Nc, dYx + (size_t)j * nBz, Nz, dYc + (size_t)j * nBc, Nc, (void*)st));
   hipLaunchKernelGGL(k_border_solve, dim3((unsigned)B), dim3(64), 0, st, B, Nz, Nc, Ns, (int)ng, delta_c, (const double*)dGrow,
-                     (const double*)dYx, (const double*)dV0x, (const double*)dC, dRho, dFlag);
+                     (const double*)dYx, (const double*)dV0x, (const double*)dC, gdiag, gshift, dRho, dFlag);
   hipLaunchKernelGGL(k_border_apply, dim3((unsigned)(((size_t)B * (Nz + Nc) + 255) / 256)), dim3(256), 0, st, B, Nz, Nc, Ns, (int)ng,
                      (const double*)dV0x, (const double*)dV0c, (const double*)dYx, (const double*)dYc, (const double*)dRho, dx, lddx, dmu,
                      lddmu, dHdx, dHdm);
@@ -1500,13 +1503,15 @@ static int bordered_step_device(Problem* p, const dto_batch* b, const double* mu
 }
 
 static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
-                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed) {
+                         double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed,
+                         const double* gdiag, const double* gshift) {
   const Layout& L = p->L;
   const int64_t B = b->B, Nz = L.Nz, Nc = L.Nc, ng = L.Ngen, Ns = Nc - ng, nnzJ = L.nnzJ;
   {
     const char* e = getenv("DTO_BORDER_HOST");
     if (!(e && atoi(e) != 0) && ng <= BORDER_MAX_NG)
-      return bordered_step_device(p, b, mu, ldmu, dw, delta_c, dx, lddx, dmu, lddmu, ok_out, stats, pin_fixed);
+      return bordered_step_device(p, b, mu, ldmu, dw, delta_c, dx, lddx, dmu, lddmu, ok_out, stats, pin_fixed, gdiag, gshift);
+    if (gdiag) return set_error(DTO_ERR_UNSUPPORTED, "inequality GeneralConstraint rows need the device border (DTO_BORDER_HOST unset, at most 16 general rows)");
   }
   hipStream_t st = (hipStream_t)b->stream;
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
@@ -1657,10 +1662,12 @@ static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64
 // general) and variables that are free or fixed by equal bounds -- no barrier.
 // ------------------------------------------------------------------------------------------------
 // out[b] = sum_k |rows[b][k]| in a fixed order (lane-strided partial sums, then a tree): the l1 constraint violation of a trial point
-static __global__ __launch_bounds__(64) void k_rows_abs_sum(const double* rows, int64_t ld, int64_t n, double* out) {
+static __global__ __launch_bounds__(64) void k_rows_abs_sum(const double* rows, int64_t ld, int64_t n, double* out, const double* shift = nullptr,
+                                                            int64_t n0 = 0, int64_t nsh = 0) {
+  // shift (optional, [B][nsh]): added to rows n0 .. n0 + nsh - 1 before the absolute value (the slacks of inequality rows)
   const int64_t b = blockIdx.x;
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 64) acc += fabs(rows[b * ld + i]);
+  for (int64_t i = threadIdx.x; i < n; i += 64) acc += fabs(rows[b * ld + i] + ((shift && i >= n0) ? shift[b * nsh + (i - n0)] : 0.0));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (threadIdx.x == 0) out[b] = acc;
@@ -1675,8 +1682,18 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   for (int64_t i = 0; i < Nz; ++i)
     if (L.var_lo[i] != L.var_hi[i] && (std::isfinite(L.var_lo[i]) || std::isfinite(L.var_hi[i])))
       return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: variables may be free or fixed (lo == hi), not bounded");
-  for (int64_t i = 0; i < Nc; ++i)
-    if (L.con_lo[i] != L.con_hi[i]) return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: equality rows only");
+  // inequality rows (c <= 0: src/general_constraint.jl:15-19 `indices_inequality`) among the GENERAL rows are carried with slacks
+  // g_i + s_i = 0, s_i >= 0 (round 4): the border's diagonal gets s_i / nu_i, its right-hand side mu / nu_i; dynamics and stage
+  // rows stay equalities on this path
+  const int64_t ng = L.Ngen, Ns = Nc - ng;
+  std::vector<char> ineq((size_t)std::max<int64_t>(1, ng), 0);
+  int64_t ni = 0;
+  for (int64_t i = 0; i < Nc; ++i) {
+    if (L.con_lo[i] == L.con_hi[i]) continue;
+    if (i < Ns || !(L.con_hi[i] == 0.0) || std::isfinite(L.con_lo[i]))
+      return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: equality rows, and inequality rows (c <= 0) among the general rows only");
+    ineq[(size_t)(i - Ns)] = 1; ++ni;
+  }
   if (b->params) return set_error(DTO_ERR_UNSUPPORTED, "GeneralConstraint solve path: shared parameters only");
   dto_options u;
   if (opt) u = *opt; else dto_options_default(&u);
@@ -1685,7 +1702,8 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   hipStream_t st = (hipStream_t)b->stream;
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
   double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *zt = nullptr, *df = nullptr, *dc = nullptr, *dal = nullptr, *dth = nullptr;
-  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal, dth}) if (q) (void)hipFree(q); };
+  double *dgd = nullptr, *dgs = nullptr, *dst = nullptr, *dnu = nullptr;   // [B][ng]: s / nu, mu / nu, trial slacks, multipliers of the general rows
+  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal, dth, dgd, dgs, dst, dnu}) if (q) (void)hipFree(q); };
 #define GTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
 #define GRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
   GTRY(hipMalloc((void**)&z, (size_t)B * Nz * sizeof(double)));
@@ -1697,6 +1715,9 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   GTRY(hipMalloc((void**)&dc, (size_t)B * Nc * sizeof(double)));
   GTRY(hipMalloc((void**)&dal, (size_t)B * sizeof(double)));
   GTRY(hipMalloc((void**)&dth, (size_t)B * sizeof(double)));
+  if (ni > 0) {
+    for (double** q : {&dgd, &dgs, &dst, &dnu}) GTRY(hipMalloc((void**)q, (size_t)B * ng * sizeof(double)));
+  }
   // the guess, with the fixed variables put on their values
   std::vector<double> hz((size_t)B * Nz);
   GTRY(hipMemcpy2DAsync(hz.data(), Nz * sizeof(double), b->x, b->ldx * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
@@ -1709,17 +1730,51 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   struct Inst {
     int status = 0, iter = 0, ls_fail = 0, filter_n = 0;
     double dlast = 0.0, theta_max = -1.0, theta_min = -1.0;
+    double mu = 0.0;   // barrier parameter (inequality general rows only)
     std::vector<double> filt;
   };
   std::vector<Inst> I((size_t)B);
+  // slacks and multipliers of the general rows on the host (the multipliers are mirrored into lam after every update)
+  std::vector<double> hs((size_t)B * std::max<int64_t>(1, ng), 0.0), hnu((size_t)B * std::max<int64_t>(1, ng), 0.0), hds((size_t)B * std::max<int64_t>(1, ng), 0.0);
+  std::vector<double> hgd((size_t)B * std::max<int64_t>(1, ng), 0.0), hgs((size_t)B * std::max<int64_t>(1, ng), 0.0), hst((size_t)B * std::max<int64_t>(1, ng), 0.0);
   std::vector<double> dwv((size_t)B), hf((size_t)B), hth((size_t)B), hal((size_t)B), hphi0((size_t)B);
   std::vector<int> okv((size_t)B);
   constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
   constexpr int TRIALS = DTO_LS_TRIALS;
   dto_batch bz = *b;
   bz.x = z; bz.ldx = Nz; bz.params = nullptr; bz.ldp = 0;
+  auto put_nu = [&]() -> int {   // host multipliers of the general rows -> their columns of lam
+    HIP_TRY(hipMemcpy2DAsync(lam + Ns, Nc * sizeof(double), hnu.data(), ng * sizeof(double), ng * sizeof(double), (size_t)B, hipMemcpyHostToDevice, st));
+    return DTO_OK;
+  };
+  if (ni > 0) {
+    // slacks from the constraint values at the guess, pushed inside (s >= 1e-2), multipliers 1 (Ipopt's bound_mult_init_val), mu_init
+    GRC(dto_eval_g_batch(h, &bz, dc, Nc));
+    std::vector<double> hg((size_t)B * ng);
+    GTRY(hipMemcpy2DAsync(hg.data(), ng * sizeof(double), dc + Ns, Nc * sizeof(double), ng * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
+    GTRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < B; ++i) {
+      I[(size_t)i].mu = o.mu_init;
+      for (int64_t q = 0; q < ng; ++q)
+        if (ineq[(size_t)q]) { hs[(size_t)(i * ng + q)] = std::max(-hg[(size_t)(i * ng + q)], 1e-2); hnu[(size_t)(i * ng + q)] = 1.0; }
+    }
+    GRC(put_nu());
+  }
+  const double kappa_sigma = 1e10;
+  const double mu_floor = std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
+  std::vector<char> mu_moved((size_t)B, 0);
   const auto t_start = std::chrono::steady_clock::now();
   for (;;) {
+    if (ni > 0) {
+      for (int64_t i = 0; i < B; ++i)
+        for (int64_t q = 0; q < ng; ++q) {
+          const size_t e = (size_t)(i * ng + q);
+          hgd[e] = ineq[(size_t)q] ? hs[e] / hnu[e] : 0.0;
+          hgs[e] = ineq[(size_t)q] ? I[(size_t)i].mu / hnu[e] : 0.0;
+        }
+      GTRY(hipMemcpyAsync(dgd, hgd.data(), (size_t)B * ng * sizeof(double), hipMemcpyHostToDevice, st));
+      GTRY(hipMemcpyAsync(dgs, hgs.data(), (size_t)B * ng * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     // ---- step at the current point: delta_w ladder per instance (Algorithm IC), all instances share the sweeps
     for (int64_t i = 0; i < B; ++i) {
       Inst& s = I[(size_t)i];
@@ -1727,7 +1782,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     }
     BorderStats bs;
     for (int attempt = 0;; ++attempt) {
-      GRC(bordered_step(p, &bz, lam, Nc, dwv.data(), o.delta_c, dz, Nz, dlam, Nc, okv.data(), &bs, true));
+      GRC(bordered_step(p, &bz, lam, Nc, dwv.data(), o.delta_c, dz, Nz, dlam, Nc, okv.data(), &bs, true, ni > 0 ? dgd : nullptr, ni > 0 ? dgs : nullptr));
       bool again = false;
       for (int64_t i = 0; i < B; ++i) {
         Inst& s = I[(size_t)i];
@@ -1760,19 +1815,49 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       Inst& s = I[(size_t)i];
       if (s.status != 0) continue;
       double th1 = 0, thinf = 0, dinf = 0, slam = 0, gd = 0;
-      for (int64_t k = 0; k < Nc; ++k) { const double v = std::fabs(bs.c[(size_t)i * Nc + k]); th1 += v; thinf = std::max(thinf, v); slam += std::fabs(hm[(size_t)i * Nc + k]); }
+      for (int64_t k = 0; k < Nc; ++k) {
+        const double sk = (k >= Ns && ineq[(size_t)(k - Ns)]) ? hs[(size_t)(i * ng + (k - Ns))] : 0.0;   // inequality rows: g + s
+        const double v = std::fabs(bs.c[(size_t)i * Nc + k] + sk); th1 += v; thinf = std::max(thinf, v); slam += std::fabs(hm[(size_t)i * Nc + k]);
+      }
       for (int64_t k = 0; k < Nz; ++k) {
         if (L.var_lo[k] != L.var_hi[k]) dinf = std::max(dinf, std::fabs(bs.rx[(size_t)i * Nz + k]));
         gd += bs.grad[(size_t)i * Nz + k] * bs.dz[(size_t)i * Nz + k];
       }
       const double sd = std::max(o.s_max, slam / (double)std::max<int64_t>(1, Nc)) / o.s_max;
-      const double e0 = std::max(dinf / sd, thinf);
+      // complementarity of the slack / multiplier pairs against mu_target (termination) and against mu (barrier update); the
+      // step of the inequality rows: ds = (mu - s nu) / nu - (s / nu) dnu, barrier term of the merit's directional derivative
+      double c0 = 0.0, cmu = 0.0, snu = 0.0, bar_d = 0.0;
+      for (int64_t q = 0; q < ng; ++q) {
+        if (!ineq[(size_t)q]) continue;
+        const size_t e = (size_t)(i * ng + q);
+        const double sv = hs[e], nv = hnu[e], dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+        c0 = std::max(c0, std::fabs(sv * nv - o.mu_target)); cmu = std::max(cmu, std::fabs(sv * nv - s.mu)); snu += std::fabs(nv);
+        hds[e] = (s.mu - sv * nv) / nv - (sv / nv) * dnu;
+        bar_d += hds[e] / sv;
+      }
+      const double scn = ni > 0 ? std::max(o.s_max, snu / (double)ni) / o.s_max : 1.0;
+      const double e0 = std::max(std::max(dinf / sd, thinf), c0 / scn);
       const double f = hf[(size_t)i];
+      mu_moved[(size_t)i] = 0;
       if (!(f == f) || !(th1 == th1) || !(dinf == dinf)) s.status = 3;
-      else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol) s.status = 1;
+      else if (e0 <= o.tol && dinf <= o.dual_inf_tol && thinf <= o.constr_viol_tol && c0 <= o.compl_inf_tol) s.status = 1;
       else if (s.iter >= o.max_iter) s.status = 2;
+      else if (ni > 0) {
+        // Ipopt's monotone rule: once the barrier problem is solved to kappa_eps mu the parameter drops (and the filter is reset);
+        // the step computed above belongs to the old mu: this instance waits one round (alpha = 0) for the step of the new one
+        double mu = s.mu;
+        for (;;) {
+          const double emu = std::max(std::max(dinf / sd, thinf), std::fabs(cmu) / scn);
+          if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
+          mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
+          cmu = 0.0;
+          for (int64_t q = 0; q < ng; ++q)
+            if (ineq[(size_t)q]) cmu = std::max(cmu, std::fabs(hs[(size_t)(i * ng + q)] * hnu[(size_t)(i * ng + q)] - mu));
+        }
+        if (mu != s.mu) { s.mu = mu; s.filter_n = 0; s.theta_max = -1.0; mu_moved[(size_t)i] = 1; }
+      }
       if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
-      th0[(size_t)i] = th1; gphid[(size_t)i] = gd;
+      th0[(size_t)i] = th1; gphid[(size_t)i] = gd - s.mu * bar_d;
       if (s.status == 0) {
         any = true;
         if (dwv[(size_t)i] > 0.0) s.dlast = dwv[(size_t)i]; else s.dlast = 0.0;
@@ -1787,13 +1872,39 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     std::vector<double> phi((size_t)B * TRIALS, 0.0), th((size_t)B * TRIALS, 0.0), chosen_a((size_t)B, -1.0);
     std::vector<char> ftype_a((size_t)B, 0);
     std::vector<int> best_a((size_t)B, 0);
+    // inequality rows: the trials start from the fraction-to-the-boundary step of the slacks, the merit is the barrier function
+    std::vector<double> apmax((size_t)B, 1.0), admax((size_t)B, 1.0);
+    for (int64_t i = 0; i < B && ni > 0; ++i) {
+      Inst& s = I[(size_t)i];
+      if (s.status != 0) continue;
+      if (mu_moved[(size_t)i]) { chosen_a[(size_t)i] = 0.0; continue; }   // waits for the step of its new barrier parameter
+      const double tau = std::max(o.tau_min, 1.0 - s.mu);
+      double lb = 0.0;
+      for (int64_t q = 0; q < ng; ++q) {
+        if (!ineq[(size_t)q]) continue;
+        const size_t e = (size_t)(i * ng + q);
+        const double dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+        if (hds[e] < 0.0) apmax[(size_t)i] = std::min(apmax[(size_t)i], -tau * hs[e] / hds[e]);
+        if (dnu < 0.0) admax[(size_t)i] = std::min(admax[(size_t)i], -tau * hnu[e] / dnu);
+        lb += std::log(hs[e]);
+      }
+      hphi0[(size_t)i] -= s.mu * lb;
+    }
     int k_done = 0;
     for (int k = 0; k < TRIALS; ++k) {
       bool undecided = false;
       for (int64_t i = 0; i < B; ++i) undecided = undecided || (I[(size_t)i].status == 0 && chosen_a[(size_t)i] < 0.0);
       if (!undecided) break;
-      const double alpha = std::ldexp(1.0, -k);
-      for (int64_t i = 0; i < B; ++i) hal[(size_t)i] = (I[(size_t)i].status == 0 && chosen_a[(size_t)i] < 0.0) ? alpha : 0.0;
+      const double alpha2 = std::ldexp(1.0, -k);
+      for (int64_t i = 0; i < B; ++i) hal[(size_t)i] = (I[(size_t)i].status == 0 && chosen_a[(size_t)i] < 0.0) ? apmax[(size_t)i] * alpha2 : 0.0;
+      if (ni > 0) {
+        for (int64_t i = 0; i < B; ++i)
+          for (int64_t q = 0; q < ng; ++q) {
+            const size_t e = (size_t)(i * ng + q);
+            hst[e] = ineq[(size_t)q] ? hs[e] + hal[(size_t)i] * hds[e] : 0.0;
+          }
+        GTRY(hipMemcpyAsync(dst, hst.data(), (size_t)B * ng * sizeof(double), hipMemcpyHostToDevice, st));
+      }
       GTRY(hipMemcpyAsync(zt, z, (size_t)B * Nz * sizeof(double), hipMemcpyDeviceToDevice, st));
       GTRY(hipMemcpyAsync(dal, hal.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, zt, (const double*)dz, (const double*)dal, Nz, Nz, Nz);
@@ -1801,7 +1912,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       bt.x = zt;
       GRC(dto_eval_f_batch(h, &bt, df));
       GRC(dto_eval_g_batch(h, &bt, dc, Nc));
-      hipLaunchKernelGGL(k_rows_abs_sum, dim3((unsigned)B), dim3(64), 0, st, (const double*)dc, Nc, Nc, dth);
+      hipLaunchKernelGGL(k_rows_abs_sum, dim3((unsigned)B), dim3(64), 0, st, (const double*)dc, Nc, Nc, dth, (const double*)(ni > 0 ? dst : nullptr), Ns, ng);
       GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
       GTRY(hipMemcpyAsync(hth.data(), dth, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
       GTRY(hipStreamSynchronize(st));
@@ -1809,7 +1920,11 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       for (int64_t i = 0; i < B; ++i) {
         Inst& s = I[(size_t)i];
         if (s.status != 0 || chosen_a[(size_t)i] >= 0.0) continue;
-        const double pk = hf[(size_t)i], tk = hth[(size_t)i];
+        const double alpha = hal[(size_t)i];
+        double pk = hf[(size_t)i];
+        const double tk = hth[(size_t)i];
+        for (int64_t q = 0; q < ng && ni > 0; ++q)
+          if (ineq[(size_t)q]) pk -= s.mu * std::log(hst[(size_t)(i * ng + q)]);
         phi[(size_t)i * TRIALS + k] = pk;
         th[(size_t)i * TRIALS + k] = tk;
         int& best = best_a[(size_t)i];
@@ -1840,8 +1955,9 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       const bool ftype = ftype_a[(size_t)i] != 0;
       const int best = best_a[(size_t)i];
       bool augment;
+      if (ni > 0 && mu_moved[(size_t)i]) { hal[(size_t)i] = 0.0; continue; }   // no step, no iteration: its barrier parameter just moved
       if (chosen < 0.0) {   // every trial rejected (all TRIALS were evaluated for this instance): the most feasible one, or the shortest
-        chosen = (th[(size_t)i * TRIALS + best] < t0) ? std::ldexp(1.0, -best) : std::ldexp(1.0, -(TRIALS - 1));
+        chosen = apmax[(size_t)i] * ((th[(size_t)i * TRIALS + best] < t0) ? std::ldexp(1.0, -best) : std::ldexp(1.0, -(TRIALS - 1)));
         s.ls_fail = 1; augment = true;
       } else { s.ls_fail = okv[(size_t)i] ? 0 : 1; augment = !ftype; }
       if (augment) {
@@ -1857,6 +1973,25 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     GTRY(hipMemcpyAsync(dal, hal.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, (const double*)dz, (const double*)dal, Nz, Nz, Nz);
     hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, lam, (const double*)dlam, (const double*)dal, Nc, Nc, Nc);
+    if (ni > 0) {
+      // general rows: equality multipliers move with the primal step, slack / multiplier pairs of the inequality rows with
+      // alpha and the dual fraction-to-the-boundary step, then Ipopt's kappa_sigma safeguard; mirrored into lam
+      for (int64_t i = 0; i < B; ++i) {
+        const double al = hal[(size_t)i];
+        if (I[(size_t)i].status != 0 && al == 0.0) continue;
+        const double ad = al == 0.0 ? 0.0 : admax[(size_t)i];
+        for (int64_t q = 0; q < ng; ++q) {
+          const size_t e = (size_t)(i * ng + q);
+          const double dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+          if (!ineq[(size_t)q]) { hnu[e] += al * dnu; continue; }
+          hs[e] += al * hds[e];
+          hnu[e] += ad * dnu;
+          const double mu_i = I[(size_t)i].mu;
+          hnu[e] = std::max(std::min(hnu[e], kappa_sigma * mu_i / hs[e]), mu_i / (kappa_sigma * hs[e]));
+        }
+      }
+      GRC(put_nu());
+    }
     if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
   }
   GTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, st));

@@ -403,7 +403,7 @@ def build_ref_general(user_jacobian=False):
                 bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=eh)
 
 
-def build_ref_general_coupled():
+def build_ref_general_coupled(inequality=None):
     """test/solve.jl:227-296 extended with a row that couples two knots: GeneralConstraint
     (z, w) -> [z[end-1:end] - xT; x_4[1] + x_8[1] - 0.9] (positions at knots 4 and 8 add up to 0.9).  The terminal rows alone
     would be folded into a stage constraint; the coupling row cannot: the solver's bordered path (dto_solver.cpp:
@@ -417,11 +417,13 @@ def build_ref_general_coupled():
     cT = Cost(lambda x, u, w: 0.1 * dot(x, x), n, 0, evaluate_hessian=True)
     nz = n * T + m * (T - 1)
     i4, i8 = 3 * (n + m), 7 * (n + m)          # 0-based offsets of x_4 and x_8 in z
-    gc = GeneralConstraint(lambda z, w: np.array([z[nz - 2] - xT[0], z[nz - 1] - xT[1], z[i4] + z[i8] - 0.9], dtype=object),
-                           nz, 0, evaluate_hessian=True)
+    # inequality = total: the coupling row becomes x_4[1] + x_8[1] - total <= 0 (indices_inequality, src/general_constraint.jl:15-19)
+    tot = 0.9 if inequality is None else float(inequality)
+    gc = GeneralConstraint(lambda z, w: np.array([z[nz - 2] - xT[0], z[nz - 1] - xT[1], z[i4] + z[i8] - tot], dtype=object),
+                           nz, 0, indices_inequality=([] if inequality is None else [3]), evaluate_hessian=True)
     bounds = [Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2) + [Bound(n, 0)]
     return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)],
-                bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=True, coupling=(i4, i8, 0.9))
+                bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=True, coupling=(i4, i8, tot))
 
 
 def build_acrobot_coupled(T=8):

@@ -225,7 +225,8 @@ int dto_kkt_solve(dto_problem* p, const double* rhs_x, int64_t ldrx, const doubl
  * 4 converged to the acceptable level, 5 diverging iterates).
  * Paths by model: lane-per-instance tiles (states <= 16; bounds, inequality rows, per-instance parameters); the tile (MFMA)
  * kernels for 64-state models (variables free, fixed or bounded; no stage constraints, one to four actions, shared or per-instance parameters); a
- * GeneralConstraint whose rows couple several knots is solved through a border (equality rows, variables free or fixed):
+ * GeneralConstraint whose rows couple several knots is solved through a border (general rows equalities or inequalities,
+ * dynamics / stage rows equalities, variables free or fixed):
  * one factorisation and n_g + 1 sweeps per step, the border algebra on the device since round 4 (DTO_BORDER_HOST=1: on the
  * host), the filter line-search loop around it driven from the host. */
 int dto_solve_batch(dto_problem* p, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,

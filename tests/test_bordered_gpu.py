@@ -123,3 +123,42 @@ def test_device_border_agrees_with_the_host_border(monkeypatch):
     scale = max(np.max(np.abs(out["1"][0])), np.max(np.abs(out["1"][1])))
     assert np.all(np.isfinite(out["0"][0])) and out["0"][2] == out["1"][2]
     assert np.max(np.abs(out["0"][0] - out["1"][0])) <= 1e-10 * scale and np.max(np.abs(out["0"][1] - out["1"][1])) <= 1e-10 * scale
+
+
+@pytest.mark.parametrize("total,active", [(0.05, True), (-0.2, True), (5.0, False)])
+def test_inequality_row_coupling_two_knots(total, active):
+    """an INEQUALITY GeneralConstraint row (src/general_constraint.jl:15-19, src/data.jl:146) that couples
+    knots 4 and 8, x_4[1] + x_8[1] <= total, next to the equality rows of test/solve.jl:227-296.  The row is carried with a slack
+    in the border (s / nu on its diagonal, mu / nu in its right-hand side), mu follows Ipopt's monotone rule.  Checked: primal
+    feasibility, the sign of the multiplier, complementarity at compl_inf_tol, stationarity of the full Lagrangian; with the
+    binding total the row is active, with the loose one the solution is that of the problem without the row."""
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_ref_general_coupled(inequality=total)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       general_constraint=p["general_constraint"], name="ref_general_coupled_ineq")
+    rng = np.random.Generator(np.random.PCG64(5))
+    dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
+    dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
+    assert dto_amd.solve(s) == 1, (s.status, s.iterations)
+    i4, i8, tot = p["coupling"]
+    z, lam = s._solution, s._duals
+    n = s.nlp
+    g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
+    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+    J = np.zeros((n.num_constraint, n.num_variables))
+    for (r, c), v in zip(n.jacobian_structure(), Jv):
+        J[r - 1, c - 1] = v
+    c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
+    nu, gi = lam[-1], c[-1]                      # the inequality row is the last constraint row
+    assert np.max(np.abs(c[:-1])) < 1e-6 and gi <= 1e-6 and nu >= -1e-9
+    assert abs(nu * gi) <= 1e-3                  # compl_inf_tol of the reference Options (mu_target = 0: nu * s -> 0)
+    r = g + J.T @ lam
+    free = np.ones(n.num_variables, bool); free[:2] = False
+    assert np.max(np.abs(r[free])) < 1e-5
+    if active:
+        # (mu_target = 1e-4 in the reference Options mapping: the slack stops at s = mu_target / nu, not at zero)
+        assert abs(z[i4] + z[i8] - tot) < 2e-2 and nu > 1e-3 and abs(nu * gi) <= 2e-4
+    else:
+        assert z[i4] + z[i8] < tot - 0.1 and nu < 1e-4
+    assert s.iterations <= 40
