@@ -1296,6 +1296,7 @@ struct BorderStats {
   // device border: where grad f, c and r_x of the point lie in the problem's workspace (valid until the next step); the caller
   // fetches them -- and the step from its own buffers -- once per iteration instead of once per inertia-correction attempt
   const double *d_grad = nullptr, *d_c = nullptr, *d_rx = nullptr;
+  bool reuse_point = false;   // in: the point did not move since the last call (another delta_w attempt): keep J, c, grad f, r_x, G
 };
 
 // ---- device side of the bordered step (round 4; DTO_BORDER_HOST=1 selects the host algebra of round 3 instead).  Only the
@@ -1318,6 +1319,29 @@ static __global__ void k_border_rx(int64_t B, int64_t Nz, int64_t Ns, int64_t nn
   }
   rx[idx] = acc;
   rhsx[idx] = -acc;
+}
+// what the host loop needs of the point and the step, per instance: theta_1, theta_inf (rows n0 .. get their slack added), the
+// dual infeasibility over the free variables, sum |lam|, grad f' dz -- five numbers instead of five vectors over PCIe
+static __global__ __launch_bounds__(64) void k_border_stats(int64_t Nz, int64_t Nc, const double* c, const double* rx, const double* g,
+                                                            const double* dz, const double* lam, const int* fixed, const double* shift,
+                                                            int64_t n0, int64_t nsh, double* out) {
+  const int64_t b = blockIdx.x;
+  const int l = threadIdx.x;
+  double th1 = 0.0, thinf = 0.0, dinf = 0.0, slam = 0.0, gd = 0.0;
+  for (int64_t k = l; k < Nc; k += 64) {
+    const double v = fabs(c[b * Nc + k] + ((shift && k >= n0) ? shift[b * nsh + (k - n0)] : 0.0));
+    th1 += v; thinf = fmax(thinf, v); slam += fabs(lam[b * Nc + k]);
+  }
+  for (int64_t k = l; k < Nz; k += 64) {
+    if (!fixed[k]) dinf = fmax(dinf, fabs(rx[b * Nz + k]));
+    gd += g[b * Nz + k] * dz[b * Nz + k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    th1 += __shfl_down(th1, off, 64); slam += __shfl_down(slam, off, 64); gd += __shfl_down(gd, off, 64);
+    thinf = fmax(thinf, __shfl_down(thinf, off, 64)); dinf = fmax(dinf, __shfl_down(dinf, off, 64));
+  }
+  if (l == 0) { double* o = out + b * 5; o[0] = th1; o[1] = thinf; o[2] = dinf; o[3] = slam; o[4] = gd; }
 }
 // per-instance delta_w on the primal diagonal; a variable with lo == hi gets a huge entry instead (its step is ~1e-16 r)
 static __global__ void k_border_sig(int64_t B, int64_t Nz, const double* dw, const int* fixed, int pin_fixed, double* sig) {
@@ -1465,14 +1489,16 @@ static int bordered_step_device(Problem* p, const dto_batch* b, const double* mu
   int* dFlag = reinterpret_cast<int*>(take((size_t)B / 2 + 4));
   double* dDw = take((size_t)B);
 #define DRC(expr) do { rc = (expr); if (rc) return rc; } while (0)
-  DRC(dto_eval_jac_g_batch(h, b, dJ, nnzJ));
-  DRC(dto_eval_g_batch(h, b, dC, Nc));
-  DRC(dto_eval_grad_f_batch(h, b, dG, Nz));
-  HIP_TRY(hipMemsetAsync(dGrow, 0, (size_t)ng * nBz * sizeof(double), st));
-  HIP_TRY(hipMemsetAsync(dZeroC, 0, nBc * sizeof(double), st));
-  hipLaunchKernelGGL(k_border_rx, dim3((unsigned)((nBz + 255) / 256)), dim3(256), 0, st, B, Nz, Ns, nnzJ, (const double*)dJ, (const double*)dG,
-                     mu, ldmu, (const int*)p->d_csc_ptr, (const int*)p->d_csc_k, (const int*)p->d_csc_row, dRxv, dRhsx, dGrow);
-  hipLaunchKernelGGL(k_border_rhsc, dim3((unsigned)((nBc + 255) / 256)), dim3(256), 0, st, B, Nc, Ns, (const double*)dC, dRhsc);
+  if (!(stats && stats->reuse_point)) {   // (a further delta_w attempt at the same point keeps all of this in the workspace)
+    DRC(dto_eval_jac_g_batch(h, b, dJ, nnzJ));
+    DRC(dto_eval_g_batch(h, b, dC, Nc));
+    DRC(dto_eval_grad_f_batch(h, b, dG, Nz));
+    HIP_TRY(hipMemsetAsync(dGrow, 0, (size_t)ng * nBz * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(dZeroC, 0, nBc * sizeof(double), st));
+    hipLaunchKernelGGL(k_border_rx, dim3((unsigned)((nBz + 255) / 256)), dim3(256), 0, st, B, Nz, Ns, nnzJ, (const double*)dJ, (const double*)dG,
+                       mu, ldmu, (const int*)p->d_csc_ptr, (const int*)p->d_csc_k, (const int*)p->d_csc_row, dRxv, dRhsx, dGrow);
+    hipLaunchKernelGGL(k_border_rhsc, dim3((unsigned)((nBc + 255) / 256)), dim3(256), 0, st, B, Nc, Ns, (const double*)dC, dRhsc);
+  }
   // per-instance delta_w through the sigma_x diagonal (pin_fixed: a variable with lo == hi keeps its value)
   HIP_TRY(hipMemcpyAsync(dDw, dw, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_border_sig, dim3((unsigned)((nBz + 255) / 256)), dim3(256), 0, st, B, Nz, (const double*)dDw, (const int*)p->d_var_fixed,
@@ -1703,7 +1729,8 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   dto_problem* h = reinterpret_cast<dto_problem*>(p);
   double *z = nullptr, *lam = nullptr, *dz = nullptr, *dlam = nullptr, *zt = nullptr, *df = nullptr, *dc = nullptr, *dal = nullptr, *dth = nullptr;
   double *dgd = nullptr, *dgs = nullptr, *dst = nullptr, *dnu = nullptr;   // [B][ng]: s / nu, mu / nu, trial slacks, multipliers of the general rows
-  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal, dth, dgd, dgs, dst, dnu}) if (q) (void)hipFree(q); };
+  double* d5 = nullptr;                                                     // [B][5] statistics of the point and the step
+  auto cleanup = [&]() { for (double* q : {z, lam, dz, dlam, zt, df, dc, dal, dth, dgd, dgs, dst, dnu, d5}) if (q) (void)hipFree(q); };
 #define GTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
 #define GRC(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
   GTRY(hipMalloc((void**)&z, (size_t)B * Nz * sizeof(double)));
@@ -1782,6 +1809,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     }
     BorderStats bs;
     for (int attempt = 0;; ++attempt) {
+      bs.reuse_point = attempt > 0;
       GRC(bordered_step(p, &bz, lam, Nc, dwv.data(), o.delta_c, dz, Nz, dlam, Nc, okv.data(), &bs, true, ni > 0 ? dgd : nullptr, ni > 0 ? dgs : nullptr));
       bool again = false;
       for (int64_t i = 0; i < B; ++i) {
@@ -1794,19 +1822,30 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       }
       if (!again) break;
     }
-    if (bs.d_grad) {   // device border: the point's vectors and the final step, once per iteration
-      bs.grad.resize((size_t)B * Nz); bs.c.resize((size_t)B * Nc); bs.rx.resize((size_t)B * Nz); bs.dz.resize((size_t)B * Nz); bs.dmu.resize((size_t)B * Nc);
-      GTRY(hipMemcpyAsync(bs.grad.data(), bs.d_grad, bs.grad.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      GTRY(hipMemcpyAsync(bs.c.data(), bs.d_c, bs.c.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      GTRY(hipMemcpyAsync(bs.rx.data(), bs.d_rx, bs.rx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      GTRY(hipMemcpyAsync(bs.dz.data(), dz, bs.dz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-      GTRY(hipMemcpyAsync(bs.dmu.data(), dlam, bs.dmu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    const bool dev_stats = bs.d_grad != nullptr;
+    std::vector<double> hst5, hdnu;
+    if (dev_stats) {
+      // device border: five numbers per instance (and the steps of the general rows' multipliers) instead of five vectors
+      if (!d5) GTRY(hipMalloc((void**)&d5, (size_t)B * 5 * sizeof(double)));
+      if (ni > 0) GTRY(hipMemcpyAsync(dst, hs.data(), (size_t)B * ng * sizeof(double), hipMemcpyHostToDevice, st));   // slack shift of theta
+      hipLaunchKernelGGL(k_border_stats, dim3((unsigned)B), dim3(64), 0, st, Nz, Nc, bs.d_c, bs.d_rx, bs.d_grad, (const double*)dz, (const double*)lam,
+                         (const int*)p->d_var_fixed, (const double*)(ni > 0 ? dst : nullptr), Ns, ng, d5);
+      hst5.resize((size_t)B * 5);
+      GTRY(hipMemcpyAsync(hst5.data(), d5, hst5.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (ng > 0) {
+        hdnu.resize((size_t)B * ng);
+        GTRY(hipMemcpy2DAsync(hdnu.data(), ng * sizeof(double), dlam + Ns, Nc * sizeof(double), ng * sizeof(double), (size_t)B, hipMemcpyDeviceToHost, st));
+      }
     }
+    auto dnu_of = [&](int64_t i, int64_t q) { return dev_stats ? hdnu[(size_t)(i * ng + q)] : bs.dmu[(size_t)i * Nc + Ns + q]; };
     // ---- convergence test (Ipopt's scaled error, reference Options), at the point the step was computed at
     GRC(dto_eval_f_batch(h, &bz, df));
     GTRY(hipMemcpyAsync(hf.data(), df, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
-    std::vector<double> hm((size_t)B * Nc);
-    GTRY(hipMemcpyAsync(hm.data(), lam, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<double> hm;
+    if (!dev_stats) {
+      hm.resize((size_t)B * Nc);
+      GTRY(hipMemcpyAsync(hm.data(), lam, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     GTRY(hipStreamSynchronize(st));
     hphi0 = hf;   // objective at the current point: the line search's phi_0
     bool any = false;
@@ -1815,13 +1854,18 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       Inst& s = I[(size_t)i];
       if (s.status != 0) continue;
       double th1 = 0, thinf = 0, dinf = 0, slam = 0, gd = 0;
-      for (int64_t k = 0; k < Nc; ++k) {
-        const double sk = (k >= Ns && ineq[(size_t)(k - Ns)]) ? hs[(size_t)(i * ng + (k - Ns))] : 0.0;   // inequality rows: g + s
-        const double v = std::fabs(bs.c[(size_t)i * Nc + k] + sk); th1 += v; thinf = std::max(thinf, v); slam += std::fabs(hm[(size_t)i * Nc + k]);
-      }
-      for (int64_t k = 0; k < Nz; ++k) {
-        if (L.var_lo[k] != L.var_hi[k]) dinf = std::max(dinf, std::fabs(bs.rx[(size_t)i * Nz + k]));
-        gd += bs.grad[(size_t)i * Nz + k] * bs.dz[(size_t)i * Nz + k];
+      if (dev_stats) {
+        const double* q5 = &hst5[(size_t)i * 5];
+        th1 = q5[0]; thinf = q5[1]; dinf = q5[2]; slam = q5[3]; gd = q5[4];
+      } else {
+        for (int64_t k = 0; k < Nc; ++k) {
+          const double sk = (k >= Ns && ineq[(size_t)(k - Ns)]) ? hs[(size_t)(i * ng + (k - Ns))] : 0.0;   // inequality rows: g + s
+          const double v = std::fabs(bs.c[(size_t)i * Nc + k] + sk); th1 += v; thinf = std::max(thinf, v); slam += std::fabs(hm[(size_t)i * Nc + k]);
+        }
+        for (int64_t k = 0; k < Nz; ++k) {
+          if (L.var_lo[k] != L.var_hi[k]) dinf = std::max(dinf, std::fabs(bs.rx[(size_t)i * Nz + k]));
+          gd += bs.grad[(size_t)i * Nz + k] * bs.dz[(size_t)i * Nz + k];
+        }
       }
       const double sd = std::max(o.s_max, slam / (double)std::max<int64_t>(1, Nc)) / o.s_max;
       // complementarity of the slack / multiplier pairs against mu_target (termination) and against mu (barrier update); the
@@ -1830,7 +1874,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       for (int64_t q = 0; q < ng; ++q) {
         if (!ineq[(size_t)q]) continue;
         const size_t e = (size_t)(i * ng + q);
-        const double sv = hs[e], nv = hnu[e], dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+        const double sv = hs[e], nv = hnu[e], dnu = dnu_of(i, q);
         c0 = std::max(c0, std::fabs(sv * nv - o.mu_target)); cmu = std::max(cmu, std::fabs(sv * nv - s.mu)); snu += std::fabs(nv);
         hds[e] = (s.mu - sv * nv) / nv - (sv / nv) * dnu;
         bar_d += hds[e] / sv;
@@ -1883,7 +1927,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       for (int64_t q = 0; q < ng; ++q) {
         if (!ineq[(size_t)q]) continue;
         const size_t e = (size_t)(i * ng + q);
-        const double dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+        const double dnu = dnu_of(i, q);
         if (hds[e] < 0.0) apmax[(size_t)i] = std::min(apmax[(size_t)i], -tau * hs[e] / hds[e]);
         if (dnu < 0.0) admax[(size_t)i] = std::min(admax[(size_t)i], -tau * hnu[e] / dnu);
         lb += std::log(hs[e]);
@@ -1982,7 +2026,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
         const double ad = al == 0.0 ? 0.0 : admax[(size_t)i];
         for (int64_t q = 0; q < ng; ++q) {
           const size_t e = (size_t)(i * ng + q);
-          const double dnu = bs.dmu[(size_t)i * Nc + Ns + q];
+          const double dnu = dnu_of(i, q);
           if (!ineq[(size_t)q]) { hnu[e] += al * dnu; continue; }
           hs[e] += al * hds[e];
           hnu[e] += ad * dnu;
