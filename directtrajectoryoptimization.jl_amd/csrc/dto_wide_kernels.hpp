@@ -938,7 +938,10 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
             yv[tid] = z[a.zoff[t + 1] + tid];
             lamv[tid] = mu[a.cdoff[t] + tid];
             fxm[tid] = (a.fixed_lo && a.fixed_lo[a.zoff[t] + tid] == a.fixed_hi[a.zoff[t] + tid]) ? 1.0 : 0.0;
+            const unsigned long long anyf = __ballot(fxm[tid] != 0.0);   // (tid < N is exactly wavefront 0)
+            if (tid == 0) cnt[6] = anyf != 0ull;
           }
+          if (t > 0 && tid == 0) cnt[6] = cnt[7];
 #pragma unroll
           for (int j = 0; j < NU; ++j) { au[j * N + tid] = 0.0; vu[j * N + tid] = 0.0; }
           nlf[tid] = 0.0;
@@ -1130,7 +1133,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
           if (l == 0) stat[3] = fmax(stat[3], v);
         }
-        if (a.fixed_lo) {
+        // (skipped when no state of this knot is fixed: the pass over three LDS matrices costs ~3 k cycles a stage)
+        if (a.fixed_lo && cnt[6]) {
           lds_barrier();
           for (int i = tid; i < N * N; i += WG) {
             const int r = i >> 6, c = i & 63;
@@ -1284,6 +1288,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         if (pre_ && tid < N) {
           xv[tid] = nx_; yv[tid] = ny_; lamv[tid] = nl_; fxm[tid] = nf_;
           if (tid < NU) sc[tid] = nu_;
+          const unsigned long long anyf = __ballot(nf_ != 0.0);
+          if (tid == 0) cnt[7] = anyf != 0ull;   // (cnt[6] of the NEXT stage: copied at its phase 0, this stage still reads cnt[6])
         }
         lds_barrier();
 #pragma unroll
