@@ -426,6 +426,20 @@ def build_ref_general_coupled(inequality=None):
                 bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=True, coupling=(i4, i8, tot))
 
 
+def build_pendulum_coupled(T=50, total=1.0, inequality=True):
+    """The pendulum swing-up (examples/pendulum/pendulum.jl, nonlinear dynamics) with one GeneralConstraint row that couples
+    knots 15 and 35: theta_15 + theta_35 - total (<= 0 with inequality=True, = 0 otherwise).  Without the row the sum is 1.449."""
+    from .model import GeneralConstraint
+    p = build_pendulum(T=T, evaluate_hessian=True)
+    n, m = 2, 1
+    nz = n * T + m * (T - 1)
+    i15, i35 = 14 * (n + m), 34 * (n + m)
+    p["general_constraint"] = GeneralConstraint(lambda z, w: np.array([z[i15] + z[i35] - total], dtype=object), nz, 0,
+                                                indices_inequality=([1] if inequality else []), evaluate_hessian=True)
+    p["coupling"] = (i15, i35, total)
+    return p
+
+
 def build_acrobot_coupled(T=8):
     """The acrobot (nonlinear dynamics, pinned endpoints) with two GeneralConstraint rows that couple knots: q1 at knot 3 minus
     q1 at knot 6 equals 0.2; q2 at knots 2 and 7 plus the action at knot 4 add up to zero.  Used for the bordered KKT step."""

@@ -162,3 +162,43 @@ def test_inequality_row_coupling_two_knots(total, active):
     else:
         assert z[i4] + z[i8] < tot - 0.1 and nu < 1e-4
     assert s.iterations <= 40
+
+
+def test_inequality_coupling_row_on_the_nonlinear_pendulum():
+    """The same on nonlinear dynamics: pendulum swing-up, T = 50 (examples/pendulum/pendulum.jl), theta_15 + theta_35 <= total.
+    Without the row the sum is 1.449: total = 1 binds (nu > 0, the sum ends at the bound up to mu_target / nu), total = 6 does not
+    (the trajectory of the problem without the row, nu ~ mu_target / slack).  KKT conditions from the product's callbacks (those
+    are checked against the oracle in test_eval_gpu.py / test_coverage_gpu.py)."""
+    import dto_amd
+    from dto_amd import problems as P
+
+    def solve(total):
+        p = P.build_pendulum_coupled(T=50, total=total, inequality=True) if total is not None else P.build_pendulum(T=50, evaluate_hessian=True)
+        s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                           general_constraint=p.get("general_constraint"), name="pendulum_coupled" if total is not None else "pendulum")
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+        dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+        assert dto_amd.solve(s) == 1, (total, s.status, s.iterations)
+        return s, p
+
+    s0, _ = solve(None)
+    i15, i35 = 14 * 3, 34 * 3
+    free_sum = s0._solution[i15] + s0._solution[i35]
+    assert 1.2 < free_sum < 1.7
+    for total in (1.0, 6.0):
+        s, p = solve(total)
+        z, lam, n = s._solution, s._duals, s.nlp
+        c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
+        g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
+        Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
+        J = np.zeros((n.num_constraint, n.num_variables))
+        for (r, cc), v in zip(n.jacobian_structure(), Jv):
+            J[r - 1, cc - 1] = v
+        nu, gi = lam[-1], c[-1]
+        assert np.max(np.abs(c[:-1])) < 1e-6 and gi <= 1e-6 and nu >= 0.0 and abs(nu * gi) <= 2e-4
+        assert np.max(np.abs(g + J.T @ lam)) < 1e-5
+        assert s.iterations <= 40
+        if total < free_sum:
+            assert abs(z[i15] + z[i35] - total) < 1e-3 and nu > 0.1
+        else:
+            assert np.max(np.abs(z - s0._solution)) < 1e-3 and nu < 1e-3
