@@ -80,6 +80,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef DTO_WIDE_SPLIT_BWD
 #define DTO_WIDE_SPLIT_BWD 1   // 1: the backward sweep is its own kernel (k_wide_bwd) that prefetches the next stage's factor record
 #endif                         //    into registers while it works on the current one; 0: the tail of k_wide_step (rounds 1-4)
+#ifndef DTO_WIDE_PACK_L
+#define DTO_WIDE_PACK_L DTO_WIDE_SPLIT_BWD   // 1: the two triangular factors of a stage go to the record as their ten lower 16 x 16
+#endif                                        //    tiles (2 560 instead of 4 160 doubles each); needs the split backward sweep
 #ifndef DTO_WIDE_LDL_INLINE
 #define DTO_WIDE_LDL_INLINE __attribute__((noinline))
 #endif
@@ -94,7 +97,9 @@ struct Dims {
   static constexpr int LI_LD = TB + 1;
   static constexpr int LI = NT * TB * LI_LD;   // inverses of the unit-lower diagonal tiles
   // factor record of one stage in HBM
-  static constexpr int F_LA = 0, F_FT = MAT, F_VT = 2 * MAT, F_LM = 3 * MAT, F_ET = 4 * MAT, F_VEC = 5 * MAT;
+  // triangular factors: lower tiles only (DTO_WIDE_PACK_L), tile-major [NT (NT + 1) / 2][TB][TB]
+  static constexpr int LTILES = NT * (NT + 1) / 2, PKL = DTO_WIDE_PACK_L ? LTILES * TB * TB : MAT;
+  static constexpr int F_LA = 0, F_FT = PKL, F_VT = PKL + MAT, F_LM = PKL + 2 * MAT, F_ET = 2 * PKL + 2 * MAT, F_VEC = 2 * PKL + 3 * MAT;
   // vectors: D_A^-1, D_M^-1, bx~, bd^, the NU action rows (A_xu, F_u, V_u after the elimination inside the action block), cost
   // gradient [N + 8], scalars of the action block (V_SC: 1 / pivot [NU], reduced right-hand side [NU], unit-lower factor [NU][NU])
   static constexpr int V_DA = 0, V_DM = N, V_BX = 2 * N, V_BD = 3 * N, V_AU = 4 * N, V_FU = V_AU + NU * N, V_VU = V_FU + NU * N,
@@ -662,6 +667,29 @@ __device__ __forceinline__ void store_fac(double* dst, const double* src) {
     if (i1 < MAT / 2) d2[i1] = a1;
     if (i2 < MAT / 2) d2[i2] = a2;
   }
+}
+
+// ---- the lower 16 x 16 tiles of a triangular factor (ten of sixteen), tile-major in the record: piece p of 1280 = (tile p >> 7,
+//      row (p >> 3) & 15, column pair p & 7), five pieces per thread
+template <int N>
+__device__ __forceinline__ int ltile_elem(int p) {
+  static_assert(N == 64, "four tiles per edge");
+  const int tile = p >> 7, r = (p >> 3) & 15, c2 = p & 7;
+  const int ib = tile >= 6 ? 3 : (tile >= 3 ? 2 : (tile >= 1 ? 1 : 0));
+  const int jb = tile - ib * (ib + 1) / 2;
+  return (ib * TB + r) * Dims<N>::LD + jb * TB + 2 * c2;
+}
+template <int N>
+__device__ __forceinline__ void store_ltiles(double* dst, const double* Mx) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d* d2 = reinterpret_cast<v2d*>(dst);
+  constexpr int NPL = Dims<N>::LTILES * TB * TB / 2 / WG;
+  static_assert(NPL * WG * 2 == Dims<N>::LTILES * TB * TB, "whole pieces per thread");
+  v2d v[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) { const int e = ltile_elem<N>(threadIdx.x + k * WG); v[k] = v2d{Mx[e], Mx[e + 1]}; }
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) d2[threadIdx.x + k * WG] = v[k];
 }
 
 // dot products over N terms, fully unrolled with four independent accumulators (LDS loads all in flight)
@@ -1249,7 +1277,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           nf_ = (a.fixed_lo && a.fixed_lo[a.zoff[t + 1] + tid] == a.fixed_hi[a.zoff[t + 1] + tid]) ? 1.0 : 0.0;
           if (tid < NU) nu_ = z[a.zoff[t + 1] + N + tid];
         }
-        store_fac<MAT>(fac + D::F_LA, MA);
+        if (DTO_WIDE_PACK_L) store_ltiles<N>(fac + D::F_LA, MA); else store_fac<MAT>(fac + D::F_LA, MA);
         store_fac<MAT>(fac + D::F_FT, MF);
         store_fac<MAT>(fac + D::F_VT, MV);
         DTO_WIDE_TICK(24);
@@ -1310,7 +1338,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         }
         DTO_WIDE_TICK(9);
         // ---- phase 10: E~ = L_M^-1 E'', bd^ = L_M^-1 bd~
-        store_fac<MAT>(fac + D::F_LM, MA);
+        if (DTO_WIDE_PACK_L) store_ltiles<N>(fac + D::F_LM, MA); else store_fac<MAT>(fac + D::F_LM, MA);
         if (w == 0) trsv_lower<N>(MA, bd);
         trsm_left_coltile<N>(ME, MA, LI, w);
         lds_barrier();
@@ -1478,6 +1506,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
     const double* fac = facb + (int64_t)t * D::FAC;
     const double* fv = fac + D::F_VEC;
     copy_mat<MAT>(ME, fac + D::F_ET);
+    static_assert(DTO_WIDE_SPLIT_BWD || !DTO_WIDE_PACK_L, "the in-kernel backward sweep reads unpacked factors");
     copy_mat<MAT>(MA, fac + D::F_LM);
     copy_mat<MAT>(MF, fac + D::F_FT);
     copy_mat<MAT>(MV, fac + D::F_VT);
@@ -1622,7 +1651,8 @@ __global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
   if (tid < DTO_WIDE_NSTAT) stat[tid] = a.stats ? a.stats[b * DTO_WIDE_NSTAT + tid] : 0.0;
 
   typedef double v2d __attribute__((ext_vector_type(2)));   // (HIP's double2 is a class: arrays of it stay in scratch)
-  v2d pe[NP], pm[NP], pf[NP], pv[NP], pa[NP];
+  constexpr int NPL = DTO_WIDE_PACK_L ? D::LTILES * TB * TB / 2 / WG : NP;   // pieces of a triangular factor
+  v2d pe[NP], pm[NPL], pf[NP], pv[NP], pa[NPL];
   double pvec[5 + 3 * NU], psc = 0.0;
   auto load_mat = [&](v2d (&r)[NP], const double* src) {
     const v2d* s2 = reinterpret_cast<const v2d*>(src);
@@ -1640,11 +1670,32 @@ __global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
       if (i < MAT / 2) d2[i] = r[k];
     }
   };
+  // triangular factors: the ten lower tiles straight from the record, written to their places in LDS (the upper tiles of MA
+  // are zeroed once below and never written)
+  auto load_l = [&](v2d (&r)[NPL], const double* src) {
+    const v2d* s2 = reinterpret_cast<const v2d*>(src);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int i = tid + k * WG;
+      if (DTO_WIDE_PACK_L || i < MAT / 2) r[k] = s2[i];
+    }
+  };
+  auto store_l = [&](double* dst, const v2d (&r)[NPL]) {
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int i = tid + k * WG;
+      if (DTO_WIDE_PACK_L) { const int e = ltile_elem<N>(i); dst[e] = r[k].x; dst[e + 1] = r[k].y; }
+      else if (i < MAT / 2) reinterpret_cast<v2d*>(dst)[i] = r[k];
+    }
+  };
+  if (DTO_WIDE_PACK_L) {
+    for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
+  }
   auto issue = [&](int t) {
     const double* fac = facb + (int64_t)t * D::FAC;
     const double* fv = fac + D::F_VEC;
     load_mat(pe, fac + D::F_ET);
-    load_mat(pm, fac + D::F_LM);
+    load_l(pm, fac + D::F_LM);
     load_mat(pf, fac + D::F_FT);
     load_mat(pv, fac + D::F_VT);
     if (tid < N) {
@@ -1661,11 +1712,11 @@ __global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
     }
   };
   issue(a.T - 2);
-  load_mat(pa, facb + (int64_t)(a.T - 2) * D::FAC + D::F_LA);
+  load_l(pa, facb + (int64_t)(a.T - 2) * D::FAC + D::F_LA);
   for (int t = a.T - 2; t >= 0; --t) {
     __syncthreads();
     store_mat(ME, pe);
-    store_mat(MA, pm);
+    store_l(MA, pm);
     store_mat(MF, pf);
     store_mat(MV, pv);
     if (tid < N) {
@@ -1693,8 +1744,8 @@ __global__ __launch_bounds__(WG) void k_wide_bwd(dto_wide_args a) {
       const double part = quad_sum(dotq_c<N>(MF, LD, lamv) + dotq_r<N>(MV, LD, yv));
       if ((tid & 3) == 0) xv[tid >> 2] = (bx[tid >> 2] - part) * dAi[tid >> 2];
     }
-    store_mat(MA, pa);   // L_M is done with (the trsv above ended at the last barrier)
-    if (t > 0) load_mat(pa, facb + (int64_t)(t - 1) * D::FAC + D::F_LA);
+    store_l(MA, pa);   // L_M is done with (the trsv above ended at the last barrier)
+    if (t > 0) load_l(pa, facb + (int64_t)(t - 1) * D::FAC + D::F_LA);
     __syncthreads();
     if (w == 0) trsv_lower_t<N>(MA, xv);
     __syncthreads();

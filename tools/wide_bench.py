@@ -29,7 +29,7 @@ n, m = 64, 1
 flop_stage = 2 * 64**3 / 3 + 3 * 64**3 + 4 * 2 * 64**3
 print(json.dumps(dict(T=T, B=B, ok=bool(ok), seconds=round(dt, 4), stages_per_s=round(B * (T - 1) / dt, 1),
                       us_per_stage_per_wg=round(dt / (T - 1) * 1e6, 2), gflops=round(B * (T - 1) * flop_stage / dt / 1e9, 1),
-                      factor_bytes_GB=round(B * T * s.footprint_wide() * 8 / 1e9, 2) if hasattr(s, "footprint_wide") else round(B * T * 21328 * 8 / 1e9, 2))))
+                      factor_bytes_GB=round(B * T * s.footprint_wide() * 8 / 1e9, 2) if hasattr(s, "footprint_wide") else round(B * T * 18128 * 8 / 1e9, 2))))
 
 # ---- evaluator callbacks on the same model: Jacobian nnz/s (HBM-write bound: the stage Jacobian is dense)
 Bj = min(B, 16)
