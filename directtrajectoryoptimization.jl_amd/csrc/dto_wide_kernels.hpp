@@ -1161,19 +1161,23 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, __shfl_xor(v, sft));
           if (l == 0) stat[3] = fmax(stat[3], v);
         }
-        // (skipped when no state of this knot is fixed: the pass over three LDS matrices costs ~3 k cycles a stage)
-        if (a.fixed_lo && cnt[6]) {
+        // (the pass itself is skipped when no state of this knot is fixed -- it costs ~3 k cycles a stage -- but its two barriers
+        //  stay: they also separate the statistics above, which read bx / buv on wavefront 3, from phase 5, where wavefront 0
+        //  changes them)
+        if (a.fixed_lo) {
           lds_barrier();
-          for (int i = tid; i < N * N; i += WG) {
-            const int r = i >> 6, c = i & 63;
-            if (fxm[r] != 0.0 || fxm[c] != 0.0) MA[r * LD + c] = (r == c) ? 1.0 : 0.0;
-            if (fxm[c] != 0.0) MF[r * LD + c] = 0.0;
-            if (fxm[r] != 0.0) MV[r * LD + c] = 0.0;
-          }
-          if (tid < N && fxm[tid] != 0.0) {
+          if (cnt[6]) {
+            for (int i = tid; i < N * N; i += WG) {
+              const int r = i >> 6, c = i & 63;
+              if (fxm[r] != 0.0 || fxm[c] != 0.0) MA[r * LD + c] = (r == c) ? 1.0 : 0.0;
+              if (fxm[c] != 0.0) MF[r * LD + c] = 0.0;
+              if (fxm[r] != 0.0) MV[r * LD + c] = 0.0;
+            }
+            if (tid < N && fxm[tid] != 0.0) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) au[j * N + tid] = 0.0;
-            bx[tid] = 0.0;
+              for (int j = 0; j < NU; ++j) au[j * N + tid] = 0.0;
+              bx[tid] = 0.0;
+            }
           }
           lds_barrier();
         }
