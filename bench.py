@@ -275,13 +275,21 @@ def main():
 
     T, B = a.horizon, a.batch
     # Safety net for the memory-sized default: solver state (~0.36 MB per instance at T = 1000, 0.49 MB when the batch may
-    # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 5 GB to spare (the estimate is the measured high-water mark); shrink by whole
-    # residencies of the sequential sweep (131 072 instances) if another process holds part of the HBM.
+    # switch to the chunked form) + z0, zout (0.08 MB) must fit what is free on this GPU with 5 GB to spare (the estimate is the
+    # measured high-water mark); shrink by whole residencies of the sequential sweep (131 072 instances) if another process
+    # holds part of the HBM.
+    if dist is not None:
+        # RCCL allocates its channel buffers at the first collective: size the batch against what is free AFTER one
+        warm = torch.zeros(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     free_b = torch.cuda.mem_get_info(dev)[0]
     # (+ 0.072 MB per instance for the second iterate / multiplier buffers of the fused UPDATE+EVAL pass: 8 (N_z + N_c) bytes)
-    # measured at the default batch: 301.6 GB in use at the high-water mark (hbm_free_min_gb 7.4 of 309) = this estimate
+    # measured at the default batch: 301.6 GB in use at the high-water mark (hbm_free_min_gb 7.4 of 309) = this estimate;
+    # with several ranks 8 GB more stay free for what RCCL and the gather of the trajectories allocate later.
     per_inst_of = lambda b: (0.41e6 if b > 131072 else 0.54e6) * (T / 1000.0) + 2 * 8.0 * 5 * T + 8.0 * 9 * T
-    while B > 131072 and B * per_inst_of(B) + 7e9 > free_b - 5e9:
+    margin = 5e9 if dist is None else 13e9
+    while B > 131072 and B * per_inst_of(B) + 7e9 > free_b - margin:
         B -= 131072
     if dist is not None:   # every rank runs the same shard size: the smallest any of them could take
         bt = torch.tensor([B], device=dev, dtype=torch.int64)
@@ -293,13 +301,34 @@ def main():
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
     n = s.nlp
     nz, nc, nj, nh = n.num_variables, n.num_constraint, n.num_jacobian, int(n.sizes.nnz_hess_key)
-    z0 = make_guesses_device(s, p, B, 1000 + rank, dev)
     st = torch.cuda.current_stream().cuda_stream
 
     # ---- solver: W warmup iterations, then exactly K timed iterations (in slices of 25 so that the throughput profile of the
     #      solve can be reported; a slice boundary is a stream synchronisation, nothing else)
     s.options.max_iter = max(1000, a.steps + a.warmup)          # the reference default; never cut a longer requested run short
-    s.begin_batch(z0.data_ptr(), B, nz, stream=st)
+    # An allocation failure in dto_solver_begin (DTO_ERR_DEVICE) must not cost the headline number: retry with one residency of
+    # the sequential sweep (131 072 instances) fewer, on every rank alike, and say so.
+    while True:
+        z0 = make_guesses_device(s, p, B, 1000 + rank, dev)
+        ok = 1
+        try:
+            s.begin_batch(z0.data_ptr(), B, nz, stream=st)
+        except RuntimeError:
+            ok = 0
+        if dist is not None:
+            okt = torch.tensor([ok], device=dev, dtype=torch.int64)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = int(okt[0])
+        if ok:
+            break
+        if B <= 131072:
+            raise RuntimeError(f"dto_solver_begin failed at the smallest batch ({B} instances)")
+        s.release_state()
+        del z0
+        torch.cuda.empty_cache()
+        if rank == 0:
+            print(f"[bench] dto_solver_begin failed at {B} instances; retrying with {B - 131072}", file=sys.stderr, flush=True)
+        B -= 131072
     if a.warmup:
         s.iterate_batch(a.warmup, stream=st)
     torch.cuda.synchronize()
