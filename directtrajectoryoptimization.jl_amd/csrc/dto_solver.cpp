@@ -390,6 +390,9 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   };
   const auto t_start = std::chrono::steady_clock::now();
   constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
+  const char* dump_prefix = getenv("DTO_WIDE_DUMP");   // debug: <prefix>_L<k>_<what>.bin of the first DTO_WIDE_DUMP_MAX launches
+  int dump_launch = 0;
+  const int dump_max = getenv("DTO_WIDE_DUMP_MAX") ? atoi(getenv("DTO_WIDE_DUMP_MAX")) : 1;
   bool any_running = true;
   while (any_running) {
     // ---- A: first factorisation attempt of every running instance
@@ -414,6 +417,26 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       WTRY(hipMemcpyAsync(h_flags.data(), d_flags, B * sizeof(int), hipMemcpyDeviceToHost, st));
       WTRY(hipMemcpyAsync(h_stats.data(), d_stats, h_stats.size() * sizeof(double), hipMemcpyDeviceToHost, st));
       WTRY(hipStreamSynchronize(st));
+      if (dump_prefix && dump_launch < dump_max) {
+        // debug (tools/wide_debug.py): everything the launch produced -- factor records, step, statistics, flags -- plus its inputs
+        auto wr = [&](const char* what, const void* dptr, size_t bytes) {
+          std::vector<char> hb(bytes);
+          if (hipMemcpy(hb.data(), dptr, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+          char fn[1024];
+          snprintf(fn, sizeof(fn), "%s_L%d_%s.bin", dump_prefix, dump_launch, what);
+          if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), 1, bytes, f); fclose(f); }
+        };
+        wr("fac", p->wide_fac, need_fac * sizeof(double));
+        wr("dz", dz, (size_t)B * Nz * sizeof(double));
+        wr("dlam", dlam, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double));
+        wr("z", z, (size_t)B * Nz * sizeof(double));
+        wr("lam", lam, (size_t)B * std::max<int64_t>(1, Nc) * sizeof(double));
+        wr("stats", d_stats, (size_t)B * DTO_WIDE_NSTAT * sizeof(double));
+        wr("flags", d_flags, (size_t)B * sizeof(int));
+        wr("dw", d_dw, (size_t)B * sizeof(double));
+        wr("active", d_active, (size_t)B * sizeof(int));
+        ++dump_launch;
+      }
       bool again = false, mu_moved = false;
       for (int64_t i = 0; i < B; ++i) {
         if (!h_active[(size_t)i]) continue;

@@ -77,6 +77,19 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef DTO_WIDE_LDL_RANK1
 #define DTO_WIDE_LDL_RANK1 1   // 0: the blocked LDL^T with one-wavefront diagonal tiles (rounds 1-3), kept for A/B runs
 #endif
+#ifndef DTO_WIDE_PROFILE
+#define DTO_WIDE_PROFILE 0     // 1: cycle stamps of workgroup 0 compiled in (tools/wide_profile.py builds its plugin with it)
+#endif
+// ---- debug shapes of the forward sweep (round 5; tests/test_wide_flagsets_gpu.py, tools/wide_debug.py)
+#ifndef DTO_WIDE_DBG_SYNC
+#define DTO_WIDE_DBG_SYNC 0    // 1: every lds_barrier() also drains the vector-memory counter (s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier)
+#endif
+#ifndef DTO_WIDE_DBG_POISON
+#define DTO_WIDE_DBG_POISON 0  // 1: the whole LDS image of k_wide_step starts as signalling NaNs: a read of something never written shows
+#endif
+#ifndef DTO_WIDE_DBG_JITTER
+#define DTO_WIDE_DBG_JITTER 0  // 1: every wavefront sleeps a pseudo-random time after each barrier: a hand-off that is not ordered fails
+#endif
 #ifndef DTO_WIDE_SPLIT_BWD
 #define DTO_WIDE_SPLIT_BWD 1   // 1: the backward sweep is its own kernel (k_wide_bwd) that prefetches the next stage's factor record
 #endif                         //    into registers while it works on the current one; 0: the tail of k_wide_step (rounds 1-4)
@@ -265,7 +278,28 @@ __device__ __forceinline__ void diag_tile(double* Mx, int ld, int o, double* d, 
 
 // barrier for phases that exchange data through LDS only: __syncthreads() also waits for every outstanding global STORE of the
 // wavefront (the factor records streaming to HBM) -- a full memory round trip at each of the barriers that follow a copy
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// INVARIANT: only LDS data is handed from thread to thread across this barrier.  No global write of k_wide_step is read
+// by another thread of the same launch (the factor records are consumed by k_wide_bwd, the next launch); a hand-off through
+// global memory needs __syncthreads() (+ a fence), as the in-kernel backward sweep (DTO_WIDE_SPLIT_BWD = 0) does.
+#if DTO_WIDE_DBG_JITTER
+__device__ __forceinline__ void dbg_jitter() {
+  // xorshift of (wavefront, clock): 0..63 x 64 cycles of s_sleep, different in every wavefront at every barrier
+  unsigned x = (unsigned)__builtin_readcyclecounter() * 2654435761u + (threadIdx.x >> 6) * 40503u;
+  x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+  const unsigned n = __builtin_amdgcn_readfirstlane(x) & 63u;
+  for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if DTO_WIDE_DBG_SYNC
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if DTO_WIDE_DBG_JITTER
+  dbg_jitter();
+#endif
+}
 
 // ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
 //      On exit: strict lower part = L, d/dinv = pivots, LI = inverses of the unit-lower diagonal tiles.
@@ -325,8 +359,12 @@ typedef __attribute__((address_space(3))) int lds_int;
 template <int N>
 __device__ DTO_WIDE_LDL_INLINE void ldl_rank1(lds_double* Mx, lds_double* d, lds_double* dinv, lds_double* LI, lds_double* colb,
                                                     lds_double* dg0, double piv_tol, lds_int* cnt, long long* prof = nullptr) {
-  long long tq_ = prof ? clock64() : 0;
+  long long tq_ = (DTO_WIDE_PROFILE && prof) ? clock64() : 0;
+#if DTO_WIDE_PROFILE
 #define DTO_LDL_TICK(slot) do { if (prof && threadIdx.x == 0) { const long long t_ = clock64(); prof[slot] += t_ - tq_; tq_ = t_; } } while (0)
+#else
+#define DTO_LDL_TICK(slot) do { (void)tq_; } while (0)
+#endif
   using D = Dims<N>;
   constexpr int LD = D::LD;
   static_assert(N == 64 && WG == 256, "thread comb: 16 x 16 threads, 4 x 4 elements each");
@@ -803,6 +841,10 @@ __device__ __forceinline__ double dotq_cs(const double* A, int ld, const double*
   return s0 + s1;
 }
 
+// Cycle stamps of workgroup 0 (tools/wide_profile.py): compiled in only with -DDTO_WIDE_PROFILE=1.  A stamp is a never-taken
+// DIVERGENT branch (threadIdx.x == 0) around memory instructions inside the stage loop -- the shape that made this compiler emit
+// wrong code at -O3 in the lane-per-instance sweeps; the product's stage loop carries none.
+#if DTO_WIDE_PROFILE
 #define DTO_WIDE_TICK(slot)                                                       \
   do {                                                                             \
     if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {                           \
@@ -811,6 +853,9 @@ __device__ __forceinline__ double dotq_cs(const double* A, int ld, const double*
       tick_ = now_;                                                                \
     }                                                                              \
   } while (0)
+#else
+#define DTO_WIDE_TICK(slot) do { (void)tick_; } while (0)
+#endif
 
 // barrier terms of one variable with bounds lo < hi (at least one finite): sig = z_L/(x-lo) + z_U/(hi-x),
 // br = mu/(x-lo) - mu/(hi-x); dz_L = mu/(x-lo) - z_L - z_L/(x-lo) dx and likewise for the upper bound are formed from the same
@@ -943,6 +988,13 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
   const double taub = fmax(a.tau_min, 1.0 - mub);
 
   long long tick_ = clock64();
+#if DTO_WIDE_DBG_POISON
+  // (before anything else of this kernel writes LDS: the statistics block above is written again below)
+  __syncthreads();
+  for (int i = tid; i < SL::DOUBLES; i += WG) sm[i] = __longlong_as_double(0x7ff4dead0000beefLL);
+  __syncthreads();
+  if (tid < 16) stat[tid] = (tid == DTO_WIDE_APMAX || tid == DTO_WIDE_ADMAX) ? 1.0 : 0.0;
+#endif
   for (int i = tid; i < MAT; i += WG) MA[i] = 0.0;
   if (tid < N) { byc[tid] = 0.0; gyp[tid] = 0.0; }
   if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
@@ -1258,8 +1310,8 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(5);
         // ---- phase 6: A = L_A D_A L_A'
-        if (DTO_WIDE_LDL_RANK1) ldl_rank1<N>((lds_double*)MA, (lds_double*)dA, (lds_double*)dAi, (lds_double*)LI, (lds_double*)colb, (lds_double*)dg0, a.piv_tol, (lds_int*)cnt, blockIdx.x == 0 ? a.prof : nullptr);
-        else ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt, blockIdx.x == 0 ? a.prof : nullptr);
+        if (DTO_WIDE_LDL_RANK1) ldl_rank1<N>((lds_double*)MA, (lds_double*)dA, (lds_double*)dAi, (lds_double*)LI, (lds_double*)colb, (lds_double*)dg0, a.piv_tol, (lds_int*)cnt, (DTO_WIDE_PROFILE && blockIdx.x == 0) ? a.prof : nullptr);
+        else ldl_blocked<N>(MA, dA, dAi, LI, a.piv_tol, cnt, (DTO_WIDE_PROFILE && blockIdx.x == 0) ? a.prof : nullptr);
         DTO_WIDE_TICK(6);
         // ---- phase 7: F~ = F L_A^-T (row tiles), V~ = L_A^-1 V (column tiles), bx~ = L_A^-1 bx
         if (w == 0) trsv_lower<N>(MA, bx);

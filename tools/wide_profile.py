@@ -1,6 +1,7 @@
 """Per-phase cycle breakdown of the wide-stage KKT kernel (workgroup 0): python tools/wide_profile.py [T] [B]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["DTO_PLUGIN_CXXFLAGS"] = (os.environ.get("DTO_PLUGIN_CXXFLAGS", "") + " -DDTO_WIDE_PROFILE=1").strip()   # stamps are compiled in on request only
 import torch
 prof = torch.zeros(32, dtype=torch.int64, device="cuda")
 os.environ["DTO_WIDE_PROF"] = hex(prof.data_ptr())
