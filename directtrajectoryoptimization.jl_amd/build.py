@@ -20,6 +20,7 @@ def _digest() -> str:
     h = hashlib.sha256()
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
     deps.append(os.path.join(_HERE, "..", "include", "dto.h"))
+    deps.append(os.path.abspath(__file__))     # the compiler flags are part of what the library is
     for d in deps:
         if os.path.isfile(d):
             with open(d, "rb") as f:
@@ -40,8 +41,9 @@ def build_runtime(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = LIB + f".tmp{os.getpid()}"
+    # (-amdgpu-remove-redundant-endcf=0: see plugin.py BASE_CXXFLAGS -- every device build keeps the exec restores)
     cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wall",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+           "-mllvm", "-amdgpu-remove-redundant-endcf=0", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

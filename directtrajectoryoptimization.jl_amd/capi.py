@@ -10,7 +10,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 2
+DTO_ABI_VERSION = 3
 DTO_OK = 0
 STATUS_NAMES = {0: "DTO_OK", 1: "DTO_ERR_INVALID", 2: "DTO_ERR_PLUGIN", 3: "DTO_ERR_DEVICE",
                 4: "DTO_ERR_UNSUPPORTED", 5: "DTO_ERR_NOT_CONVERGED"}
@@ -58,14 +58,19 @@ class COptions(C.Structure):
                 ("delta_c", C.c_double), ("delta_w_init", C.c_double), ("check_every", C.c_int), ("max_cpu_time", C.c_double),
                 ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int), ("acceptable_dual_inf_tol", C.c_double),
                 ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
-                ("acceptable_obj_change_tol", C.c_double), ("diverging_iterates_tol", C.c_double), ("mu_target", C.c_double)]
+                ("acceptable_obj_change_tol", C.c_double), ("diverging_iterates_tol", C.c_double), ("mu_target", C.c_double),
+                ("line_search", C.c_int), ("penalty_switch_theta", C.c_double)]
+
+
+DTO_LS_FILTER, DTO_LS_PENALTY_FILTER = 0, 1
+DTO_STATUS_CPU_TIME = 6
 
 
 # enum dto_scal (csrc/dto_kkt_kernels.hpp)
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
            "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog",
-           "acc_count", "f_last", "xmax", "nneg"]
+           "acc_count", "f_last", "xmax", "nneg", "ls_mode", "ascale"]
 
 
 class DtoError(RuntimeError):

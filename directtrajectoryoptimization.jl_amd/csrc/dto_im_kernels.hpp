@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void kim_init(dto_im_args a) {
     });
   }
   if (blockIdx.x % a.nwin_l == 0 && threadIdx.x == 0) {
-    sc[SC_STATUS] = 0.0; sc[SC_ITER] = 0.0; sc[SC_MU] = mu0; sc[SC_PENALTY] = 1.0; sc[SC_DELTA_W] = 0.0;
+    sc[SC_STATUS] = 0.0; sc[SC_ITER] = 0.0; sc[SC_MU] = mu0; sc[SC_PENALTY] = 0.0; sc[SC_LS_MODE] = o.ls_penalty ? 1.0 : 2.0; sc[SC_ASCALE] = 1.0; sc[SC_DELTA_W] = 0.0;
     sc[SC_DELTA_LAST] = 0.0; sc[SC_LS_FAIL] = 0.0; sc[SC_NFACT] = 0.0; sc[SC_ALPHA] = 0.0;
     sc[SC_THETA_MAX] = -1.0; sc[SC_THETA_MIN] = -1.0; sc[SC_FILTER_N] = 0.0; sc[SC_LS_KIND] = 0.0; sc[SC_QN_RESET] = 1.0;
     sc[SC_FULL_STREAK] = 0.0; sc[SC_SHORT_STREAK] = 0.0; sc[SC_WATCHDOG] = 0.0; sc[SC_ACC_COUNT] = 0.0; sc[SC_F_LAST] = 1e300;
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(WAVE, WPS) void kim_bwd(dto_im_args a) {
   wait_vm();
   if (live) {
     sc[SC_DMERIT] = acc.gphid;
-    sc[SC_ALPHA_PMAX] = acc.apmax;
+    sc[SC_ALPHA_PMAX] = acc.apmax * (sc[SC_LS_MODE] == 1.0 ? sc[SC_ASCALE] : 1.0);
     sc[SC_ALPHA_DMAX] = acc.admax;
   }
   }

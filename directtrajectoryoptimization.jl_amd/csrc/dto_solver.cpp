@@ -173,6 +173,9 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   if (const char* e = getenv("DTO_WATCHDOG")) sscanf(e, "%d,%d", &o.watchdog_trigger, &o.watchdog_trials);  // experiment knob
   o.newton_only = 0; o.fixed_delta_w = 0.0;
   o.warm = 0; o.mu_warm = 0.0;
+  // two-phase line search (k_ls_reduce): l1-penalty while theta_inf > penalty_switch_theta, then Ipopt's filter
+  o.ls_penalty = u.line_search == DTO_LS_PENALTY_FILTER ? 1 : 0; o.ls_switch = u.penalty_switch_theta;
+  if (const char* e = getenv("DTO_LS_MERIT")) o.ls_penalty = atoi(e);   // experiment knob (same name as the C port's)
 }
 
 struct BorderStats;
@@ -389,9 +392,10 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     return lrc;
   };
   const auto t_start = std::chrono::steady_clock::now();
+  bool timed_out = false;   // Options.max_cpu_time expired: the running instances come back with DTO_STATUS_CPU_TIME
   constexpr double G_TH = 1e-5, G_PHI = 1e-8, S_TH = 1.1, S_PHI = 2.3, ETA = 1e-8;
   const char* dump_prefix = getenv("DTO_WIDE_DUMP");   // debug: <prefix>_L<k>_<what>.bin of the first DTO_WIDE_DUMP_MAX launches
-  int dump_launch = 0;
+  int dump_launch = 0, dump_merit = 0;
   const int dump_max = getenv("DTO_WIDE_DUMP_MAX") ? atoi(getenv("DTO_WIDE_DUMP_MAX")) : 1;
   bool any_running = true;
   while (any_running) {
@@ -530,6 +534,11 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     { const int lrc = launch(DTO_WIDE_MERIT); if (lrc) { cleanup(); return hip_fail((hipError_t)lrc, "wide merit"); } }
     WTRY(hipMemcpyAsync(h_merit.data(), d_merit, h_merit.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     WTRY(hipStreamSynchronize(st));
+    if (dump_prefix && dump_merit < dump_max) {   // debug: the line-search table of this iteration
+      char fn[1024];
+      snprintf(fn, sizeof(fn), "%s_M%d_merit.bin", dump_prefix, dump_merit++);
+      if (FILE* f = fopen(fn, "wb")) { fwrite(h_merit.data(), sizeof(double), h_merit.size(), f); fclose(f); }
+    }
     for (int64_t i = 0; i < B; ++i) {
       h_alpha[(size_t)i] = 0.0;
       if (!h_active[(size_t)i]) continue;
@@ -596,7 +605,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
     hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, z, (const double*)dz, (const double*)d_alpha, Nz, Nz, Nz);
     if (Nc > 0)
       hipLaunchKernelGGL(k_rows_axpy, dim3((unsigned)(B * AXPY_BLOCKS_PER_ROW)), dim3(256), 0, st, lam, (const double*)dlam, (const double*)d_alpha, Nc, Nc, Nc);
-    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
+    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) { timed_out = true; break; }
   }
   WTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), B, hipMemcpyDeviceToDevice, st));
   if (mu_out && Nc > 0)
@@ -604,7 +613,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
   WTRY(hipStreamSynchronize(st));
 #undef WTRY
   for (int64_t i = 0; i < B; ++i) {
-    if (status) status[i] = I[(size_t)i].status;
+    if (status) status[i] = (I[(size_t)i].status == 0 && timed_out) ? DTO_STATUS_CPU_TIME : I[(size_t)i].status;
     if (iterations) iterations[i] = I[(size_t)i].iter;
   }
   cleanup();
@@ -1276,13 +1285,16 @@ static int im_run(Problem* p, double* x_out, int64_t ldxo, double* mu_out, int64
   int rc, running = 1;
   const int group = std::max(1, S.user.check_every);
   const auto t_start = std::chrono::steady_clock::now();
+  bool timed_out = false;
   const int64_t pass_cap = ((int64_t)S.user.max_iter + 1) * (S.opt.max_refactor + 2) + 2;
   for (int64_t done = 0; running > 0 && done < pass_cap;) {
     for (int k = 0; k < group; ++k, ++done)
       if ((rc = im_pass(p, st, -1))) return rc;
     if ((rc = im_count(p, st, -1, &running, nullptr))) return rc;
-    if (S.user.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time)
+    if (S.user.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time) {
+      timed_out = true;
       break;
+    }
   }
   if (x_out) {
     if (ldxo < p->L.Nz) return set_error(DTO_ERR_INVALID, "ldxo < num_variables");
@@ -1294,7 +1306,7 @@ static int im_run(Problem* p, double* x_out, int64_t ldxo, double* mu_out, int64
   }
   if ((rc = im_fetch_scalars(p, st))) return rc;
   for (int64_t i = 0; i < S.B; ++i) {
-    if (status) status[i] = (int32_t)im_hscal(S, i, SC_STATUS);
+    if (status) { status[i] = (int32_t)im_hscal(S, i, SC_STATUS); if (status[i] == 0 && timed_out) status[i] = DTO_STATUS_CPU_TIME; }
     if (iterations) iterations[i] = (int32_t)im_hscal(S, i, SC_ITER);
   }
   return DTO_OK;
@@ -1814,6 +1826,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
   const double mu_floor = std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
   std::vector<char> mu_moved((size_t)B, 0);
   const auto t_start = std::chrono::steady_clock::now();
+  bool timed_out = false;
   for (;;) {
     if (ni > 0) {
       for (int64_t i = 0; i < B; ++i)
@@ -2059,13 +2072,13 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       }
       GRC(put_nu());
     }
-    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) break;
+    if (u.max_cpu_time > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > u.max_cpu_time) { timed_out = true; break; }
   }
   GTRY(hipMemcpy2DAsync(x_out, ldxo * sizeof(double), z, Nz * sizeof(double), Nz * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, st));
   if (mu_out) GTRY(hipMemcpy2DAsync(mu_out, ldmuo * sizeof(double), lam, Nc * sizeof(double), Nc * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, st));
   GTRY(hipStreamSynchronize(st));
   for (int64_t i = 0; i < B; ++i) {
-    if (status) status[i] = I[(size_t)i].status;
+    if (status) status[i] = (I[(size_t)i].status == 0 && timed_out) ? DTO_STATUS_CPU_TIME : I[(size_t)i].status;
     if (iterations) iterations[i] = I[(size_t)i].iter;
   }
   cleanup();
@@ -2092,6 +2105,7 @@ int dto_options_default(dto_options* o) {
   o->acceptable_tol = 1e-6; o->acceptable_iter = 15; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
   o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5;
   o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
+  o->line_search = DTO_LS_PENALTY_FILTER; o->penalty_switch_theta = 1.0;
   return DTO_OK;
 }
 
@@ -2554,6 +2568,7 @@ int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
   const int chunk = std::max(1, S.user.check_every);
   int done_iters = 0;
   const auto t_start = std::chrono::steady_clock::now();
+  bool timed_out = false;
   // max_iter + 1 evaluations: the last one only classifies the final iterate
   while (done_iters <= S.user.max_iter) {
     const int n = std::min(chunk, S.user.max_iter + 1 - done_iters);
@@ -2565,15 +2580,17 @@ int dto_solver_run(dto_problem* h, double* x_out, int64_t ldxo, double* mu_out, 
     if (n_run == 0) break;
     // tiles are only worth running while they hold work: close the gaps once a quarter of the active lanes has finished
     if (S.G_active > 1 && n_run < (int64_t)48 * S.G_active && (rc = dto::repack(p, st, nullptr))) return rc;
-    // Options.max_cpu_time (src/options.jl:10): the instances still running are handed back as they are (status 0)
+    // Options.max_cpu_time (src/options.jl:10): the instances still running are handed back as they are (DTO_STATUS_CPU_TIME)
     if (S.user.max_cpu_time > 0.0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time)
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > S.user.max_cpu_time) {
+      timed_out = true;
       break;
+    }
   }
   if ((rc = dto_solver_end(h, x_out, ldxo, mu_out, ldmuo, (void*)st))) return rc;
   HIP_TRY(hipStreamSynchronize(st));
   for (int64_t i = 0; i < S.B; ++i) {
-    if (status) status[i] = (int32_t)dto::hscal(S, i, SC_STATUS);
+    if (status) { status[i] = (int32_t)dto::hscal(S, i, SC_STATUS); if (status[i] == 0 && timed_out) status[i] = DTO_STATUS_CPU_TIME; }
     if (iterations) iterations[i] = (int32_t)dto::hscal(S, i, SC_ITER);
   }
   return DTO_OK;

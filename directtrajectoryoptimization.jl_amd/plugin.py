@@ -633,6 +633,17 @@ def _extra_flags() -> List[str]:
 # pass behind an `s_nop 15` that drains the matrix pipe (csrc/dto_wide_kernels.hpp: mm_row4)
 WIDE_CXXFLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
+# Every device build: keep the exec-mask restore of EVERY divergent region (round 5, DESIGN.md section 4.3 "root cause").
+# AMD clang 22 (ROCm 7.2) drops the restore of an inner `if` whose end coincides with the end of the enclosing divergent region
+# (`s_and_saveexec` becomes `s_and_b64 exec, exec, cond`, SILowerControlFlow's redundant-endcf removal, before register
+# allocation); the register allocator may then place a reload of a split live range in the merge block between the two ends,
+# where it executes with the INNER mask: the lanes outside it keep a stale register.  That was the wrong-result mode of the
+# fused sweeps (round 3/4: a never-taken `if (prof && tid == 0)` inside the stage loop) and of the solver-mode use of
+# k_wide_step (`if (w == 0) { ...; if (a.stats) { ...; if (l == 0) ...; } }` around a register whose value the pass over the
+# fixed states needs in every lane).  tools/check_exec_merge.py finds the pattern in the ISA; tests/test_exec_merge_guard.py
+# pins it.
+BASE_CXXFLAGS = ["-mllvm", "-amdgpu-remove-redundant-endcf=0"]
+
 
 def _prepare_plugin(st: Structure, name: str):
     """(path of the plugin .so, compile command or None if it is already built).  Not thread-safe (the structural-key
@@ -644,7 +655,7 @@ def _prepare_plugin(st: Structure, name: str):
         key_src = generate_source(st, name)
     finally:
         _cg.STRUCTURAL_KEYS = False
-    flags = (WIDE_CXXFLAGS if st.wide else []) + _extra_flags()
+    flags = BASE_CXXFLAGS + (WIDE_CXXFLAGS if st.wide else []) + _extra_flags()
     digest = hashlib.sha256((key_src + _kernel_headers_digest() + GENERATOR_VERSION + " ".join(flags)).encode()).hexdigest()[:16]
     os.makedirs(PLUGIN_DIR, exist_ok=True)
     base = os.path.join(PLUGIN_DIR, f"{name}_{digest}")

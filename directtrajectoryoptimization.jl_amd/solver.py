@@ -53,6 +53,11 @@ class Options:
     # derivatives derived from the traced expressions (they cost nothing here) with a one-time HessianModeNotice, "exact": the
     # same without the notice; "sr1": per-stage SR1 blocks, no second derivatives evaluated (Solver.hessian_mode reports it).
     hessian_approximation: str = "auto"
+    # not reference fields either (dto_options.line_search / penalty_switch_theta, include/dto.h): "penalty-filter" chooses the
+    # step size on the l1 exact-penalty function while max |c_i| > penalty_switch_theta and hands over to Ipopt's filter then;
+    # "filter" is the filter line search from the first iteration (what Ipopt runs for the reference)
+    line_search: str = "penalty-filter"
+    penalty_switch_theta: float = 1.0
 
 
 class Indices:
@@ -346,6 +351,10 @@ def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
     c.acceptable_dual_inf_tol, c.acceptable_constr_viol_tol = float(o.acceptable_dual_inf_tol), float(o.acceptable_constr_viol_tol)
     c.acceptable_compl_inf_tol, c.acceptable_obj_change_tol = float(o.acceptable_compl_inf_tol), float(o.acceptable_obj_change_tol)
     c.diverging_iterates_tol, c.mu_target = float(o.diverging_iterates_tol), float(o.mu_target)
+    if o.line_search not in ("penalty-filter", "filter"):
+        raise ValueError(f"Options.line_search must be 'penalty-filter' or 'filter', not {o.line_search!r}")
+    c.line_search = capi.DTO_LS_PENALTY_FILTER if o.line_search == "penalty-filter" else capi.DTO_LS_FILTER
+    c.penalty_switch_theta = float(o.penalty_switch_theta)
     return c
 
 
@@ -768,7 +777,7 @@ def solve(solver: Solver):
     solver.status, solver.iterations = int(status.value), int(iters.value)
     if solver.options.print_level >= 5:
         # the reference prints Ipopt's iteration log at this level (src/options.jl:23); here: one summary line
-        names = {0: "cut off (max_cpu_time)", 1: "converged", 2: "maximum iterations reached", 3: "failed (non-finite iterate)"}
+        names = {0: "running", 6: "cut off (max_cpu_time)", 1: "converged", 2: "maximum iterations reached", 3: "failed (non-finite iterate)"}
         try:
             f = solver.nlp.eval_objective(solver._solution)
         except Exception:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 2
+#define DTO_ABI_VERSION 3
 
 enum dto_status {
   DTO_OK = 0,
@@ -169,7 +169,7 @@ typedef struct dto_options {
   double delta_w_init;      /* 1e-4  first primal regularisation tried when the inertia is wrong */
   int check_every;          /* host polls the batch for completion every this many iterations */
   double max_cpu_time;      /* 300   src/options.jl:10: wall-clock limit of one dto_solve[_batch] call in seconds; instances
-                               still running when it expires are returned as they are with status 0 ("cut off") */
+                               still running when it expires are returned as they are with DTO_STATUS_CPU_TIME (6) */
   /* Ipopt's "acceptable" termination (src/options.jl:15-20): an instance stops with status 4 after `acceptable_iter`
    * consecutive iterations whose scaled error is <= acceptable_tol, whose unscaled residuals are within the three
    * acceptable_*_tol values and whose objective changed by less than acceptable_obj_change_tol (relative). 0 = off. */
@@ -183,7 +183,18 @@ typedef struct dto_options {
   double mu_target;                  /* 1e-4  src/options.jl:22: the barrier parameter is not driven below it and the
                                         complementarity in every termination test is measured against it (Ipopt's
                                         mu_target semantics); only matters for problems with bounds / inequality rows */
+  /* ABI 3: globalisation.  DTO_LS_FILTER = Ipopt's filter line search from the first iteration (what the reference runs,
+   * src/solver.jl:45-47).  DTO_LS_PENALTY_FILTER (default) = while the iterate is far from the constraint manifold
+   * (max |c_i| > penalty_switch_theta) the step size is chosen on the l1 exact-penalty function, then the filter takes over:
+   * same minimisers class, acrobot T = 1000 from the reference's straight-line guess in a median of ~60 instead of ~630
+   * iterations.  Lane-per-instance solver path; the tile (64-state) and bordered paths run the filter. */
+  int line_search;                   /* DTO_LS_PENALTY_FILTER */
+  double penalty_switch_theta;       /* 1.0 */
 } dto_options;
+enum { DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 };
+/* per-instance status reported by dto_solve[_batch] / dto_solver_run / dto_solver_stats */
+enum { DTO_STATUS_RUNNING = 0, DTO_STATUS_CONVERGED = 1, DTO_STATUS_MAX_ITER = 2, DTO_STATUS_NONFINITE = 3,
+       DTO_STATUS_ACCEPTABLE = 4, DTO_STATUS_DIVERGING = 5, DTO_STATUS_CPU_TIME = 6 /* cut off by max_cpu_time */ };
 int dto_options_default(dto_options* o);
 
 /* One regularised Newton-KKT step at given (x, mu), all constraints treated as equalities and bounds
@@ -221,7 +232,7 @@ int dto_kkt_solve(dto_problem* p, const double* rhs_x, int64_t ldrx, const doubl
  * x0: DEVICE [B][ldx] initial guesses (what initialize_states!/initialize_controls! set,
  * src/solver.jl:23-39); x_out/mu_out: DEVICE [B][ld*] final accepted iterates (get_trajectory,
  * src/solver.jl:41-43, returns the last *evaluated* point in the reference -- here it is the accepted one);
- * status/iterations: HOST [B] (0 running/cut off, 1 converged, 2 max_iter, 3 failed: non-finite iterate,
+ * status/iterations: HOST [B] (0 running, 6 cut off by max_cpu_time, 1 converged, 2 max_iter, 3 failed: non-finite iterate,
  * 4 converged to the acceptable level, 5 diverging iterates).
  * Paths by model: lane-per-instance tiles (states <= 16; bounds, inequality rows, per-instance parameters); the tile (MFMA)
  * kernels for 64-state models (variables free, fixed or bounded; no stage constraints, one to four actions, shared or per-instance parameters); a

@@ -17,7 +17,7 @@
 # tests/c_abi/drive_solve.c exercises from plain C.
 
 const libdto = get(ENV, "DTO_AMD_LIB", joinpath(@__DIR__, "..", "directtrajectoryoptimization.jl_amd", "libdto_hip.so"))
-const DTO_ABI_VERSION = Cint(2)
+const DTO_ABI_VERSION = Cint(3)
 
 struct DtoSpec                      # include/dto.h: dto_problem_spec
     abi_version::Cint
@@ -51,6 +51,8 @@ struct DtoOptions                   # include/dto.h: dto_options (src/options.jl
     acceptable_obj_change_tol::Float64
     diverging_iterates_tol::Float64
     mu_target::Float64
+    line_search::Cint               # DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 (default)
+    penalty_switch_theta::Float64
 end
 
 struct DtoBatch                     # include/dto.h: dto_batch (DEVICE pointers)
@@ -68,7 +70,7 @@ DtoOptions(o::Options) = DtoOptions(o.tol, o.s_max, o.max_iter, o.dual_inf_tol, 
                                     0.1, 1.0e-8, 1.0e-4, 10, o.max_cpu_time,
                                     o.acceptable_tol, o.acceptable_iter, o.acceptable_dual_inf_tol,
                                     o.acceptable_constr_viol_tol, o.acceptable_compl_inf_tol, o.acceptable_obj_change_tol,
-                                    o.diverging_iterates_tol, o.mu_target)
+                                    o.diverging_iterates_tol, o.mu_target, Cint(1), 1.0)
 
 mutable struct GPUEvaluator <: MOI.AbstractNLPEvaluator
     handle::Ptr{Cvoid}

@@ -48,6 +48,8 @@ typedef struct {
   double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
   double delta_c, delta_w_init, delta_w_max, delta_w_exact_cap, kappa_w_minus, kappa_w_plus, kappa_w_plus_first, piv_tol;
   int max_refactor, watchdog_trigger, watchdog_trials, max_soc;
+  int ls_penalty;        /* 1: l1-penalty line search while the iterate is far from the constraint manifold, then the filter */
+  double ls_switch;      /* ... until theta_inf <= ls_switch (dto_options.penalty_switch_theta) */
 } port_options;
 
 typedef struct {
@@ -71,8 +73,10 @@ typedef struct {
   int status, iter, nfact, nsoc, filter_n, ls_fail, full_streak, short_streak, watchdog, acc_count, ls_kind;
   double f, f_last, th1, thinf, dinf, compl, e0, logbar, xmax, mu, merit0;
   double szmax, iszmax, sumlam, sumz;
+  double delta_lm;
   double delta_w, delta_last, gamma, alpha, alpha_pmax, alpha_dmax, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
+  int ls_mode; double nu_pen, ascale;   /* line-search phase (1 penalty, 2 filter), penalty parameter, trial-step scale of the penalty phase */
 } port_solver;
 
 static int np_of(const port_solver* S, int t) { return t < S->T - 1 ? S->n + S->m : S->n; }
@@ -95,6 +99,9 @@ void port_default_options(port_options* o) {
   if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &o->watchdog_trigger, &o->watchdog_trials);
   if (getenv("DTO_EXACT_CAP")) o->delta_w_exact_cap = atof(getenv("DTO_EXACT_CAP"));
   if (getenv("DTO_MAX_SOC")) o->max_soc = atoi(getenv("DTO_MAX_SOC"));
+  o->ls_penalty = 1; o->ls_switch = 1.0;
+  if (getenv("DTO_LS_MERIT")) o->ls_penalty = atoi(getenv("DTO_LS_MERIT"));          /* experiment knobs */
+  if (getenv("DTO_LS_SWITCH_INF")) o->ls_switch = atof(getenv("DTO_LS_SWITCH_INF"));
 }
 
 port_solver* port_create(const char* model, int T, const int* con, const double* lo, const double* hi, int max_iter) {
@@ -151,11 +158,13 @@ void port_set_int(port_solver* S, const char* name, int v) {
   else if (!strcmp(name, "watchdog_trigger")) S->o.watchdog_trigger = v;
   else if (!strcmp(name, "watchdog_trials")) S->o.watchdog_trials = v;
   else if (!strcmp(name, "acceptable_iter")) S->o.acceptable_iter = v;
+  else if (!strcmp(name, "ls_penalty")) S->o.ls_penalty = v;
 }
 void port_set_double(port_solver* S, const char* name, double v) {
   if (!strcmp(name, "mu_target")) S->o.mu_target = v;
   else if (!strcmp(name, "tol")) S->o.tol = v;
   else if (!strcmp(name, "delta_w_exact_cap")) S->o.delta_w_exact_cap = v;
+  else if (!strcmp(name, "ls_switch")) S->o.ls_switch = v;
 }
 
 /* slack index of row j of stage t (-1: equality row) */
@@ -207,7 +216,8 @@ void port_begin(port_solver* S, const double* z0) {
   S->status = 0; S->iter = 0; S->nfact = 0; S->nsoc = 0; S->filter_n = 0; S->ls_fail = 0; S->full_streak = 0; S->short_streak = 0;
   S->watchdog = 0; S->acc_count = 0; S->ls_kind = 0;
   S->mu = o->mu_init; S->f_last = 1e300;
-  S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
+  S->delta_lm = 0; S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
+  S->ls_mode = o->ls_penalty ? 1 : 2; S->nu_pen = 0.0; S->ascale = 1.0;
 }
 
 /* ---- derivative blocks of every stage + residual norms (k_stage_eval + k_conv on the GPU) ---- */
@@ -491,6 +501,21 @@ static void factor_solve(port_solver* S) {
   double dw = 0.0, gam = 1.0;
   if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * dlast, o->delta_w_init));
   else if (dlast > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * dlast);
+  {
+    static double lm = -1, lup, ldn, lthr;
+    if (lm < 0) { lm = getenv("DTO_LM") ? atof(getenv("DTO_LM")) : 0.0; lup = getenv("DTO_LM_UP") ? atof(getenv("DTO_LM_UP")) : 4.0;
+      ldn = getenv("DTO_LM_DN") ? atof(getenv("DTO_LM_DN")) : 1.0 / 3.0; lthr = getenv("DTO_LM_THR") ? atof(getenv("DTO_LM_THR")) : 0.25; }
+    if (lm > 0 && S->iter > 0) {
+      if (S->alpha >= S->alpha_pmax) S->delta_lm = S->delta_lm * ldn > o->delta_w_init ? S->delta_lm * ldn : 0.0;
+      else if (S->alpha <= lthr * S->alpha_pmax && (!getenv("DTO_LM_NEAR") || S->th1 <= atof(getenv("DTO_LM_NEAR")) * S->theta_min)) S->delta_lm = fmin(lm, fmax(o->delta_w_init, lup * fmax(S->delta_lm, S->delta_w)));
+      if (dw < S->delta_lm) dw = S->delta_lm;
+    }
+  }
+  {
+    static double up = -1, thr = 0.2;
+    if (up < 0) { up = getenv("DTO_SHORT_UP") ? atof(getenv("DTO_SHORT_UP")) : 0.0; if (getenv("DTO_SHORT_ALPHA")) thr = atof(getenv("DTO_SHORT_ALPHA")); }
+    if (up > 0 && S->iter > 0 && !S->ls_fail && S->alpha < thr) dw = fmin(o->delta_w_exact_cap, fmax(o->delta_w_init, up * S->delta_w));
+  }
   int ok = 0;
   for (int attempt = 0;; ++attempt) {
     ok = forward_sweep(S, dw, gam, NULL);
@@ -631,12 +656,45 @@ static int second_order_correction(port_solver* S, double th_first) {
 /* k_linesearch + k_ls_reduce */
 static void line_search(port_solver* S) {
   double phi[LS_TRIALS], th[LS_TRIALS];
-  const double amax = S->alpha_pmax;
+  const double amax = S->alpha_pmax * (S->ls_mode == 1 ? S->ascale : 1.0);
   double alpha = amax;
   for (int k = 0; k < LS_TRIALS; ++k) { trial_point(S, alpha, &phi[k], &th[k], NULL); alpha *= 0.5; }
   const double th0 = S->th1;
+  if (getenv("DTO_LS_TRACE") && S->iter >= atoi(getenv("DTO_LS_TRACE")) && S->iter < atoi(getenv("DTO_LS_TRACE")) + 12) {
+    double dn = 0; for (int i = 0; i < S->Nz; ++i) dn = fmax(dn, fabs(S->dz[i]));
+    fprintf(stderr, "it %d th0 %.3e phi0 %.10e gphid %.3e amax %.3g |dz|inf %.3e dw %.2e thmin %.2e nfilt %d wd %d\n", S->iter, th0, S->merit0, S->gphid, amax, dn, S->delta_w, S->theta_min, S->filter_n, S->watchdog);
+    double a2 = amax; for (int k = 0; k < LS_TRIALS; ++k) { int ft; int ok = trial_ok(S, a2, th[k], phi[k], &ft); fprintf(stderr, "   a %.4f th %.3e dphi %.3e ok %d ftype %d filt %d\n", a2, th[k], phi[k] - S->merit0, ok, ft, filter_ok(S, th[k], phi[k])); a2 *= 0.5; }
+  }
   double chosen = -1.0;
   int ftype = 0, best = 0;
+  /* Two-phase globalisation (round 5; DESIGN.md section 5, profiles/r05/third_party_cfg3_T1000.json): far from the constraint
+   * manifold (theta_inf > ls_switch) the filter takes any step that lowers the violation, whatever it does to the objective --
+   * from the reference's straight-line guesses that is a jump to objective values 20 x the guess's, followed by hundreds of
+   * iterations back down along the manifold.  There the step size is chosen on the l1 exact-penalty function instead; once the
+   * iterate is near the manifold the filter (with its fast local convergence) takes over for good. */
+  if (S->ls_mode == 1 && S->thinf <= S->o.ls_switch) { S->ls_mode = 2; S->filter_n = 0; }
+  if (S->ls_mode == 1) {
+    /* l1 exact-penalty merit phi + nu theta, Armijo backtracking (Nocedal & Wright 18.3; Ipopt's line_search_method=penalty) */
+    const double rho = 0.1, eta = 1e-4, dphi = S->gphid;
+    if (th0 > 0.0) {
+      const double need = dphi / ((1.0 - rho) * th0);
+      if (S->nu_pen < need) S->nu_pen = need + 1.0;
+    }
+    const double nu = S->nu_pen, m0 = S->merit0 + nu * th0, D = dphi - nu * th0;
+    alpha = amax;
+    for (int k = 0; k < LS_TRIALS; ++k) {
+      const double mk = phi[k] + nu * th[k];
+      if (mk == mk && mk <= m0 + eta * alpha * D + 1e-13 * fabs(m0)) { chosen = alpha; break; }
+      alpha *= 0.5;
+    }
+    if (chosen < 0.0) { chosen = 0.0; S->alpha_dmax = 0.0; S->ascale = fmax(S->ascale / 256.0, 1e-12); }
+    else if (chosen >= amax) S->ascale = fmin(1.0, S->ascale * 4.0);
+    S->ls_fail = 0;
+    S->ls_kind = chosen > 0.0 ? 5 : -1;
+    S->alpha = chosen;
+    S->full_streak = (chosen >= amax) ? S->full_streak + 1 : 0;
+    return;
+  }
   const int wd_left = S->watchdog, watchdog = wd_left > 0;  /* rollback-free watchdog: see k_ls_reduce */
   if (S->o.max_soc > 0 && !watchdog) {
     int ft;
@@ -653,7 +711,7 @@ static void line_search(port_solver* S) {
     int ft;
     int ok = trial_ok(S, alpha, tk, pk, &ft);
     /* watchdog steps skip the filter but may not let the violation explode (there is no rollback): theta <= 3 max(theta_0, 1) */
-    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max && tk <= 3.0 * fmax(th0, 1.0);
+    if (watchdog) ok = (tk == tk) && (pk == pk) && tk <= S->theta_max && tk <= 3.0 * fmax(th0, getenv("DTO_WD_FLOOR") ? atof(getenv("DTO_WD_FLOOR")) : 1.0);
     if (ok && !watchdog) ok = filter_ok(S, tk, pk);
     if (ok) { chosen = alpha; ftype = ft; break; }
     alpha *= 0.5;
@@ -666,6 +724,7 @@ static void line_search(port_solver* S) {
     /* every trial is catastrophic (even the most feasible one multiplies the violation by > 100): a direction like that is
      * not worth any step -- stay where we are, primal and dual, and let ls_fail regularise the next system more */
     if (!(th[best] <= LS_NULL_STEP * fmax(th0, 1.0))) { chosen = 0.0; S->alpha_dmax = 0.0; }
+    if (getenv("DTO_NULL_ALWAYS") && !(th[best] < th0)) { chosen = 0.0; S->alpha_dmax = 0.0; }
     S->ls_fail = 1; augment = 1;
   } else { S->ls_fail = 0; augment = !ftype && !watchdog; }
   if (watchdog) { S->watchdog = wd_left - 1; S->short_streak = 0; }

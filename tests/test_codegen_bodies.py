@@ -18,14 +18,17 @@ from dto_amd.symbolic.codegen import emit_body, is_affine, trig_arguments
 
 
 def _compile(tmp_path, name, funcs):
-    # the bodies call DTO_SINCOS: the same straight-line sin + cos the device code uses (csrc/dto_math.hpp compiles as C++ and C)
-    src = ["#define _GNU_SOURCE", "#include <math.h>", "#define DTO_SINCOS(x, s, c) sincos((x), (s), (c))"]
+    # the bodies call DTO_SINCOS: compiled against csrc/dto_math.hpp itself, i.e. the same straight-line sin + cos the device
+    # code uses (the header is host-compilable C++; -ffp-contract=off as on the device, where every fma is explicit)
+    csrc = os.path.join(os.path.dirname(os.path.abspath(dto_amd.__file__)), "csrc")
+    src = ["#include <cmath>", "#include <cstring>", '#include "dto_math.hpp"', 'extern "C" {']
     for fn, params, body in funcs:
         src.append(f"void {fn}({params}) {{\n{body}\n}}")
-    c = tmp_path / f"{name}.c"
+    src.append("}")
+    c = tmp_path / f"{name}.cpp"
     c.write_text("\n".join(src))
     so = tmp_path / f"{name}.so"
-    subprocess.run(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so), str(c), "-lm"], check=True)
+    subprocess.run(["g++", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-I", csrc, "-o", str(so), str(c)], check=True)
     return C.CDLL(str(so))
 
 

@@ -20,8 +20,9 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     # name: extra compiler flags of the plugin
+    "stamps_in": "-DDTO_WIDE_PROFILE=1",     # the product's shape until round 4 (all solver tests passed): the reference of the diffs
     "prod": "",
-    "stamps_in": "-DDTO_WIDE_PROFILE=1",
+    "sync": "-DDTO_WIDE_DBG_SYNC=1",
     "nsa": "-fno-strict-aliasing",
     "nsa_sync": "-fno-strict-aliasing -DDTO_WIDE_DBG_SYNC=1",
     "nsa_poison": "-fno-strict-aliasing -DDTO_WIDE_DBG_POISON=1",
@@ -34,74 +35,88 @@ VARIANTS = {
     "nsa_sgpr_mem": "-fno-strict-aliasing -mllvm -amdgpu-spill-sgpr-to-vgpr=0",
     "stamps_in_nsa": "-DDTO_WIDE_PROFILE=1 -fno-strict-aliasing",
 }
-T_RUN, B_RUN, TARGET = 24, 3, 0.3
 DUMP_DIR = "/tmp/wide_dbg"
+CASES = {
+    # name: (T, B, NU): pad64 = tests/test_wide_gpu.py::test_wide_solve_converges_to_a_kkt_point[24-0.3-physical];
+    # emb24u2 = the first solve of ::test_24_state_two_action_parametric_problem_through_the_embedding (24 states, two actions,
+    # parameters; every knot has fixed -- padding -- states)
+    "pad64": (24, 3, 1),
+    "emb24u2": (25, 1, 2),
+}
 
 
-def _solver(T=T_RUN):
+def _problem(case):
     import dto_amd
     from dto_amd import problems as P
-    p = P.build_acrobot_padded(T=T, target=TARGET, terminal="physical")
-    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    T, B, NU = CASES[case]
+    if case == "pad64":
+        p = P.build_acrobot_padded(T=T, target=0.3, terminal="physical")
+        s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot_padded")
+    else:
+        p = P.build_acrobot_padded(T=T, n=24, m=2, target=0.4, terminal="physical", parameters=(1.2, 0.8))
+        s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                           parameters=p["parameters"], name="acrobot24u2")
     return s, p
 
 
-def prebuild(names):
-    from dto_amd import problems as P
-    from dto_amd.plugin import Structure, _prepare_plugin, _compile_plugin
+def prebuild(names, case):
+    """every variant's plugins, eight compiler processes at a time (constructing the Solver compiles what is missing)"""
     from concurrent.futures import ThreadPoolExecutor
-    jobs = []
-    for name in names:
-        os.environ["DTO_PLUGIN_CXXFLAGS"] = VARIANTS[name]
-        p = P.build_acrobot_padded(T=T_RUN, target=TARGET, terminal="physical")
-        st = Structure(p["dynamics"], p["objective"], p["constraints"], None, True)
-        so, cmd = _prepare_plugin(st, "acrobot_padded")
-        jobs.append((name, so, cmd))
-    os.environ.pop("DTO_PLUGIN_CXXFLAGS", None)
+
+    def one(name):
+        env = dict(os.environ, DTO_PLUGIN_CXXFLAGS=VARIANTS[name])
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "build1", name, "--case", case], env=env, capture_output=True, text=True)
+        return name, r.returncode, (r.stdout + r.stderr)[-300:].replace("\n", " | ")
     with ThreadPoolExecutor(max_workers=8) as ex:
-        for name, so in zip(names, ex.map(lambda j: _compile_plugin(j[0], j[1], j[2], False), jobs)):
-            print(f"{name:16s} {os.path.basename(so)}", flush=True)
+        for name, rc, tail in ex.map(one, names):
+            print(f"{name:16s} rc={rc} {tail if rc else ''}", flush=True)
 
 
-def run(name):
+def run(name, case):
     import torch
     import dto_amd
     from dto_amd.plugin import COMPILED
+    T, B, NU = CASES[case]
     os.makedirs(DUMP_DIR, exist_ok=True)
-    os.environ["DTO_WIDE_DUMP"] = os.path.join(DUMP_DIR, name)
+    os.environ["DTO_WIDE_DUMP"] = os.path.join(DUMP_DIR, f"{case}_{name}")
     os.environ.setdefault("DTO_WIDE_DUMP_MAX", "4")
-    s, p = _solver()
-    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
-    Z = np.zeros((B_RUN, nz))
-    for b in range(B_RUN):
-        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
-        dto_amd.initialize_states(s, xs)
-        dto_amd.initialize_controls(s, [0.1 * u for u in us])
-        Z[b] = s._z0
-    z0 = torch.tensor(Z, device="cuda")
-    zo = torch.full((B_RUN, nz), float("nan"), device="cuda", dtype=torch.float64)
-    lo = torch.full((B_RUN, nc), float("nan"), device="cuda", dtype=torch.float64)
-    status, iters = s.solve_batch(z0.data_ptr(), B_RUN, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
-    torch.cuda.synchronize()
-    # the plain KKT step of the same build at a random point (the use that stays correct)
-    rng = np.random.default_rng(5)
-    Zr, Mr = torch.tensor(rng.random((B_RUN, nz)), device="cuda"), torch.tensor(rng.random((B_RUN, nc)), device="cuda")
-    dx, dl = torch.empty_like(Zr), torch.empty_like(Mr)
-    ok = s.kkt_step_batch(Zr.data_ptr(), B_RUN, nz, Mr.data_ptr(), nc, 2.0, 1e-5, dx.data_ptr(), nz, dl.data_ptr(), nc)
-    torch.cuda.synchronize()
-    print(json.dumps(dict(variant=name, flags=VARIANTS.get(name, "?"), status=status.tolist(), iterations=iters.tolist(),
-                          z_nan=int(torch.isnan(zo).sum()), plain_step_ok=bool(ok), plain_step_nan=int(torch.isnan(dx).sum()),
-                          plain_step_norm=float(dx.abs().max()), compiled_here=list(COMPILED))), flush=True)
+    s, p = _problem(case)
+    if case == "pad64":
+        nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+        Z = np.zeros((B, nz))
+        for b in range(B):
+            xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+            dto_amd.initialize_states(s, xs)
+            dto_amd.initialize_controls(s, [0.1 * u for u in us])
+            Z[b] = s._z0
+        z0 = torch.tensor(Z, device="cuda")
+        zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+        lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+        status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+        torch.cuda.synchronize()
+        status, iters, znan = status.tolist(), iters.tolist(), int(torch.isnan(zo).sum())
+    else:
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+        dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+        st = dto_amd.solve(s)
+        status, iters, znan = [int(st)], [int(s.iterations)], int(np.isnan(s._solution).sum())
+    print(json.dumps(dict(variant=name, case=case, flags=VARIANTS.get(name, "?"), status=status, iterations=iters, z_nan=znan,
+                          compiled_here=list(COMPILED))), flush=True)
 
 
 # ---- factor record layout (csrc/dto_wide_kernels.hpp: Dims<64, 1>)
-N, NU, LD = 64, 1, 65
+N, LD = 64, 65
 MAT, PKL = 64 * 65, 10 * 256
 FIELDS = [("L_A(tiles)", 0, PKL, False), ("F~", PKL, MAT, True), ("V~", PKL + MAT, MAT, True), ("L_M(tiles)", PKL + 2 * MAT, PKL, False),
           ("E~", 2 * PKL + 2 * MAT, MAT, True)]
 FV = 2 * PKL + 3 * MAT
-VECS = [("1/D_A", 0, 64), ("1/D_M", 64, 64), ("bx~", 128, 64), ("bd^", 192, 64), ("A_xu", 256, 64), ("F_u", 320, 64), ("V_u", 384, 64),
-        ("grad cost", 448, 65), ("1/piv_u", 520, 1), ("bu", 521, 1)]
+
+
+def vecs(NU):
+    v_au = 4 * N; v_fu = v_au + NU * N; v_vu = v_fu + NU * N; v_gc = v_vu + NU * N; v_sc = v_gc + N + 8
+    return [("1/D_A", 0, 64), ("1/D_M", 64, 64), ("bx~", 128, 64), ("bd^", 192, 64), ("A_xu", v_au, NU * N), ("F_u", v_fu, NU * N),
+            ("V_u", v_vu, NU * N), ("grad cost", v_gc, N + NU), ("1/piv_u", v_sc, NU), ("bu", v_sc + NU, NU)] + \
+           ([("L_u", v_sc + 2 * NU, NU * NU)] if NU > 1 else [])
 
 
 def _cmp(a, b, tol=1e-9):
@@ -112,16 +127,25 @@ def _cmp(a, b, tol=1e-9):
     return np.nonzero(bad)[0]
 
 
-def diff(ref, name, out):
+def diff(ref, name, out, case):
+    T, B, NU = CASES[case]
+    VECS = vecs(NU)
+
     def load(v, k, what, dt=np.float64):
-        fn = os.path.join(DUMP_DIR, f"{v}_L{k}_{what}.bin")
+        fn = os.path.join(DUMP_DIR, f"{case}_{v}_L{k}_{what}.bin")
         return np.fromfile(fn, dtype=dt) if os.path.exists(fn) else None
+    for k in range(4):   # line-search tables (phi, theta_1 at the eight trial steps) of the first iterations
+        fn_a, fn_b = (os.path.join(DUMP_DIR, f"{case}_{v}_M{k}_merit.bin") for v in (ref, name))
+        if os.path.exists(fn_a) and os.path.exists(fn_b):
+            ma, mb = np.fromfile(fn_a).reshape(B, -1), np.fromfile(fn_b).reshape(B, -1)
+            d = _cmp(ma.ravel(), mb.ravel())
+            out.append(f"  merit table {k}: {d.size} of {ma.size} differ" + ("" if not d.size else "; instance 0 ref " +
+                       np.array2string(ma[0], precision=5, max_line_width=400) + " this " + np.array2string(mb[0], precision=5, max_line_width=400)))
     for k in range(8):
         fa, fb = load(ref, k, "fac"), load(name, k, "fac")
         if fa is None or fb is None:
             out.append(f"  launch {k}: no dump ({'ref' if fa is None else name}) -- stop")
             return
-        B, T = B_RUN, T_RUN
         fs = fa.size // (B * T)
         fa, fb = fa.reshape(B, T, fs), fb.reshape(B, T, fs)
         line = [f"  launch {k}:"]
@@ -171,33 +195,43 @@ def diff(ref, name, out):
         out.append(" ".join(line))
 
 
-def run_all(out_dir, names):
+def run_all(out_dir, names, case):
     os.makedirs(out_dir, exist_ok=True)
     lines = []
     for name in names:
         env = dict(os.environ, DTO_PLUGIN_CXXFLAGS=VARIANTS[name])
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "run", name], env=env, capture_output=True, text=True, timeout=900)
-        res = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        lines.append(f"== {name}  [{VARIANTS[name]}]  rc={r.returncode}")
-        lines.append("  " + (res[-1] if res else "NO RESULT: " + r.stderr[-600:].replace("\n", " | ")))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "run", name, "--case", case], env=env, capture_output=True, text=True, timeout=600)
+            rc, so, se = r.returncode, r.stdout, r.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, so, se = -9, "", "TIMEOUT " + str(e)
+        res = [ln for ln in so.splitlines() if ln.startswith("{")]
+        lines.append(f"== {case} / {name}  [{VARIANTS[name]}]  rc={rc}")
+        lines.append("  " + (res[-1] if res else "NO RESULT: " + se[-600:].replace("\n", " | ")))
         if name != names[0]:
             try:
-                diff(names[0], name, lines)
+                diff(names[0], name, lines, case)
             except Exception as e:   # keep going: the other variants still tell something
                 lines.append(f"  diff failed: {e!r}")
-        with open(os.path.join(out_dir, "wide_debug_summary.txt"), "w") as f:
+        with open(os.path.join(out_dir, f"wide_debug_summary_{case}.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
 if __name__ == "__main__":
-    cmd = sys.argv[1] if len(sys.argv) > 1 else "all"
-    names = [a for a in sys.argv[2:] if not a.startswith("--")] or list(VARIANTS)
+    argv = sys.argv[1:]
+    opt = {}
+    for key in ("--out", "--case"):
+        if key in argv:
+            i = argv.index(key); opt[key] = argv[i + 1]; del argv[i:i + 2]
+    cmd = argv[0] if argv else "all"
+    names = argv[1:] or list(VARIANTS)
+    case = opt.get("--case", "pad64")
     if cmd == "prebuild":
-        prebuild(names)
+        prebuild(names, case)
+    elif cmd == "build1":
+        _problem(case)
     elif cmd == "run":
-        run(sys.argv[2])
+        run(names[0], case)
     elif cmd == "all":
-        out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "gpurun_out", "wide_debug")
-        names = [n for n in names if n != out]
-        run_all(out, names)
+        run_all(opt.get("--out", os.path.join(ROOT, "gpurun_out", "wide_debug")), names, case)
