@@ -175,7 +175,9 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.warm = 0; o.mu_warm = 0.0;
   // two-phase line search (k_ls_reduce): l1-penalty while theta_inf > penalty_switch_theta, then Ipopt's filter
   o.ls_penalty = u.line_search == DTO_LS_PENALTY_FILTER ? 1 : 0; o.ls_switch = u.penalty_switch_theta;
-  if (const char* e = getenv("DTO_LS_MERIT")) o.ls_penalty = atoi(e);   // experiment knob (same name as the C port's)
+  if (const char* e = getenv("DTO_LS_MERIT")) o.ls_penalty = atoi(e);   // experiment knobs (same names as the C port's)
+  o.pen_gn = 1;
+  if (const char* e = getenv("DTO_PEN_GN")) o.pen_gn = atoi(e);
 }
 
 struct BorderStats;

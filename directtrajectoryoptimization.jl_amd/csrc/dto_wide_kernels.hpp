@@ -301,6 +301,18 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// Hand-off through LDS INSIDE one wavefront: lanes store their own entries, then wave-uniform code (the generated model bodies,
+// the row products) loads ALL of them.  The hardware runs a wavefront's LDS instructions in order, but to the compiler a lane's
+// load of what ANOTHER lane stored is not ordered after that store: it may hoist the load above a store it sees as conditional
+// (k_wide_merit: `if (l < NU) pk[N + l] = ...` followed by the model code reading pk[N] -- in -fno-strict-aliasing builds the
+// load went first and theta of every trial point was evaluated with the action of the previous one; the solves then ran into
+// the iteration limit.  Second root cause of round 5).  A wavefront-scope fence orders the two for the
+// compiler and emits no instruction.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- blocked right-looking LDL^T of the N x N matrix in LDS (lower tiles), all WG threads.
 //      On exit: strict lower part = L, d/dinv = pivots, LI = inverses of the unit-lower diagonal tiles.
 template <int N>
@@ -789,6 +801,9 @@ __device__ __forceinline__ double quad_sum(double v) {
   o = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));
   return v + o;
 }
+#ifndef DTO_WIDE_SPARSE_U
+#define DTO_WIDE_SPARSE_U 1   // 1: rank-one terms of the action elimination restricted to the states the actions couple to (phase 5)
+#endif
 #ifndef DTO_WIDE_RMW_UNROLL
 #define DTO_WIDE_RMW_UNROLL 2   // element-wise passes over the LDS matrices (rank-one terms of the actions): iterations in flight
 #endif
@@ -1275,6 +1290,33 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int j = 0; j < NU; ++j) { ip[j] = ipv[j]; bu[j] = buv[j]; }
         }
+        // A_xu and V_u are nonzero only at the states the actions couple to through second derivatives (KD::AU_N / VU_N of them,
+        // listed by the generator: 1 + 1 of 64 + 64 for the acrobot embedding): the rank-one terms then touch AU_N (AU_N + VU_N + N)
+        // + VU_N N entries instead of all 4 N^2 -- a few short loops instead of a read-modify-write pass over the four LDS matrices
+        // (phase 5: 7.9 k -> 1.4 k cycles).  Written in round 4 and parked: with it the solver-mode use returned NaN steps at -O3 --
+        // the exec-mask fault of the terminal stage ("root cause"), which this edit merely moved into view.
+        constexpr bool SPARSE_U = DTO_WIDE_SPARSE_U && (KD::AU_N + KD::VU_N) <= 24;
+        if constexpr (SPARSE_U) {
+          constexpr int NA = KD::AU_N, NV = KD::VU_N;
+          // (four loops, one per matrix: selecting the matrix per thread inside one loop makes the compiler address LDS through
+          //  flat pointers)
+          auto rank1 = [&](double* Mx, const double* ur, const double* vc, int r, int c) {
+            double dsum = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) dsum += ur[j * N + r] * ip[j] * vc[j * N + c];
+            Mx[r * LD + c] -= dsum;
+          };
+          if constexpr (NA > 0) {
+            for (int i = tid; i < N * NA; i += WG) rank1(MF, fu, au, i / NA, KD::au_s(i % NA));
+            for (int i = tid; i < NA * NA; i += WG) rank1(MA, au, au, KD::au_s(i / NA), KD::au_s(i % NA));
+          }
+          if constexpr (NV > 0) {
+            for (int i = tid; i < N * NV; i += WG) rank1(ME, fu, vu, i / NV, KD::vu_s(i % NV));
+          }
+          if constexpr (NA > 0 && NV > 0) {
+            for (int i = tid; i < NA * NV; i += WG) rank1(MV, au, vu, KD::au_s(i / NV), KD::vu_s(i % NV));
+          }
+        } else {
 #pragma unroll DTO_WIDE_RMW_UNROLL
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
@@ -1288,6 +1330,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
           MF[r * LD + c] -= df;
           MV[r * LD + c] -= dv;
           ME[r * LD + c] -= de;
+        }
         }
         if (tid < N) {
           double sx = 0.0, sd = 0.0, sy = 0.0;
@@ -1441,6 +1484,16 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
         lds_barrier();
         DTO_WIDE_TICK(11);
         // the y-y part of this stage's Hessian and the u rank-one term complete P'
+        if constexpr (SPARSE_U) {
+          constexpr int NV = KD::VU_N;
+          for (int i = tid; i < NV * NV; i += WG) {
+            const int r = KD::vu_s(i / (NV > 0 ? NV : 1)), c = KD::vu_s(i % (NV > 0 ? NV : 1));
+            double dvv = 0.0;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) dvv += vu[j * N + r] * vu[j * N + c] * ip[j];
+            MA[r * LD + c] -= dvv;
+          }
+        } else {
 #pragma unroll DTO_WIDE_RMW_UNROLL
         for (int i = tid; i < N * N; i += WG) {
           const int r = i >> 6, c = i & 63;
@@ -1448,6 +1501,7 @@ __global__ __launch_bounds__(WG) void k_wide_step(dto_wide_args a) {
 #pragma unroll
           for (int j = 0; j < NU; ++j) dvv += vu[j * N + r] * vu[j * N + c] * ip[j];
           MA[r * LD + c] -= dvv;
+        }
         }
         lds_barrier();
         if constexpr (DY::NH > 0) {
@@ -1928,6 +1982,7 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
       if (ln) xv[l] = z[a.zoff[t] + l];
       if (l < NUK) uv[l] = z[a.zoff[t] + N + l];
       if constexpr (HAS_DYN) { if (ln) yv[l] = z[a.zoff[t + 1] + l]; }
+      wave_lds_fence();   // every lane's entry of the point is in LDS before the wave-uniform model code reads them
       if constexpr (OP == DTO_OP_OBJ) {
         CO::eval(xv, uv, wp, ov);
         if (l == 0) a.scratch[b * a.T + t] = ov[0];
@@ -1941,7 +1996,9 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
           using DY = typename M::template Dyn<KD::DYN>;
           if (ln) ov[l] = 0.0;
           DY::eval_nl(xv, uv, yv, wp, hv);
+          wave_lds_fence();
           if (l < DY::NNL) ov[DY::nl_row(l)] = hv[l];
+          wave_lds_fence();   // lane nl_row(q) reads what lane q stored
           if (ln) {
             const double* row = fe_s + l * NC;
             double acc = ov[l] + dot_rr<N>(row, xv) + dot_rr<N>(row + N + NU, yv);
@@ -1973,21 +2030,25 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
         const double* mu = a.mu + b * a.ldmu;
         const int h0 = a.hoff[t], hlen = a.hoff[t + 1] - h0;
         for (int i = l; i < hlen; i += 64) ov[i] = 0.0;
+        wave_lds_fence();   // (the key image is updated by different lanes in turn: every hand-over is fenced)
         if constexpr (CO::SNH > 0) {
           CO::shess(xv, uv, wp, chv);
           const int* mrow = a.hmap_cost + kind * a.hmap_stride;
           for (int i = l; i < CO::SNH; i += 64) ov[mrow[i]] += a.sigma * chv[i];
+          wave_lds_fence();
         }
         if constexpr (HAS_DYN) {
           using DY = typename M::template Dyn<KD::DYN>;
           if constexpr (DY::NH > 0) {
             if (ln) lamv[l] = mu[a.cdoff[t] + l];
+            wave_lds_fence();
             DY::hess(xv, uv, yv, wp, lamv, hv);
             const int* mrow = a.hmap_dyn_own + kind * a.hmap_stride;
             for (int i = l; i < DY::NH; i += 64) {
               const int m = mrow[i];
               if (m >= 0) ov[m] += hv[i];
             }
+            wave_lds_fence();
           }
         }
         // rows of this stage also receive the y-rows of the previous stage's dynamics Hessian
@@ -2005,6 +2066,7 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
                   lamv[l] = mu[a.cdoff[t - 1] + l];
                 }
                 if (l < NU) uv[l] = z[a.zoff[t - 1] + N + l];
+                wave_lds_fence();
                 DP::hess(xv, uv, yv, a.w + b * a.ldw + a.woff[t - 1], lamv, hv);
                 const int* mrow = a.hmap_dyn_next + kind * a.hmap_stride;
                 for (int i = l; i < DP::NH; i += 64) {
@@ -2015,10 +2077,12 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
             }
           });
         }
+        wave_lds_fence();
         double* o = a.out + b * a.ldout + h0;
         for (int i = l; i < hlen; i += 64) o[i] = ov[i];
       }
     });
+    wave_lds_fence();   // the next knot of this wavefront rewrites the point and the images
   }
 }
 
@@ -2092,6 +2156,7 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
       double lin0 = 0.0, lind = 0.0;
       if constexpr (HAS_DYN) {
         yv[l] = z[a.zoff[t + 1] + l]; dy[l] = dz[a.zoff[t + 1] + l];
+        wave_lds_fence();   // the row products below read every lane's entries
         const double* row = fe_s + l * NC;
         // (the four 64-term products in one pass over the row, eight terms in flight: as four fully unrolled dot_rr calls this
         //  kernel spilled 360 registers)
@@ -2119,6 +2184,8 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
       for (int k = 0; k < DTO_WIDE_TRIALS; ++k) {
         pk[l] = pv[l] + alpha * dp[l];
         if (l < NUK) pk[N + l] = pv[N + l] + alpha * dp[N + l];
+        if constexpr (HAS_DYN) yk[l] = yv[l] + alpha * dy[l];
+        wave_lds_fence();   // the trial point is complete in LDS before the model code reads it (see wave_lds_fence)
         CO::eval(pk, pk + N, wp, nl + 8);
         if (l == 0) facc[k] += nl[8];
         if (barrier) {
@@ -2138,7 +2205,6 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
         }
         if constexpr (HAS_DYN) {
           using DY = typename M::template Dyn<KD::DYN>;
-          yk[l] = yv[l] + alpha * dy[l];
           DY::eval_nl(pk, pk + N, yk, wp, nl);
           double r = lin0 + alpha * lind;
 #pragma unroll
@@ -2147,6 +2213,7 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
           const double sum = wave_sum(fabs(r));
           if (l == 0) tacc[k] += sum;
         }
+        wave_lds_fence();   // the next trial rewrites the point
         alpha *= 0.5;
       }
     });

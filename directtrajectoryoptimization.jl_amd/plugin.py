@@ -28,7 +28,7 @@ from .symbolic import expr as E
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PLUGIN_DIR = os.path.join(_HERE, "_plugins")
-GENERATOR_VERSION = "8"
+GENERATOR_VERSION = "9"
 WIDE_MIN_STATE = 17   # above this the lane-per-instance register kernels give way to the tile (MFMA) kernels
 WIDE_STATE = 64       # the state dimension the tile kernels are built for
 WIDE_MAX_ACTION = 4   # actions per knot on the tile path (LDS budget of one workgroup)
@@ -352,6 +352,8 @@ def generate_wide_source(st: Structure, name: str) -> str:
         host_tables.append(_int_array(f"cost{i}_hc", c.sparsity[1] if st.evaluate_hessian else []))
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
+    dev_extra: List[str] = []
+    dev_extra_at = len(out)
     out.append("struct Model {")
     out.append(f"  static constexpr int WIDE_N = {st.wide_n}, WIDE_NU = {st.wide_nu}, N_KIND = {len(st.kinds)}, N_WKIND = {len(wkinds)};")
     max_key = max([1] + [st.key_slots(k) for k in st.kinds])
@@ -374,7 +376,35 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("  }")
     out.append("};")
     for i, (d, c) in enumerate(wkinds):
-        out.append(f"template <> struct Model::WKind<{i}> {{ static constexpr int DYN = {d}, COST = {c}; }};")
+        # states that the actions couple to through second derivatives: rows of A_xu (x-u entries of the cost and of lam' d'')
+        # and of V_u (u-y entries of lam' d'').  The rank-one terms of the action elimination touch only these rows / columns of
+        # the stage matrices (csrc/dto_wide_kernels.hpp, phase 5): for the acrobot embedding 1 + 1 of 64 + 64.  (Several actions:
+        # the union over the actions -- the elimination inside the action block mixes their rows.)
+        au_s, vu_s = set(), set()
+        if d >= 0:
+            dd = st.dyn[d]
+            nx, nu = dd.num_state, dd.num_action
+            if st.evaluate_hessian:
+                for r1, c1 in zip(dd.hessian_sparsity[0], dd.hessian_sparsity[1]):
+                    r, cc = r1 - 1, c1 - 1
+                    for a_, b_ in ((r, cc), (cc, r)):
+                        if a_ < nx and nx <= b_ < nx + nu:
+                            au_s.add(a_)
+                        if nx <= a_ < nx + nu and b_ >= nx + nu:
+                            vu_s.add(b_ - nx - nu)
+            cc_ = st.cost[c]
+            for r1, c1 in zip(cc_.solver_sparsity[0], cc_.solver_sparsity[1]):
+                r, q = r1 - 1, c1 - 1
+                for a_, b_ in ((r, q), (q, r)):
+                    if a_ < nx and b_ >= nx:
+                        au_s.add(a_)
+        au_l, vu_l = sorted(au_s), sorted(vu_s)
+        dev_extra.append(_dev_int_array(f"wk{i}_aus", au_l))
+        dev_extra.append(_dev_int_array(f"wk{i}_vus", vu_l))
+        out.append(f"template <> struct Model::WKind<{i}> {{ static constexpr int DYN = {d}, COST = {c}, AU_N = {len(au_l)}, VU_N = {len(vu_l)};")
+        out.append(_lookup("au_s", f"wk{i}_aus") + _lookup("vu_s", f"wk{i}_vus"))
+        out.append("};")
+    out[dev_extra_at:dev_extra_at] = dev_extra
     out.extend(classes)
     out.extend(host_tables)
     rows = []

@@ -95,7 +95,7 @@ class PortSolver:
             self.set(k, v)
 
     def set(self, name, value):
-        if isinstance(value, (int, np.integer)) and name in ("max_soc", "max_iter", "watchdog_trigger", "watchdog_trials", "acceptable_iter", "ls_penalty"):
+        if isinstance(value, (int, np.integer)) and name in ("max_soc", "max_iter", "watchdog_trigger", "watchdog_trials", "acceptable_iter", "ls_penalty", "pen_gn"):
             lib().port_set_int(self._h, name.encode(), int(value))
         else:
             lib().port_set_double(self._h, name.encode(), float(value))

@@ -264,7 +264,7 @@ def test_max_cpu_time_cuts_the_solve_off():
     from dto_amd import problems as P
     p = P.build_acrobot(T=1000, evaluate_hessian=True)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                       options=dto_amd.Options(max_cpu_time=0.05, max_iter=100000), name="acrobot")
+                       options=dto_amd.Options(max_cpu_time=0.002, max_iter=100000), name="acrobot")   # (the limit is polled every ten iterations)
     xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
     dto_amd.initialize_states(s, xs)
     dto_amd.initialize_controls(s, us)
