@@ -59,10 +59,12 @@ class COptions(C.Structure):
                 ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int), ("acceptable_dual_inf_tol", C.c_double),
                 ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
                 ("acceptable_obj_change_tol", C.c_double), ("diverging_iterates_tol", C.c_double), ("mu_target", C.c_double),
-                ("line_search", C.c_int), ("penalty_switch_theta", C.c_double)]
+                ("line_search", C.c_int), ("penalty_switch_theta", C.c_double),
+                ("hessian_approximation", C.c_int)]
 
 
 DTO_LS_FILTER, DTO_LS_PENALTY_FILTER = 0, 1
+DTO_HESSIAN_EXACT, DTO_HESSIAN_LBFGS = 0, 1
 DTO_STATUS_CPU_TIME = 6
 
 
@@ -70,7 +72,7 @@ DTO_STATUS_CPU_TIME = 6
 SCALARS = ["status", "iter", "mu", "penalty", "delta_w", "f", "theta1", "theta_inf", "dinf", "compl", "e0", "logbar",
            "alpha_pmax", "alpha_dmax", "dmerit", "alpha", "ls_fail", "nfact", "merit0", "delta_last",
            "theta_max", "theta_min", "filter_n", "ls_kind", "gamma", "need", "try_dw", "try_gam", "attempt", "qn_reset", "full_streak", "short_streak", "watchdog",
-           "acc_count", "f_last", "xmax", "nneg", "ls_mode", "ascale"]
+           "acc_count", "f_last", "xmax", "nneg", "ls_mode", "ascale", "qn_sigma", "qn_skip", "qn_gcorr"]
 
 
 class DtoError(RuntimeError):

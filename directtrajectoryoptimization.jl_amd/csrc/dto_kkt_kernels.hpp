@@ -52,6 +52,12 @@ enum dto_kkt_op {
   DTO_KKT_BWD_EARLY = 16,    // back substitution of the tiles whose forward sweep has published its tag (second stream)
   DTO_KKT_BWD_REST = 17,     // ... and of the tiles DTO_KKT_BWD_EARLY left
   DTO_KKT_BWD_GATE = 18,     // one wavefront that returns when every forward block of the launch has started
+  // limited-memory BFGS mode (dto_options.hessian_approximation = DTO_HESSIAN_LBFGS; round 5): see "limited-memory BFGS" below
+  DTO_KKT_QN_BEGIN = 19,     // after EVAL: secant pair of the last step, history, sigma, the small matrices S'S and S'Y
+  DTO_KKT_QN_RHS = 20,       // stage records r_p := r_p0 - (a column of U | U q | nothing), one more factorisation requested
+  DTO_KKT_QN_COL = 21,       // Z_col := dz - v0 (col = -1: v0 := dz)
+  DTO_KKT_QN_SMALL = 22,     // U'Z, U'v0, C = M - U'Z, q = C^-1 U'v0, correction of the directional derivative
+  DTO_KKT_QN_SAVE = 23,      // after LS_REDUCE: grad_x L(x_k, lam_{k+1}) and alpha dz for the next secant pair
   DTO_KKT_OP_COUNT
 };
 
@@ -64,6 +70,7 @@ enum dto_scal {
   SC_ACC_COUNT, SC_F_LAST, SC_XMAX, SC_NNEG,
   SC_LS_MODE,   // line-search phase: 1 = l1-penalty (far from the constraint manifold), 2 = filter (ls_reduce_body)
   SC_ASCALE,    // penalty phase: scale of the trial step sizes (shrinks 256 x when all eight trials fail, recovers 4 x per full step)
+  SC_QN_SIGMA, SC_QN_SKIP, SC_QN_GCORR,   // limited-memory BFGS: sigma of B_0 = sigma I, consecutive skipped updates, q'(U'dz)
   SC_COUNT
 };
 
@@ -101,6 +108,8 @@ struct dto_solver_opts {
   int watchdog_trigger, watchdog_trials;  // Ipopt: watchdog_shortened_iter_trigger (10), watchdog_trial_iter_max (3); 0 = off
   int ls_penalty;       // 1: l1-penalty line search while theta_inf > ls_switch, then the filter (dto_options.line_search)
   int pen_gn;           // 1: Gauss-Newton Hessian model during the penalty phase (conv_body)
+  int qn_lbfgs;         // 1: limited-memory BFGS instead of the exact Hessian of the Lagrangian (dto_options.hessian_approximation)
+  double cost_hess_scale;  // 1, or 0 in limited-memory mode: factor on the objective Hessian inside the stage blocks
   double ls_switch;     // dto_options.penalty_switch_theta
   int newton_only;      // 1: ignore bounds/inequality structure, fixed delta_w (dto_kkt_step_batch, dto_kkt_factor/solve)
   double fixed_delta_w;
@@ -158,6 +167,8 @@ struct dto_kkt_args {
   // slot -> instance map after dto_solver_repack moved the running instances to the front (NULL: identity)
   const int* inst_of_slot;
   int fwd_rounds;  // sequential sweep: inertia-correction rounds per launch (0 = all)
+  double* qn;      // limited-memory BFGS: per tile (4 QN_M + 4) Nz + QN_SMALL rows (S, Y, Z, r_p0, grad L, s, v0, small matrices), or NULL
+  int qn_mode, qn_col;   // DTO_KKT_QN_RHS: 0 column qn_col of U, 1 U q, 2 restore; DTO_KKT_QN_COL: column (-1: save v0)
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
@@ -788,6 +799,9 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     *soa(a.scal, g, SC_COUNT, SC_NNEG) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_LS_MODE) = (o.ls_penalty && !o.newton_only) ? 1.0 : 2.0;
     *soa(a.scal, g, SC_COUNT, SC_ASCALE) = 1.0;
+    *soa(a.scal, g, SC_COUNT, SC_QN_SIGMA) = 1.0;   // Ipopt: limited_memory_init_val = 1
+    *soa(a.scal, g, SC_COUNT, SC_QN_SKIP) = 0.0;
+    *soa(a.scal, g, SC_COUNT, SC_QN_GCORR) = 0.0;
   }
 }
 
@@ -1391,6 +1405,7 @@ __device__ __forceinline__ void conv_body(const dto_solver_opts& o, double* sc, 
       sc[SC_TRY_GAM << SH] = 0.0;
       sc[SC_TRY_DW << SH] = fmax(sc[SC_TRY_DW << SH], o.delta_w_init);
     }
+    if (o.qn_lbfgs) sc[SC_TRY_GAM << SH] = 0.0;   // no second derivatives at all: K0 = [sigma I + Sigma + delta_w I, J'; J, -D]
   }
 }
 
@@ -1561,6 +1576,13 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
     } else {
 #pragma unroll
       for (int i = 0; i < CO::NHL; ++i) hl[i] = R(D::R_CH + i);
+    }
+    // (limited-memory mode: B_0 = sigma I replaces the objective Hessian too -- scale 0; otherwise 1: x * 1.0 is exact.
+    //  Not for the element-BFGS plugins, which never run in that mode: with the multiply there, AMD clang 22 stops with
+    //  "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_private_base" on the SR1 acrobot plugin.)
+    if constexpr (!D::QN) {
+#pragma unroll
+      for (int i = 0; i < CO::NHL; ++i) hl[i] *= o.cost_hess_scale;
     }
     CO::scatter_hess_lower(hl, S);  // the pp block of S is packed exactly like W
   }
@@ -1985,7 +2007,7 @@ __device__ __forceinline__ void retry_update_t(const dto_solver_opts& o, int Nc,
       dw = o.delta_w_init;
     }
   } else {
-    dw *= o.kappa_w_plus;
+    dw = (dw == 0.0) ? o.delta_w_init : dw * o.kappa_w_plus;   // (dw = 0 with gam = 0: the limited-memory mode's first probe)
     if (dw > o.delta_w_max) dw = o.delta_w_max;
   }
   sc[SC_TRY_DW << SH] = dw;
@@ -2011,7 +2033,8 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
     if (!__any(need)) return;
     const double mu = sc[SC_MU << 6];
-    const double dw = sc[SC_TRY_DW << 6], gam = sc[SC_TRY_GAM << 6];
+    // (limited-memory mode: the diagonal sigma I of B_0 rides on the primal regularisation)
+    const double dw = sc[SC_TRY_DW << 6] + (a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_TRY_GAM << 6];
     const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
     Carry<M> cy;
     Spike<M> sp;
@@ -2426,7 +2449,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   constexpr int N = M::MAX_NX;
   const double mu = sc[SC_MU << 6];
   const double tau = fmax(o.tau_min, 1.0 - mu);
-  const double dw = sc[SC_DELTA_W << 6], gam = sc[SC_GAMMA << 6];  // the accepted factorisation
+  const double dw = sc[SC_DELTA_W << 6] + (a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_GAMMA << 6];  // the accepted factorisation
   const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
   double xL[N], xn[N];
 #pragma unroll
@@ -2957,6 +2980,317 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// limited-memory BFGS (round 5).  The reference's default -- Solver(...; evaluate_hessian=false),
+// src/solver.jl:7, and its own acrobot / car examples -- leaves Ipopt on hessian_approximation = limited-memory: the Hessian of
+// the Lagrangian is the compact L-BFGS matrix of Byrd, Nocedal & Schnabel (1994)
+//     B = sigma I - W M^-1 W',   W = [sigma S, Y],   M = [[sigma S'S, L], [L', -D]]     (S, Y: the last QN_M = 6 secant pairs;
+//                                                                                        L, D: strictly lower part / diagonal of S'Y)
+// with y_k = grad_x L(x_{k+1}, lam_{k+1}) - grad_x L(x_k, lam_{k+1}), sigma = s'y / s's of the newest pair
+// (limited_memory_initialization = scalar1), the update skipped when s'y <= sqrt(eps) |s| |y|, the history dropped after two
+// skips in a row.  sigma I is block diagonal, so K0 = [sigma I + Sigma + delta_w I, J'; J, -D_c] is what the sweeps factorise
+// with the constraint curvature off (gam = 0), the objective Hessian scaled away (cost_hess_scale = 0) and sigma riding on
+// delta_w; the 2 QN_M columns of U = [W; 0] are a dense border:
+//     K v = b,  K = K0 - U M^-1 U':    v = v0 + Z q,   v0 = K0^-1 b,   Z = K0^-1 U,   C = M - U'Z,   q = C^-1 U'v0.
+// Every solve with K0 is a plain forward + backward sweep of the SOLVER kernels at the same point with a modified stage record:
+// K0 v_a = -(r_p0 - u + barrier terms; c; d) gives v_a - v0 = K0^-1 (u; 0; 0) by linearity (no kernel learns about right-hand
+// sides), and the corrected step itself is one more such solve with u = U q -- its fraction-to-the-boundary limits and slack
+// steps come out of the back substitution as always; only grad phi' d needs q'(U'dz) added, and U'dz = U'v0 + (U'Z) q is known.
+// The kernels below are one wavefront per tile, lane = instance, plain loops over the rows: everything per instance (dot
+// products, the 12 x 12 algebra) is lane-local.  Mirrors oracle/cpu_port/solver_port.c: qn_update / qn_factor_solve / qn_save.
+// ------------------------------------------------------------------------------------------------
+constexpr int QN_M = 6, QN_M2 = 2 * QN_M;
+constexpr int QN_SS = 0, QN_SY = QN_SS + QN_M * QN_M, QN_UZ = QN_SY + QN_M * QN_M, QN_UV = QN_UZ + QN_M2 * QN_M2, QN_Q = QN_UV + QN_M2,
+              QN_SMALL = QN_Q + QN_M2;
+struct QnRows {
+  int64_t Nz;
+  __host__ __device__ int64_t S(int j) const { return (int64_t)j * Nz; }
+  __host__ __device__ int64_t Y(int j) const { return (int64_t)(QN_M + j) * Nz; }
+  __host__ __device__ int64_t Z(int j) const { return (int64_t)(2 * QN_M + j) * Nz; }
+  __host__ __device__ int64_t rp0() const { return (int64_t)(4 * QN_M) * Nz; }
+  __host__ __device__ int64_t gl() const { return rp0() + Nz; }
+  __host__ __device__ int64_t qs() const { return gl() + Nz; }
+  __host__ __device__ int64_t v0() const { return qs() + Nz; }
+  __host__ __device__ int64_t small() const { return v0() + Nz; }
+  __host__ __device__ int64_t total() const { return small() + QN_SMALL; }
+};
+__device__ __forceinline__ double* qn_tile(const dto_kkt_args& a, int64_t g) {
+  return a.qn + ((g * QnRows{a.Nz}.total()) << 6) + threadIdx.x;
+}
+__device__ __forceinline__ double qn_u(const double* q, const QnRows& R, int col, int64_t row, double sigma) {
+  return col < QN_M ? sigma * q[(R.S(col) + row) << 6] : q[(R.Y(col - QN_M) + row) << 6];
+}
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const bool have = sc[SC_ITER << 6] > 0.0 && sc[SC_ALPHA << 6] > 0.0;
+  // ---- the Lagrangian gradient of the new point (stage records) -> r_p0; y = r_p0 - grad_x L(x_k, lam_{k+1}) kept in the gl rows
+  double sy = 0.0, ss = 0.0, yy = 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      using D = KindDims<M, K>;
+      const SoaIO<M, K> io(a, g, t);
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) {
+        const int64_t row = io.z0 + i;
+        const double rp = io.rec(D::R_RP + i);
+        const bool fx = uload(a.lo, row) == uload(a.hi, row);
+        const double y = (fx || !have) ? 0.0 : rp - q[(R.gl() + row) << 6];
+        const double sv = (fx || !have) ? 0.0 : q[(R.qs() + row) << 6];
+        q[(R.rp0() + row) << 6] = rp;
+        q[(R.gl() + row) << 6] = y;
+        q[(R.qs() + row) << 6] = sv;
+        sy += sv * y; ss += sv * sv; yy += y * y;
+      }
+    });
+  }
+  // ---- curvature test (Ipopt skips the update; two skips in a row restart the approximation)
+  const bool accept = have && sy > 1.4901161193847656e-08 * sqrt(ss) * sqrt(yy);
+  bool reset = false;
+  if (have) {
+    const double skipped = accept ? 0.0 : sc[SC_QN_SKIP << 6] + 1.0;
+    reset = skipped >= 2.0;
+    sc[SC_QN_SKIP << 6] = reset ? 0.0 : skipped;
+  }
+  if (accept) sc[SC_QN_SIGMA << 6] = fmin(1e8, fmax(1e-8, sy / ss));
+  if (reset) sc[SC_QN_SIGMA << 6] = 1.0;
+  // ---- history: oldest pair out, newest in (per lane: a lane that skipped keeps its rows)
+  for (int64_t row = 0; row < a.Nz; ++row) {
+    double sj[QN_M], yj[QN_M];
+#pragma unroll
+    for (int j = 0; j < QN_M; ++j) { sj[j] = q[(R.S(j) + row) << 6]; yj[j] = q[(R.Y(j) + row) << 6]; }
+    const double sn = q[(R.qs() + row) << 6], yn = q[(R.gl() + row) << 6];
+#pragma unroll
+    for (int j = 0; j < QN_M; ++j) {
+      const double s_new = j + 1 < QN_M ? sj[j + 1 < QN_M ? j + 1 : j] : sn, y_new = j + 1 < QN_M ? yj[j + 1 < QN_M ? j + 1 : j] : yn;
+      q[(R.S(j) + row) << 6] = reset ? 0.0 : (accept ? s_new : sj[j]);
+      q[(R.Y(j) + row) << 6] = reset ? 0.0 : (accept ? y_new : yj[j]);
+    }
+  }
+  // ---- S'S and S'Y of the history as it stands
+  double SS[QN_M * QN_M], SY[QN_M * QN_M];
+#pragma unroll
+  for (int i = 0; i < QN_M * QN_M; ++i) SS[i] = SY[i] = 0.0;
+  for (int64_t row = 0; row < a.Nz; ++row) {
+    double sj[QN_M], yj[QN_M];
+#pragma unroll
+    for (int j = 0; j < QN_M; ++j) { sj[j] = q[(R.S(j) + row) << 6]; yj[j] = q[(R.Y(j) + row) << 6]; }
+#pragma unroll
+    for (int aa = 0; aa < QN_M; ++aa) {
+#pragma unroll
+      for (int bb = 0; bb < QN_M; ++bb) {
+        if (bb <= aa) SS[aa * QN_M + bb] += sj[aa] * sj[bb];
+        SY[aa * QN_M + bb] += sj[aa] * yj[bb];
+      }
+    }
+  }
+#pragma unroll
+  for (int aa = 0; aa < QN_M; ++aa) {
+#pragma unroll
+    for (int bb = 0; bb < QN_M; ++bb) {
+      q[(R.small() + QN_SS + aa * QN_M + bb) << 6] = SS[(bb <= aa ? aa : bb) * QN_M + (bb <= aa ? bb : aa)];
+      q[(R.small() + QN_SY + aa * QN_M + bb) << 6] = SY[aa * QN_M + bb];
+    }
+  }
+}
+
+// stage records: r_p := r_p0 - u  (mode 0: u = column qn_col of U; 1: u = U q; 2: u = 0 and grad phi' d gets its correction);
+// modes 0 / 1 request ONE more factorisation with the (delta_w, gam = 0) the iteration accepted
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const double sigma = sc[SC_QN_SIGMA << 6];
+  double qc[QN_M2];
+#pragma unroll
+  for (int j = 0; j < QN_M2; ++j) qc[j] = a.qn_mode == 1 ? q[(R.small() + QN_Q + j) << 6] : 0.0;
+  for (int t = 0; t < a.T; ++t) {
+    dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      using D = KindDims<M, K>;
+      const SoaIO<M, K> io(a, g, t);
+      double* recw = const_cast<double*>(io.recp);
+#pragma unroll
+      for (int i = 0; i < D::NP; ++i) {
+        const int64_t row = io.z0 + i;
+        double v = q[(R.rp0() + row) << 6];
+        if (a.qn_mode == 0) v -= qn_u(q, R, a.qn_col, row, sigma);
+        if (a.qn_mode == 1) {
+#pragma unroll
+          for (int j = 0; j < QN_M2; ++j) v -= qc[j] * qn_u(q, R, j, row, sigma);
+        }
+        recw[pair_at(D::R_RP + i)] = v;
+      }
+    });
+  }
+  if (a.qn_mode == 2) {
+    sc[SC_DMERIT << 6] += sc[SC_QN_GCORR << 6];
+  } else {
+    sc[SC_NEED << 6] = 1.0;
+    sc[SC_ATTEMPT << 6] = (double)a.opt.max_refactor;   // this attempt is the one that gets used, whatever its inertia
+    sc[SC_TRY_DW << 6] = sc[SC_DELTA_W << 6];
+    sc[SC_TRY_GAM << 6] = 0.0;
+  }
+}
+
+// Z_col := dz - v0 (qn_col >= 0), v0 := dz (qn_col = -1)
+static __global__ __launch_bounds__(WAVE) void k_qn_col(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  for (int64_t row = 0; row < a.Nz; ++row) {
+    const double d = *soa(a.dz, g, a.Nz, row);
+    if (a.qn_col < 0) q[(R.v0() + row) << 6] = d;
+    else q[(R.Z(a.qn_col) + row) << 6] = d - q[(R.v0() + row) << 6];
+  }
+}
+
+// U'Z and U'v0 by row loops, then per lane: M, C = M - U'Z, q = C^-1 U'v0 (Gaussian elimination with partial pivoting in the
+// lane's LDS column), q'(U'dz) for the directional derivative.  Empty history slots (zero columns) are decoupled.
+static __global__ __launch_bounds__(WAVE) void k_qn_small(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const double sigma = sc[SC_QN_SIGMA << 6];
+  __shared__ double lds[(QN_M2 * QN_M2 + 2 * QN_M2) * WAVE];
+  double* Cm = lds + threadIdx.x;                        // Cm[(a * QN_M2 + b) * WAVE]
+  double* tv = lds + QN_M2 * QN_M2 * WAVE + threadIdx.x;  // U'v0, then q
+  double* uzq = tv + QN_M2 * WAVE;                        // (U'Z) q
+  // U'Z: two passes of six rows of U (72 accumulators each)
+  for (int half = 0; half < 2; ++half) {
+    double acc[QN_M * QN_M2], av[QN_M];
+#pragma unroll
+    for (int i = 0; i < QN_M * QN_M2; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < QN_M; ++i) av[i] = 0.0;
+    for (int64_t row = 0; row < a.Nz; ++row) {
+      double u[QN_M], z[QN_M2];
+#pragma unroll
+      for (int j = 0; j < QN_M; ++j) u[j] = half == 0 ? sigma * q[(R.S(j) + row) << 6] : q[(R.Y(j) + row) << 6];
+#pragma unroll
+      for (int j = 0; j < QN_M2; ++j) z[j] = q[(R.Z(j) + row) << 6];
+      const double v0 = q[(R.v0() + row) << 6];
+#pragma unroll
+      for (int aa = 0; aa < QN_M; ++aa) {
+        av[aa] += u[aa] * v0;
+#pragma unroll
+        for (int bb = 0; bb < QN_M2; ++bb) acc[aa * QN_M2 + bb] += u[aa] * z[bb];
+      }
+    }
+#pragma unroll
+    for (int aa = 0; aa < QN_M; ++aa) {
+      tv[(half * QN_M + aa) * WAVE] = av[aa];
+#pragma unroll
+      for (int bb = 0; bb < QN_M2; ++bb) Cm[((half * QN_M + aa) * QN_M2 + bb) * WAVE] = acc[aa * QN_M2 + bb];
+    }
+  }
+  // keep U'Z (for the correction of the directional derivative), form C = M - sym(U'Z)
+  double gcorr_t[QN_M2];
+#pragma unroll
+  for (int j = 0; j < QN_M2; ++j) gcorr_t[j] = tv[j * WAVE];
+  for (int aa = 0; aa < QN_M2; ++aa)
+    for (int bb = 0; bb < QN_M2; ++bb) q[(R.small() + QN_UZ + aa * QN_M2 + bb) << 6] = Cm[(aa * QN_M2 + bb) * WAVE];
+  for (int aa = 0; aa < QN_M2; ++aa)
+    for (int bb = 0; bb <= aa; ++bb) {
+      const double uz = 0.5 * (Cm[(aa * QN_M2 + bb) * WAVE] + Cm[(bb * QN_M2 + aa) * WAVE]);
+      double m;
+      if (aa < QN_M) m = sigma * q[(R.small() + QN_SS + aa * QN_M + bb) << 6];                                    // sigma S'S
+      else if (bb < QN_M) m = (aa - QN_M) < bb ? q[(R.small() + QN_SY + bb * QN_M + (aa - QN_M)) << 6] : 0.0;     // L' (row a of Y, column b of S: s_b'y_a for b > a)
+      else m = aa == bb ? -q[(R.small() + QN_SY + (aa - QN_M) * QN_M + (aa - QN_M)) << 6] : 0.0;                 // -D
+      Cm[(aa * QN_M2 + bb) * WAVE] = Cm[(bb * QN_M2 + aa) * WAVE] = m - uz;
+    }
+  // empty slots: s_j = 0 (history not full yet, or just restarted): rows / columns j and QN_M + j are decoupled
+  for (int j = 0; j < QN_M; ++j) {
+    if (q[(R.small() + QN_SS + j * QN_M + j) << 6] == 0.0) {
+      for (int k = 0; k < QN_M2; ++k) {
+        Cm[(j * QN_M2 + k) * WAVE] = Cm[(k * QN_M2 + j) * WAVE] = 0.0;
+        Cm[((QN_M + j) * QN_M2 + k) * WAVE] = Cm[(k * QN_M2 + QN_M + j) * WAVE] = 0.0;
+      }
+      Cm[(j * QN_M2 + j) * WAVE] = 1.0; Cm[((QN_M + j) * QN_M2 + QN_M + j) * WAVE] = 1.0;
+      tv[j * WAVE] = 0.0; tv[(QN_M + j) * WAVE] = 0.0;
+    }
+  }
+  // q = C^-1 t
+  bool singular = false;
+  for (int k = 0; k < QN_M2; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < QN_M2; ++r) if (fabs(Cm[(r * QN_M2 + k) * WAVE]) > fabs(Cm[(piv * QN_M2 + k) * WAVE])) piv = r;
+    if (piv != k) {
+      for (int c = 0; c < QN_M2; ++c) { const double t_ = Cm[(k * QN_M2 + c) * WAVE]; Cm[(k * QN_M2 + c) * WAVE] = Cm[(piv * QN_M2 + c) * WAVE]; Cm[(piv * QN_M2 + c) * WAVE] = t_; }
+      const double t_ = tv[k * WAVE]; tv[k * WAVE] = tv[piv * WAVE]; tv[piv * WAVE] = t_;
+    }
+    const double d = Cm[(k * QN_M2 + k) * WAVE];
+    if (!(fabs(d) > 1e-300)) { singular = true; continue; }
+    for (int r = k + 1; r < QN_M2; ++r) {
+      const double f = Cm[(r * QN_M2 + k) * WAVE] / d;
+      if (f == 0.0) continue;
+      for (int c = k; c < QN_M2; ++c) Cm[(r * QN_M2 + c) * WAVE] -= f * Cm[(k * QN_M2 + c) * WAVE];
+      tv[r * WAVE] -= f * tv[k * WAVE];
+    }
+  }
+  for (int k = QN_M2 - 1; k >= 0; --k) {
+    double acc = tv[k * WAVE];
+    for (int c = k + 1; c < QN_M2; ++c) acc -= Cm[(k * QN_M2 + c) * WAVE] * tv[c * WAVE];
+    const double d = Cm[(k * QN_M2 + k) * WAVE];
+    tv[k * WAVE] = (fabs(d) > 1e-300) ? acc / d : 0.0;
+  }
+  // q'(U'dz) = q'(U'v0 + (U'Z) q)
+  double gcorr = 0.0;
+  for (int aa = 0; aa < QN_M2; ++aa) {
+    double r = gcorr_t[0];
+#pragma unroll
+    for (int j = 0; j < QN_M2; ++j) r = (j == aa) ? gcorr_t[j] : r;
+    for (int bb = 0; bb < QN_M2; ++bb) r += q[(R.small() + QN_UZ + aa * QN_M2 + bb) << 6] * (singular ? 0.0 : tv[bb * WAVE]);
+    gcorr += (singular ? 0.0 : tv[aa * WAVE]) * r;
+  }
+  for (int j = 0; j < QN_M2; ++j) q[(R.small() + QN_Q + j) << 6] = singular ? 0.0 : tv[j * WAVE];
+  sc[SC_QN_GCORR << 6] = gcorr;
+  (void)uzq;
+}
+
+// after the line search: grad_x L(x_k, lam_{k+1}) = r_p0 + alpha J(x_k)' dlam, with J'dlam from the first block row of the system
+// just solved, (B + Sigma + delta_w I) dz + J'dlam = -(r_p0 + barrier terms) and B dz = sigma dz - U q; and s = alpha dz
+static __global__ __launch_bounds__(WAVE) void k_qn_save(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const double sigma = sc[SC_QN_SIGMA << 6], al = sc[SC_ALPHA << 6], dw = sc[SC_DELTA_W << 6], mu = sc[SC_MU << 6];
+  double qc[QN_M2];
+#pragma unroll
+  for (int j = 0; j < QN_M2; ++j) qc[j] = q[(R.small() + QN_Q + j) << 6];
+  for (int64_t row = 0; row < a.Nz; ++row) {
+    const double lo = uload(a.lo, row), hi = uload(a.hi, row);
+    const double rp0 = q[(R.rp0() + row) << 6], dzv = *soa(a.dz, g, a.Nz, row);
+    double uq = 0.0;
+#pragma unroll
+    for (int j = 0; j < QN_M2; ++j) uq += qc[j] * qn_u(q, R, j, row, sigma);
+    double sig = sigma + dw, bt = 0.0;
+    if (lo != hi && a.zl) {
+      const double p = *soa(a.z, g, a.Nz, row);
+      if (finite_lo(lo)) { sig += *soa(a.zl, g, a.Nz, row) / (p - lo); bt -= mu / (p - lo); }
+      if (finite_hi(hi)) { sig += *soa(a.zu, g, a.Nz, row) / (hi - p); bt += mu / (hi - p); }
+    }
+    const bool fx = lo == hi;
+    q[(R.gl() + row) << 6] = fx ? 0.0 : rp0 + al * (-(rp0 + bt) - sig * dzv + uq);
+    q[(R.qs() + row) << 6] = fx ? 0.0 : al * dzv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
 template <class M>
@@ -3058,6 +3392,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         break;
       case DTO_KKT_RHS: hipLaunchKernelGGL(k_rhs_record<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_REARM: hipLaunchKernelGGL(k_rearm, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_BEGIN: hipLaunchKernelGGL(k_qn_begin<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_RHS: hipLaunchKernelGGL(k_qn_rhs<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_COL: hipLaunchKernelGGL(k_qn_col, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_SMALL: hipLaunchKernelGGL(k_qn_small, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_SAVE: hipLaunchKernelGGL(k_qn_save, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       default: return -1;
     }
     return (int)hipGetLastError();

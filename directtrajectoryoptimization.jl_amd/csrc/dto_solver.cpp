@@ -57,6 +57,8 @@ struct SolverState {
   int sweep_tag = 0;
   hipStream_t stream_lo = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  double* qn = nullptr;                          // limited-memory BFGS: history, columns and small matrices per tile (QnRows)
+  size_t qn_len = 0;
   double *z_alt = nullptr, *lam_alt = nullptr;   // second iterate / multiplier buffers of the fused UPDATE+EVAL pass (lazy)
   int fuse_state = 0;                            // 0 not decided, 1 buffers allocated, -1 not available (memory, switch)
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
@@ -82,11 +84,12 @@ struct SolverState {
                     (void*)zl, (void*)zu, (void*)s, (void*)zs, (void*)dz, (void*)dlam, (void*)ds, (void*)rec,
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
-                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag, (void*)fwd_started})
+                    (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag, (void*)fwd_started,
+                    (void*)qn})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
-    z_alt = lam_alt = nullptr; fuse_state = 0; tile_fwd_tag = tile_bwd_tag = fwd_started = nullptr; sweep_tag = 0;
+    z_alt = lam_alt = nullptr; fuse_state = 0; qn = nullptr; qn_len = 0; tile_fwd_tag = tile_bwd_tag = fwd_started = nullptr; sweep_tag = 0;
     if (stream_lo) { (void)hipStreamDestroy(stream_lo); stream_lo = nullptr; }
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
@@ -177,6 +180,8 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.ls_penalty = u.line_search == DTO_LS_PENALTY_FILTER ? 1 : 0; o.ls_switch = u.penalty_switch_theta;
   if (const char* e = getenv("DTO_LS_MERIT")) o.ls_penalty = atoi(e);   // experiment knobs (same names as the C port's)
   o.pen_gn = 1;
+  o.qn_lbfgs = u.hessian_approximation == DTO_HESSIAN_LBFGS ? 1 : 0;
+  o.cost_hess_scale = o.qn_lbfgs ? 0.0 : 1.0;
   if (const char* e = getenv("DTO_PEN_GN")) o.pen_gn = atoi(e);
 }
 
@@ -875,6 +880,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.rec = S.rec; a.fac = S.fac; a.part = S.part; a.lspart = S.lspart; a.scal = S.scal; a.filt = S.filt;
   a.inst_of_slot = S.d_inst_of_slot;
   a.fwd_rounds = fwd_rounds_per_launch();
+  a.qn = S.qn; a.qn_mode = 0; a.qn_col = 0;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
@@ -886,6 +892,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
 static bool fused_update_available(Problem* p) {
   SolverState& S = *p->solver;
   if (const char* e = getenv("DTO_FUSE_UPDATE")) if (atoi(e) == 0) return false;   // read per call: tests flip it
+  if (S.opt.qn_lbfgs) return false;   // the limited-memory mode saves its secant data between LS_REDUCE and UPDATE
   if (S.fuse_state != 0) return S.fuse_state > 0;
   S.fuse_state = -1;
   const size_t lanes = (size_t)S.G * 64;
@@ -2108,6 +2115,7 @@ int dto_options_default(dto_options* o) {
   o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5;
   o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
   o->line_search = DTO_LS_PENALTY_FILTER; o->penalty_switch_theta = 1.0;
+  o->hessian_approximation = DTO_HESSIAN_EXACT;
   return DTO_OK;
 }
 
@@ -2191,7 +2199,20 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   if (opt) u = *opt; else dto_options_default(&u);
   S.user = u;
   dto::default_opts(S.opt, u);
+  if (S.info.quasi_newton) S.opt.pen_gn = 0;   // per-stage SR1 blocks: dropping them for the penalty phase would also restart them
   hipStream_t st = (hipStream_t)b->stream;
+  if (S.opt.qn_lbfgs) {
+    if (p->L.Ngen != 0 || S.info.quasi_newton)
+      return set_error(DTO_ERR_UNSUPPORTED, "hessian_approximation = limited-memory: lane-per-instance solver path without GeneralConstraint rows");
+    const size_t need = (size_t)S.G * (size_t)dto::QnRows{p->L.Nz}.total() * 64;
+    if (S.qn_len < need) {
+      if (S.qn) (void)hipFree(S.qn);
+      S.qn = nullptr; S.qn_len = 0;
+      HIP_TRY(hipMalloc((void**)&S.qn, need * sizeof(double)));
+      S.qn_len = need;
+    }
+    HIP_TRY(hipMemsetAsync(S.qn, 0, need * sizeof(double), st));
+  }
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
   const size_t lanes = (size_t)S.G * 64;
@@ -2217,7 +2238,8 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   // tiles behind G_active, finished instances, are not touched and stay valid there)
   SolverState& S = *p->solver;
   const int n_fused = dto::fused_update_available(p) ? ((n - 1) / 2) * 2 : 0;
-  const bool overlap = dto::overlap_sweeps(p, st);
+  const bool qn = S.opt.qn_lbfgs != 0;
+  const bool overlap = !qn && dto::overlap_sweeps(p, st);
   static const bool gate = [] { const char* e = getenv("DTO_OVERLAP_GATE"); return !e || atoi(e) != 0; }();
   for (int it = 0; it < n; ++it) {
     if (it > 0 && it <= n_fused) {
@@ -2228,6 +2250,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
     } else {
       if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
     }
+    if (qn && (rc = dto::kkt_launch(p, DTO_KKT_QN_BEGIN, a, st))) return rc;   // secant pair of the last step, history, sigma
     if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
     if (overlap) {
       // forward sweeps on the caller's stream, early back substitutions on the low-priority one, the rest and the post pass
@@ -2254,8 +2277,28 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
     } else {
       if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
     }
+    if (qn) {
+      // limited-memory BFGS (csrc/dto_kkt_kernels.hpp): the step above is v0 = K0^-1 b; one solve per column of U = [sigma S, Y],
+      // the 12 x 12 system per instance, and the corrected step as one more solve (its step-length limits come with it)
+      a.qn_col = -1;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COL, a, st))) return rc;
+      for (int col = 0; col < dto::QN_M2; ++col) {
+        a.qn_mode = 0; a.qn_col = col;
+        if ((rc = dto::kkt_launch(p, DTO_KKT_QN_RHS, a, st))) return rc;
+        if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+        if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COL, a, st))) return rc;
+      }
+      if ((rc = dto::kkt_launch(p, DTO_KKT_QN_SMALL, a, st))) return rc;
+      a.qn_mode = 1;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_QN_RHS, a, st))) return rc;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+      a.qn_mode = 2;
+      if ((rc = dto::kkt_launch(p, DTO_KKT_QN_RHS, a, st))) return rc;
+      a.qn_mode = 0; a.qn_col = 0;
+    }
     if ((rc = dto::kkt_launch(p, DTO_KKT_LINESEARCH, a, st))) return rc;
     if ((rc = dto::kkt_launch(p, DTO_KKT_LS_REDUCE, a, st))) return rc;
+    if (qn && (rc = dto::kkt_launch(p, DTO_KKT_QN_SAVE, a, st))) return rc;
     if (!(it + 1 < n && it + 1 <= n_fused))
       if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE, a, st))) return rc;
   }
@@ -2639,6 +2682,8 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   if (opt) u = *opt; else dto_options_default(&u);
   S.user = u;
   dto::default_opts(S.opt, u);
+  if (S.info.quasi_newton) S.opt.pen_gn = 0;
+  if (S.opt.qn_lbfgs && !S.qn) return set_error(DTO_ERR_INVALID, "dto_solver_begin_warm: the previous solve did not run in limited-memory mode");
   S.opt.warm = 1;
   S.opt.mu_warm = mu0;
   S.G_active = S.G;   // every instance runs again (the slot map of an earlier dto_solver_repack stays valid)

@@ -340,7 +340,7 @@ class NLPData:
                                                       out_ptr, ldo, stream or None))
 
 
-def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
+def _c_options(o: "Options", check_every: int = 10, lbfgs: bool = False) -> "capi.COptions":
     c = capi.COptions()
     capi.check(capi.lib().dto_options_default(C.byref(c)))
     c.tol, c.s_max, c.max_iter = o.tol, o.s_max, int(o.max_iter)
@@ -355,6 +355,7 @@ def _c_options(o: "Options", check_every: int = 10) -> "capi.COptions":
         raise ValueError(f"Options.line_search must be 'penalty-filter' or 'filter', not {o.line_search!r}")
     c.line_search = capi.DTO_LS_PENALTY_FILTER if o.line_search == "penalty-filter" else capi.DTO_LS_FILTER
     c.penalty_switch_theta = float(o.penalty_switch_theta)
+    c.hessian_approximation = capi.DTO_HESSIAN_LBFGS if lbfgs else capi.DTO_HESSIAN_EXACT
     return c
 
 
@@ -400,13 +401,19 @@ class Solver:
         self._solve_nlp = self.nlp
         self._mu_to_reference = None
         s_dyn, s_obj, s_con, s_eh, changed = list(dynamics), list(objective), list(constraints), bool(evaluate_hessian), False
-        if self.options.hessian_approximation not in ("auto", "exact", "sr1"):
-            raise ValueError("Options.hessian_approximation must be 'auto', 'exact' or 'sr1'")
-        # how the solver gets its Hessian of the Lagrangian (reported: Solver.hessian_mode)
-        self.hessian_mode = "exact" if s_eh else ("sr1" if self.options.hessian_approximation == "sr1" else "exact-from-trace")
-        if self.hessian_mode == "exact-from-trace" and self.options.hessian_approximation == "auto":
-            _notice_default_mode()
-        if not s_eh and self.options.hessian_approximation != "sr1":
+        ha = self.options.hessian_approximation
+        if ha not in ("auto", "exact", "sr1", "lbfgs"):
+            raise ValueError("Options.hessian_approximation must be 'auto', 'exact', 'lbfgs' or 'sr1'")
+        # How the solver gets its Hessian of the Lagrangian (reported: Solver.hessian_mode).  evaluate_hessian=False is the
+        # reference's default (src/solver.jl:7) and leaves Ipopt on its limited-memory BFGS: "auto" does the same ("lbfgs",
+        # dto_options.hessian_approximation = DTO_HESSIAN_LBFGS) wherever the lane-per-instance solver path runs the problem; the
+        # tile path (17 .. 64 states), multi-knot GeneralConstraint rows and user-Jacobian dynamics keep round 4's substitutes
+        # (exact second derivatives of the traced expressions, announced once; per-stage SR1 blocks).
+        want_lbfgs = (ha == "lbfgs") or (ha == "auto" and not s_eh)
+        if ha == "lbfgs" and s_eh:
+            pass   # asked for explicitly on a problem that has Hessians: the approximation is used all the same
+        self.hessian_mode = "exact" if (s_eh and not want_lbfgs) else ("sr1" if ha == "sr1" else ("lbfgs" if want_lbfgs else "exact-from-trace"))
+        if not s_eh and ha != "sr1":
             # Default mode: the expressions are there, so the solver differentiates them twice itself; the MOI surface of
             # self.nlp still reports [:Grad, :Jac] exactly like the reference (src/moi.jl:122).
             up = _with_exact_hessians(s_dyn, s_obj, s_con)
@@ -424,11 +431,33 @@ class Solver:
                 s_dyn, s_obj, s_con, s_bounds, zmap, mumap = padded
                 self._pad = (zmap, mumap)
                 changed = True
+        # 17 .. 63 states that the embedding cannot take: the problem gets evaluator callbacks (a tile-family plugin of its own
+        # size) but no solver -- say so here, not as "plugin has no KKT kernels" at the first solve
+        from .plugin import WIDE_MIN_STATE as _WMIN, WIDE_STATE as _WST
+        n_max = max(d.num_state for d in s_dyn)
+        if _WMIN <= n_max < _WST and self._pad is None:
+            why = ("a GeneralConstraint" if gen is not None else "the per-stage SR1 mode (no second derivatives to embed)" if not s_eh else
+                   "stage constraints, more than four actions, varying dimensions or user-Jacobian dynamics")
+            self.solve_unsupported = (f"problems with {_WMIN} .. {_WST - 1} states are solved through the 64-state embedding of the tile "
+                                      f"kernels, which does not take {why}: the MOI callbacks of this Solver work, solve!/solve_batch do not")
+        else:
+            self.solve_unsupported = None
         if gen is not None:
             folded = fold_general_constraint(s_dyn, s_obj, s_con, gen, s_eh)
             if folded is not None:
                 s_con, self._mu_to_reference = folded
                 gen, changed = None, True
+        if self.hessian_mode == "lbfgs":
+            traced = s_eh                        # (user-Jacobian dynamics cannot be differentiated: their plugin carries SR1 blocks)
+            if not traced:
+                self.hessian_mode = "sr1"
+            elif gen is not None or self._pad is not None or max(d.num_state for d in s_dyn) >= 17:
+                if ha == "lbfgs":
+                    raise ValueError("Options(hessian_approximation='lbfgs'): the limited-memory mode runs on the lane-per-instance "
+                                     "solver path (at most 16 states, no GeneralConstraint rows over several knots)")
+                self.hessian_mode = "exact-from-trace"
+        if self.hessian_mode == "exact-from-trace" and ha == "auto":
+            _notice_default_mode()
         if changed:
             self._solve_nlp = NLPData(s_dyn, s_obj, s_con, s_bounds, evaluate_hessian=s_eh, general_constraint=gen,
                                       parameters=parameters, name=name if gen is None and self._mu_to_reference is None else name + "_folded")
@@ -485,8 +514,10 @@ class Solver:
         """Solve B instances resident on the device; returns (status[B], iterations[B]) numpy int32 arrays.
         params_ptr: optional DEVICE [B][ldp] per-instance parameter vectors (flattened w_1..w_T) replacing the shared ones.
         mu_out: solver row order, see multipliers_to_reference."""
+        if self.solve_unsupported:
+            raise ValueError(self.solve_unsupported)
         b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
-        co = _c_options(self.options, check_every)
+        co = _c_options(self.options, check_every, lbfgs=self.hessian_mode == "lbfgs")
         self._B = B
         status = np.zeros(B, dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
@@ -497,7 +528,7 @@ class Solver:
 
     def begin_batch(self, x0_ptr, B, ldx, stream=0, params_ptr=0, ldp=0):
         b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
-        co = _c_options(self.options)
+        co = _c_options(self.options, lbfgs=self.hessian_mode == "lbfgs")
         capi.check(self._solve_nlp._lib.dto_solver_begin(self._solve_nlp._h, C.byref(co), C.byref(b)))
         self._B = B
 
@@ -505,7 +536,7 @@ class Solver:
         """dto_solver_begin_warm: re-solve from the device-resident state of the previous solve (receding-horizon MPC).
         x0_ptr = 0 keeps the final iterate; mu0 <= 0 keeps the barrier parameter."""
         b = self._solve_nlp._batch(x0_ptr, B, ldx or self._solve_nlp.num_variables, stream, params_ptr, ldp)
-        co = _c_options(self.options)
+        co = _c_options(self.options, lbfgs=self.hessian_mode == "lbfgs")
         capi.check(self._solve_nlp._lib.dto_solver_begin_warm(self._solve_nlp._h, C.byref(co), C.byref(b), float(mu0)))
         self._B = B
 
@@ -761,11 +792,13 @@ def fold_general_constraint(dynamics, objective, constraints, general, evaluate_
 
 def solve(solver: Solver):
     """solve!(solver) -- src/solver.jl:45-47: run the GPU interior-point solve from the initial guess."""
+    if solver.solve_unsupported:
+        raise ValueError(solver.solve_unsupported)
     n = solver._solve_nlp
     x = np.zeros(n.num_variables)
     mu = np.zeros(max(1, n.num_constraint))
     status, iters = C.c_int32(0), C.c_int32(0)
-    co = _c_options(solver.options)
+    co = _c_options(solver.options, lbfgs=solver.hessian_mode == "lbfgs")
     capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver.pad_batch(solver._z0))), capi.dptr(x), capi.dptr(mu),
                                 C.byref(status), C.byref(iters)))
     solver._solution = solver.unpad_batch(x)

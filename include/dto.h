@@ -190,8 +190,15 @@ typedef struct dto_options {
    * iterations.  Lane-per-instance solver path; the tile (64-state) and bordered paths run the filter. */
   int line_search;                   /* DTO_LS_PENALTY_FILTER */
   double penalty_switch_theta;       /* 1.0 */
+  /* ABI 3: what stands in for the Hessian of the Lagrangian.  DTO_HESSIAN_EXACT: second derivatives of the traced expressions.
+   * DTO_HESSIAN_LBFGS: Ipopt's hessian_approximation = limited-memory, i.e. what the reference runs when a problem is built
+   * with evaluate_hessian = false (src/solver.jl:7, its default and its own acrobot / car examples): compact L-BFGS, history 6,
+   * sigma = s'y / s's, updates skipped without curvature -- no second derivatives are evaluated.  Lane-per-instance solver
+   * path without GeneralConstraint rows (DTO_ERR_UNSUPPORTED otherwise). */
+  int hessian_approximation;         /* DTO_HESSIAN_EXACT */
 } dto_options;
 enum { DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 };
+enum { DTO_HESSIAN_EXACT = 0, DTO_HESSIAN_LBFGS = 1 };
 /* per-instance status reported by dto_solve[_batch] / dto_solver_run / dto_solver_stats */
 enum { DTO_STATUS_RUNNING = 0, DTO_STATUS_CONVERGED = 1, DTO_STATUS_MAX_ITER = 2, DTO_STATUS_NONFINITE = 3,
        DTO_STATUS_ACCEPTABLE = 4, DTO_STATUS_DIVERGING = 5, DTO_STATUS_CPU_TIME = 6 /* cut off by max_cpu_time */ };

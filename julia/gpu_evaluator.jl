@@ -53,6 +53,7 @@ struct DtoOptions                   # include/dto.h: dto_options (src/options.jl
     mu_target::Float64
     line_search::Cint               # DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 (default)
     penalty_switch_theta::Float64
+    hessian_approximation::Cint     # DTO_HESSIAN_EXACT = 0, DTO_HESSIAN_LBFGS = 1 (Ipopt's limited-memory mode)
 end
 
 struct DtoBatch                     # include/dto.h: dto_batch (DEVICE pointers)
@@ -66,11 +67,13 @@ end
 
 dto_check(rc) = rc == 0 || error(unsafe_string(ccall((:dto_last_error, libdto), Cstring, ())))
 
-DtoOptions(o::Options) = DtoOptions(o.tol, o.s_max, o.max_iter, o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol,
+# limited_memory: what the reference means by evaluate_hessian = false (src/solver.jl:7: Ipopt's hessian_approximation stays
+# "limited-memory") -- the callers below pass !ev.hessian_lagrangian
+DtoOptions(o::Options; limited_memory::Bool = false) = DtoOptions(o.tol, o.s_max, o.max_iter, o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol,
                                     0.1, 1.0e-8, 1.0e-4, 10, o.max_cpu_time,
                                     o.acceptable_tol, o.acceptable_iter, o.acceptable_dual_inf_tol,
                                     o.acceptable_constr_viol_tol, o.acceptable_compl_inf_tol, o.acceptable_obj_change_tol,
-                                    o.diverging_iterates_tol, o.mu_target, Cint(1), 1.0)
+                                    o.diverging_iterates_tol, o.mu_target, Cint(1), 1.0, Cint(limited_memory ? 1 : 0))
 
 mutable struct GPUEvaluator <: MOI.AbstractNLPEvaluator
     handle::Ptr{Cvoid}
@@ -164,7 +167,7 @@ guess is what `initialize_states!` / `initialize_controls!` stored (src/solver.j
 4 = acceptable level, see include/dto.h.
 """
 function solve!(solver::Solver, ev::GPUEvaluator; options = Options())
-    opt = DtoOptions(options)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
     x0 = Float64[something(MOI.get(solver.data.optimizer, MOI.VariablePrimalStart(), v), 0.0) for v in solver.data.variables]
     x = similar(x0)
     μ = zeros(max(1, ev.num_constraint))
@@ -197,7 +200,7 @@ Solve the columns of `X0` (num_variables × B initial guesses) as B independent 
 function solve_batch(ev::GPUEvaluator, X0::Matrix{Float64}; options = Options(), parameters = nothing)
     nz, B = size(X0)
     nz == ev.num_variables || error("X0 must have num_variables rows")
-    opt = DtoOptions(options)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
     dx0 = dto_device_array(X0)                                   # column-major nz × B == instance-major [B][nz]
     dx = dto_device_array(zeros(nz, B))
     dpar = parameters === nothing ? Ptr{Float64}(C_NULL) : dto_device_array(Matrix{Float64}(parameters))
@@ -223,7 +226,7 @@ barrier parameter stay on the device (`dto_solver_begin_warm`), only the per-ins
 change.  Returns (X, status, iterations).
 """
 function resolve_warm!(ev::GPUEvaluator, B::Int, parameters::Matrix{Float64}; options = Options(), mu0 = 0.0)
-    opt = DtoOptions(options)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
     nz = ev.num_variables
     dpar = dto_device_array(parameters)
     dx = dto_device_array(zeros(nz, B))

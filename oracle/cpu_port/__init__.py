@@ -32,10 +32,10 @@ def lib():
         L.port_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.port_set_double.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         for name in ("port_status", "port_iterations", "port_nfact", "port_nsoc", "port_ls_kind", "port_num_variables",
-                     "port_num_constraint", "port_num_slacks"):
+                     "port_num_constraint", "port_num_slacks", "port_qn_pairs"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = C.c_int
-        for name in ("port_objective", "port_constr_viol", "port_dual_inf", "port_alpha", "port_delta_w", "port_mu"):
+        for name in ("port_objective", "port_constr_viol", "port_dual_inf", "port_alpha", "port_delta_w", "port_mu", "port_qn_sigma"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = C.c_double
         for name in ("port_z", "port_lam"):
@@ -95,7 +95,7 @@ class PortSolver:
             self.set(k, v)
 
     def set(self, name, value):
-        if isinstance(value, (int, np.integer)) and name in ("max_soc", "max_iter", "watchdog_trigger", "watchdog_trials", "acceptable_iter", "ls_penalty", "pen_gn"):
+        if isinstance(value, (int, np.integer)) and name in ("max_soc", "max_iter", "watchdog_trigger", "watchdog_trials", "acceptable_iter", "ls_penalty", "pen_gn", "lbfgs"):
             lib().port_set_int(self._h, name.encode(), int(value))
         else:
             lib().port_set_double(self._h, name.encode(), float(value))
@@ -125,6 +125,14 @@ class PortSolver:
     @property
     def nfact(self):
         return lib().port_nfact(self._h)
+
+    @property
+    def qn_sigma(self):
+        return lib().port_qn_sigma(self._h)
+
+    @property
+    def qn_pairs(self):
+        return lib().port_qn_pairs(self._h)
 
     @property
     def nsoc(self):

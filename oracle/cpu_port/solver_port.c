@@ -37,6 +37,7 @@
 #define LS_NULL_STEP 100.0
 #define LS_TRIALS 8
 #define FILTER_CAP 24
+#define QN_MAX 12
 
 typedef struct {
   /* mirrors dto_options (include/dto.h) + the interior-point constants of csrc/dto_solver.cpp:default_opts */
@@ -77,6 +78,12 @@ typedef struct {
   double delta_lm;
   double delta_w, delta_last, gamma, alpha, alpha_pmax, alpha_dmax, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
+  /* limited-memory BFGS mode (the reference's default: Solver(...; evaluate_hessian=false) leaves Ipopt on
+   * hessian_approximation=limited-memory, src/solver.jl:7): compact representation B = sigma I - W M^-1 W' (Byrd, Nocedal &
+   * Schnabel 1994), the 2k columns of W a dense border of the block-tridiagonal system */
+  int qn_mode, qn_m, qn_k, qn_skipped;
+  double qn_sigma;
+  double *qn_S, *qn_Y, *qn_gl, *qn_s;   /* [m][Nz] pairs, grad_x L(x_k, lam_{k+1}), alpha dz of the last step */
   int ls_mode; double nu_pen, ascale;   /* line-search phase (1 penalty, 2 filter), penalty parameter, trial-step scale of the penalty phase */
 } port_solver;
 
@@ -109,6 +116,7 @@ void port_default_options(port_options* o) {
   if (getenv("DTO_LS_SWITCH_INF")) o->ls_switch = atof(getenv("DTO_LS_SWITCH_INF"));
 }
 
+void port_set_int(port_solver* S, const char* name, int v);
 port_solver* port_create(const char* model, int T, const int* con, const double* lo, const double* hi, int max_iter) {
   const port_model* M = NULL;
   for (int i = 0; i < PORT_NMODELS; ++i)
@@ -147,6 +155,7 @@ port_solver* port_create(const char* model, int T, const int* con, const double*
   ALLOC(s, S->Ni); ALLOC(zs, S->Ni); ALLOC(ds, S->Ni); ALLOC(save_ds, S->Ni);
 #undef ALLOC
   S->st = (stage_t*)calloc(T, sizeof(stage_t));
+  if (getenv("DTO_LBFGS")) port_set_int(S, "lbfgs", atoi(getenv("DTO_LBFGS")));   /* experiment knob */
   return S;
 }
 
@@ -154,7 +163,8 @@ void port_destroy(port_solver* S) {
   if (!S) return;
   free(S->con); free(S->ccoff); free(S->ioff); free(S->lo); free(S->hi);
   free(S->z); free(S->dz); free(S->zl); free(S->zu); free(S->save_dz); free(S->lam); free(S->dlam); free(S->soc_c);
-  free(S->soc_buf); free(S->save_dlam); free(S->s); free(S->zs); free(S->ds); free(S->save_ds); free(S->st); free(S);
+  free(S->soc_buf); free(S->save_dlam); free(S->s); free(S->zs); free(S->ds); free(S->save_ds); free(S->st);
+  free(S->qn_S); free(S->qn_Y); free(S->qn_gl); free(S->qn_s); free(S);
 }
 
 void port_set_int(port_solver* S, const char* name, int v) {
@@ -164,6 +174,13 @@ void port_set_int(port_solver* S, const char* name, int v) {
   else if (!strcmp(name, "watchdog_trials")) S->o.watchdog_trials = v;
   else if (!strcmp(name, "acceptable_iter")) S->o.acceptable_iter = v;
   else if (!strcmp(name, "ls_penalty")) S->o.ls_penalty = v;
+  else if (!strcmp(name, "lbfgs")) {   /* v = history length (Ipopt: limited_memory_max_history = 6); 0 = exact Hessians */
+    S->qn_mode = v > 0 ? 2 : 0; S->qn_m = v > QN_MAX ? QN_MAX : v;
+    if (v > 0 && !S->qn_S) {
+      S->qn_S = (double*)calloc((size_t)QN_MAX * S->Nz, sizeof(double)); S->qn_Y = (double*)calloc((size_t)QN_MAX * S->Nz, sizeof(double));
+      S->qn_gl = (double*)calloc(S->Nz, sizeof(double)); S->qn_s = (double*)calloc(S->Nz, sizeof(double));
+    }
+  }
   else if (!strcmp(name, "pen_gn")) S->o.pen_gn = v;
 }
 void port_set_double(port_solver* S, const char* name, double v) {
@@ -224,6 +241,7 @@ void port_begin(port_solver* S, const double* z0) {
   S->mu = o->mu_init; S->f_last = 1e300;
   S->delta_lm = 0; S->delta_w = 0; S->delta_last = 0; S->gamma = 1.0; S->alpha = 0; S->theta_max = -1; S->theta_min = -1;
   S->ls_mode = o->ls_penalty ? 1 : 2; S->nu_pen = 0.0; S->ascale = 1.0;
+  S->qn_k = 0; S->qn_sigma = 1.0; S->qn_skipped = 0;
 }
 
 /* ---- derivative blocks of every stage + residual norms (k_stage_eval + k_conv on the GPU) ---- */
@@ -351,8 +369,12 @@ static int forward_sweep(port_solver* S, double dw, double gam, const double* rh
     {
       memset(A, 0, sizeof(A));
       memset(X, 0, sizeof(X));
+      if (S->qn_mode == 2) {   /* limited-memory mode: K0 carries sigma I, the low-rank part is a border (qn_factor_solve) */
+        for (int i = 0; i < np; ++i) A[i][i] = S->qn_sigma;
+      } else {
       for (int i = 0; i < np; ++i)
         for (int j = 0; j <= i; ++j) A[i][j] = s->W[TRI(i, j)] + gam * (s->WD[TRI(i, j)] + s->WC[TRI(i, j)]);
+      }
       for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) A[i][j] += Pm[i * n + j];
       for (int i = 0; i < np; ++i) {
@@ -502,8 +524,274 @@ static void backward_sweep(port_solver* S) {
   S->gphid = gphid; S->alpha_pmax = apmax; S->alpha_dmax = admax;
 }
 
+/* ---- limited-memory BFGS ---------------------------------------------------------------------------------------------- */
+/* K0 v = (rx; rc) with the factors forward_sweep stored (same recursions as forward_sweep / backward_sweep) */
+static void solve_stored(port_solver* S, const double* rx, const double* rc, double* vx, double* vc) {
+  const int n = S->n, T = S->T;
+  double py[MAXN], xn[MAXN];
+  double* ys = (double*)malloc((size_t)T * MAXBD * sizeof(double));
+  memset(py, 0, sizeof(py));
+  for (int t = 0; t < T; ++t) {
+    const stage_t* s = &S->st[t];
+    const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), bd = np + q + ny, z0 = zoff(S, t);
+    double* y = ys + (size_t)t * MAXBD;
+    for (int i = 0; i < np; ++i) y[i] = (S->lo[z0 + i] == S->hi[z0 + i]) ? 0.0 : rx[z0 + i] - (i < n ? py[i] : 0.0);
+    for (int j = 0; j < q; ++j) y[np + j] = rc[S->ccoff[t] + j];
+    for (int k = 0; k < ny; ++k) y[np + q + k] = rc[t * n + k];
+    for (int i = 1; i < bd; ++i)
+      for (int k = 0; k < i; ++k) y[i] -= s->L[i * MAXBD + k] * y[k];
+    for (int c = 0; c < ny; ++c) {
+      double acc = 0;
+      for (int i = 0; i < bd; ++i) acc += s->X[i * MAXN + c] * s->dinv[i] * y[i];
+      py[c] = acc;
+    }
+  }
+  memset(xn, 0, sizeof(xn));
+  for (int t = T - 1; t >= 0; --t) {
+    const stage_t* s = &S->st[t];
+    const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), bd = np + q + ny, z0 = zoff(S, t);
+    const double* y = ys + (size_t)t * MAXBD;
+    double v[MAXBD];
+    for (int i = 0; i < bd; ++i) {
+      double r = y[i];
+      for (int c = 0; c < ny; ++c) r -= s->X[i * MAXN + c] * xn[c];
+      v[i] = r * s->dinv[i];
+    }
+    for (int i = bd - 1; i >= 1; --i)
+      for (int k = 0; k < i; ++k) v[k] -= s->L[i * MAXBD + k] * v[i];
+    for (int i = 0; i < np; ++i) vx[z0 + i] = v[i];
+    for (int j = 0; j < q; ++j) vc[S->ccoff[t] + j] = v[np + j];
+    for (int k = 0; k < ny; ++k) vc[t * n + k] = v[np + q + k];
+    for (int i = 0; i < n; ++i) xn[i] = v[i];
+  }
+  free(ys);
+}
+
+/* eigenvalue signs of a small symmetric matrix (cyclic Jacobi): returns the number of negative eigenvalues, *tiny = 1 if one is
+ * numerically zero */
+static int small_inertia(const double* A, int m, int* tiny) {
+  double B[2 * QN_MAX][2 * QN_MAX];
+  double scale = 0;
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { B[i][j] = A[i * m + j]; scale = fmax(scale, fabs(B[i][j])); }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < i; ++j) off += B[i][j] * B[i][j];
+    if (off <= 1e-30 * scale * scale) break;
+    for (int p = 0; p < m; ++p)
+      for (int q = p + 1; q < m; ++q) {
+        if (fabs(B[p][q]) < 1e-300) continue;
+        const double th = (B[q][q] - B[p][p]) / (2.0 * B[p][q]);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0)), c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < m; ++k) { const double a = B[k][p], b = B[k][q]; B[k][p] = c * a - sn * b; B[k][q] = sn * a + c * b; }
+        for (int k = 0; k < m; ++k) { const double a = B[p][k], b = B[q][k]; B[p][k] = c * a - sn * b; B[q][k] = sn * a + c * b; }
+      }
+  }
+  int neg = 0; *tiny = 0;
+  for (int i = 0; i < m; ++i) { if (B[i][i] < 0) ++neg; if (fabs(B[i][i]) <= 1e-13 * scale) *tiny = 1; }
+  return neg;
+}
+
+/* dense solve with partial pivoting, A (m x m, destroyed) x = b (in place) */
+static void small_solve(double* A, double* b, int m) {
+  for (int j = 0; j < m; ++j) {
+    int p = j;
+    for (int i = j + 1; i < m; ++i) if (fabs(A[i * m + j]) > fabs(A[p * m + j])) p = i;
+    if (p != j) { for (int k = 0; k < m; ++k) { const double t = A[j * m + k]; A[j * m + k] = A[p * m + k]; A[p * m + k] = t; } const double t = b[j]; b[j] = b[p]; b[p] = t; }
+    const double inv = 1.0 / A[j * m + j];
+    for (int i = j + 1; i < m; ++i) {
+      const double l = A[i * m + j] * inv;
+      if (l == 0.0) continue;
+      for (int k = j; k < m; ++k) A[i * m + k] -= l * A[j * m + k];
+      b[i] -= l * b[j];
+    }
+  }
+  for (int j = m - 1; j >= 0; --j) { double acc = b[j]; for (int k = j + 1; k < m; ++k) acc -= A[j * m + k] * b[k]; b[j] = acc / A[j * m + j]; }
+}
+
+/* after the step: grad_x L(x_k, lam_{k+1}) = grad_x L(x_k, lam_k) + alpha J(x_k)' dlam, from the stage blocks of x_k (still in
+ * S->st), and the primal step -- the next iteration forms y_k = grad_x L(x_{k+1}, lam_{k+1}) - this (Ipopt's limited-memory
+ * update uses the Lagrangian gradients at the new multipliers) */
+static void qn_save(port_solver* S) {
+  const int n = S->n, T = S->T;
+  const double al = S->alpha;
+  for (int t = 0; t < T; ++t) {
+    const stage_t* s = &S->st[t];
+    const int np = np_of(S, t), q = q_of(S, t), z0 = zoff(S, t);
+    for (int i = 0; i < np; ++i) {
+      double g = s->rp[i];
+      if (t < T - 1) for (int k = 0; k < n; ++k) g += al * s->F[k * np + i] * dlam_dyn(S, t)[k];
+      if (S->con[t] >= 0) { const port_con_class* C = &S->M->cls[S->con[t]]; if (i < C->np) for (int j = 0; j < q; ++j) g += al * s->G[j * C->np + i] * S->dlam[S->ccoff[t] + j]; }
+      if (t > 0 && i < n) { const stage_t* sp = &S->st[t - 1]; for (int k = 0; k < n; ++k) g += al * sp->E[k * n + i] * dlam_dyn(S, t - 1)[k]; }
+      S->qn_gl[z0 + i] = g;
+      S->qn_s[z0 + i] = al * S->dz[z0 + i];
+    }
+  }
+}
+
+/* at the new point (after eval_all): push the pair (s, y) unless the curvature condition fails (Ipopt skips the update then) */
+static void qn_update(port_solver* S) {
+  const int Nz = S->Nz;
+  if (S->iter == 0 || S->alpha <= 0.0) return;
+  double* y = (double*)malloc(Nz * sizeof(double));
+  double sy = 0, ss = 0, yy = 0;
+  for (int t = 0; t < S->T; ++t) {
+    const int np = np_of(S, t), z0 = zoff(S, t);
+    for (int i = 0; i < np; ++i) {
+      const int zi = z0 + i;
+      const int fx = S->lo[zi] == S->hi[zi];
+      y[zi] = fx ? 0.0 : S->st[t].rp[i] - S->qn_gl[zi];
+      if (fx) S->qn_s[zi] = 0.0;
+      sy += S->qn_s[zi] * y[zi]; ss += S->qn_s[zi] * S->qn_s[zi]; yy += y[zi] * y[zi];
+    }
+  }
+  if (!(sy > 1.4901161193847656e-08 * sqrt(ss) * sqrt(yy))) {
+    /* Ipopt: limited_memory_max_skipping = 2 consecutive skips, then the approximation starts again */
+    if (++S->qn_skipped >= 2) { S->qn_k = 0; S->qn_skipped = 0; }
+    free(y);
+    return;
+  }
+  S->qn_skipped = 0;
+  if (S->qn_k == S->qn_m) {
+    memmove(S->qn_S, S->qn_S + Nz, (size_t)(S->qn_m - 1) * Nz * sizeof(double));
+    memmove(S->qn_Y, S->qn_Y + Nz, (size_t)(S->qn_m - 1) * Nz * sizeof(double));
+    S->qn_k--;
+  }
+  memcpy(S->qn_S + (size_t)S->qn_k * Nz, S->qn_s, Nz * sizeof(double));
+  memcpy(S->qn_Y + (size_t)S->qn_k * Nz, y, Nz * sizeof(double));
+  S->qn_k++;
+  /* Ipopt limited_memory_initialization = scalar1: sigma = s'y / s's of the newest pair */
+  S->qn_sigma = fmin(1e8, fmax(1e-8, sy / ss));
+  free(y);
+}
+
+/* step of the eliminated slack multipliers, fraction to the boundary and the directional derivative of the barrier objective for
+ * a step (dz, dlam) that did not come out of backward_sweep (same formulas) */
+static void step_info(port_solver* S) {
+  const port_options* o = &S->o;
+  const int T = S->T;
+  const double mu = S->mu, tau = fmax(o->tau_min, 1.0 - mu);
+  double gphid = 0, apmax = 1.0, admax = 1.0;
+  for (int t = T - 1; t >= 0; --t) {
+    stage_t* s = &S->st[t];
+    const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), z0 = zoff(S, t);
+    for (int i = 0; i < np; ++i) {
+      const double dp = S->dz[z0 + i];
+      gphid += s->rp[i] * dp;
+      const double lo = S->lo[z0 + i], hi = S->hi[z0 + i], p = S->z[z0 + i];
+      if (lo == hi) continue;
+      if (finite_lo(lo)) {
+        const double zl = S->zl[z0 + i], gap = p - lo, dzl = mu / gap - zl - (zl / gap) * dp;
+        if (dp < 0.0) apmax = fmin(apmax, -tau * gap / dp);
+        if (dzl < 0.0) admax = fmin(admax, -tau * zl / dzl);
+        gphid -= mu / gap * dp;
+      }
+      if (finite_hi(hi)) {
+        const double zu = S->zu[z0 + i], gap = hi - p, dzu = mu / gap - zu + (zu / gap) * dp;
+        if (dp > 0.0) apmax = fmin(apmax, tau * gap / dp);
+        if (dzu < 0.0) admax = fmin(admax, -tau * zu / dzu);
+        gphid += mu / gap * dp;
+      }
+    }
+    for (int j = 0; j < q; ++j) {
+      const double dnu = S->dlam[S->ccoff[t] + j], nu = S->lam[S->ccoff[t] + j], r = s->c[j];
+      double dsv = 0.0;
+      const int k = slack_of(S, t, j);
+      if (k >= 0) {
+        const double sv = S->s[k], zv = S->zs[k];
+        dsv = -(sv / zv) * (nu - mu / sv + dnu);
+        const double dzs = mu / sv - zv - (zv / sv) * dsv;
+        S->ds[k] = dsv;
+        if (dsv < 0.0) apmax = fmin(apmax, -tau * sv / dsv);
+        if (dzs < 0.0) admax = fmin(admax, -tau * zv / dzs);
+        gphid -= mu / sv * dsv;
+      }
+      gphid += nu * (r - o->delta_c * dnu + dsv);
+    }
+    for (int k = 0; k < ny; ++k) gphid += lam_dyn(S, t)[k] * (s->d[k] - o->delta_c * dlam_dyn(S, t)[k]);
+  }
+  S->gphid = gphid; S->alpha_pmax = apmax; S->alpha_dmax = admax;
+}
+
+/* K = K0 - U M^-1 U', U = [W; 0], W = [sigma S, Y], M = [[sigma S'S, L], [L', -D]]:
+ *   v = v0 + Z C^-1 U' v0,  v0 = K0^-1 b,  Z = K0^-1 U,  C = M - U' Z        (Sherman-Morrison-Woodbury)
+ * inertia(K) = inertia(K0) + inertia(C) - inertia(M) (Haynsworth, both ways round): K0 must have (Nz, Nc, 0) and C as many
+ * negative eigenvalues as M, else delta_w goes up the ladder -- with curvature-checked pairs that is the exception */
+static void qn_factor_solve(port_solver* S) {
+  const port_options* o = &S->o;
+  const int Nz = S->Nz, Nc = S->Nc, k = S->qn_k, m2 = 2 * k;
+  const double sig = S->qn_sigma;
+  /* first delta_w: the rules of conv_body (the ladder state delta_last stays 0 in this mode: gam = 0 never records it) */
+  double dw = 0.0;
+  if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * S->delta_last, o->delta_w_init));
+  else if (S->delta_last > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * S->delta_last);
+  if (S->ls_mode == 1 && o->pen_gn) dw = fmax(dw, o->delta_w_init);
+  double* U = (double*)malloc((size_t)(m2 > 0 ? m2 : 1) * Nz * sizeof(double));
+  double* Zx = (double*)malloc((size_t)(m2 > 0 ? m2 : 1) * Nz * sizeof(double));
+  double* zc = (double*)malloc((Nc > 0 ? Nc : 1) * sizeof(double));
+  double* zero_c = (double*)calloc(Nc > 0 ? Nc : 1, sizeof(double));
+  double Mm[4 * QN_MAX * QN_MAX], Cm[4 * QN_MAX * QN_MAX], rhs[2 * QN_MAX];
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < Nz; ++i) { U[(size_t)j * Nz + i] = sig * S->qn_S[(size_t)j * Nz + i]; U[(size_t)(k + j) * Nz + i] = S->qn_Y[(size_t)j * Nz + i]; }
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b < k; ++b) {
+      double ss = 0, sy = 0;
+      for (int i = 0; i < Nz; ++i) { ss += S->qn_S[(size_t)a * Nz + i] * S->qn_S[(size_t)b * Nz + i]; sy += S->qn_S[(size_t)a * Nz + i] * S->qn_Y[(size_t)b * Nz + i]; }
+      Mm[a * m2 + b] = sig * ss;
+      Mm[a * m2 + k + b] = a > b ? sy : 0.0;           /* L: strictly lower part of S'Y */
+      Mm[(k + b) * m2 + a] = a > b ? sy : 0.0;
+      Mm[(k + a) * m2 + k + b] = a == b ? -sy : 0.0;   /* -D */
+    }
+  int tiny_m = 0;
+  const int neg_m = m2 > 0 ? small_inertia(Mm, m2, &tiny_m) : 0;
+  int ok = 0;
+  for (int attempt = 0;; ++attempt) {
+    ok = forward_sweep(S, dw, 0.0, NULL);
+    S->nfact++;
+    if (ok && m2 > 0) {
+      for (int j = 0; j < m2; ++j) solve_stored(S, U + (size_t)j * Nz, zero_c, Zx + (size_t)j * Nz, zc);
+      for (int a = 0; a < m2; ++a)
+        for (int b = 0; b < m2; ++b) {
+          double acc = 0;
+          for (int i = 0; i < Nz; ++i) acc += U[(size_t)a * Nz + i] * Zx[(size_t)b * Nz + i];
+          Cm[a * m2 + b] = Mm[a * m2 + b] - acc;
+        }
+      for (int a = 0; a < m2; ++a) for (int b = 0; b < a; ++b) { const double av = 0.5 * (Cm[a * m2 + b] + Cm[b * m2 + a]); Cm[a * m2 + b] = Cm[b * m2 + a] = av; }
+      int tiny_c = 0;
+      const int neg_c = small_inertia(Cm, m2, &tiny_c);
+      if (neg_c != neg_m || tiny_c) ok = 0;
+    }
+    if (ok || attempt >= o->max_refactor) break;
+    dw = dw == 0.0 ? o->delta_w_init : dw * o->kappa_w_plus;   /* retry_update_t, gam = 0 */
+    if (dw > o->delta_w_max) dw = o->delta_w_max;
+  }
+  backward_sweep(S);                                   /* v0 = K0^-1 (-r) in (dz, dlam) */
+  if (m2 > 0) {
+    for (int a = 0; a < m2; ++a) { double acc = 0; for (int i = 0; i < Nz; ++i) acc += U[(size_t)a * Nz + i] * S->dz[i]; rhs[a] = acc; }
+    small_solve(Cm, rhs, m2);
+    /* the multiplier part of Z: one more pass per column would double the solves; dlam follows from dz through the stage rows
+     * instead -- recompute it with ONE solve of K0 for the corrected right-hand side:  K0 v = b + U (M^-1 U' v)  and
+     * M^-1 U' v = C^-1 U' v0 (push-through identity) */
+    double* bx = (double*)malloc(Nz * sizeof(double));
+    double* bc = (double*)malloc((Nc > 0 ? Nc : 1) * sizeof(double));
+    double* vx = (double*)malloc(Nz * sizeof(double));
+    /* b = -(r_p'; c'): rebuild it from K0 v0: cheaper to solve for the correction only: K0 dv = U q */
+    for (int i = 0; i < Nz; ++i) { double acc = 0; for (int a = 0; a < m2; ++a) acc += U[(size_t)a * Nz + i] * rhs[a]; bx[i] = acc; }
+    solve_stored(S, bx, zero_c, vx, bc);
+    for (int i = 0; i < Nz; ++i) S->dz[i] += vx[i];
+    for (int i = 0; i < Nc; ++i) S->dlam[i] += bc[i];
+    free(bx); free(bc); free(vx);
+    step_info(S);
+  }
+  S->delta_w = dw;
+  if (dw == 0.0) S->delta_last = 0.0;
+  S->gamma = 0.0;
+  S->ls_fail = ok ? 0 : 1;
+  free(U); free(Zx); free(zc); free(zero_c);
+}
+
 /* inertia correction: k_conv's choice of the first delta_w + k_kkt_sep's ladder */
 static void factor_solve(port_solver* S) {
+  if (S->qn_mode == 2) { qn_factor_solve(S); return; }
   const port_options* o = &S->o;
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
@@ -782,10 +1070,12 @@ static void update(port_solver* S) {
 int port_iterate(port_solver* S) {
   if (S->status != 0) return 0;
   eval_all(S);
+  if (S->qn_mode == 2) qn_update(S);
   convergence(S);
   if (S->status != 0) return 0;
   factor_solve(S);
   line_search(S);
+  if (S->qn_mode == 2) qn_save(S);
   update(S);
   S->iter++;
   return 1;
@@ -797,6 +1087,8 @@ int port_iterations(const port_solver* S) { return S->iter; }
 int port_nfact(const port_solver* S) { return S->nfact; }
 int port_nsoc(const port_solver* S) { return S->nsoc; }
 int port_ls_kind(const port_solver* S) { return S->ls_kind; }
+double port_qn_sigma(const port_solver* S) { return S->qn_sigma; }
+int port_qn_pairs(const port_solver* S) { return S->qn_k; }
 int port_num_variables(const port_solver* S) { return S->Nz; }
 int port_num_constraint(const port_solver* S) { return S->Nc; }
 int port_num_slacks(const port_solver* S) { return S->Ni; }

@@ -75,3 +75,24 @@ def test_port_batch_driver_matches_single_solves():
         assert s.solve(Z[b]) == 1
         ref.append(s.iterations)
     assert list(it) == ref and np.all(st == 1) and total == sum(ref)
+
+
+def test_port_limited_memory_mode_converges_without_second_derivatives():
+    """oracle/cpu_port in its L-BFGS mode (the mirror of dto_options.hessian_approximation = DTO_HESSIAN_LBFGS; the reference's
+    default, src/solver.jl:7): the same minimisers as with exact Hessians, one factorisation per iteration (B is positive definite
+    by the curvature test: no inertia ladder), more iterations -- a quasi-Newton count."""
+    import numpy as np
+    from oracle.cpu_port import PortSolver, guesses
+    for model, T, nseed, cap in (("pendulum", 50, 4, 80), ("acrobot", 101, 4, 400), ("car", 51, 2, 700)):
+        Z, _, _ = guesses(model, T, nseed, 1000)
+        for b in range(nseed):
+            ex = PortSolver(model, T, max_iter=1000)
+            ex.solve(Z[b])
+            qn = PortSolver(model, T, max_iter=1000, lbfgs=6)
+            qn.solve(Z[b])
+            assert ex.status == 1 and qn.status == 1, (model, b, ex.status, qn.status)
+            assert qn.iterations <= cap and (model != "pendulum" or ex.iterations < qn.iterations), (model, b, ex.iterations, qn.iterations)
+            assert qn.nfact <= qn.iterations + 3, (model, b, qn.nfact, qn.iterations)
+            assert 0 < qn.qn_pairs <= 6 and qn.qn_sigma > 0
+            if model == "pendulum":
+                assert np.max(np.abs(qn.z - ex.z)) <= 1e-4 * max(1.0, np.max(np.abs(ex.z)))

@@ -104,7 +104,9 @@ def test_first_iterations_match_the_soa_engine(model, T, B):
             # a nonconvex solve those differences have been fed back through the iterates (multipliers of 3e5 at a random guess,
             # three factorisations of systems conditioned like 1e8 in a row): 1e-5; measured 1e-6 .. 3e-7 depending on how the
             # compiler contracts the multiply-adds of the SoA sweeps.
-            tol = 1e-5 if k > 1 else (1e-7 if "multipliers" in n else 2e-8)
+            # (round 5: cartpole's first steps are Gauss-Newton steps of the penalty phase, delta_w = 1e-4 -- a less well
+            #  conditioned system than the ladder's: 5e-8)
+            tol = 1e-5 if k > 1 else (1e-7 if "multipliers" in n else 5e-8)
             assert np.max(np.abs(a[n] - b[n])) <= tol * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
 
 

@@ -146,7 +146,7 @@ def test_julia_structs_mirror_the_header():
     assert int(re.search(r"#define\s+DTO_ABI_VERSION\s+(\d+)", header).group(1)) == \
         int(re.search(r"const DTO_ABI_VERSION = Cint\((\d+)\)", jl).group(1))
     # the constructor DtoOptions(o::Options) passes one value per field
-    m = re.search(r"DtoOptions\(o::Options\)\s*=\s*DtoOptions\((.*?)\)\n\n", jl, flags=re.S)
+    m = re.search(r"DtoOptions\(o::Options[^)]*\)\s*=\s*DtoOptions\((.*?)\)\n\n", jl, flags=re.S)
     assert m and len(_split_top(m.group(1))) == len(cs["dto_options"])
 
 

@@ -1,0 +1,99 @@
+"""The reference's default solve mode on the GPU (Missing 2): a problem built with evaluate_hessian=false --
+src/solver.jl:7, and what the reference's own acrobot and car examples run (examples/acrobot/acrobot.jl:122-123,
+examples/car/car.jl:63) -- leaves Ipopt on hessian_approximation = limited-memory.  Here: compact L-BFGS (history 6) whose
+low-rank part is a dense border of the block-tridiagonal system (csrc/dto_kkt_kernels.hpp, "limited-memory BFGS";
+dto_options.hessian_approximation = DTO_HESSIAN_LBFGS), mirrored in the C port (oracle/cpu_port/solver_port.c: qn_*).
+
+  * the four reference configs from 64 seeded guesses each: >= 62 of 64 converge (cartpole: its one deterministic guess), every
+    converged point is a KKT point of the ORACLE's problem and passes the reference's own endpoint asserts (test/solve.jl:136-137);
+  * no second derivative is used: the step of an iteration equals the port's step with the same history to 1e-6 (first
+    iterations of a pendulum solve), and the port's Hessian model is sigma I + low rank by construction;
+  * the mode is reachable through dto_options alone (Options(hessian_approximation="lbfgs") on a problem WITH Hessians).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(model, T, evaluate_hessian=False, **opts):
+    import dto_amd
+    from dto_amd import problems as P
+    p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=evaluate_hessian)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=evaluate_hessian,
+                       options=dto_amd.Options(**opts), name=model)
+    return s, p
+
+
+def _guesses(s, p, B):
+    import dto_amd
+    nz = s._solve_nlp.num_variables
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, us)
+        Z[b] = s._z0
+    return Z
+
+
+@pytest.mark.parametrize("model,T,B,need", [("pendulum", 50, 64, 64), ("car", 51, 64, 62), ("cartpole", 200, 1, 1), ("acrobot", 101, 64, 62)])
+def test_default_mode_converges_on_the_reference_configs(model, T, B, need):
+    import torch
+    from test_solve_gpu import kkt_report, oracle_for
+    s, p = _solver(model, T)
+    assert s.hessian_mode == "lbfgs"
+    nz, nc = s._solve_nlp.num_variables, s._solve_nlp.num_constraint
+    Z = _guesses(s, p, B)
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert int(np.sum(st == 1)) >= need, (model, np.bincount(st), np.median(it))
+    onlp = oracle_for(model, T)
+    zo, lo = zo.cpu().numpy(), lo.cpu().numpy()
+    idx = s.nlp.indices
+    for b in [b_ for b_ in range(0, B, max(1, B // 8)) if st[b_] == 1]:
+        rep = kkt_report(onlp, zo[b], lo[b])
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["bound_compl"] <= 1e-3, (model, b, rep)
+        assert np.linalg.norm(zo[b][np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3      # test/solve.jl:136
+        assert np.linalg.norm(zo[b][np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3     # test/solve.jl:137
+    print(f"[lbfgs] {model} T={T}: {int(np.sum(st == 1))}/{B} converged, median {np.median(it):.0f} iterations (max {it.max()})")
+
+
+def test_steps_match_the_port_in_limited_memory_mode():
+    """First iterations of a pendulum T = 50 solve, iterate by iterate against oracle/cpu_port in its lbfgs mode (same secant
+    pairs, same sigma, same 12 x 12 border system -- a different route to grad_x L(x_k, lam_{k+1}): J'dlam there, the first block
+    row of the solved system here)."""
+    import torch
+    from oracle.cpu_port import PortSolver
+    s, p = _solver("pendulum", 50)
+    nz = s._solve_nlp.num_variables
+    Z = _guesses(s, p, 1)
+    ps = PortSolver("pendulum", 50, max_iter=1000, lbfgs=6)
+    ps.begin(Z[0])
+    z0 = torch.tensor(Z, device="cuda")
+    s.begin_batch(z0.data_ptr(), 1, nz)
+    for k in range(12):
+        s.iterate_batch(1)
+        ps.iterate()
+        zg = s.peek_batch("z")[0]
+        zp = ps.z
+        assert np.max(np.abs(zg - zp)) <= 1e-6 * max(1.0, np.max(np.abs(zp))), (k, np.max(np.abs(zg - zp)))
+        assert abs(float(s.scalar_batch("qn_sigma")[0]) - ps.qn_sigma) <= 1e-6 * max(1.0, ps.qn_sigma), k
+    s.release_state()
+
+
+def test_mode_is_an_option_of_the_c_abi():
+    """Options(hessian_approximation="lbfgs") on a problem built WITH Hessians: same plugin, the approximation replaces them."""
+    import dto_amd
+    s, p = _solver("pendulum", 50, evaluate_hessian=True, hessian_approximation="lbfgs")
+    e, _ = _solver("pendulum", 50, evaluate_hessian=True)
+    assert s.hessian_mode == "lbfgs" and e.hessian_mode == "exact"
+    for sol in (s, e):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+        dto_amd.initialize_states(sol, xs); dto_amd.initialize_controls(sol, us)
+        assert dto_amd.solve(sol) == 1
+    assert s.iterations > e.iterations                     # a quasi-Newton iteration count, not the Newton one
+    assert np.max(np.abs(s._solution - e._solution)) <= 1e-4 * np.max(np.abs(e._solution))

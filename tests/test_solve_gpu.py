@@ -154,7 +154,7 @@ def test_default_mode_without_exact_hessians(model, T, cap):
     assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1] - p["xT"]) < 1e-3
 
 
-@pytest.mark.parametrize("model,T,cap", [("car", 51, 80), ("pendulum", 50, 40)])
+@pytest.mark.parametrize("model,T,cap", [("car", 51, 80), ("pendulum", 50, 45)])
 def test_quasi_newton_mode(model, T, cap):
     """Options(hessian_approximation="sr1"): per-stage SR1 approximations of the element Hessians (csrc/dto_kkt_kernels.hpp,
     k_stage_eval) -- the mode that is also used when the dynamics come with a user-provided Jacobian.  It must stay within a
@@ -343,6 +343,9 @@ def test_watchdog_state_machine():
             if float(s.scalar_batch("status")[0]) != 0:
                 break
             al, ap, kind = (float(s.scalar_batch(k)[0]) for k in ("alpha", "alpha_pmax", "ls_kind"))
+            if float(s.scalar_batch("ls_mode")[0]) == 1.0:  # penalty phase (round 5; the guess is far from the manifold): the
+                assert kind in (5.0, -1.0)                  # filter and its watchdog have not started yet
+                continue
             if left > 0:                                   # a watchdog iteration
                 assert kind == 3.0 and al <= ap, (it, kind, al, ap)       # full step unless it would blow the violation up 3x
                 if float(s.scalar_batch("mu")[0]) == mu0:  # (a barrier update resets the filter)

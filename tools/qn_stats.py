@@ -8,7 +8,11 @@ from dto_amd import problems as P
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for model, T in (("pendulum", 50), ("acrobot", 101), ("cartpole", 200), ("car", 51), ("acrobot", 301)):
-    for mode in ("auto", "sr1"):      # (a partitioned damped BFGS was tried in round 4 and never converged: tools/experiments/)
+    # "lbfgs" = the default of evaluate_hessian=false since round 5 (compact L-BFGS, dto_options.hessian_approximation); "exact" =
+    # second derivatives of the traced expressions; "sr1" = per-stage SR1 blocks (a partitioned damped BFGS was tried in round 4
+    # and never converged: tools/experiments/)
+    import time
+    for mode in ("lbfgs", "exact", "sr1"):
         p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=False)
         try:
             s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False,
@@ -23,10 +27,12 @@ for model, T in (("pendulum", 50), ("acrobot", 101), ("cartpole", 200), ("car", 
             dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, us)
             Z[b] = s._z0
         z0 = torch.tensor(Z, device="cuda"); zo = torch.empty_like(z0)
+        t0 = time.perf_counter()
         st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz)
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         f = []
         for b in range(min(B, 8)):
             f.append(round(float(s.nlp.eval_objective(zo[b].cpu().numpy())), 3))
         print(json.dumps(dict(model=model, T=T, mode=mode, converged=int(np.sum(st == 1)), n=B, it_median=float(np.median(it)),
-                              it_max=int(it.max()), status=np.bincount(st, minlength=6).tolist(), f=f)), flush=True)
+                              it_max=int(it.max()), seconds=round(dt, 3), hessian_mode=s.hessian_mode, status=np.bincount(st, minlength=6).tolist(), f=f)), flush=True)
