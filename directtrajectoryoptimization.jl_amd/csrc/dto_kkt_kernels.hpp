@@ -35,6 +35,12 @@
 #include "dto_model_plugin.h"
 
 // ---- ops --------------------------------------------------------------------------------------
+// 0 compiles the limited-memory mode's three touches of the sweep kernels out (A/B measurements of their cost: the mode then
+// fails its tests, never ship a build with it)
+#ifndef DTO_QN_HOT
+#define DTO_QN_HOT 1
+#endif
+
 enum dto_kkt_op {
   DTO_KKT_PACK = 0,        // instance-major z (and lam) -> SoA tiles
   DTO_KKT_UNPACK = 1,      // SoA tiles -> instance-major
@@ -1580,7 +1586,7 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
     // (limited-memory mode: B_0 = sigma I replaces the objective Hessian too -- scale 0; otherwise 1: x * 1.0 is exact.
     //  Not for the element-BFGS plugins, which never run in that mode: with the multiply there, AMD clang 22 stops with
     //  "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_private_base" on the SR1 acrobot plugin.)
-    if constexpr (!D::QN) {
+    if constexpr (!D::QN && DTO_QN_HOT) {
 #pragma unroll
       for (int i = 0; i < CO::NHL; ++i) hl[i] *= o.cost_hess_scale;
     }
@@ -2034,7 +2040,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     if (!__any(need)) return;
     const double mu = sc[SC_MU << 6];
     // (limited-memory mode: the diagonal sigma I of B_0 rides on the primal regularisation)
-    const double dw = sc[SC_TRY_DW << 6] + (a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_TRY_GAM << 6];
+    const double dw = sc[SC_TRY_DW << 6] + (DTO_QN_HOT && a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_TRY_GAM << 6];
     const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
     Carry<M> cy;
     Spike<M> sp;
@@ -2449,7 +2455,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
   constexpr int N = M::MAX_NX;
   const double mu = sc[SC_MU << 6];
   const double tau = fmax(o.tau_min, 1.0 - mu);
-  const double dw = sc[SC_DELTA_W << 6] + (a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_GAMMA << 6];  // the accepted factorisation
+  const double dw = sc[SC_DELTA_W << 6] + (DTO_QN_HOT && a.opt.qn_lbfgs ? sc[SC_QN_SIGMA << 6] : 0.0), gam = sc[SC_GAMMA << 6];  // the accepted factorisation
   const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
   double xL[N], xn[N];
 #pragma unroll

@@ -76,6 +76,7 @@ typedef struct {
   double f, f_last, th1, thinf, dinf, compl, e0, logbar, xmax, mu, merit0;
   double szmax, iszmax, sumlam, sumz;
   double delta_lm;
+  double piv_min;
   double delta_w, delta_last, gamma, alpha, alpha_pmax, alpha_dmax, gphid, theta_max, theta_min;
   double filt[2 * FILTER_CAP];
   /* limited-memory BFGS mode (the reference's default: Solver(...; evaluate_hessian=false) leaves Ipopt on
@@ -360,6 +361,7 @@ static int forward_sweep(port_solver* S, double dw, double gam, const double* rh
   double Pm[MAXN * MAXN], py[MAXN];
   memset(Pm, 0, sizeof(Pm)); memset(py, 0, sizeof(py));
   int ok = 1, nneg = 0;
+  S->piv_min = 0.0;
   for (int t = 0; t < T; ++t) {
     stage_t* s = &S->st[t];
     const int np = np_of(S, t), q = q_of(S, t), ny = ny_of(S, t), bd = np + q + ny, z0 = zoff(S, t);
@@ -421,6 +423,7 @@ static int forward_sweep(port_solver* S, double dw, double gam, const double* rh
         for (int i = j + 1; i < bd; ++i) cmax = fmax(cmax, fabs(A[i][j]));
         if (!(fabs(dj) > o->piv_tol * fmax(1.0, cmax))) { stage_ok = 0; dj = (dj < 0 ? -1.0 : 1.0) * fmax(fabs(dj), o->piv_tol); }
         if (dj < 0) ++stage_neg;
+        if (j < np && dj < 0 && (S->piv_min == 0.0 || (getenv("DTO_PIV_MIN") && dj < S->piv_min))) S->piv_min = dj;   /* (experiment DTO_PIV_JUMP: first [most] negative primal pivot of the sweep) */
         const double inv = 1.0 / dj;
         s->dinv[j] = inv;
         for (int i = j + 1; i < bd; ++i) {
@@ -825,8 +828,13 @@ static void factor_solve(port_solver* S) {
     if (ok || attempt >= o->max_refactor) break;
     if (gam != 0.0) {
       const int skip_ladder = (S->gamma == 0.0) && (S->iter % 4 != 0);
+      const double dw_failed = dw;
       if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o->delta_w_init : fmax(o->delta_w_init, o->kappa_w_minus * dlast);
       else if (!skip_ladder) dw *= (dlast == 0.0) ? o->kappa_w_plus_first : o->kappa_w_plus;
+      {   /* experiment: jump the ladder to the level the most negative primal pivot of the failed sweep asks for */
+        static double kj = -1; if (kj < 0) kj = getenv("DTO_PIV_JUMP") ? atof(getenv("DTO_PIV_JUMP")) : 0.0;
+        if (kj > 0 && !skip_ladder && S->piv_min < 0) { const double want = dw_failed + kj * -S->piv_min; if (want > dw) dw = want; }
+      }
       if (skip_ladder || dw > o->delta_w_exact_cap) { gam = 0.0; dw = o->delta_w_init; }
     } else {
       dw *= o->kappa_w_plus;

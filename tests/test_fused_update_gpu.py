@@ -52,7 +52,14 @@ def _run(s, Z, fused, calls):
                                             ("cartpole", 200, 3, True), ("acrobot_bounds", 101, 65, True),
                                             ("pendulum", 50, 64, False)])
 def test_fused_update_does_not_change_a_bit(model, T, B, hess):
-    s, p = product_solver(model, T, evaluate_hessian=hess)
+    if hess:
+        s, p = product_solver(model, T, evaluate_hessian=True)
+    else:   # per-stage SR1 records; the default of evaluate_hessian=False (limited-memory) does not fuse UPDATE with EVAL at all
+        import dto_amd
+        from dto_amd import problems as P
+        p = getattr(P, f"build_{model}")(T=T, evaluate_hessian=False)
+        s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False,
+                           options=dto_amd.Options(hessian_approximation="sr1"), name=model)
     Z = _guesses(s, p, B, seed=3)
     # calls of 1 and 2 iterations run nothing fused; 7 -> 6 fused passes, 4 -> 2: the number per call is even
     calls = [7, 1, 4, 2, 9]

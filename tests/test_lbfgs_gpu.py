@@ -56,7 +56,7 @@ def test_default_mode_converges_on_the_reference_configs(model, T, B, need):
     idx = s.nlp.indices
     for b in [b_ for b_ in range(0, B, max(1, B // 8)) if st[b_] == 1]:
         rep = kkt_report(onlp, zo[b], lo[b])
-        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["bound_compl"] <= 1e-3, (model, b, rep)
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["compl"] <= 1e-3, (model, b, rep)
         assert np.linalg.norm(zo[b][np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3      # test/solve.jl:136
         assert np.linalg.norm(zo[b][np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3     # test/solve.jl:137
     print(f"[lbfgs] {model} T={T}: {int(np.sum(st == 1))}/{B} converged, median {np.median(it):.0f} iterations (max {it.max()})")
