@@ -81,7 +81,8 @@ enum dto_scal {
 };
 
 constexpr int DTO_NPART = 10;   // residual partials written by k_stage_eval
-constexpr int DTO_SB = 8;       // consecutive stages one wavefront of the stage-parallel kernels walks (partials summed in registers)
+constexpr int DTO_SB = 8;       // consecutive stages one wavefront of the stage-parallel kernels walks (partials summed in registers):
+                                // the value for batches that fill the GPU; dto_kkt_args.sb carries the one in use (1 for a batch of one)
 constexpr int DTO_LS_TRIALS = 8;
 constexpr double DTO_LS_NULL_STEP = 100.0;  // k_ls_reduce: no step at all when even the most feasible trial multiplies the violation by more
 constexpr int DTO_FILTER_CAP = 24;  // filter entries kept per instance (ring)
@@ -173,6 +174,8 @@ struct dto_kkt_args {
   // slot -> instance map after dto_solver_repack moved the running instances to the front (NULL: identity)
   const int* inst_of_slot;
   int fwd_rounds;  // sequential sweep: inertia-correction rounds per launch (0 = all)
+  int sb;          // consecutive stages per wavefront of the stage-parallel kernels (k_stage_eval, k_linesearch, k_update_eval): DTO_SB, less for small batches
+  int sep_cr;      // 1: separator system of a tile with few running instances by cyclic reduction, lanes = separators (kkt_sep_cr)
   double* qn;      // limited-memory BFGS: per tile (4 QN_M + 4) Nz + QN_SMALL rows (S, Y, Z, r_p0, grad L, s, v0, small matrices), or NULL
   int qn_mode, qn_col;   // DTO_KKT_QN_RHS: 0 column qn_col of U, 1 U q, 2 restore; DTO_KKT_QN_COL: column (-1: save v0)
   // instance-major mirrors for pack/unpack
@@ -670,6 +673,12 @@ __device__ __forceinline__ bool finite_hi(double v) { return v < 1e300; }
 // ------------------------------------------------------------------------------------------------
 // pack / unpack between the C-ABI's instance-major buffers and SoA tiles
 // ------------------------------------------------------------------------------------------------
+// SC_STATUS of a lane that holds no instance (the tail of the last tile): any non-zero status means "not running" to every kernel
+constexpr double DTO_ST_NO_INSTANCE = 9.0;
+__device__ __forceinline__ bool lane_is_instance(const dto_kkt_args& a, int64_t g) {
+  const int64_t slot = g * 64 + threadIdx.x;
+  return (a.inst_of_slot ? (int64_t)a.inst_of_slot[slot] : slot) < a.B;
+}
 static __global__ __launch_bounds__(256) void k_pack(dto_kkt_args a, int64_t n, double* dst, unsigned nrb) {
   // grid: G * nrb, nrb = ceil(n/4) row blocks (tile index in grid.x: grid.y is limited to 65535); block 256 = 4 rows x 64 lanes
   const int64_t tile = blockIdx.x / nrb;
@@ -782,7 +791,9 @@ __global__ __launch_bounds__(WAVE) void k_init(dto_kkt_args a) {
     }
   });
   if (t == 0) {
-    *soa(a.scal, g, SC_COUNT, SC_STATUS) = 0.0;
+    // the lanes of the last tile behind the batch are no instances: "finished" from the start (until round 5 they ran a solve
+    // from the all-zero guess -- harmless, but a tile's inertia-correction rounds then waited for them too)
+    *soa(a.scal, g, SC_COUNT, SC_STATUS) = lane_is_instance(a, g) ? 0.0 : DTO_ST_NO_INSTANCE;
     *soa(a.scal, g, SC_COUNT, SC_ITER) = 0.0;
     *soa(a.scal, g, SC_COUNT, SC_MU) = o.newton_only ? 0.0 : mu0;
     *soa(a.scal, g, SC_COUNT, SC_PENALTY) = 0.0;   // nu of the l1-penalty phase (ls_reduce_body)
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(WAVE) void k_rhs_record(dto_kkt_args a) {
 
 static __global__ __launch_bounds__(WAVE) void k_rearm(dto_kkt_args a) {
   double* sc = a.scal + (((int64_t)blockIdx.x * SC_COUNT) << 6) + threadIdx.x;
-  sc[SC_STATUS << 6] = 0.0;
+  sc[SC_STATUS << 6] = lane_is_instance(a, blockIdx.x) ? 0.0 : DTO_ST_NO_INSTANCE;
   sc[SC_NEED << 6] = 1.0;
   sc[SC_ATTEMPT << 6] = 0.0;
   sc[SC_TRY_DW << 6] = a.opt.fixed_delta_w;
@@ -865,16 +876,16 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
   // a wavefront walks DTO_SB consecutive stages: the residual partials are summed in registers in stage order (one row set
   // per block instead of one per stage goes to memory), and E_t' lambda_t is handed to the next stage instead of
   // re-evaluating the previous stage's Jacobian there
-  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
+  const int nblk = (a.T + a.sb - 1) / a.sb;
   const int64_t g = blockIdx.x / nblk;
   const int blk = blockIdx.x % nblk;
   const dto_solver_opts& o = a.opt;
-  const int t_begin = blk * DTO_SB;
+  const int t_begin = blk * a.sb;
   double al = 0.0, ad = 0.0, mu_u = 0.0;
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) {  // finished instance: its record stays frozen
     if constexpr (UPD) {
       // ... and its iterate moves to the other buffer unchanged
-      const int te = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
+      const int te = (blk + 1) * a.sb < a.T ? (blk + 1) * a.sb : a.T;
       for (int i = uload(a.zoff, t_begin); i < uload(a.zoff, te); ++i) *soa(a.z_next, g, a.Nz, i) = *soa(a.z, g, a.Nz, i);
       for (int i = uload(a.cdoff, t_begin); i < uload(a.cdoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
       for (int i = uload(a.ccoff, t_begin); i < uload(a.ccoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
@@ -909,7 +920,7 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
          A_logbar = 0.0, A_xmax = 0.0;
   double ecarry[M::MAX_NX], enext[M::MAX_NX];   // E_{t-1}' lambda_{t-1} from the previous stage / E_t' lambda_t for the next
   bool have_carry = false;
-  const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
+  const int t_end = (blk + 1) * a.sb < a.T ? (blk + 1) * a.sb : a.T;
   for (int t = t_begin; t < t_end; ++t) {
   dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
@@ -1288,8 +1299,8 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.0;
   // a block of DTO_SB stages belongs to the chunk that holds its first stage (every block is counted exactly once)
-  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
-  const int b0 = (uload(a.cstart, p) + DTO_SB - 1) / DTO_SB, b1 = (uload(a.cstart, p + 1) + DTO_SB - 1) / DTO_SB;
+  const int nblk = (a.T + a.sb - 1) / a.sb;
+  const int b0 = (uload(a.cstart, p) + a.sb - 1) / a.sb, b1 = (uload(a.cstart, p + 1) + a.sb - 1) / a.sb;
   for (int t = b0; t < b1; ++t) {
     const double* row = in + (((g * nblk + t) * NV) << 6) + threadIdx.x;
 #pragma unroll
@@ -1420,6 +1431,9 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double f = 0, th1 = 0, thinf = 0, dinf = 0, szmax = 0, iszmax = 0, slam = 0, sz = 0, lb = 0, xmax = 0;
+  // (partially unrolled: the loads of several chunks in flight at once -- with one running lane this loop is a chain of
+  //  memory latencies, 23 us for 64 chunks; the sums are still taken in chunk order)
+#pragma unroll 8
   for (int c = 0; c < a.P; ++c) {
     const double* part = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
     f += part[0 << 6];
@@ -2159,10 +2173,224 @@ __global__ __launch_bounds__(WAVE, DTO_SEQ_FWD_OCC) void k_kkt_fwd_seq(dto_kkt_a
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The separator system of ONE instance by block cyclic reduction, lanes = separators (a batch of one / a few instances: the
+// lane-per-instance elimination below walks the P - 1 separators one after the other with one active lane -- 4 us each, 250 us
+// of a 830 us iteration at T = 1000, profiles/r05/single_instance_kernel_trace_*.txt).  The reduced matrix is symmetric block
+// tridiagonal (diagonal blocks A_j, sub-diagonal blocks Lo_j = K[s_j, s_{j-1}]); at level h = 1, 2, 4, ... the nodes with
+// j mod 2h = h - 1 are eliminated -- A_e = L D L', F = A_e^-1 Lo_e, G = A_e^-1 Lo_{e+h}', y = A_e^-1 r_e -- and their
+// neighbours j mod 2h = 2h - 1 take the Schur complements; log2 levels down, log2 levels of back substitution up, neighbour
+// blocks through LDS.  It is a block LDL' under a symmetric permutation: the count of negative pivots is the inertia all the
+// same (Sylvester), and for the positive definite matrix this must be for the step to be accepted every pivot is positive.
+// ------------------------------------------------------------------------------------------------
+#ifndef DTO_SEP_CR_MAX_INST
+#define DTO_SEP_CR_MAX_INST 4
+#endif
+__device__ __forceinline__ void sep_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+template <class M>
+__device__ __forceinline__ void kkt_sep_cr(const dto_kkt_args& a, const int64_t g, const int li, bool& ok_out, int& nneg_out) {
+  using CS = ChunkSum<M>;
+  constexpr int N = CS::N, NT = CS::NT, NN = N * N;
+  __shared__ double sh_lo[64 * NN], sh_f[64 * NN], sh_g[64 * NN], sh_y[64 * N], sh_x[64 * N];
+  const dto_solver_opts& o = a.opt;
+  const int j = threadIdx.x;   // separator j = x at the head of chunk j + 1
+  const int ns = a.P - 1;
+  const bool act = j < ns;
+  auto csp = [&](int p) { return a.csum + (((g * a.P + p) * CS::SIZE) << 6) + li; };
+  bool ok = true;
+  int nneg = 0;
+  if (j < a.P) {               // the chunks' own verdicts: lane j reads chunk j
+    const double* cs = csp(j);
+    if (cs[(int64_t)CS::OK << 6] == 0.0) ok = false;
+    nneg = (int)cs[(int64_t)CS::NNEG << 6];
+  }
+  double A[NT], Lo[NN], r[N], F[NN], G[NN], y[N], dinv[N];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) A[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NN; ++i) Lo[i] = F[i] = G[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { A[tri(i, i)] = 1.0; r[i] = y[i] = 0.0; dinv[i] = 1.0; }
+  if (act) {
+    const int p = j + 1;
+    const double* cl = csp(p - 1);
+    const double* cr = csp(p);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) A[i] = cl[(int64_t)(CS::P + i) << 6] + cr[(int64_t)(CS::RLL + i) << 6];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = cr[(int64_t)(CS::RL + i) << 6] - cl[(int64_t)(CS::PY + i) << 6];
+    const int z0 = a.zoff[a.cstart[p]];
+    bool fx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) fx[i] = !o.newton_only && (a.lo[z0 + i] == a.hi[z0 + i]);
+    if (p > 1) {
+      const int zp = a.zoff[a.cstart[p - 1]];
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const bool fc = !o.newton_only && (a.lo[zp + c] == a.hi[zp + c]);
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) Lo[aa * N + c] = (fc || fx[aa]) ? 0.0 : cl[(int64_t)(CS::CX + aa * N + c) << 6];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (fx[i]) {
+#pragma unroll
+        for (int r2 = 0; r2 < N; ++r2) {
+          if (r2 > i) A[tri(r2, i)] = 0.0;
+          if (r2 < i) A[tri(i, r2)] = 0.0;
+        }
+        A[tri(i, i)] = 1.0;
+        r[i] = 0.0;
+      }
+    }
+  }
+  // ---- reduction
+  for (int h = 1; h <= ns; h <<= 1) {
+    const int m = j & (2 * h - 1);
+    const bool elim = act && m == h - 1, surv = act && m == 2 * h - 1;
+    if (elim || surv) {
+#pragma unroll
+      for (int i = 0; i < NN; ++i) sh_lo[j * NN + i] = Lo[i];
+    }
+    sep_lds_fence();
+    if (elim) {
+      const bool right = j + h < ns;
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+          F[aa * N + c] = Lo[aa * N + c];
+          G[aa * N + c] = right ? sh_lo[(j + h) * NN + c * N + aa] : 0.0;   // K[s_e, s_{e+h}] = Lo_{e+h}'
+        }
+        y[aa] = r[aa];
+      }
+      ldl_inplace<N>(A, dinv, o.piv_tol, ok, nneg);
+#pragma unroll
+      for (int i = 1; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          const double l = A[tri(i, k)];
+#pragma unroll
+          for (int c = 0; c < N; ++c) {
+            F[i * N + c] -= l * F[k * N + c];
+            G[i * N + c] -= l * G[k * N + c];
+          }
+          y[i] -= l * y[k];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+          F[i * N + c] *= dinv[i];
+          G[i * N + c] *= dinv[i];
+        }
+        y[i] *= dinv[i];
+      }
+#pragma unroll
+      for (int i = N - 1; i >= 1; --i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          const double l = A[tri(i, k)];
+#pragma unroll
+          for (int c = 0; c < N; ++c) {
+            F[k * N + c] -= l * F[i * N + c];
+            G[k * N + c] -= l * G[i * N + c];
+          }
+          y[k] -= l * y[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NN; ++i) {
+        sh_f[j * NN + i] = F[i];
+        sh_g[j * NN + i] = G[i];
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) sh_y[j * N + i] = y[i];
+    }
+    sep_lds_fence();
+    if (surv) {
+      const int e = j - h;   // eliminated neighbour on the left: always there
+      double nl[NN];
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+        for (int bb = 0; bb < N; ++bb) {
+          double accg = 0.0, accf = 0.0;
+#pragma unroll
+          for (int c = 0; c < N; ++c) {
+            accg += Lo[aa * N + c] * sh_g[e * NN + c * N + bb];
+            accf += Lo[aa * N + c] * sh_f[e * NN + c * N + bb];
+          }
+          if (bb <= aa) A[tri(aa, bb)] -= accg;
+          nl[aa * N + bb] = -accf;
+        }
+        double accy = 0.0;
+#pragma unroll
+        for (int c = 0; c < N; ++c) accy += Lo[aa * N + c] * sh_y[e * N + c];
+        r[aa] -= accy;
+      }
+      if (j + h < ns) {      // ... and on the right
+        const int e2 = j + h;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+          for (int bb = 0; bb <= aa; ++bb) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) acc += sh_lo[e2 * NN + c * N + aa] * sh_f[e2 * NN + c * N + bb];
+            A[tri(aa, bb)] -= acc;
+          }
+          double accy = 0.0;
+#pragma unroll
+          for (int c = 0; c < N; ++c) accy += sh_lo[e2 * NN + c * N + aa] * sh_y[e2 * N + c];
+          r[aa] -= accy;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NN; ++i) Lo[i] = nl[i];
+    }
+    sep_lds_fence();
+  }
+  // ---- back substitution, top level first
+  int htop = 1;
+  while (2 * htop <= ns) htop <<= 1;
+  for (int h = htop; h >= 1; h >>= 1) {
+    const bool elim = act && (j & (2 * h - 1)) == h - 1;
+    if (elim) {
+      const bool left = j - h >= 0, right = j + h < ns;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double v = y[i];
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+          if (left) v -= F[i * N + c] * sh_x[(j - h) * N + c];
+          if (right) v -= G[i * N + c] * sh_x[(j + h) * N + c];
+        }
+        r[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) sh_x[j * N + i] = r[i];
+      double* xs = a.xsep + (((g * a.P + (j + 1)) * N) << 6) + li;
+#pragma unroll
+      for (int i = 0; i < N; ++i) xs[(int64_t)i << 6] = r[i];
+    }
+    sep_lds_fence();
+  }
+  // ---- verdict of the whole factorisation: every chunk and every separator block
+  ok_out = __ballot(!ok) == 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) nneg += __shfl_xor(nneg, d);
+  nneg_out = nneg;
+}
+
 // reduced system over the separators + inertia + retry state machine.  grid = G waves.
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+__device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_t g) {
   const dto_solver_opts& o = a.opt;
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   const bool need = sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0;
@@ -2170,6 +2398,19 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
   using CS = ChunkSum<M>;
   using SF = SepFac<M>;
   constexpr int N = CS::N, NT = CS::NT;
+  if constexpr (N <= 6) {     // (registers and LDS of kkt_sep_cr grow with N^2)
+    const unsigned long long nm = __ballot(need);
+    if (a.sep_cr && __popcll(nm) <= DTO_SEP_CR_MAX_INST) {
+      for (unsigned long long rest = nm; rest; rest &= rest - 1) {
+        const int li = __ffsll((long long)rest) - 1;
+        bool okc;
+        int nnegc;
+        kkt_sep_cr<M>(a, g, li, okc, nnegc);
+        if ((int)threadIdx.x == li) retry_update(a, sc, okc, nnegc);
+      }
+      return;
+    }
+  }
   auto csp = [&](int p) { return a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x; };
   auto sfp = [&](int p) { return a.sfac + (((g * a.P + p) * SF::SIZE) << 6) + threadIdx.x; };
   bool ok = true;
@@ -2300,6 +2541,8 @@ __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) {
   }
   if (need) retry_update(a, sc, ok, nneg);
 }
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) { kkt_sep_body<M>(a, blockIdx.x); }
 
 struct StepAcc {
   double apmax, admax, gphid, rlam;
@@ -2576,6 +2819,9 @@ __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) 
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double apmax = 1.0, admax = 1.0, gphid = 0.0;
+  // (partially unrolled: the loads of several chunks in flight at once -- with one running lane this loop is a chain of
+  //  memory latencies, 23 us for 64 chunks; the sums are still taken in chunk order)
+#pragma unroll 8
   for (int p = 0; p < a.P; ++p) {
     const double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
     apmax = fmin(apmax, ca[0 << 6]);
@@ -2591,10 +2837,11 @@ __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) 
 }
 static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) { kkt_post_body(a, blockIdx.x); }
 
+
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
   // a wavefront walks DTO_SB consecutive stages and sums the merit partials of the eight trial step sizes in registers
-  const int nblk = (a.T + DTO_SB - 1) / DTO_SB;
+  const int nblk = (a.T + a.sb - 1) / a.sb;
   const int64_t g = blockIdx.x / nblk;
   const int blk = blockIdx.x % nblk;
   const dto_solver_opts& o = a.opt;
@@ -2608,8 +2855,8 @@ __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
   double* acc = s_acc + threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 2 * DTO_LS_TRIALS; ++k) acc[k * WAVE] = 0.0;
-  const int t_end = (blk + 1) * DTO_SB < a.T ? (blk + 1) * DTO_SB : a.T;
-  for (int t = blk * DTO_SB; t < t_end; ++t) {
+  const int t_end = (blk + 1) * a.sb < a.T ? (blk + 1) * a.sb : a.T;
+  for (int t = blk * a.sb; t < t_end; ++t) {
   dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     using D = KindDims<M, K>;
@@ -2890,6 +3137,9 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
   double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
 #pragma unroll
   for (int k = 0; k < DTO_LS_TRIALS; ++k) phi[k] = th[k] = 0.0;
+  // (partially unrolled: the loads of several chunks in flight at once -- with one running lane this loop is a chain of
+  //  memory latencies, 23 us for 64 chunks; the sums are still taken in chunk order)
+#pragma unroll 8
   for (int c = 0; c < a.P; ++c) {
     const double* in = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
 #pragma unroll
@@ -3304,7 +3554,7 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   const dto_kkt_args& a = *args;
   const unsigned gt = (unsigned)((int64_t)a.G * a.T);
-  const unsigned gb = (unsigned)((int64_t)a.G * ((a.T + DTO_SB - 1) / DTO_SB));  // blocks of DTO_SB stages
+  const unsigned gb = (unsigned)((int64_t)a.G * ((a.T + a.sb - 1) / a.sb));  // blocks of DTO_SB stages
   {
     switch (op) {
       case DTO_KKT_PACK:

@@ -64,6 +64,7 @@ struct SolverState {
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
   double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr, *cpart = nullptr;
+  int sb = 8;           // stages per wavefront of the stage-parallel kernels (dto_kkt_args.sb)
   int P = 1;            // chunks of the time-partitioned factorisation (current)
   int P0 = 1;           // ... as chosen when the batch was loaded; P_cap: what the chunk arrays are sized for
   int P_cap = 1;
@@ -706,7 +707,9 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   //   32 768: 2 chunks 25.5, seq. 22.5;   49 152: 2 chunks 41.9, seq. 25.9;   57 344: 43.6 / 28.1
   // -- otherwise the sequential sweeps (one launch for all inertia-correction rounds, next stage in flight) are faster
   int P_new = S.forced_P > 0 ? S.forced_P : auto_chunks(G_new, n_simd);
-  P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / 8))));
+  // (chunks of at least `min_chunk` stages: every chunk but the first pays for its spike; DTO_MIN_CHUNK is a measurement knob)
+  static const int min_chunk = [] { const char* e = getenv("DTO_MIN_CHUNK"); return e ? std::max(1, atoi(e)) : 4; }();
+  P_new = std::max(1, std::min(P_new, std::min(64, S.forced_P > 0 ? L.T : std::max(1, L.T / min_chunk))));
   // per-stage state dimensions (dimensions(), src/dynamics.jl:206-211): the sequential sweep takes them as they come; the
   // time-partitioned form assumes one separator size, so such problems run with a single chunk
   bool uniform_nx = true;
@@ -824,7 +827,14 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   if ((rc = dev_alloc(&S.rec, lanes * S.rec_total))) return rc;
   if ((rc = dev_alloc(&S.fac, lanes * S.fac_total))) return rc;
   // residual / merit partials: one row set per block of DTO_SB stages (k_stage_eval, k_linesearch), not per stage
-  const size_t nblk = ((size_t)L.T + DTO_SB - 1) / DTO_SB;
+  // (small batches: fewer stages per wavefront, down to one -- a batch of one then evaluates its T stages on T wavefronts
+  //  instead of walking 8 at a time on T / 8: 37 -> ~8 us for the line search of one acrobot T=101 instance; DTO_STAGE_BLOCK sets it)
+  {
+    const int64_t want = ((int64_t)S.G * L.T) / 1024;
+    S.sb = (int)std::max<int64_t>(1, std::min<int64_t>(DTO_SB, want));
+    if (const char* e = getenv("DTO_STAGE_BLOCK")) S.sb = std::max(1, std::min((int)DTO_SB, atoi(e)));
+  }
+  const size_t nblk = ((size_t)L.T + S.sb - 1) / S.sb;
   if ((rc = dev_alloc(&S.part, lanes * nblk * S.info.npart))) return rc;
   if ((rc = dev_alloc(&S.lspart, lanes * nblk * 2 * S.info.ls_trials))) return rc;
   if ((rc = dev_alloc(&S.scal, lanes * S.info.nscal))) return rc;
@@ -884,6 +894,14 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.prof = nullptr;
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
+  a.sb = S.sb;
+  {
+    // cyclic reduction over the separators for batches of at most DTO_SEP_CR_MAX_INST instances -- decided by the BATCH, not by
+    // how many lanes of a tile happen to need a factorisation: the arithmetic of an instance must not depend on its neighbours
+    // (tests/test_entry_points_gpu.py: repacking changes nothing).  DTO_SEP_CR=0: off (read at every call: tests flip it)
+    const char* e = getenv("DTO_SEP_CR");
+    a.sep_cr = ((!e || atoi(e) != 0) && S.B <= DTO_SEP_CR_MAX_INST) ? 1 : 0;
+  }
   a.opt = S.opt;
 }
 
@@ -2157,8 +2175,11 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   if ((rc = dto::kkt_launch(p, DTO_KKT_EVAL, a, st))) return rc;
   if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
   // CONV may flag "converged"/"failed" for this artificial point; the step is wanted regardless
-  for (int g = 0; g < S.G; ++g)
-    HIP_TRY(hipMemsetAsync(S.scal + ((size_t)g * S.info.nscal + SC_STATUS) * 64, 0, 64 * sizeof(double), st));
+  // (only the lanes that hold an instance: the tail of the last tile stays "no instance")
+  for (int g = 0; g < S.G; ++g) {
+    const size_t live = (size_t)std::min<int64_t>(64, S.B - (int64_t)g * 64);
+    HIP_TRY(hipMemsetAsync(S.scal + ((size_t)g * S.info.nscal + SC_STATUS) * 64, 0, live * sizeof(double), st));
+  }
   if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
   if ((rc = dto::unpack(p, a, 2, dx, lddx, st))) return rc;
   if ((rc = dto::unpack(p, a, 3, dmu, lddmu, st))) return rc;
