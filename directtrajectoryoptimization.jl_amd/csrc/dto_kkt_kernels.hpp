@@ -174,6 +174,10 @@ struct dto_kkt_args {
   // slot -> instance map after dto_solver_repack moved the running instances to the front (NULL: identity)
   const int* inst_of_slot;
   int fwd_rounds;  // sequential sweep: inertia-correction rounds per launch (0 = all)
+  // time-partitioned form: per tile four arrival counters (chunk sums -> convergence test, chunk sweeps -> separator system, back
+  // substitutions -> step partials, merit partials -> step size): the wavefront that arrives LAST does the tile's joining step in
+  // the same launch (tile_last_arrival); NULL: one launch per step as in rounds 2-4 (DTO_FUSE_JOIN=0, bit-identical)
+  int* csync;
   int sb;          // consecutive stages per wavefront of the stage-parallel kernels (k_stage_eval, k_linesearch, k_update_eval): DTO_SB, less for small batches
   int sep_cr;      // 1: separator system of a tile with few running instances by cyclic reduction, lanes = separators (kkt_sep_cr)
   double* qn;      // limited-memory BFGS: per tile (4 QN_M + 4) Nz + QN_SMALL rows (S, Y, Z, r_p0, grad L, s, v0, small matrices), or NULL
@@ -1290,8 +1294,28 @@ __global__ __launch_bounds__(WAVE) void k_update_eval(dto_kkt_args a) { stage_ev
 // chunk in stage order (sum, or max for the slots in `maxmask`); k_conv / k_ls_reduce then fold P chunk rows
 // instead of T stage rows.  grid = G*P waves.
 // ------------------------------------------------------------------------------------------------
+// The per-tile join of a step that many wavefronts of one launch contribute to (P chunk wavefronts per tile): every wavefront
+// arrives at the tile's counter after its own work (release), and the one that finds it at n - 1 is the last -- it resets the
+// counter, acquires, and runs the join (separator system, convergence test, ...) in the same launch instead of a launch of its
+// own.  No wavefront ever waits for another: no residency requirement, works for any grid.  A batch of one is bound by its
+// chain of dependent launches (27 per iteration before, ~4 us each when there is little to do: profiles/r05/).
+// (Measured, profiles/r05/join_in_launch_ab.txt: a gain where most rounds have nothing to do or the tile has few chunks -- pendulum
+// T=50 0.10 -> 0.05 ms per iteration, car T=51 0.10 -> 0.09 -- and a loss with many chunks at work -- acrobot T=1000, 64 chunks:
+// 0.39 -> 0.45; counting the arrivals in two levels on separate cache lines changed nothing, so it is not the counter.  The host
+// therefore hands out the counters only up to 16 chunks: dto_solver.cpp, fill_kkt_args.)
+__device__ __forceinline__ bool tile_last_arrival(int* ctr, int n) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  int old = 0;
+  if (threadIdx.x == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old + 1 != n) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
 template <int NV>
-static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, const double* in, unsigned maxmask) {
+__device__ __forceinline__ void part_reduce_body(const dto_kkt_args& a, const double* in, unsigned maxmask) {
   const int64_t g = blockIdx.x / a.P;
   const int p = blockIdx.x % a.P;
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) return;
@@ -1301,6 +1325,8 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
   // a block of DTO_SB stages belongs to the chunk that holds its first stage (every block is counted exactly once)
   const int nblk = (a.T + a.sb - 1) / a.sb;
   const int b0 = (uload(a.cstart, p) + a.sb - 1) / a.sb, b1 = (uload(a.cstart, p + 1) + a.sb - 1) / a.sb;
+  // (partially unrolled: the rows of several blocks in flight at once; the sums are still taken in block order)
+#pragma unroll 4
   for (int t = b0; t < b1; ++t) {
     const double* row = in + (((g * nblk + t) * NV) << 6) + threadIdx.x;
 #pragma unroll
@@ -1312,6 +1338,10 @@ static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, con
   double* out = a.cpart + (((g * a.P + p) * 16) << 6) + threadIdx.x;
 #pragma unroll
   for (int k = 0; k < NV; ++k) out[(int64_t)k << 6] = acc[k];
+}
+template <int NV>
+static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, const double* in, unsigned maxmask) {
+  part_reduce_body<NV>(a, in, maxmask);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1426,8 +1456,7 @@ __device__ __forceinline__ void conv_body(const dto_solver_opts& o, double* sc, 
   }
 }
 
-static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_mult, int64_t n_bnd) {
-  const int64_t g = blockIdx.x;
+__device__ __forceinline__ void conv_tile(const dto_kkt_args& a, const int64_t g, int64_t n_mult, int64_t n_bnd) {
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double f = 0, th1 = 0, thinf = 0, dinf = 0, szmax = 0, iszmax = 0, slam = 0, sz = 0, lb = 0, xmax = 0;
@@ -1448,6 +1477,13 @@ static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_
     xmax = fmax(xmax, part[9 << 6]);
   }
   conv_body<6>(a.opt, sc, ConvSums{f, th1, thinf, dinf, szmax, iszmax, slam, sz, lb, xmax}, n_mult, n_bnd);
+}
+static __global__ __launch_bounds__(WAVE) void k_conv(dto_kkt_args a, int64_t n_mult, int64_t n_bnd) { conv_tile(a, blockIdx.x, n_mult, n_bnd); }
+// chunk sums and, in the last wavefront of a tile to finish them, the convergence test (grid = G * P)
+static __global__ __launch_bounds__(WAVE) void k_part_reduce_conv(dto_kkt_args a, const double* in, unsigned maxmask, int64_t n_mult, int64_t n_bnd) {
+  part_reduce_body<DTO_NPART>(a, in, maxmask);
+  const int64_t g = blockIdx.x / a.P;
+  if (tile_last_arrival(a.csync + g * 4 + 0, a.P)) conv_tile(a, g, n_mult, n_bnd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2837,6 +2873,26 @@ __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) 
 }
 static __global__ __launch_bounds__(WAVE) void k_kkt_post(dto_kkt_args a) { kkt_post_body(a, blockIdx.x); }
 
+// Time-partitioned form with the joins inside the launches (tile_last_arrival): one round = ONE launch (the chunk sweeps, and in
+// the last wavefront of a tile to finish, the separator system with the inertia verdict), the back substitutions and the
+// reduction of their step partials another.
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_fwd_sep(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.P;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (!__any(sc[SC_STATUS << 6] == 0.0 && sc[SC_NEED << 6] != 0.0)) return;   // the same for every chunk wavefront of the tile
+  kkt_fwd_body<M, true>(a);
+  if (tile_last_arrival(a.csync + g * 4 + 1, a.P)) kkt_sep_body<M>(a, g);
+}
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_bwd_post(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.P;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (__all(sc[SC_STATUS << 6] != 0.0)) return;                                // ... of the tile
+  kkt_bwd_body<M, true>(a);
+  if (tile_last_arrival(a.csync + g * 4 + 2, a.P)) kkt_post_body(a, g);
+}
+
 
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_linesearch(dto_kkt_args a) {
@@ -3130,8 +3186,7 @@ __device__ __forceinline__ void ls_reduce_body(const dto_solver_opts& o, double*
   sc[SC_FULL_STREAK << SH] = (chosen >= sc[SC_ALPHA_PMAX << SH]) ? sc[SC_FULL_STREAK << SH] + 1.0 : 0.0;
 }
 
-static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+__device__ __forceinline__ void ls_reduce_tile(const dto_kkt_args& a, const int64_t g) {
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   double phi[DTO_LS_TRIALS], th[DTO_LS_TRIALS];
@@ -3149,6 +3204,13 @@ static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) {
     }
   }
   ls_reduce_body<6>(a.opt, sc, a.filt + ((g * (2 * DTO_FILTER_CAP)) << 6) + threadIdx.x, phi, th);
+}
+static __global__ __launch_bounds__(WAVE) void k_ls_reduce(dto_kkt_args a) { ls_reduce_tile(a, blockIdx.x); }
+// chunk sums of the merit partials and, in the last wavefront of a tile to finish them, the choice of the step size (grid = G * P)
+static __global__ __launch_bounds__(WAVE) void k_part_reduce_ls(dto_kkt_args a, const double* in) {
+  part_reduce_body<2 * DTO_LS_TRIALS>(a, in, 0u);
+  const int64_t g = blockIdx.x / a.P;
+  if (tile_last_arrival(a.csync + g * 4 + 3, a.P)) ls_reduce_tile(a, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3588,6 +3650,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_EVAL: hipLaunchKernelGGL(k_stage_eval<M>, dim3(gb), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_CONV:
         // slots 2..5 and 9 (theta_inf, dual inf, max s*z, max 1/(s*z), max |x|) are maxima, the others sums
+        if (a.P > 1 && a.csync) {
+          hipLaunchKernelGGL(k_part_reduce_conv, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a, (const double*)a.part,
+                             0x23Cu, a.n_mult, a.n_bnd);
+          break;
+        }
         hipLaunchKernelGGL(k_part_reduce<DTO_NPART>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
                            (const double*)a.part, 0x23Cu);
         hipLaunchKernelGGL(k_conv, dim3((unsigned)a.G), dim3(WAVE), 0, st, a, a.n_mult, a.n_bnd);
@@ -3595,6 +3662,11 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_FACTOR_SOLVE: {
         const unsigned gp = (unsigned)((int64_t)a.G * a.P);
         const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
+        if (a.P > 1 && a.csync) {
+          for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_kkt_fwd_sep<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          hipLaunchKernelGGL(k_kkt_bwd_post<M>, dim3(gp), dim3(WAVE), 0, st, a);
+          break;
+        }
         if (a.P > 1) {
           for (int r = 0; r < rounds; ++r) {
             hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
@@ -3637,6 +3709,10 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_POST: hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LINESEARCH: hipLaunchKernelGGL(k_linesearch<M>, dim3(gb), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_LS_REDUCE:
+        if (a.P > 1 && a.csync) {
+          hipLaunchKernelGGL(k_part_reduce_ls, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a, (const double*)a.lspart);
+          break;
+        }
         hipLaunchKernelGGL(k_part_reduce<2 * DTO_LS_TRIALS>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a,
                            (const double*)a.lspart, 0u);
         hipLaunchKernelGGL(k_ls_reduce, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);

@@ -64,6 +64,7 @@ struct SolverState {
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
   double *rec = nullptr, *fac = nullptr, *part = nullptr, *lspart = nullptr, *scal = nullptr, *filt = nullptr;
   double *csum = nullptr, *sfac = nullptr, *xsep = nullptr, *cacc = nullptr, *cpart = nullptr;
+  int* csync = nullptr; // per tile: arrival counters of the in-launch joins of the time-partitioned form (dto_kkt_args.csync)
   int sb = 8;           // stages per wavefront of the stage-parallel kernels (dto_kkt_args.sb)
   int P = 1;            // chunks of the time-partitioned factorisation (current)
   int P0 = 1;           // ... as chosen when the batch was loaded; P_cap: what the chunk arrays are sized for
@@ -86,7 +87,7 @@ struct SolverState {
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
                     (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag, (void*)fwd_started,
-                    (void*)qn})
+                    (void*)qn, (void*)csync})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
@@ -94,7 +95,7 @@ struct SolverState {
     if (stream_lo) { (void)hipStreamDestroy(stream_lo); stream_lo = nullptr; }
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
-    csum = sfac = xsep = cacc = cpart = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
+    csum = sfac = xsep = cacc = cpart = nullptr; csync = nullptr; d_cstart = nullptr; d_cstart_all = nullptr; wtile = nullptr; use_wtile = false;
     sigx = sigc = nullptr; use_sigx = use_sigc = assembled = false;
     d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
     inst_of_slot.clear(); slot_of_inst.clear();
@@ -861,6 +862,7 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
   if ((rc = dev_alloc(&S.xsep, lanes * (size_t)S.P_cap * S.info.nx))) return rc;
   if ((rc = dev_alloc(&S.cacc, lanes * (size_t)S.P_cap * 4))) return rc;
   if ((rc = dev_alloc(&S.cpart, lanes * (size_t)S.P_cap * 16))) return rc;
+  if ((rc = dev_alloc(&S.csync, (size_t)S.G * 4))) return rc;
   S.h_scal.assign(lanes * S.info.nscal, 0.0);
   // the zero fills and table copies above ran on the null stream; the kernels run on the caller's stream, which may be a
   // non-blocking one: order them once here (allocation time only)
@@ -895,6 +897,12 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
   a.sb = S.sb;
+  {
+    // the joins of the time-partitioned form inside the launches: up to 16 chunks (measured: a gain there, a loss beyond --
+    // csrc/dto_kkt_kernels.hpp, tile_last_arrival).  DTO_FUSE_JOIN=0: off (read at every call: tests flip it)
+    const char* e = getenv("DTO_FUSE_JOIN");
+    a.csync = ((!e || atoi(e) != 0) && S.P <= 16) ? S.csync : nullptr;
+  }
   {
     // cyclic reduction over the separators for batches of at most DTO_SEP_CR_MAX_INST instances -- decided by the BATCH, not by
     // how many lanes of a tile happen to need a factorisation: the arithmetic of an instance must not depend on its neighbours

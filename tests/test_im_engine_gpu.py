@@ -105,8 +105,9 @@ def test_first_iterations_match_the_soa_engine(model, T, B):
             # three factorisations of systems conditioned like 1e8 in a row): 1e-5; measured 1e-6 .. 3e-7 depending on how the
             # compiler contracts the multiply-adds of the SoA sweeps.
             # (round 5: cartpole's first steps are Gauss-Newton steps of the penalty phase, delta_w = 1e-4 -- a less well
-            #  conditioned system than the ladder's: 5e-8)
-            tol = 1e-5 if k > 1 else (1e-7 if "multipliers" in n else 5e-8)
+            #  conditioned system than the ladder's: 5e-8; with the SoA engine's small-batch form -- 50 chunks of four stages,
+            #  separator system by cyclic reduction -- 5.4e-8 was observed: 1e-7)
+            tol = 1e-5 if k > 1 else 1e-7
             assert np.max(np.abs(a[n] - b[n])) <= tol * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
 
 
