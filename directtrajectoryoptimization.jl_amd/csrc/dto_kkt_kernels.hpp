@@ -64,6 +64,7 @@ enum dto_kkt_op {
   DTO_KKT_QN_COL = 21,       // Z_col := dz - v0 (col = -1: v0 := dz)
   DTO_KKT_QN_SMALL = 22,     // U'Z, U'v0, C = M - U'Z, q = C^-1 U'v0, correction of the directional derivative
   DTO_KKT_QN_SAVE = 23,      // after LS_REDUCE: grad_x L(x_k, lam_{k+1}) and alpha dz for the next secant pair
+  DTO_KKT_QN_COLS_RHS = 24,  // column state (the columns of U as instances of their own): r_p -= column (slot mod QN_M2) of the main state's U
   DTO_KKT_OP_COUNT
 };
 
@@ -181,6 +182,7 @@ struct dto_kkt_args {
   int sb;          // consecutive stages per wavefront of the stage-parallel kernels (k_stage_eval, k_linesearch, k_update_eval): DTO_SB, less for small batches
   int sep_cr;      // 1: separator system of a tile with few running instances by cyclic reduction, lanes = separators (kkt_sep_cr)
   double* qn;      // limited-memory BFGS: per tile (4 QN_M + 4) Nz + QN_SMALL rows (S, Y, Z, r_p0, grad L, s, v0, small matrices), or NULL
+  const double* qn_main; // DTO_KKT_QN_COLS_RHS (launched on the column state): the main state's `qn`
   int qn_mode, qn_col;   // DTO_KKT_QN_RHS: 0 column qn_col of U, 1 U q, 2 restore; DTO_KKT_QN_COL: column (-1: save v0)
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
@@ -3319,6 +3321,9 @@ __global__ __launch_bounds__(WAVE) void k_update(dto_kkt_args a) {
 constexpr int QN_M = 6, QN_M2 = 2 * QN_M;
 constexpr int QN_SS = 0, QN_SY = QN_SS + QN_M * QN_M, QN_UZ = QN_SY + QN_M * QN_M, QN_UV = QN_UZ + QN_M2 * QN_M2, QN_Q = QN_UV + QN_M2,
               QN_SMALL = QN_Q + QN_M2;
+// the row loops of this mode run on QN_NB wavefronts per tile (a batch of one has ONE running lane: a loop over the N_z rows
+// in one wavefront is a chain of N_z memory latencies -- 0.55 ms for k_qn_small at T = 101, profiles/r05/)
+constexpr int QN_NB = 16, QN_GRAM = QN_M2 * QN_M2 + QN_M2;
 struct QnRows {
   int64_t Nz;
   __host__ __device__ int64_t S(int j) const { return (int64_t)j * Nz; }
@@ -3329,8 +3334,14 @@ struct QnRows {
   __host__ __device__ int64_t qs() const { return gl() + Nz; }
   __host__ __device__ int64_t v0() const { return qs() + Nz; }
   __host__ __device__ int64_t small() const { return v0() + Nz; }
-  __host__ __device__ int64_t total() const { return small() + QN_SMALL; }
+  __host__ __device__ int64_t part() const { return small() + QN_SMALL; }     // QN_NB partial sums of U'Z and U'v0 (k_qn_gram)
+  __host__ __device__ int64_t total() const { return part() + (int64_t)QN_NB * QN_GRAM; }
 };
+// rows [r0, r1) of block `blk` of QN_NB
+__device__ __forceinline__ void qn_row_block(int64_t n, int blk, int64_t& r0, int64_t& r1) {
+  r0 = (n * blk) / QN_NB;
+  r1 = (n * (blk + 1)) / QN_NB;
+}
 __device__ __forceinline__ double* qn_tile(const dto_kkt_args& a, int64_t g) {
   return a.qn + ((g * QnRows{a.Nz}.total()) << 6) + threadIdx.x;
 }
@@ -3338,17 +3349,42 @@ __device__ __forceinline__ double qn_u(const double* q, const QnRows& R, int col
   return col < QN_M ? sigma * q[(R.S(col) + row) << 6] : q[(R.Y(col - QN_M) + row) << 6];
 }
 
+// QN_BEGIN in three launches, each on QN_NB wavefronts per tile (k_qn_fin: one) -- partial sums go through the `part` rows:
+//   k_qn_pair: the Lagrangian gradient of the new point (stage records) -> r_p0; y = r_p0 - grad_x L(x_k, lam_{k+1}) into the gl rows,
+//              s into the qs rows; partial s'y, s's, y'y of the block's stages
+//   k_qn_hist: curvature test (every block sums the partials and decides alike: Ipopt skips the update; two skips in a row restart
+//              the approximation), history rows of the block: oldest pair out, newest in; partial S'S and S'Y of its rows
+//   k_qn_fin:  S'S, S'Y; sigma and the skip count
+constexpr int QN_P_SY = 0, QN_P_SS = 1, QN_P_YY = 2, QN_P_G = 3;   // offsets inside a block's QN_GRAM partial rows
+struct QnDecision { bool have, accept, reset; double sy, ss, skipped; };
+__device__ __forceinline__ QnDecision qn_decide(const double* sc, const double* q, const QnRows& R) {
+  QnDecision d;
+  d.have = sc[SC_ITER << 6] > 0.0 && sc[SC_ALPHA << 6] > 0.0;
+  double sy = 0.0, ss = 0.0, yy = 0.0;
+#pragma unroll
+  for (int b = 0; b < QN_NB; ++b) {
+    sy += q[(R.part() + (int64_t)b * QN_GRAM + QN_P_SY) << 6];
+    ss += q[(R.part() + (int64_t)b * QN_GRAM + QN_P_SS) << 6];
+    yy += q[(R.part() + (int64_t)b * QN_GRAM + QN_P_YY) << 6];
+  }
+  d.sy = sy; d.ss = ss;
+  d.accept = d.have && sy > 1.4901161193847656e-08 * sqrt(ss) * sqrt(yy);
+  d.skipped = d.accept ? 0.0 : sc[SC_QN_SKIP << 6] + 1.0;
+  d.reset = d.have && d.skipped >= 2.0;
+  return d;
+}
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
-  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+__global__ __launch_bounds__(WAVE) void k_qn_pair(dto_kkt_args a) {   // grid = G * QN_NB (stages in QN_NB blocks)
+  const int64_t g = blockIdx.x / QN_NB;
+  const int blk = (int)(blockIdx.x % QN_NB);
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const QnRows R{a.Nz};
   double* q = qn_tile(a, g);
   const bool have = sc[SC_ITER << 6] > 0.0 && sc[SC_ALPHA << 6] > 0.0;
-  // ---- the Lagrangian gradient of the new point (stage records) -> r_p0; y = r_p0 - grad_x L(x_k, lam_{k+1}) kept in the gl rows
   double sy = 0.0, ss = 0.0, yy = 0.0;
-  for (int t = 0; t < a.T; ++t) {
+  const int t0 = (int)(((int64_t)a.T * blk) / QN_NB), t1 = (int)(((int64_t)a.T * (blk + 1)) / QN_NB);
+  for (int t = t0; t < t1; ++t) {
     dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
       constexpr int K = decltype(kc)::value;
       using D = KindDims<M, K>;
@@ -3367,18 +3403,27 @@ __global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
       }
     });
   }
-  // ---- curvature test (Ipopt skips the update; two skips in a row restart the approximation)
-  const bool accept = have && sy > 1.4901161193847656e-08 * sqrt(ss) * sqrt(yy);
-  bool reset = false;
-  if (have) {
-    const double skipped = accept ? 0.0 : sc[SC_QN_SKIP << 6] + 1.0;
-    reset = skipped >= 2.0;
-    sc[SC_QN_SKIP << 6] = reset ? 0.0 : skipped;
-  }
-  if (accept) sc[SC_QN_SIGMA << 6] = fmin(1e8, fmax(1e-8, sy / ss));
-  if (reset) sc[SC_QN_SIGMA << 6] = 1.0;
-  // ---- history: oldest pair out, newest in (per lane: a lane that skipped keeps its rows)
-  for (int64_t row = 0; row < a.Nz; ++row) {
+  double* out = q + ((R.part() + (int64_t)blk * QN_GRAM) << 6);
+  out[(int64_t)QN_P_SY << 6] = sy;
+  out[(int64_t)QN_P_SS << 6] = ss;
+  out[(int64_t)QN_P_YY << 6] = yy;
+}
+static __global__ __launch_bounds__(WAVE) void k_qn_hist(dto_kkt_args a) {   // grid = G * QN_NB (rows in QN_NB blocks)
+  const int64_t g = blockIdx.x / QN_NB;
+  const int blk = (int)(blockIdx.x % QN_NB);
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const QnDecision d = qn_decide(sc, q, R);
+  const bool accept = d.accept, reset = d.reset;
+  int64_t r0, r1;
+  qn_row_block(a.Nz, blk, r0, r1);
+  double SS[QN_M * QN_M], SY[QN_M * QN_M];
+#pragma unroll
+  for (int i = 0; i < QN_M * QN_M; ++i) SS[i] = SY[i] = 0.0;
+#pragma unroll 2
+  for (int64_t row = r0; row < r1; ++row) {
     double sj[QN_M], yj[QN_M];
 #pragma unroll
     for (int j = 0; j < QN_M; ++j) { sj[j] = q[(R.S(j) + row) << 6]; yj[j] = q[(R.Y(j) + row) << 6]; }
@@ -3386,18 +3431,11 @@ __global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
 #pragma unroll
     for (int j = 0; j < QN_M; ++j) {
       const double s_new = j + 1 < QN_M ? sj[j + 1 < QN_M ? j + 1 : j] : sn, y_new = j + 1 < QN_M ? yj[j + 1 < QN_M ? j + 1 : j] : yn;
-      q[(R.S(j) + row) << 6] = reset ? 0.0 : (accept ? s_new : sj[j]);
-      q[(R.Y(j) + row) << 6] = reset ? 0.0 : (accept ? y_new : yj[j]);
+      const double so = reset ? 0.0 : (accept ? s_new : sj[j]), yo = reset ? 0.0 : (accept ? y_new : yj[j]);
+      q[(R.S(j) + row) << 6] = so;
+      q[(R.Y(j) + row) << 6] = yo;
+      sj[j] = so; yj[j] = yo;      // (only after every old value of the row has been read: s_new / y_new above use the loads)
     }
-  }
-  // ---- S'S and S'Y of the history as it stands
-  double SS[QN_M * QN_M], SY[QN_M * QN_M];
-#pragma unroll
-  for (int i = 0; i < QN_M * QN_M; ++i) SS[i] = SY[i] = 0.0;
-  for (int64_t row = 0; row < a.Nz; ++row) {
-    double sj[QN_M], yj[QN_M];
-#pragma unroll
-    for (int j = 0; j < QN_M; ++j) { sj[j] = q[(R.S(j) + row) << 6]; yj[j] = q[(R.Y(j) + row) << 6]; }
 #pragma unroll
     for (int aa = 0; aa < QN_M; ++aa) {
 #pragma unroll
@@ -3407,12 +3445,36 @@ __global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
       }
     }
   }
+  double* out = q + ((R.part() + (int64_t)blk * QN_GRAM + QN_P_G) << 6);
 #pragma unroll
-  for (int aa = 0; aa < QN_M; ++aa) {
+  for (int i = 0; i < QN_M * QN_M; ++i) {
+    out[(int64_t)i << 6] = SS[i];
+    out[(int64_t)(QN_M * QN_M + i) << 6] = SY[i];
+  }
+}
+static __global__ __launch_bounds__(WAVE) void k_qn_fin(dto_kkt_args a) {   // grid = G
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const QnDecision d = qn_decide(sc, q, R);
+  if (d.have) sc[SC_QN_SKIP << 6] = d.reset ? 0.0 : d.skipped;
+  if (d.accept) sc[SC_QN_SIGMA << 6] = fmin(1e8, fmax(1e-8, d.sy / d.ss));
+  if (d.reset) sc[SC_QN_SIGMA << 6] = 1.0;
+#pragma unroll 4
+  for (int i = 0; i < 2 * QN_M * QN_M; ++i) {
+    double acc = 0.0;
 #pragma unroll
-    for (int bb = 0; bb < QN_M; ++bb) {
-      q[(R.small() + QN_SS + aa * QN_M + bb) << 6] = SS[(bb <= aa ? aa : bb) * QN_M + (bb <= aa ? bb : aa)];
-      q[(R.small() + QN_SY + aa * QN_M + bb) << 6] = SY[aa * QN_M + bb];
+    for (int b = 0; b < QN_NB; ++b) acc += q[(R.part() + (int64_t)b * QN_GRAM + QN_P_G + i) << 6];
+    const int e = i % (QN_M * QN_M), aa = e / QN_M, bb = e % QN_M;
+    if (i < QN_M * QN_M) {
+      if (bb <= aa) {      // S'S: the lower triangle was accumulated, both halves are stored
+        q[(R.small() + QN_SS + aa * QN_M + bb) << 6] = acc;
+        q[(R.small() + QN_SS + bb * QN_M + aa) << 6] = acc;
+      }
+    } else {
+      q[(R.small() + QN_SY + aa * QN_M + bb) << 6] = acc;
     }
   }
 }
@@ -3420,8 +3482,9 @@ __global__ __launch_bounds__(WAVE) void k_qn_begin(dto_kkt_args a) {
 // stage records: r_p := r_p0 - u  (mode 0: u = column qn_col of U; 1: u = U q; 2: u = 0 and grad phi' d gets its correction);
 // modes 0 / 1 request ONE more factorisation with the (delta_w, gam = 0) the iteration accepted
 template <class M>
-__global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+__global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {   // grid = G * T waves (tile, stage)
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
   double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const QnRows R{a.Nz};
@@ -3430,7 +3493,7 @@ __global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {
   double qc[QN_M2];
 #pragma unroll
   for (int j = 0; j < QN_M2; ++j) qc[j] = a.qn_mode == 1 ? q[(R.small() + QN_Q + j) << 6] : 0.0;
-  for (int t = 0; t < a.T; ++t) {
+  {
     dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
       constexpr int K = decltype(kc)::value;
       using D = KindDims<M, K>;
@@ -3449,6 +3512,7 @@ __global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {
       }
     });
   }
+  if (t != 0) return;
   if (a.qn_mode == 2) {
     sc[SC_DMERIT << 6] += sc[SC_QN_GCORR << 6];
   } else {
@@ -3459,41 +3523,73 @@ __global__ __launch_bounds__(WAVE) void k_qn_rhs(dto_kkt_args a) {
   }
 }
 
+// The QN_M2 solves K0 z_c = u_c of an iteration side by side (small batches): a second solver state whose slot s * QN_M2 + c is a
+// copy of the main state's slot s (dto_solver.cpp: k_qn_cols_copy) gets column c of that slot's U subtracted from its r_p here --
+// one FACTOR_SOLVE of the column state then does what QN_M2 x (QN_RHS, FACTOR_SOLVE, QN_COL) did one after the other, and
+// k_qn_cols_gather takes Z_c = dz_c - v0 back.  grid = G' * T waves (column tile, stage).
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_qn_cols_rhs(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const int64_t slot = g * 64 + threadIdx.x, ms = slot / QN_M2;     // main slot
+  const int col = (int)(slot % QN_M2);
+  const QnRows R{a.Nz};
+  const double* q = a.qn_main + (((ms >> 6) * R.total()) << 6) + (ms & 63);
+  const double sigma = sc[SC_QN_SIGMA << 6];
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    const SoaIO<M, K> io(a, g, t);
+    double* recw = const_cast<double*>(io.recp);
+#pragma unroll
+    for (int i = 0; i < D::NP; ++i) recw[pair_at(D::R_RP + i)] -= qn_u(q, R, col, io.z0 + i, sigma);
+  });
+  if (t == 0) {
+    sc[SC_NEED << 6] = 1.0;
+    sc[SC_ATTEMPT << 6] = (double)a.opt.max_refactor;   // this attempt is the one that gets used, whatever its inertia
+    sc[SC_TRY_DW << 6] = sc[SC_DELTA_W << 6];
+    sc[SC_TRY_GAM << 6] = 0.0;
+  }
+}
+
 // Z_col := dz - v0 (qn_col >= 0), v0 := dz (qn_col = -1)
-static __global__ __launch_bounds__(WAVE) void k_qn_col(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+static __global__ __launch_bounds__(WAVE) void k_qn_col(dto_kkt_args a) {   // grid = G * QN_NB
+  const int64_t g = blockIdx.x / QN_NB;
   const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const QnRows R{a.Nz};
   double* q = qn_tile(a, g);
-  for (int64_t row = 0; row < a.Nz; ++row) {
+  int64_t r0, r1;
+  qn_row_block(a.Nz, (int)(blockIdx.x % QN_NB), r0, r1);
+#pragma unroll 4
+  for (int64_t row = r0; row < r1; ++row) {
     const double d = *soa(a.dz, g, a.Nz, row);
     if (a.qn_col < 0) q[(R.v0() + row) << 6] = d;
     else q[(R.Z(a.qn_col) + row) << 6] = d - q[(R.v0() + row) << 6];
   }
 }
 
-// U'Z and U'v0 by row loops, then per lane: M, C = M - U'Z, q = C^-1 U'v0 (Gaussian elimination with partial pivoting in the
-// lane's LDS column), q'(U'dz) for the directional derivative.  Empty history slots (zero columns) are decoupled.
-static __global__ __launch_bounds__(WAVE) void k_qn_small(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
-  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+// partial sums of U'Z (QN_M2 x QN_M2) and U'v0 over the rows of one block; grid = G * QN_NB
+static __global__ __launch_bounds__(WAVE) void k_qn_gram(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / QN_NB;
+  const int blk = (int)(blockIdx.x % QN_NB);
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const QnRows R{a.Nz};
   double* q = qn_tile(a, g);
   const double sigma = sc[SC_QN_SIGMA << 6];
-  __shared__ double lds[(QN_M2 * QN_M2 + 2 * QN_M2) * WAVE];
-  double* Cm = lds + threadIdx.x;                        // Cm[(a * QN_M2 + b) * WAVE]
-  double* tv = lds + QN_M2 * QN_M2 * WAVE + threadIdx.x;  // U'v0, then q
-  double* uzq = tv + QN_M2 * WAVE;                        // (U'Z) q
-  // U'Z: two passes of six rows of U (72 accumulators each)
-  for (int half = 0; half < 2; ++half) {
+  int64_t r0, r1;
+  qn_row_block(a.Nz, blk, r0, r1);
+  for (int half = 0; half < 2; ++half) {     // two passes of six rows of U (72 accumulators each)
     double acc[QN_M * QN_M2], av[QN_M];
 #pragma unroll
     for (int i = 0; i < QN_M * QN_M2; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < QN_M; ++i) av[i] = 0.0;
-    for (int64_t row = 0; row < a.Nz; ++row) {
+#pragma unroll 2
+    for (int64_t row = r0; row < r1; ++row) {
       double u[QN_M], z[QN_M2];
 #pragma unroll
       for (int j = 0; j < QN_M; ++j) u[j] = half == 0 ? sigma * q[(R.S(j) + row) << 6] : q[(R.Y(j) + row) << 6];
@@ -3507,12 +3603,42 @@ static __global__ __launch_bounds__(WAVE) void k_qn_small(dto_kkt_args a) {
         for (int bb = 0; bb < QN_M2; ++bb) acc[aa * QN_M2 + bb] += u[aa] * z[bb];
       }
     }
+    double* out = q + ((R.part() + (int64_t)blk * QN_GRAM) << 6);
 #pragma unroll
     for (int aa = 0; aa < QN_M; ++aa) {
-      tv[(half * QN_M + aa) * WAVE] = av[aa];
+      out[(int64_t)(QN_M2 * QN_M2 + half * QN_M + aa) << 6] = av[aa];
 #pragma unroll
-      for (int bb = 0; bb < QN_M2; ++bb) Cm[((half * QN_M + aa) * QN_M2 + bb) * WAVE] = acc[aa * QN_M2 + bb];
+      for (int bb = 0; bb < QN_M2; ++bb) out[(int64_t)((half * QN_M + aa) * QN_M2 + bb) << 6] = acc[aa * QN_M2 + bb];
     }
+  }
+}
+
+// U'Z and U'v0 from k_qn_gram's partial sums, then per lane: M, C = M - U'Z, q = C^-1 U'v0 (Gaussian elimination with partial pivoting in the
+// lane's LDS column), q'(U'dz) for the directional derivative.  Empty history slots (zero columns) are decoupled.
+static __global__ __launch_bounds__(WAVE) void k_qn_small(dto_kkt_args a) {
+  const int64_t g = blockIdx.x;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const QnRows R{a.Nz};
+  double* q = qn_tile(a, g);
+  const double sigma = sc[SC_QN_SIGMA << 6];
+  __shared__ double lds[(QN_M2 * QN_M2 + 2 * QN_M2) * WAVE];
+  double* Cm = lds + threadIdx.x;                        // Cm[(a * QN_M2 + b) * WAVE]
+  double* tv = lds + QN_M2 * QN_M2 * WAVE + threadIdx.x;  // U'v0, then q
+  double* uzq = tv + QN_M2 * WAVE;                        // (U'Z) q
+  // U'Z and U'v0: the QN_NB partial sums of k_qn_gram, in block order
+#pragma unroll 4
+  for (int i = 0; i < QN_M2 * QN_M2; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < QN_NB; ++b) acc += q[(R.part() + (int64_t)b * QN_GRAM + i) << 6];
+    Cm[i * WAVE] = acc;
+  }
+  for (int j = 0; j < QN_M2; ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < QN_NB; ++b) acc += q[(R.part() + (int64_t)b * QN_GRAM + QN_M2 * QN_M2 + j) << 6];
+    tv[j * WAVE] = acc;
   }
   // keep U'Z (for the correction of the directional derivative), form C = M - sym(U'Z)
   double gcorr_t[QN_M2];
@@ -3580,8 +3706,8 @@ static __global__ __launch_bounds__(WAVE) void k_qn_small(dto_kkt_args a) {
 
 // after the line search: grad_x L(x_k, lam_{k+1}) = r_p0 + alpha J(x_k)' dlam, with J'dlam from the first block row of the system
 // just solved, (B + Sigma + delta_w I) dz + J'dlam = -(r_p0 + barrier terms) and B dz = sigma dz - U q; and s = alpha dz
-static __global__ __launch_bounds__(WAVE) void k_qn_save(dto_kkt_args a) {
-  const int64_t g = blockIdx.x;
+static __global__ __launch_bounds__(WAVE) void k_qn_save(dto_kkt_args a) {   // grid = G * QN_NB
+  const int64_t g = blockIdx.x / QN_NB;
   const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
   if (sc[SC_STATUS << 6] != 0.0) return;
   const QnRows R{a.Nz};
@@ -3590,7 +3716,10 @@ static __global__ __launch_bounds__(WAVE) void k_qn_save(dto_kkt_args a) {
   double qc[QN_M2];
 #pragma unroll
   for (int j = 0; j < QN_M2; ++j) qc[j] = q[(R.small() + QN_Q + j) << 6];
-  for (int64_t row = 0; row < a.Nz; ++row) {
+  int64_t r0, r1;
+  qn_row_block(a.Nz, (int)(blockIdx.x % QN_NB), r0, r1);
+#pragma unroll 2
+  for (int64_t row = r0; row < r1; ++row) {
     const double lo = uload(a.lo, row), hi = uload(a.hi, row);
     const double rp0 = q[(R.rp0() + row) << 6], dzv = *soa(a.dz, g, a.Nz, row);
     double uq = 0.0;
@@ -3724,11 +3853,22 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         break;
       case DTO_KKT_RHS: hipLaunchKernelGGL(k_rhs_record<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
       case DTO_KKT_REARM: hipLaunchKernelGGL(k_rearm, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_QN_BEGIN: hipLaunchKernelGGL(k_qn_begin<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_QN_RHS: hipLaunchKernelGGL(k_qn_rhs<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_QN_COL: hipLaunchKernelGGL(k_qn_col, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_QN_SMALL: hipLaunchKernelGGL(k_qn_small, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
-      case DTO_KKT_QN_SAVE: hipLaunchKernelGGL(k_qn_save, dim3((unsigned)a.G), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_BEGIN:
+        hipLaunchKernelGGL(k_qn_pair<M>, dim3((unsigned)a.G * QN_NB), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_qn_hist, dim3((unsigned)a.G * QN_NB), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_qn_fin, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_QN_RHS: hipLaunchKernelGGL(k_qn_rhs<M>, dim3(gt), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_COL: hipLaunchKernelGGL(k_qn_col, dim3((unsigned)a.G * QN_NB), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_SMALL:
+        hipLaunchKernelGGL(k_qn_gram, dim3((unsigned)a.G * QN_NB), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_qn_small, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_QN_SAVE: hipLaunchKernelGGL(k_qn_save, dim3((unsigned)a.G * QN_NB), dim3(WAVE), 0, st, a); break;
+      case DTO_KKT_QN_COLS_RHS:
+        if (!a.qn_main) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_qn_cols_rhs<M>, dim3(gt), dim3(WAVE), 0, st, a);
+        break;
       default: return -1;
     }
     return (int)hipGetLastError();

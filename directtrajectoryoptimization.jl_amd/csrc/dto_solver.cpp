@@ -58,6 +58,7 @@ struct SolverState {
   hipStream_t stream_lo = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* qn = nullptr;                          // limited-memory BFGS: history, columns and small matrices per tile (QnRows)
+  SolverState* cols = nullptr;                   // ... and, for small batches, a second state whose instances are the columns of U
   size_t qn_len = 0;
   double *z_alt = nullptr, *lam_alt = nullptr;   // second iterate / multiplier buffers of the fused UPDATE+EVAL pass (lazy)
   int fuse_state = 0;                            // 0 not decided, 1 buffers allocated, -1 not available (memory, switch)
@@ -100,6 +101,7 @@ struct SolverState {
     d_inst_of_slot = d_src_slot = nullptr; repack_tmp = nullptr; repack_tmp_len = 0; G_active = 0;
     inst_of_slot.clear(); slot_of_inst.clear();
     B = 0; G = 0;
+    if (cols) { cols->release(); delete cols; cols = nullptr; }
   }
 };
 
@@ -2201,6 +2203,57 @@ int dto_kkt_step_batch(dto_problem* h, const dto_batch* b, const double* mu, int
   return DTO_OK;
 }
 
+// ---- limited-memory mode, small batches: the columns of U as instances of a second state ---------------------------------
+// slot s' = s * QN_M2 + c of the column state is a copy of the main state's slot s (iterate, multipliers, bound multipliers,
+// slacks, per-instance parameters, stage records, scalars); csrc/dto_kkt_kernels.hpp: k_qn_cols_rhs then subtracts column c.
+// Every SoA array is [tile][row][64 lanes] (the records pair-interleaved: position (r >> 1) * 128 + 2 lane + (r & 1)).
+namespace dto {
+static __global__ __launch_bounds__(64) void k_qn_cols_copy(dto_kkt_args am, dto_kkt_args ac, int ncol, int nblk) {
+  const int64_t gc = blockIdx.x / nblk;
+  const int blk = blockIdx.x % nblk;
+  const int lc = threadIdx.x;
+  const int64_t sc_ = gc * 64 + lc, ms = sc_ / ncol;
+  const int64_t gm = ms >> 6;
+  const int lm = (int)(ms & 63);
+  const bool in_range = gm < am.G;
+  auto rows = [&](double* dst, const double* src, int64_t n) {
+    if (!dst || !src || n == 0 || !in_range) return;
+    const int64_t r0 = (n * blk) / nblk, r1 = (n * (blk + 1)) / nblk;
+    for (int64_t r = r0; r < r1; ++r) dst[((gc * n + r) << 6) + lc] = src[((gm * n + r) << 6) + lm];
+  };
+  rows(ac.z, am.z, am.Nz);
+  rows(ac.lam, am.lam, am.Nc);
+  rows(ac.zl, am.zl, am.Nz);
+  rows(ac.zu, am.zu, am.Nz);
+  rows(ac.s, am.s, am.Ni);
+  rows(ac.zs, am.zs, am.Ni);
+  if (am.wtile && ac.wtile) rows(const_cast<double*>(ac.wtile), am.wtile, am.Nw);
+  if (in_range) {
+    const int64_t n = am.rec_total, r0 = (n * blk) / nblk, r1 = (n * (blk + 1)) / nblk;
+    for (int64_t r = r0; r < r1; ++r)
+      ac.rec[((gc * n) << 6) + ((r >> 1) << 7) + 2 * lc + (r & 1)] = am.rec[((gm * n) << 6) + ((r >> 1) << 7) + 2 * lm + (r & 1)];
+  }
+  if (blk == 0) {
+    for (int k = 0; k < SC_COUNT; ++k)
+      ac.scal[((gc * SC_COUNT + k) << 6) + lc] = in_range ? am.scal[((gm * SC_COUNT + k) << 6) + lm] : (k == SC_STATUS ? DTO_ST_NO_INSTANCE : 0.0);
+  }
+}
+// Z_c := dz_c - v0 back into the main state's history block (what DTO_KKT_QN_COL does for one column at a time)
+static __global__ __launch_bounds__(64) void k_qn_cols_gather(dto_kkt_args am, dto_kkt_args ac, int ncol, int nblk) {
+  const int64_t gm = blockIdx.x / ((int64_t)ncol * nblk);
+  const int rem = (int)(blockIdx.x % ((int64_t)ncol * nblk));
+  const int c = rem / nblk, blk = rem % nblk;
+  const int lm = threadIdx.x;
+  if (am.scal[((gm * SC_COUNT + SC_STATUS) << 6) + lm] != 0.0) return;
+  const int64_t sc_ = (gm * 64 + lm) * ncol + c, gc = sc_ >> 6;
+  const int lc = (int)(sc_ & 63);
+  const QnRows R{am.Nz};
+  double* q = am.qn + ((gm * R.total()) << 6) + lm;
+  const int64_t n = am.Nz, r0 = (n * blk) / nblk, r1 = (n * (blk + 1)) / nblk;
+  for (int64_t r = r0; r < r1; ++r) q[(R.Z(c) + r) << 6] = ac.dz[((gc * n + r) << 6) + lc] - q[(R.v0() + r) << 6];
+}
+}  // namespace dto
+
 int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b) {
   Problem* p = reinterpret_cast<Problem*>(h);
   if (!p || !b || !b->x) return set_error(DTO_ERR_INVALID, "null argument");
@@ -2241,6 +2294,29 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
       S.qn_len = need;
     }
     HIP_TRY(hipMemsetAsync(S.qn, 0, need * sizeof(double), st));
+    // small batches: the QN_M2 column solves of an iteration side by side, as the instances of a second state (12 x the memory of
+    // the batch; DTO_QN_COLS=0: one after the other as for large batches)
+    const char* ce = getenv("DTO_QN_COLS");   // read at every begin: tests flip it
+    const bool cols_on = !ce || atoi(ce) != 0;
+    if (cols_on && (int64_t)S.G * 64 * dto::QN_M2 <= 65536) {
+      if (!S.cols) S.cols = new dto::SolverState();
+      dto::SolverState& C = *S.cols;
+      C.forced_P = 0;
+      p->solver = &C;
+      rc = dto::ensure_state(p, (int64_t)S.G * 64 * dto::QN_M2);
+      p->solver = &S;
+      if (rc) return rc;
+      C.opt = S.opt; C.user = S.user;
+      dto::reset_slot_map(C);
+      C.use_sigx = C.use_sigc = C.assembled = false;
+      C.use_wtile = false;
+      if (S.use_wtile) {
+        if (!C.wtile && (rc = dto::dev_alloc(&C.wtile, (size_t)C.G * 64 * (size_t)p->L.Nw))) return rc;
+        C.use_wtile = true;
+      }
+    } else if (S.cols) {
+      S.cols->release(); delete S.cols; S.cols = nullptr;
+    }
   }
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
@@ -2311,11 +2387,29 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
       // the 12 x 12 system per instance, and the corrected step as one more solve (its step-length limits come with it)
       a.qn_col = -1;
       if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COL, a, st))) return rc;
-      for (int col = 0; col < dto::QN_M2; ++col) {
-        a.qn_mode = 0; a.qn_col = col;
-        if ((rc = dto::kkt_launch(p, DTO_KKT_QN_RHS, a, st))) return rc;
-        if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
-        if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COL, a, st))) return rc;
+      if (S.cols) {
+        // all columns at once: copy every running slot QN_M2 times into the column state, subtract the columns, ONE factor + solve
+        // of that state (its own chunk count: it is a batch of 12 x the slots), take the Z_c back
+        dto::SolverState& C = *S.cols;
+        dto_kkt_args ac;
+        p->solver = &C;
+        dto::fill_kkt_args(p, ac);
+        p->solver = &S;
+        ac.qn_main = S.qn;
+        const int nblk = 16;
+        hipLaunchKernelGGL(dto::k_qn_cols_copy, dim3((unsigned)((int64_t)C.G * nblk)), dim3(64), 0, st, a, ac, (int)dto::QN_M2, nblk);
+        HIP_TRY(hipGetLastError());
+        if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COLS_RHS, ac, st))) return rc;
+        if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, ac, st))) return rc;
+        hipLaunchKernelGGL(dto::k_qn_cols_gather, dim3((unsigned)((int64_t)a.G * dto::QN_M2 * nblk)), dim3(64), 0, st, a, ac, (int)dto::QN_M2, nblk);
+        HIP_TRY(hipGetLastError());
+      } else {
+        for (int col = 0; col < dto::QN_M2; ++col) {
+          a.qn_mode = 0; a.qn_col = col;
+          if ((rc = dto::kkt_launch(p, DTO_KKT_QN_RHS, a, st))) return rc;
+          if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
+          if ((rc = dto::kkt_launch(p, DTO_KKT_QN_COL, a, st))) return rc;
+        }
       }
       if ((rc = dto::kkt_launch(p, DTO_KKT_QN_SMALL, a, st))) return rc;
       a.qn_mode = 1;

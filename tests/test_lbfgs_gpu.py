@@ -97,3 +97,34 @@ def test_mode_is_an_option_of_the_c_abi():
         assert dto_amd.solve(sol) == 1
     assert s.iterations > e.iterations                     # a quasi-Newton iteration count, not the Newton one
     assert np.max(np.abs(s._solution - e._solution)) <= 1e-4 * np.max(np.abs(e._solution))
+
+
+@pytest.mark.parametrize("model,T,B", [("pendulum", 50, 1), ("acrobot", 101, 3), ("car", 51, 70), ("cartpole", 101, 2)])
+def test_columns_as_instances_match_the_columns_one_after_the_other(model, T, B):
+    """Small batches solve the 12 systems K0 z_c = u_c of an iteration side by side, as the instances of a second solver state
+    (csrc/dto_solver.cpp: k_qn_cols_copy / k_qn_cols_gather, csrc/dto_kkt_kernels.hpp: k_qn_cols_rhs) -- one factor + solve
+    instead of twelve.  DTO_QN_COLS=0 (read at every begin) runs them one after the other on the batch's own state: the same
+    systems (the column state picks its own chunk count: rounding apart), so the first iterates agree closely and both solves
+    converge."""
+    import os
+    import torch
+    s, p = _solver(model, T)
+    nz = s._solve_nlp.num_variables
+    Z = _guesses(s, p, B)
+    z0 = torch.tensor(Z, device="cuda")
+    got = {}
+    for cols in (False, True):
+        os.environ["DTO_QN_COLS"] = "1" if cols else "0"
+        try:
+            s.begin_batch(z0.data_ptr(), B, nz)
+            s.iterate_batch(6)
+            zk = s.peek_batch("z")[:B].copy()
+            zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+            st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz)
+            torch.cuda.synchronize()
+            got[cols] = (zk, st.copy(), it.copy())
+        finally:
+            del os.environ["DTO_QN_COLS"]
+    scale = max(1.0, np.max(np.abs(got[False][0])))
+    assert np.max(np.abs(got[True][0] - got[False][0])) <= 1e-7 * scale, np.max(np.abs(got[True][0] - got[False][0]))
+    assert np.all(got[False][1] == 1) and np.all(got[True][1] == 1), (got[False][1], got[True][1])
