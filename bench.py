@@ -164,10 +164,35 @@ def dense_block_measurement(dev, T=2000, B=256):
                 kkt_steps_per_sec=round(B / (ms * 1e-3), 1),
                 sqp_iterations_per_sec=round(sqp_its / sqp_dt, 1), sqp_sample=f"{sqp_its} iterations in {sqp_dt:.2f} s (first 3 iterations from the straight-line guess)",
                 roofline=dict(bound="mfma", achieved=round(tflops, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                              frac=round(tflops / FP64_MFMA_PEAK_TFLOPS, 5), flop_per_stage=int(flop_stage)),
+                              frac=round(tflops / FP64_MFMA_PEAK_TFLOPS, 5), flop_per_stage=int(flop_stage),
+                              **_wide_counter_figures(B, T, ms)),
                 jacobian=dict(kernel="k_wide_eval<JAC>", instances=Bj, nnz_per_sec=Bj * nj / (jms * 1e-3), avg_launch_ms=round(jms, 4),
                               achieved_GBps=round(jbytes / (jms * 1e-3) / 1e9, 1),
                               frac_of_hbm_peak=round(jbytes / (jms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)))
+
+
+def _wide_counter_figures(B, T, ms):
+    """What the matrix-pipe counters of the committed profiler pass say about the same kernel pair (NOT measured in this run: PMC
+    counters need a profiler pass): MFMA instructions issued per KKT step -> executed flops over THIS run's launch time, and the
+    fraction of the matrix pipes' cycles that were busy in the profiled run.  The formula above (SURVEY section 8d's flops per
+    stage) credits more flops than the kernel issues as MFMA work; both are reported."""
+    for rnd in ("r05", "r04"):
+        fn = os.path.join("profiles", rnd, "pmc_wide_step_summary.json" if rnd == "r05" else "pmc_wide_step_summary_final.json")
+        try:
+            with open(os.path.join(ROOT, fn)) as f:
+                d = json.load(f)["derived"]
+            if B != 256 or T != 2000:
+                return {}
+            mfma = d["mfma_f64_instructions"]                  # v_mfma_f64_16x16x4_f64: 2 048 flop each
+            tf = mfma * 2048.0 / (ms * 1e-3) / 1e12
+            return dict(counters=dict(source=fn + " (rocprofv3 --pmc pass of tools/wide_bench.py 2000 256, tools/prof_wide_mfma.sh)",
+                                      mfma_f64_instructions_per_step=int(mfma), executed_mfma_tflops=round(tf, 3),
+                                      executed_frac=round(tf / FP64_MFMA_PEAK_TFLOPS, 5),
+                                      matrix_pipe_busy_frac=round(d["mfma_pipe_utilisation"], 4),
+                                      wavefront_waiting_frac=round(d["wave_waiting_fraction"], 4)))
+        except Exception:
+            continue
+    return {}
 
 
 def cpu_baseline(a):
@@ -463,7 +488,7 @@ def main():
     # HBM bytes per launch: NOT measured in this run (PMC counters need a profiler pass) -- taken from the committed
     # rocprofv3 --pmc passes of this same command and batch size if there are any, with the file named; else null
     traffic, traffic_source = None, None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         fn = os.path.join("profiles", rnd, f"pmc_traffic_acrobot_T{T}_B{B}.json")
         try:
             with open(os.path.join(ROOT, fn)) as f:
@@ -473,10 +498,11 @@ def main():
         except Exception:
             continue
     # `bound` follows the contract (the kernel is priced against the HBM roofline: it is a streaming sweep whose arithmetic is
-    # FP64 vector, not MFMA); what actually limits k_kkt_fwd_seq is recorded next to it (profiles/r03: SQ counters)
-    limited_by = ("instruction issue at one wavefront per SIMD (FP64 vector unit active 63 % of a wavefront's cycles, 17 % waiting) and "
-                  "lock-step inertia-correction rounds (a tile pays for its slowest lane); not HBM: profiles/r03/"
-                  "sq_counters_soa_sweeps_B131072_final.txt, DESIGN.md section 4.2") if kname[dom].startswith("k_kkt_fwd") else None
+    # FP64 vector, not MFMA); what actually limits k_kkt_fwd_seq is recorded next to it (profiles/r05: SQ counters)
+    limited_by = ("instruction issue at one wavefront per SIMD (FP64 vector unit active 63.5 % of a wavefront's cycles, 16.6 % waiting) and "
+                  "lock-step inertia-correction rounds (a tile pays for its slowest lane: 2.9 round-equivalents per launch over iterations "
+                  "0 - 24 for 1.5 factorisations per instance); not HBM: profiles/r05/sq_counters_soa_sweeps_B524288_steps20.txt, "
+                  "DESIGN.md section 4.2") if kname[dom].startswith("k_kkt_fwd") else None
     roofline = dict(kernel=kname[dom], bound="hbm", limited_by=limited_by, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 [ -f "$ROOT/bench.py" ] || { echo "run from the repo root (bench.py not found under $ROOT)" >&2; exit 1; }
-CMD="$ROOT/bench.py --loop-only --steps 8 --warmup 2 --batch $B"
+CMD="$ROOT/bench.py --loop-only --steps ${STEPS:-8} --warmup ${WARMUP:-2} --batch $B"
 cd /tmp
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
