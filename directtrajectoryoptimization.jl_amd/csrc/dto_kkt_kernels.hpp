@@ -570,10 +570,14 @@ struct SoaRunIO {
 #ifndef DTO_KKT_PROFILE
 #define DTO_KKT_PROFILE 0
 #endif
-template <class M, int K, bool BOUNDED, bool BWD>
+#ifndef DTO_CHUNK_PREFETCH
+#define DTO_CHUNK_PREFETCH 1   // the chunk sweeps of the time-partitioned form request the next stage's rows ahead too (round 5)
+#endif
+// SPK: the carry record of a chunk behind the first also holds the spike coupling (D::FAC instead of D::F_CX rows)
+template <class M, int K, bool BOUNDED, bool BWD, bool SPK = false>
 struct StageIn {
   using D = KindDims<M, K>;
-  static constexpr int NP = D::NP, NY = D::NY, Q = D::Q, NCAR = BWD ? D::F_CX : 0;
+  static constexpr int NP = D::NP, NY = D::NY, Q = D::Q, NCAR = BWD ? (SPK ? D::FAC : D::F_CX) : 0;
   static constexpr bool HAS_P = D::FUSED || BOUNDED;
   double rec[D::REC > 0 ? D::REC : 1], p[HAS_P && NP > 0 ? NP : 1], y[D::FUSED && NY > 0 ? NY : 1], lam[NY > 0 ? NY : 1],
       nu[Q > 0 ? Q : 1], zl[BOUNDED && NP > 0 ? NP : 1], zu[BOUNDED && NP > 0 ? NP : 1], s[Q > 0 ? Q : 1], zs[Q > 0 ? Q : 1],
@@ -617,11 +621,11 @@ struct StageIn {
 };
 
 // SoaRunIO whose reads come out of a StageIn (writes, the linear-solver extras and the parameters stay direct)
-template <class M, int K, bool BOUNDED, bool BWD>
+template <class M, int K, bool BOUNDED, bool BWD, bool SPK = false>
 struct SoaPreIO : SoaRunIO<M, K, BOUNDED> {
   using Base = SoaRunIO<M, K, BOUNDED>;
   using D = KindDims<M, K>;
-  using In = StageIn<M, K, BOUNDED, BWD>;
+  using In = StageIn<M, K, BOUNDED, BWD, SPK>;
   const In& in;
   __device__ __forceinline__ SoaPreIO(const dto_kkt_args& a_, const SoaBufs& b_, const dto_stage_run& r, int t_, const In& in_)
       : Base(a_, b_, r, t_), in(in_) {}
@@ -2154,6 +2158,44 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
         });
       }
     } else {
+#if DTO_CHUNK_PREFETCH
+    // the chunk's stages run by run, as the sequential form walks the horizon: offsets by arithmetic, the rows of the next stage
+    // requested before the arithmetic of this one (a chunk sweep is one dependent chain per lane like the sequential one; until
+    // round 5 every stage began with its own round trip to memory: 5.5 us per stage for 3.5 of arithmetic)
+    const SoaBufs bufs(a, g);
+    for (int r = 0; r < a.n_runs; ++r) {
+      const dto_stage_run run = load_run(a.runs, r);
+      const int ra = run.t0 > t0 ? run.t0 : t0, rb = run.t1 < t1 ? run.t1 : t1;
+      if (ra >= rb) continue;
+      dispatch_uniform<M>(run.kind, [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        auto sweep = [&](auto bounded, auto spk) {
+          constexpr bool SPKv = decltype(spk)::value;
+          // a kind without a previous dynamics is stage 0 and can only be in chunk 0: no spike instantiation
+          if constexpr (!SPKv || M::template Kind<K>::PREV >= 0) {
+            using IO = SoaPreIO<M, K, decltype(bounded)::value, false, SPKv>;
+            constexpr bool PRE = sizeof(typename IO::In) <= DTO_SEQ_PREFETCH_MAX * sizeof(double);
+            typename IO::In nxt, cur;
+            if (PRE) nxt.load(bufs, run, ra);
+            for (int t = ra; t < rb; ++t) {
+              if (PRE) {
+                cur = nxt;
+                nxt.load(bufs, run, t + 1 < rb ? t + 1 : rb - 1);
+              } else {
+                cur.load(bufs, run, t);
+              }
+              stage_forward<M, K, SPKv>(a.opt, IO(a, bufs, run, t, cur), mu, dw, gam, SPKv && t == t0, need, cy, sp, ok, nneg,
+                                        SPKv ? false : keep_lost);
+            }
+          }
+        };
+        using T_ = std::integral_constant<bool, true>;
+        using F_ = std::integral_constant<bool, false>;
+        if (p == 0) { if (run.bounded) sweep(T_{}, F_{}); else sweep(F_{}, F_{}); }
+        else { if (run.bounded) sweep(T_{}, T_{}); else sweep(F_{}, T_{}); }
+      });
+    }
+#else
     for (int t = t0; t < t1; ++t) {
       if (p == 0) {
         dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
@@ -2169,6 +2211,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
         });
       }
     }
+#endif
     }
     if constexpr (!CHUNKED) {
       if (need) retry_update(a, sc, ok, nneg);
@@ -2784,6 +2827,39 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
       });
     }
   } else {
+#if DTO_CHUNK_PREFETCH
+    const SoaBufs bufs(a, g);
+    for (int r = a.n_runs - 1; r >= 0; --r) {
+      const dto_stage_run run = load_run(a.runs, r);
+      const int ra = run.t0 > t0 ? run.t0 : t0, rb = run.t1 < t1 ? run.t1 : t1;
+      if (ra >= rb) continue;
+      dispatch_uniform<M>(run.kind, [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        auto sweep = [&](auto bounded, auto spk) {
+          constexpr bool SPKv = decltype(spk)::value;
+          if constexpr (!SPKv || M::template Kind<K>::PREV >= 0) {
+            using IO = SoaPreIO<M, K, decltype(bounded)::value, true, SPKv>;
+            constexpr bool PRE = sizeof(typename IO::In) <= DTO_SEQ_PREFETCH_MAX * sizeof(double);
+            typename IO::In nxt, cur;
+            if (PRE) nxt.load(bufs, run, rb - 1);
+            for (int t = rb - 1; t >= ra; --t) {
+              if (PRE) {
+                cur = nxt;
+                nxt.load(bufs, run, t - 1 > ra ? t - 1 : ra);
+              } else {
+                cur.load(bufs, run, t);
+              }
+              stage_backward<M, K, SPKv>(a.opt, IO(a, bufs, run, t, cur), mu, tau, dw, gam, SPKv && t == t0, xL, xn, acc);
+            }
+          }
+        };
+        using T_ = std::integral_constant<bool, true>;
+        using F_ = std::integral_constant<bool, false>;
+        if (p == 0) { if (run.bounded) sweep(T_{}, F_{}); else sweep(F_{}, F_{}); }
+        else { if (run.bounded) sweep(T_{}, T_{}); else sweep(F_{}, T_{}); }
+      });
+    }
+#else
     for (int t = t1 - 1; t >= t0; --t) {
       if (p == 0) {
         dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
@@ -2798,6 +2874,7 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
         });
       }
     }
+#endif
   }
   double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
   ca[0 << 6] = acc.apmax;
