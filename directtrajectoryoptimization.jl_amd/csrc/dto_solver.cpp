@@ -667,10 +667,18 @@ static bool overlap_sweeps(Problem* p, hipStream_t st) {
   return S.ev_fork && S.ev_join;
 }
 // chunks of the time-partitioned factorisation for `tiles` tiles when the caller leaves the choice to the library: as many as
-// keep every chunk wavefront resident at once, if that is at least three; else the plain sequential sweeps (see ensure_state)
+// keep every chunk wavefront resident at once while that is at least eight; see below for larger batches
+// Round 5 (chunk sweeps with the next stage's rows requested ahead; profiles/r05/partition_sweep_T1000.jsonl, ms per iteration):
+//   12 288 instances: 5 chunks 9.3, 8 chunks 7.8;   16 384: 4 -> 9.9, 8 -> 9.6;   20 480: 3 -> 12.3, 6 -> 12.1, 8 -> 12.5;
+//   24 576: sequential 18.9, 8 chunks 13.8;   32 768: sequential 20.3, 6 chunks 17.9;   49 152: sequential 24.2, 6 chunks 27.3
+// -- beyond one residency the chunk wavefronts queue, and still win up to ~36 000 instances: eight chunks up to 7/16 of the SIMD
+// count in tiles, six up to 9/16, the sequential sweeps after that.
 static int auto_chunks(int64_t tiles, int n_simd) {
   const int64_t fit = tiles > 0 ? (int64_t)n_simd / tiles : 1;
-  return fit >= 3 ? (int)std::min<int64_t>(fit, 64) : 1;
+  if (fit >= 8) return (int)std::min<int64_t>(fit, 64);
+  if (tiles * 16 <= (int64_t)7 * n_simd) return 8;
+  if (tiles * 16 <= (int64_t)9 * n_simd) return 6;
+  return 1;
 }
 static int fwd_rounds_per_launch() {
   static const int v = [] { const char* e = getenv("DTO_FWD_ROUNDS"); return e ? atoi(e) : 0; }();
@@ -722,11 +730,11 @@ static int ensure_state(Problem* p, int64_t B, bool allow_general = false) {
     P_new = 1;
   }
   // what the chunk arrays would be sized for: a sequential batch (P = 1) with uniform dimensions may later run with up to
-  // 4 chunks (dto_solver_repack) -- unless it is so large (more than two residencies of the sequential sweep) that the
+  // 8 chunks (dto_solver_repack) -- unless it is so large (more than two residencies of the sequential sweep) that the
   // switch, which waits for <= 512 tiles, would hardly ever come: such a batch stays sequential and stores its carries
   // without the spike coupling (14 instead of 30 rows per acrobot stage: 128 KB per instance at T = 1000)
   const int P_cap_new = (P_new == 1 && uniform_nx && S.forced_P == 0 && (int64_t)G_new <= 2 * (int64_t)n_simd)
-                            ? std::max(1, std::min(4, L.T / 8)) : P_new;
+                            ? std::max(1, std::min(8, L.T / 8)) : P_new;   // (8 since round 5: auto_chunks)
   // the state is reused only if the chunk layout is the same too (a dto_solver_set_partitions between two batches of one
   // size changes P_cap and with it the carry records: ADVICE r2)
   if (S.B == B && S.z && S.P0 == P_new && S.P_cap == P_cap_new) {
@@ -1071,8 +1079,8 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
     // only while the chunk waves (one per SIMD: 512-VGPR kernels) still fit the GPU at once; just above one residency the
     // in-kernel round loop of the sequential form is faster (262 144 instances, full solves: 1.285 M it/s with the switch
     // at 7/8 of the SIMDs, 1.295 M with this rule, 1.304 M without any switch -- the batch never gets that small).
-    // The same ">= 3 chunks or sequential" rule as when a batch is loaded (auto_chunks returns 1 or >= 3; the cstart tables
-    // hold every P in [1, P_cap]): two chunks were measured slower than the sequential sweeps
+    // The same rule as when a batch is loaded (auto_chunks returns 1 or >= 6; the cstart tables hold every P in [1, P_cap]):
+    // two to five chunks were measured slower than the sequential sweeps or than eight (profiles/r05/)
     const int P_new = std::max(1, std::min(S.P_cap, auto_chunks(g_new, S.n_simd)));
     set_partitions_now(S, P_new);
   }
