@@ -190,6 +190,33 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
 }
 
 struct BorderStats;
+// Ipopt's scaled optimality error (Waechter & Biegler 2006, (5)-(6)) and monotone barrier update (7), shared by the two host-driven
+// barrier loops of this file (tile path: wide_solve_batch; bordered path: general_solve_batch) -- the in-kernel iteration has the
+// same expressions in conv_body (the two loops had drifted apart -- the bordered one left the slack multipliers out of
+// s_d and reset theta_max with the filter).  On a decrease of mu the FILTER is reset, theta_max / theta_min stay (Ipopt, step A-3).
+struct ErrScale { double sd, sc; };
+static inline ErrScale ipopt_scaling(const dto_solver_opts& o, double sum_mult, int64_t n_mult, double sum_bound_mult, int64_t n_bound) {
+  ErrScale e;
+  e.sd = std::max(o.s_max, (sum_mult + sum_bound_mult) / (double)std::max<int64_t>(1, n_mult + n_bound)) / o.s_max;
+  e.sc = n_bound > 0 ? std::max(o.s_max, sum_bound_mult / (double)n_bound) / o.s_max : 1.0;
+  return e;
+}
+static inline double barrier_mu_floor(const dto_solver_opts& o) {
+  return std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
+}
+// mu -> the first value of the monotone sequence at which the barrier problem is NOT yet solved to kappa_eps mu (or the floor);
+// err_rest: max(dual infeasibility / s_d, constraint violation); compl_at(mu): complementarity error against mu
+template <class ComplAt>
+static inline double monotone_mu(const dto_solver_opts& o, double mu, double err_rest, double sc, ComplAt&& compl_at) {
+  const double mu_floor = barrier_mu_floor(o);
+  for (;;) {
+    const double emu = std::max(err_rest, compl_at(mu) / sc);
+    if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
+    mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
+  }
+  return mu;
+}
+
 static int bordered_step(Problem* p, const dto_batch* b, const double* mu, int64_t ldmu, const double* dw, double delta_c,
                          double* dx, int64_t lddx, double* dmu, int64_t lddmu, int* ok_out, BorderStats* stats, bool pin_fixed = false,
                          const double* gdiag = nullptr, const double* gshift = nullptr);
@@ -462,8 +489,8 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
           const double f = sv[DTO_WIDE_F], th1 = sv[DTO_WIDE_TH1], thinf = sv[DTO_WIDE_THINF], dinf = sv[DTO_WIDE_DINF];
           // Ipopt's scaling with the bound multipliers included; complementarity measured against mu_target (as k_conv does)
           const double sumz = barrier ? sv[DTO_WIDE_SUMZ] : 0.0;
-          const double sd = std::max(o.s_max, (sv[DTO_WIDE_SUMLAM] + sumz) / (double)std::max<int64_t>(1, Nc + n_bnd)) / o.s_max;
-          const double scn = std::max(o.s_max, sumz / (double)std::max<int64_t>(1, n_bnd)) / o.s_max;
+          const ErrScale es = ipopt_scaling(o, sv[DTO_WIDE_SUMLAM], Nc, sumz, n_bnd);
+          const double sd = es.sd, scn = es.sc;
           auto compl_at = [&](double m) {
             if (!barrier) return 0.0;
             const double szmin = sv[DTO_WIDE_ISZMAX] > 0.0 ? 1.0 / sv[DTO_WIDE_ISZMAX] : 1e300;
@@ -483,16 +510,8 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
           else if (barrier) {
             // monotone barrier update (Waechter & Biegler (7)) with mu_target as the floor; the step just computed belongs to
             // the old mu: instances whose mu moved are evaluated again before anything is decided about their factorisation
-            const double mu_floor = std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
-            double m = s.mu;
-            bool changed = false;
-            for (int k = 0; k < 8; ++k) {
-              const double emu = std::max(std::max(dinf / sd, thinf), compl_at(m) / scn);
-              if (!(emu <= o.kappa_eps * m) || m <= mu_floor) break;
-              m = std::max(mu_floor, std::min(o.kappa_mu * m, std::pow(m, o.theta_mu)));
-              changed = true;
-            }
-            if (changed) { s.mu = m; h_mu[(size_t)i] = m; s.filter_n = 0; mu_moved = true; }
+            const double m = monotone_mu(o, s.mu, std::max(dinf / sd, thinf), scn, compl_at);
+            if (m != s.mu) { s.mu = m; h_mu[(size_t)i] = m; s.filter_n = 0; mu_moved = true; }
           }
           if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
           if (s.status != 0) { h_active[(size_t)i] = 0; continue; }
@@ -1868,7 +1887,6 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
     GRC(put_nu());
   }
   const double kappa_sigma = 1e10;
-  const double mu_floor = std::max(o.mu_target, std::min(o.tol, o.compl_inf_tol) / (o.kappa_eps + 1.0));
   std::vector<char> mu_moved((size_t)B, 0);
   const auto t_start = std::chrono::steady_clock::now();
   bool timed_out = false;
@@ -1948,7 +1966,6 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
           gd += bs.grad[(size_t)i * Nz + k] * bs.dz[(size_t)i * Nz + k];
         }
       }
-      const double sd = std::max(o.s_max, slam / (double)std::max<int64_t>(1, Nc)) / o.s_max;
       // complementarity of the slack / multiplier pairs against mu_target (termination) and against mu (barrier update); the
       // step of the inequality rows: ds = (mu - s nu) / nu - (s / nu) dnu, barrier term of the merit's directional derivative
       double c0 = 0.0, cmu = 0.0, snu = 0.0, bar_d = 0.0;
@@ -1960,7 +1977,10 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
         hds[e] = (s.mu - sv * nv) / nv - (sv / nv) * dnu;
         bar_d += hds[e] / sv;
       }
-      const double scn = ni > 0 ? std::max(o.s_max, snu / (double)ni) / o.s_max : 1.0;
+      // (the slack's bound multiplier of a slack-eliminated row IS its nu: it counts among the bound multipliers, as the slack
+      //  multipliers do in conv_body)
+      const ErrScale es = ipopt_scaling(o, slam, Nc, snu, ni);
+      const double sd = es.sd, scn = es.sc;
       const double e0 = std::max(std::max(dinf / sd, thinf), c0 / scn);
       const double f = hf[(size_t)i];
       mu_moved[(size_t)i] = 0;
@@ -1970,16 +1990,14 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
       else if (ni > 0) {
         // Ipopt's monotone rule: once the barrier problem is solved to kappa_eps mu the parameter drops (and the filter is reset);
         // the step computed above belongs to the old mu: this instance waits one round (alpha = 0) for the step of the new one
-        double mu = s.mu;
-        for (;;) {
-          const double emu = std::max(std::max(dinf / sd, thinf), std::fabs(cmu) / scn);
-          if (!(emu <= o.kappa_eps * mu) || mu <= mu_floor) break;
-          mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
-          cmu = 0.0;
+        const double mu = monotone_mu(o, s.mu, std::max(dinf / sd, thinf), scn, [&](double m) {
+          double c = 0.0;
           for (int64_t q = 0; q < ng; ++q)
-            if (ineq[(size_t)q]) cmu = std::max(cmu, std::fabs(hs[(size_t)(i * ng + q)] * hnu[(size_t)(i * ng + q)] - mu));
-        }
-        if (mu != s.mu) { s.mu = mu; s.filter_n = 0; s.theta_max = -1.0; mu_moved[(size_t)i] = 1; }
+            if (ineq[(size_t)q]) c = std::max(c, std::fabs(hs[(size_t)(i * ng + q)] * hnu[(size_t)(i * ng + q)] - m));
+          return c;
+        });
+        (void)cmu;
+        if (mu != s.mu) { s.mu = mu; s.filter_n = 0; mu_moved[(size_t)i] = 1; }
       }
       if (s.theta_max < 0.0) { s.theta_max = 1e4 * std::max(1.0, th1); s.theta_min = 1e-4 * std::max(1.0, th1); }
       th0[(size_t)i] = th1; gphid[(size_t)i] = gd - s.mu * bar_d;

@@ -48,10 +48,12 @@ class Options:
     print_frequency_iter: int = 1
     print_frequency_time: float = 0.0
     skip_finalize_solution_call: str = "no"
-    # not a reference field: what the GPU solver uses for the Hessian of the Lagrangian when the problem was built with
-    # evaluate_hessian=false (where the reference leaves Ipopt on its limited-memory Hessian).  "auto": exact second
-    # derivatives derived from the traced expressions (they cost nothing here) with a one-time HessianModeNotice, "exact": the
-    # same without the notice; "sr1": per-stage SR1 blocks, no second derivatives evaluated (Solver.hessian_mode reports it).
+    # not a reference field: what the GPU solver uses for the Hessian of the Lagrangian (dto_options.hessian_approximation).
+    # "auto": for a problem built with evaluate_hessian=false -- where the reference leaves Ipopt on its limited-memory Hessian --
+    # compact L-BFGS ("lbfgs", round 5) on the lane-per-instance path; on the paths that have no such mode (17 .. 64 states,
+    # multi-knot GeneralConstraint rows) exact second derivatives derived from the traced expressions with a one-time
+    # HessianModeNotice.  "exact": those second derivatives, no notice (the fastest mode here: they cost nothing extra);
+    # "lbfgs": also for a problem WITH Hessians; "sr1": per-stage SR1 blocks (Solver.hessian_mode reports what runs).
     hessian_approximation: str = "auto"
     # not reference fields either (dto_options.line_search / penalty_switch_theta, include/dto.h): "penalty-filter" chooses the
     # step size on the l1 exact-penalty function while max |c_i| > penalty_switch_theta and hands over to Ipopt's filter then;
@@ -368,17 +370,17 @@ _NOTICED = False
 
 def _notice_default_mode():
     """The reference's default (evaluate_hessian=false, src/solver.jl:7) leaves Ipopt on its limited-memory quasi-Newton Hessian.
-    Here the traced expressions are differentiated twice and the exact Hessian of the Lagrangian is used instead -- said out
-    loud, once, because it is NOT what the reference does: Options(hessian_approximation="sr1") gives a mode that evaluates no
-    second derivatives (per-stage SR1 blocks; 13 against 9 iterations on pendulum T=50, 48 of 64 acrobot T=101 seeds within 1000
-    iterations against 64 of 64: profiles/r04/quasi_newton_modes_reference_configs.txt)."""
+    Since round 5 so does this solver on the lane-per-instance path (compact L-BFGS).  On the paths without that mode -- 17 .. 64
+    states (tile kernels), multi-knot GeneralConstraint rows (bordered system) -- the traced expressions are differentiated twice
+    and the exact Hessian of the Lagrangian is used instead: said out loud, once, because it is NOT what the reference does."""
     global _NOTICED
     if not _NOTICED:
         _NOTICED = True
         import warnings
-        warnings.warn("evaluate_hessian=false: the GPU solver differentiates the traced expressions twice and iterates with the exact "
-                      "Hessian of the Lagrangian (the reference leaves Ipopt on its limited-memory quasi-Newton Hessian here); "
-                      "Options(hessian_approximation='sr1') selects the quasi-Newton mode, 'exact' silences this notice",
+        warnings.warn("evaluate_hessian=false on a problem with more than 16 states or with multi-knot GeneralConstraint rows: the GPU "
+                      "solver differentiates the traced expressions twice and iterates with the exact Hessian of the Lagrangian (the "
+                      "reference leaves Ipopt on its limited-memory quasi-Newton Hessian here, and so does this solver on smaller "
+                      "problems); Options(hessian_approximation='exact') silences this notice",
                       HessianModeNotice, stacklevel=3)
 
 
