@@ -42,7 +42,7 @@ def test_tile_path_problems_keep_the_announced_substitute():
         s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False, name="acrobot_padded")
         s2 = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False, name="acrobot_padded")
     notes = [x for x in w if issubclass(x.category, S.HessianModeNotice)]
-    assert len(notes) == 1 and "sr1" in str(notes[0].message)
+    assert len(notes) == 1 and "more than 16 states" in str(notes[0].message) and "'exact'" in str(notes[0].message)
     assert s.hessian_mode == "exact-from-trace" and s2.hessian_mode == "exact-from-trace"
     with pytest.raises(ValueError):
         dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=False,
