@@ -1036,7 +1036,9 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   SolverState& S = *p->solver;
   const Layout& L = p->L;
   const int lanes = S.G * 64;
-  if (S.info.quasi_newton) { if (n_running_out) *n_running_out = -1; return DTO_OK; }
+  // (quasi-Newton state stays with its slot: the per-stage SR1 blocks live in the records, the limited-memory history in `qn` --
+  //  neither moves, so such batches are not repacked; finished lanes are skipped by every kernel all the same)
+  if (S.info.quasi_newton || S.opt.qn_lbfgs) { if (n_running_out) *n_running_out = -1; return DTO_OK; }
   if (S.inst_of_slot.empty()) {
     S.inst_of_slot.resize(lanes); S.slot_of_inst.resize(lanes);
     for (int i = 0; i < lanes; ++i) S.inst_of_slot[i] = S.slot_of_inst[i] = i;
@@ -2422,6 +2424,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
         dto::fill_kkt_args(p, ac);
         p->solver = &S;
         ac.qn_main = S.qn;
+        ac.opt = a.opt;            // (a warm re-begin may have changed the options of the batch: the columns follow)
         const int nblk = 16;
         hipLaunchKernelGGL(dto::k_qn_cols_copy, dim3((unsigned)((int64_t)C.G * nblk)), dim3(64), 0, st, a, ac, (int)dto::QN_M2, nblk);
         HIP_TRY(hipGetLastError());

@@ -128,3 +128,31 @@ def test_columns_as_instances_match_the_columns_one_after_the_other(model, T, B)
     scale = max(1.0, np.max(np.abs(got[False][0])))
     assert np.max(np.abs(got[True][0] - got[False][0])) <= 1e-7 * scale, np.max(np.abs(got[True][0] - got[False][0]))
     assert np.all(got[False][1] == 1) and np.all(got[True][1] == 1), (got[False][1], got[True][1])
+
+
+def test_history_stays_with_its_slot_in_batches_of_several_tiles():
+    """The limited-memory history lives in per-slot rows that dto_solver_repack does not move: batches in this mode are not
+    repacked (round 5: a repack of a three-tile batch handed running instances the history of the slots they moved into).
+    130 acrobot T=101 instances: the repack entry point reports "not applicable", every instance converges, and converged points
+    of every tile are KKT points of the oracle's problem."""
+    import torch
+    from test_solve_gpu import kkt_report, oracle_for
+    s, p = _solver("acrobot", 101)
+    nz, nc = s._solve_nlp.num_variables, s._solve_nlp.num_constraint
+    B = 130
+    Z = _guesses(s, p, B)
+    z0 = torch.tensor(Z, device="cuda")
+    s.begin_batch(z0.data_ptr(), B, nz)
+    s.iterate_batch(30)
+    assert s.repack_batch() == -1
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert int(np.sum(st == 1)) >= 126, (np.bincount(st), np.median(it))
+    onlp = oracle_for("acrobot", 101)
+    zo, lo = zo.cpu().numpy(), lo.cpu().numpy()
+    for b in (0, 63, 64, 100, 128, 129):
+        if st[b] == 1:
+            rep = kkt_report(onlp, zo[b], lo[b])
+            assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5, (b, rep)
