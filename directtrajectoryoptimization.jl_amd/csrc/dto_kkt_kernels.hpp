@@ -41,6 +41,15 @@
 #define DTO_QN_HOT 1
 #endif
 
+// the linear-solver entry points (dto_kkt_step_batch, dto_kkt_assemble / factor / solve) share the sweep kernels with the solver:
+// `newton_only` switches bounds / slack handling off and the caller's Sigma_x / Sigma_c on.  -DDTO_NO_NEWTON_ONLY=1 folds those
+// branches away inside the stage algebra (measurement: what the shared instantiation costs the solver's sweeps)
+#ifdef DTO_NO_NEWTON_ONLY
+#define DTO_NEWTON(o) false
+#else
+#define DTO_NEWTON(o) ((o).newton_only != 0)
+#endif
+
 enum dto_kkt_op {
   DTO_KKT_PACK = 0,        // instance-major z (and lam) -> SoA tiles
   DTO_KKT_UNPACK = 1,      // SoA tiles -> instance-major
@@ -1737,14 +1746,14 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
   }
   bool fixed[NP > 0 ? NP : 1];
   StageBounds<NP> sb;
-  if (!o.newton_only) io.bounds(sb);
+  if (!DTO_NEWTON(o)) io.bounds(sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     double rp = R(D::R_RP + i);
     double sig = dw;
     fixed[i] = false;
-    if (o.newton_only && io.has_sigx()) sig += io.sigx(i);
-    if (!o.newton_only) {
+    if (DTO_NEWTON(o) && io.has_sigx()) sig += io.sigx(i);
+    if (!DTO_NEWTON(o)) {
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo == hi) {
         fixed[i] = true;
@@ -1770,8 +1779,8 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
   for (int j = 0; j < Q; ++j) {
     double dc = o.delta_c;
     double r = R(D::R_C + j);
-    if (o.newton_only && io.has_sigc()) dc += io.sigc_con(j);
-    if (!o.newton_only && D::ineq(j)) {
+    if (DTO_NEWTON(o) && io.has_sigc()) dc += io.sigc_con(j);
+    if (!DTO_NEWTON(o) && D::ineq(j)) {
       const double sv = io.slack(j);
       const double zv = io.slack_mult(j);
       const double nu = io.nu(j);
@@ -1785,7 +1794,7 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
 #pragma unroll
   for (int k = 0; k < NY; ++k) {
     double dc = o.delta_c;
-    if (o.newton_only && io.has_sigc()) dc += io.sigc_dyn(k);
+    if (DTO_NEWTON(o) && io.has_sigc()) dc += io.sigc_dyn(k);
     S[tri(NP + Q + k, NP + Q + k)] = -dc;
     y[NP + Q + k] = -R(D::R_D + k);
   }
@@ -2109,7 +2118,7 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
     bool ok = true;
     int nneg = 0;
     // the attempt after which retry_update stops whatever the inertia: its factorisation is the one that gets used
-    const bool keep_lost = a.opt.newton_only || (int)sc[SC_ATTEMPT << 6] >= a.opt.max_refactor;
+    const bool keep_lost = DTO_NEWTON(a.opt) || (int)sc[SC_ATTEMPT << 6] >= a.opt.max_refactor;
     if constexpr (!CHUNKED) {
       // walk the horizon run by run: kind dispatch and table look-ups once per run, arithmetic offsets inside
       const SoaBufs bufs(a, g);
@@ -2688,13 +2697,13 @@ __device__ __forceinline__ void stage_backward(const dto_solver_opts& o, const I
   }
   // primal step, fraction to the boundary, barrier directional derivative
   StageBounds<NP> sb;
-  if (!o.newton_only) io.bounds(sb);
+  if (!DTO_NEWTON(o)) io.bounds(sb);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const double dp = v[i];
     io.put_dp(i, dp);
     acc.gphid += R(D::R_RP + i) * dp;
-    if (!o.newton_only) {
+    if (!DTO_NEWTON(o)) {
       const double lo = sb.lo[i], hi = sb.hi[i];
       if (lo != hi) {
         const double p = sb.p[i];
@@ -2725,7 +2734,7 @@ __device__ __forceinline__ void stage_backward(const dto_solver_opts& o, const I
     const double r = R(D::R_C + j);
     io.put_dnu(j, dnu);
     double dsv = 0.0;
-    if (!o.newton_only && D::ineq(j)) {
+    if (!DTO_NEWTON(o) && D::ineq(j)) {
       const double sv = io.slack(j);
       const double zv = io.slack_mult(j);
       dsv = -(sv / zv) * (nu - mu / sv + dnu);

@@ -2349,6 +2349,8 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   dto_kkt_args a;
   dto::fill_kkt_args(p, a);
   const size_t lanes = (size_t)S.G * 64;
+  // (the arrival counters of the in-launch joins reset themselves; a batch starts from zero whatever happened to the last one)
+  if (S.csync) HIP_TRY(hipMemsetAsync(S.csync, 0, (size_t)S.G * 4 * sizeof(int), st));
   HIP_TRY(hipMemsetAsync(S.lam, 0, std::max<size_t>(1, lanes * p->L.Nc) * sizeof(double), st));
   if ((rc = dto::pack(p, a, 0, b->x, b->ldx, st))) return rc;
   if ((rc = dto::kkt_launch(p, DTO_KKT_INIT, a, st))) return rc;
