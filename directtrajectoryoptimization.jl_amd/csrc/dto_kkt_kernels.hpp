@@ -1314,18 +1314,26 @@ __global__ __launch_bounds__(WAVE) void k_update_eval(dto_kkt_args a) { stage_ev
 // counter, acquires, and runs the join (separator system, convergence test, ...) in the same launch instead of a launch of its
 // own.  No wavefront ever waits for another: no residency requirement, works for any grid.  A batch of one is bound by its
 // chain of dependent launches (27 per iteration before, ~4 us each when there is little to do: profiles/r05/).
-// (Measured, profiles/r05/join_in_launch_ab.txt: a gain where most rounds have nothing to do or the tile has few chunks -- pendulum
-// T=50 0.10 -> 0.05 ms per iteration, car T=51 0.10 -> 0.09 -- and a loss with many chunks at work -- acrobot T=1000, 64 chunks:
-// 0.39 -> 0.45; counting the arrivals in two levels on separate cache lines changed nothing, so it is not the counter.  The host
-// therefore hands out the counters only up to 16 chunks: dto_solver.cpp, fill_kkt_args.)
+// (Measured: with an agent-scope release fence in every arriving wavefront the in-launch joins lost beyond 16 chunks --
+// profiles/r05/join_in_launch_ab.txt; with the join data itself at agent scope, below, a batch of one gains at every chunk count
+// -- join_in_launch_sc1_ab.txt: acrobot T=101 0.104 -> 0.089 ms per iteration, T=1000 0.323 -> 0.300, pendulum T=50 0.095 -> 0.045
+// -- while batches of 16 - 384 tiles lose 0 - 5 %: the host hands out the counters up to two tiles, dto_solver.cpp: fill_kkt_args.)
+// What a join reads of the other wavefronts' work -- chunk summaries, chunk sums, step partials: a few rows each -- is written and
+// read at agent scope (global_store / global_load ... sc1: through to memory, past the per-XCD L2), so that the arrival needs no
+// L2 write-back (`buffer_wbl2`: what a release fence at agent scope costs EVERY arriving wavefront -- with it the in-launch joins
+// were a loss beyond 16 chunks, profiles/r05/join_in_launch_ab.txt) and the last wavefront no L2 invalidation: the arriving
+// wavefront waits for its own stores (s_waitcnt vmcnt(0)), then counts itself in; everything else it wrote (carry records, steps)
+// is for later launches and becomes visible at the end of this one as always.
+__device__ __forceinline__ void st_join(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_join(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool tile_last_arrival(int* ctr, int n) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int old = 0;
   if (threadIdx.x == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __builtin_amdgcn_readfirstlane(old);
   if (old + 1 != n) return false;
   if (threadIdx.x == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
   return true;
 }
 
@@ -1352,7 +1360,7 @@ __device__ __forceinline__ void part_reduce_body(const dto_kkt_args& a, const do
   }
   double* out = a.cpart + (((g * a.P + p) * 16) << 6) + threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) out[(int64_t)k << 6] = acc[k];
+  for (int k = 0; k < NV; ++k) st_join(&out[(int64_t)k << 6], acc[k]);
 }
 template <int NV>
 static __global__ __launch_bounds__(WAVE) void k_part_reduce(dto_kkt_args a, const double* in, unsigned maxmask) {
@@ -1480,16 +1488,16 @@ __device__ __forceinline__ void conv_tile(const dto_kkt_args& a, const int64_t g
 #pragma unroll 8
   for (int c = 0; c < a.P; ++c) {
     const double* part = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
-    f += part[0 << 6];
-    th1 += part[1 << 6];
-    thinf = fmax(thinf, part[2 << 6]);
-    dinf = fmax(dinf, part[3 << 6]);
-    szmax = fmax(szmax, part[4 << 6]);
-    iszmax = fmax(iszmax, part[5 << 6]);
-    slam += part[6 << 6];
-    sz += part[7 << 6];
-    lb += part[8 << 6];
-    xmax = fmax(xmax, part[9 << 6]);
+    f += ld_join(&part[0 << 6]);
+    th1 += ld_join(&part[1 << 6]);
+    thinf = fmax(thinf, ld_join(&part[2 << 6]));
+    dinf = fmax(dinf, ld_join(&part[3 << 6]));
+    szmax = fmax(szmax, ld_join(&part[4 << 6]));
+    iszmax = fmax(iszmax, ld_join(&part[5 << 6]));
+    slam += ld_join(&part[6 << 6]);
+    sz += ld_join(&part[7 << 6]);
+    lb += ld_join(&part[8 << 6]);
+    xmax = fmax(xmax, ld_join(&part[9 << 6]));
   }
   conv_body<6>(a.opt, sc, ConvSums{f, th1, thinf, dinf, szmax, iszmax, slam, sz, lb, xmax}, n_mult, n_bnd);
 }
@@ -2231,18 +2239,18 @@ __device__ __forceinline__ void kkt_fwd_body(const dto_kkt_args& a) {
       double* cs = a.csum + (((g * a.P + p) * CS::SIZE) << 6) + threadIdx.x;
 #pragma unroll
       for (int i = 0; i < CS::NT; ++i) {
-        cs[(int64_t)(CS::P + i) << 6] = cy.P[i];
-        cs[(int64_t)(CS::RLL + i) << 6] = sp.RLL[i];
+        st_join(&cs[(int64_t)(CS::P + i) << 6], cy.P[i]);
+        st_join(&cs[(int64_t)(CS::RLL + i) << 6], sp.RLL[i]);
       }
 #pragma unroll
       for (int i = 0; i < CS::N; ++i) {
-        cs[(int64_t)(CS::PY + i) << 6] = cy.py[i];
-        cs[(int64_t)(CS::RL + i) << 6] = sp.rL[i];
+        st_join(&cs[(int64_t)(CS::PY + i) << 6], cy.py[i]);
+        st_join(&cs[(int64_t)(CS::RL + i) << 6], sp.rL[i]);
       }
 #pragma unroll
-      for (int i = 0; i < CS::N * CS::N; ++i) cs[(int64_t)(CS::CX + i) << 6] = sp.Cx[i];
-      cs[(int64_t)CS::OK << 6] = ok ? 1.0 : 0.0;
-      cs[(int64_t)CS::NNEG << 6] = (double)nneg;
+      for (int i = 0; i < CS::N * CS::N; ++i) st_join(&cs[(int64_t)(CS::CX + i) << 6], sp.Cx[i]);
+      st_join(&cs[(int64_t)CS::OK << 6], ok ? 1.0 : 0.0);
+      st_join(&cs[(int64_t)CS::NNEG << 6], (double)nneg);
       return;
     }
   }
@@ -2294,8 +2302,8 @@ __device__ __forceinline__ void kkt_sep_cr(const dto_kkt_args& a, const int64_t 
   int nneg = 0;
   if (j < a.P) {               // the chunks' own verdicts: lane j reads chunk j
     const double* cs = csp(j);
-    if (cs[(int64_t)CS::OK << 6] == 0.0) ok = false;
-    nneg = (int)cs[(int64_t)CS::NNEG << 6];
+    if (ld_join(&cs[(int64_t)CS::OK << 6]) == 0.0) ok = false;
+    nneg = (int)ld_join(&cs[(int64_t)CS::NNEG << 6]);
   }
   double A[NT], Lo[NN], r[N], F[NN], G[NN], y[N], dinv[N];
 #pragma unroll
@@ -2309,9 +2317,9 @@ __device__ __forceinline__ void kkt_sep_cr(const dto_kkt_args& a, const int64_t 
     const double* cl = csp(p - 1);
     const double* cr = csp(p);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) A[i] = cl[(int64_t)(CS::P + i) << 6] + cr[(int64_t)(CS::RLL + i) << 6];
+    for (int i = 0; i < NT; ++i) A[i] = ld_join(&cl[(int64_t)(CS::P + i) << 6]) + ld_join(&cr[(int64_t)(CS::RLL + i) << 6]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = cr[(int64_t)(CS::RL + i) << 6] - cl[(int64_t)(CS::PY + i) << 6];
+    for (int i = 0; i < N; ++i) r[i] = ld_join(&cr[(int64_t)(CS::RL + i) << 6]) - ld_join(&cl[(int64_t)(CS::PY + i) << 6]);
     const int z0 = a.zoff[a.cstart[p]];
     bool fx[N];
 #pragma unroll
@@ -2322,7 +2330,7 @@ __device__ __forceinline__ void kkt_sep_cr(const dto_kkt_args& a, const int64_t 
       for (int c = 0; c < N; ++c) {
         const bool fc = !o.newton_only && (a.lo[zp + c] == a.hi[zp + c]);
 #pragma unroll
-        for (int aa = 0; aa < N; ++aa) Lo[aa * N + c] = (fc || fx[aa]) ? 0.0 : cl[(int64_t)(CS::CX + aa * N + c) << 6];
+        for (int aa = 0; aa < N; ++aa) Lo[aa * N + c] = (fc || fx[aa]) ? 0.0 : ld_join(&cl[(int64_t)(CS::CX + aa * N + c) << 6]);
       }
     }
 #pragma unroll
@@ -2507,8 +2515,8 @@ __device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_
   int nneg = 0;
   for (int p = 0; p < a.P; ++p) {
     const double* cs = csp(p);
-    if (cs[(int64_t)CS::OK << 6] == 0.0) ok = false;
-    nneg += (int)cs[(int64_t)CS::NNEG << 6];
+    if (ld_join(&cs[(int64_t)CS::OK << 6]) == 0.0) ok = false;
+    nneg += (int)ld_join(&cs[(int64_t)CS::NNEG << 6]);
   }
   // forward elimination over separators p = 1 .. P-1
   double Lp[N * (N + 1) / 2], dip[N], wp[N];  // factor of the previous separator block
@@ -2517,9 +2525,9 @@ __device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_
     const double* cr = csp(p);
     double Dg[NT], r[N], Bt[N * N];  // Bt[c][aa] = K[s_p(aa), s_{p-1}(c)] = CX of chunk p-1, transposed access below
 #pragma unroll
-    for (int i = 0; i < NT; ++i) Dg[i] = cl[(int64_t)(CS::P + i) << 6] + cr[(int64_t)(CS::RLL + i) << 6];
+    for (int i = 0; i < NT; ++i) Dg[i] = ld_join(&cl[(int64_t)(CS::P + i) << 6]) + ld_join(&cr[(int64_t)(CS::RLL + i) << 6]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = cr[(int64_t)(CS::RL + i) << 6] - cl[(int64_t)(CS::PY + i) << 6];
+    for (int i = 0; i < N; ++i) r[i] = ld_join(&cr[(int64_t)(CS::RL + i) << 6]) - ld_join(&cl[(int64_t)(CS::PY + i) << 6]);
     const int z0 = uload(a.zoff, uload(a.cstart, p));
     bool fx[N];
 #pragma unroll
@@ -2533,7 +2541,7 @@ __device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_
       for (int c = 0; c < N; ++c) {
         const bool fc = !o.newton_only && (uload(a.lo, zp + c) == uload(a.hi, zp + c));
 #pragma unroll
-        for (int aa = 0; aa < N; ++aa) Mm[c * N + aa] = (fc || fx[aa]) ? 0.0 : cx[(int64_t)(aa * N + c) << 6];
+        for (int aa = 0; aa < N; ++aa) Mm[c * N + aa] = (fc || fx[aa]) ? 0.0 : ld_join(&cx[(int64_t)(aa * N + c) << 6]);
       }
 #pragma unroll
       for (int i = 1; i < N; ++i) {
@@ -2886,10 +2894,10 @@ __device__ __forceinline__ void kkt_bwd_body(const dto_kkt_args& a) {
 #endif
   }
   double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
-  ca[0 << 6] = acc.apmax;
-  ca[1 << 6] = acc.admax;
-  ca[2 << 6] = acc.gphid;
-  ca[3 << 6] = acc.rlam;
+  st_join(&ca[0 << 6], acc.apmax);
+  st_join(&ca[1 << 6], acc.admax);
+  st_join(&ca[2 << 6], acc.gphid);
+  st_join(&ca[3 << 6], acc.rlam);
 }
 
 template <class M>
@@ -2948,9 +2956,9 @@ __device__ __forceinline__ void kkt_post_body(const dto_kkt_args& a, int64_t g) 
 #pragma unroll 8
   for (int p = 0; p < a.P; ++p) {
     const double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
-    apmax = fmin(apmax, ca[0 << 6]);
-    admax = fmin(admax, ca[1 << 6]);
-    gphid += ca[2 << 6];
+    apmax = fmin(apmax, ld_join(&ca[0 << 6]));
+    admax = fmin(admax, ld_join(&ca[1 << 6]));
+    gphid += ld_join(&ca[2 << 6]);
   }
   // directional derivative of the barrier objective along the step (filter line search, switching condition)
   sc[SC_DMERIT << 6] = gphid;
@@ -3287,8 +3295,8 @@ __device__ __forceinline__ void ls_reduce_tile(const dto_kkt_args& a, const int6
     const double* in = a.cpart + (((g * a.P + c) * 16) << 6) + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < DTO_LS_TRIALS; ++k) {
-      phi[k] += in[(int64_t)(2 * k) << 6];
-      th[k] += in[(int64_t)(2 * k + 1) << 6];
+      phi[k] += ld_join(&in[(int64_t)(2 * k) << 6]);
+      th[k] += ld_join(&in[(int64_t)(2 * k + 1) << 6]);
     }
   }
   ls_reduce_body<6>(a.opt, sc, a.filt + ((g * (2 * DTO_FILTER_CAP)) << 6) + threadIdx.x, phi, th);

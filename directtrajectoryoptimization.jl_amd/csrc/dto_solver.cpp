@@ -927,10 +927,13 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
   a.sb = S.sb;
   {
-    // the joins of the time-partitioned form inside the launches: up to 16 chunks (measured: a gain there, a loss beyond --
-    // csrc/dto_kkt_kernels.hpp, tile_last_arrival).  DTO_FUSE_JOIN=0: off (read at every call: tests flip it)
+    // the joins of the time-partitioned form inside the launches: batches of at most two tiles (measured, profiles/r05/
+    // join_in_launch_sc1_ab.txt: a batch of one gains 7 - 50 % at every chunk count since the join data moves at agent scope;
+    // 1 024 - 24 576 instances lose 0 - 5 %).  DTO_FUSE_JOIN=0: off (read at every call: tests flip it); DTO_FUSE_JOIN_TILES: the limit
     const char* e = getenv("DTO_FUSE_JOIN");
-    a.csync = ((!e || atoi(e) != 0) && S.P <= 16) ? S.csync : nullptr;
+    const char* mt = getenv("DTO_FUSE_JOIN_TILES");
+    const int max_tiles = mt ? atoi(mt) : 2;
+    a.csync = ((!e || atoi(e) != 0) && (S.G_active > 0 ? S.G_active : S.G) <= max_tiles) ? S.csync : nullptr;
   }
   {
     // cyclic reduction over the separators for batches of at most DTO_SEP_CR_MAX_INST instances -- decided by the BATCH, not by
