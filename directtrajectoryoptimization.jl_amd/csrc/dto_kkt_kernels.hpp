@@ -1301,8 +1301,16 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
 
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_stage_eval(dto_kkt_args a) { stage_eval_body<M, false>(a); }
+#ifndef DTO_UPD_OCC
+#define DTO_UPD_OCC 0   // measurement: minimum wavefronts per SIMD asked of the compiler for k_update_eval (0: its own choice, 2)
+#endif
+#if DTO_UPD_OCC > 0
+template <class M>
+__global__ __launch_bounds__(WAVE, DTO_UPD_OCC) void k_update_eval(dto_kkt_args a) { stage_eval_body<M, true>(a); }
+#else
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_update_eval(dto_kkt_args a) { stage_eval_body<M, true>(a); }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // first level of the deterministic reductions: every (tile, chunk) wave folds the per-stage partials of its
