@@ -189,7 +189,8 @@ struct dto_kkt_args {
   // the same launch (tile_last_arrival); NULL: one launch per step as in rounds 2-4 (DTO_FUSE_JOIN=0, bit-identical)
   int* csync;
   int sb;          // consecutive stages per wavefront of the stage-parallel kernels (k_stage_eval, k_linesearch, k_update_eval): DTO_SB, less for small batches
-  int sep_cr;      // 1: separator system of a tile with few running instances by cyclic reduction, lanes = separators (kkt_sep_cr)
+  int sep_cr;      // separator system by cyclic reduction, lanes = separators (kkt_sep_cr): 1 = inside the tile's wavefront (batches of
+                   // at most DTO_SEP_CR_MAX_INST instances), 2 = one wavefront per instance (k_kkt_sep_cr: larger batches, many chunks)
   double* qn;      // limited-memory BFGS: per tile (4 QN_M + 4) Nz + QN_SMALL rows (S, Y, Z, r_p0, grad L, s, v0, small matrices), or NULL
   const double* qn_main; // DTO_KKT_QN_COLS_RHS (launched on the column state): the main state's `qn`
   int qn_mode, qn_col;   // DTO_KKT_QN_RHS: 0 column qn_col of U, 1 U q, 2 restore; DTO_KKT_QN_COL: column (-1: save v0)
@@ -2506,7 +2507,7 @@ __device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_
   constexpr int N = CS::N, NT = CS::NT;
   if constexpr (N <= 6) {     // (registers and LDS of kkt_sep_cr grow with N^2)
     const unsigned long long nm = __ballot(need);
-    if (a.sep_cr && __popcll(nm) <= DTO_SEP_CR_MAX_INST) {
+    if (a.sep_cr == 1 && __popcll(nm) <= DTO_SEP_CR_MAX_INST) {
       for (unsigned long long rest = nm; rest; rest &= rest - 1) {
         const int li = __ffsll((long long)rest) - 1;
         bool okc;
@@ -2649,6 +2650,23 @@ __device__ __forceinline__ void kkt_sep_body(const dto_kkt_args& a, const int64_
 }
 template <class M>
 __global__ __launch_bounds__(WAVE) void k_kkt_sep(dto_kkt_args a) { kkt_sep_body<M>(a, blockIdx.x); }
+// The cyclic reduction for batches of MORE than DTO_SEP_CR_MAX_INST instances with many chunks (dto_kkt_args.sep_cr == 2: at least
+// 16 chunks, decided by the batch): one wavefront per (tile, lane) instead of one per tile -- 64 instances x 63 separators take
+// ~20 us side by side where the lane-per-instance elimination walks the separators one after the other (4 us each).  grid = G * 64.
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_sep_cr(dto_kkt_args a) {
+  using CS = ChunkSum<M>;
+  if constexpr (CS::N <= 6) {
+    const int64_t g = blockIdx.x >> 6;
+    const int li = (int)(blockIdx.x & 63);
+    double* scl = a.scal + ((g * SC_COUNT) << 6) + li;   // the instance's column of the scalar block
+    if (!(scl[SC_STATUS << 6] == 0.0 && scl[SC_NEED << 6] != 0.0)) return;
+    bool okc;
+    int nnegc;
+    kkt_sep_cr<M>(a, g, li, okc, nnegc);
+    if (threadIdx.x == 0) retry_update(a, scl, okc, nnegc);
+  }
+}
 
 struct StepAcc {
   double apmax, admax, gphid, rlam;
@@ -3893,7 +3911,10 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_FACTOR_SOLVE: {
         const unsigned gp = (unsigned)((int64_t)a.G * a.P);
         const int rounds = a.opt.newton_only ? 1 : a.opt.max_refactor + 1;
-        if (a.P > 1 && a.csync) {
+        // separator system: in the last chunk wavefront of a tile (small batches), one wavefront per instance (cyclic reduction:
+        // many chunks), or one wavefront per tile (lane-per-instance elimination)
+        const bool sep_wide = a.P > 1 && a.sep_cr == 2 && ChunkSum<M>::N <= 6;
+        if (a.P > 1 && a.csync && !sep_wide) {
           for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_kkt_fwd_sep<M>, dim3(gp), dim3(WAVE), 0, st, a);
           hipLaunchKernelGGL(k_kkt_bwd_post<M>, dim3(gp), dim3(WAVE), 0, st, a);
           break;
@@ -3901,7 +3922,12 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
         if (a.P > 1) {
           for (int r = 0; r < rounds; ++r) {
             hipLaunchKernelGGL(k_kkt_fwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
-            hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+            if (sep_wide) hipLaunchKernelGGL(k_kkt_sep_cr<M>, dim3((unsigned)a.G * 64u), dim3(WAVE), 0, st, a);
+            else hipLaunchKernelGGL(k_kkt_sep<M>, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
+          }
+          if (a.csync) {
+            hipLaunchKernelGGL(k_kkt_bwd_post<M>, dim3(gp), dim3(WAVE), 0, st, a);
+            break;
           }
           hipLaunchKernelGGL(k_kkt_bwd<M>, dim3(gp), dim3(WAVE), 0, st, a);
         } else {

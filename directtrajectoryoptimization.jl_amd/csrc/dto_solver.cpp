@@ -939,8 +939,11 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
     // cyclic reduction over the separators for batches of at most DTO_SEP_CR_MAX_INST instances -- decided by the BATCH, not by
     // how many lanes of a tile happen to need a factorisation: the arithmetic of an instance must not depend on its neighbours
     // (tests/test_entry_points_gpu.py: repacking changes nothing).  DTO_SEP_CR=0: off (read at every call: tests flip it)
+    // larger batches with at least 16 chunks: the same elimination on one wavefront per instance (k_kkt_sep_cr) -- the
+    // lane-per-instance form walks the separators one after the other: 63 x 4 us at 64 chunks against ~20 us
     const char* e = getenv("DTO_SEP_CR");
-    a.sep_cr = ((!e || atoi(e) != 0) && S.B <= DTO_SEP_CR_MAX_INST) ? 1 : 0;
+    const bool cr_on = !e || atoi(e) != 0;
+    a.sep_cr = !cr_on ? 0 : (S.B <= DTO_SEP_CR_MAX_INST ? 1 : (S.P >= 16 ? 2 : 0));
   }
   a.opt = S.opt;
 }

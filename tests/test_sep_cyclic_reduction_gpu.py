@@ -69,8 +69,34 @@ def test_cyclic_reduction_matches_the_sequential_elimination_and_the_dense_solve
             assert np.max(np.abs(dx_c[b] - rx)) <= 1e-8 * sc and np.max(np.abs(dl_c[b] - rl)) <= 1e-8 * sc
 
 
+@pytest.mark.parametrize("model,T,dw,partitions,B", [("acrobot", 101, 60.0, 16, 70), ("acrobot", 1000, 60.0, 32, 5),
+                                                     ("acrobot", 1000, 60.0, 64, 130), ("cartpole", 200, 400.0, 25, 64)])
+def test_one_wavefront_per_instance_for_larger_batches_with_many_chunks(model, T, dw, partitions, B):
+    """More than four instances and at least 16 chunks: the same cyclic reduction on one wavefront per (tile, lane)
+    (k_kkt_sep_cr) instead of the lane-per-instance elimination -- same bars as above."""
+    from test_kkt_gpu import dense_kkt_solve
+    from test_baseline_sizes_gpu import oracle_for
+    s, _ = product_solver(model, T)
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    rng = np.random.default_rng(5 * T + partitions + B)
+    Z, MU = rng.random((B, nz)), rng.random((B, nc))
+    ok_s, dx_s, dl_s = _step(s, Z, MU, dw, 1e-5, partitions, cr=False)
+    ok_c, dx_c, dl_c = _step(s, Z, MU, dw, 1e-5, partitions, cr=True)
+    assert ok_s and ok_c
+    scale = max(np.max(np.abs(dx_s)), np.max(np.abs(dl_s)))
+    assert 0 < np.max(np.abs(dx_c - dx_s)) <= 1e-9 * scale and np.max(np.abs(dl_c - dl_s)) <= 1e-9 * scale
+    if T <= 200:
+        onlp = oracle_for(model, T)
+        for b in (0, B // 2, B - 1):
+            rx, rl, inertia, cond = dense_kkt_solve(onlp, Z[b], MU[b], dw, 1e-5)
+            assert inertia == (nz, nc)
+            sc = max(np.max(np.abs(rx)), np.max(np.abs(rl)))
+            assert np.max(np.abs(dx_c[b] - rx)) <= 1e-8 * sc and np.max(np.abs(dl_c[b] - rl)) <= 1e-8 * sc
+
+
 def test_more_running_instances_than_the_threshold_take_the_sequential_elimination():
-    """Five instances in a tile: the lane-per-instance form, whatever the switch says -- bit-identical results."""
+    """Five instances in a tile and fewer than 16 chunks: the lane-per-instance form, whatever the switch says -- bit-identical
+    results."""
     s, _ = product_solver("acrobot", 101)
     nz, nc = s.nlp.num_variables, s.nlp.num_constraint
     rng = np.random.default_rng(3)
