@@ -445,20 +445,32 @@ def main():
     reps = 9
     nf_a = float(np.sum(s.scalar_batch("nfact")))
     it_a = float(np.sum(s.scalar_batch("iter")))
+    # (an event pair around every launch, ONE synchronisation at the end: synchronising after each kernel let the GPU idle
+    #  between them and inflated the figures -- k_update_eval 51 ms where the traced loop has 32, profiles/r05/headline_loop_per_launch_ms.json)
+    marks = []
+
+    def timed(op):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        s.launch_op(op, stream=st)
+        e1.record()
+        marks.append((op, e0, e1))
+
     for r in range(reps):
         first = "eval"
         if fused and r > 0:
             try:
-                tot["update_eval"] += event_time_ms(lambda: s.launch_op("update_eval", stream=st), 1)
-                cnt["update_eval"] += 1
+                timed("update_eval")
                 first = None
             except RuntimeError:      # no memory for the second buffers: the two-kernel sequence
                 fused = False
-                tot["update"] += event_time_ms(lambda: s.launch_op("update", stream=st), 1)
-                cnt["update"] += 1
+                timed("update")
         for o in ([first] if first else []) + mid + ([] if (fused and r < reps - 1) else ["update"]):
-            tot[o] += event_time_ms(lambda: s.launch_op(o, stream=st), 1)
-            cnt[o] += 1
+            timed(o)
+    torch.cuda.synchronize()
+    for op, e0, e1 in marks:
+        tot[op] += e0.elapsed_time(e1)
+        cnt[op] += 1
     nf_b = float(np.sum(s.scalar_batch("nfact")))
     it_b = float(np.sum(s.scalar_batch("iter")))
     avg_ms = {k: tot[k] / max(cnt[k], 1) for k in kname}
@@ -511,9 +523,9 @@ def main():
                     working_fraction_of_launches=round(min(1.0, (it_b - it_a) / max(B * reps, 1)) if rounds == 1 else working, 4),
                     bound_note="priced against the HBM roofline as the bench contract prescribes (streaming sweep, FP64 vector arithmetic, no MFMA); "
                                "see limited_by for what the counters say limits this kernel",
-                    replay="kernel-by-kernel replay: sequential launches on one stream with a HIP event pair around each, no second-stream "
-                           "overlap -- the timed loop runs k_kkt_bwd_early beside k_kkt_fwd_seq and k_kkt_bwd_rest after it instead of "
-                           "k_kkt_bwd_seq, so the replayed kernels sum to more than ms_per_step",
+                    replay="kernel-by-kernel replay: the launches of nine iterations back to back on one stream with a HIP event pair around "
+                           "each (one synchronisation at the end), no second-stream overlap -- the timed loop runs k_kkt_bwd_early beside "
+                           "k_kkt_fwd_seq and k_kkt_bwd_rest after it instead of k_kkt_bwd_seq, so the replayed kernels sum to more than ms_per_step",
                     kernel_ms_per_iteration={kname[k]: round(v, 4) for k, v in per_iter_ms.items()},
                     kernel_avg_launch_ms={kname[k]: round(v, 5) for k, v in avg_ms.items()})
 

@@ -905,10 +905,25 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
   if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) {  // finished instance: its record stays frozen
     if constexpr (UPD) {
       // ... and its iterate moves to the other buffer unchanged
+      // (a tile that mixes finished and running lanes executes this path AND the one below.  k_update_eval grows from 30 to 52 ms
+      //  between iterations 15 and 30 of the bench's batch, while the first instances finish and nothing has been repacked yet;
+      //  the copy below with eight rows in flight did not change that -- the cause is still open)
       const int te = (blk + 1) * a.sb < a.T ? (blk + 1) * a.sb : a.T;
-      for (int i = uload(a.zoff, t_begin); i < uload(a.zoff, te); ++i) *soa(a.z_next, g, a.Nz, i) = *soa(a.z, g, a.Nz, i);
-      for (int i = uload(a.cdoff, t_begin); i < uload(a.cdoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
-      for (int i = uload(a.ccoff, t_begin); i < uload(a.ccoff, te); ++i) *soa(a.lam_next, g, a.Nc, i) = *soa(a.lam, g, a.Nc, i);
+      const int zi0 = uload(a.zoff, t_begin), zi1 = uload(a.zoff, te), di0 = uload(a.cdoff, t_begin), di1 = uload(a.cdoff, te),
+                ci0 = uload(a.ccoff, t_begin), ci1 = uload(a.ccoff, te);
+      // (eight loads, then eight stores: the compiler cannot tell the two buffers apart and keeps a load behind the store before it)
+      auto copy_rows = [&](double* dst, const double* src, int64_t n, int i0, int i1) {
+        for (int i = i0; i < i1; i += 8) {
+          double tmp[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) tmp[k] = (i + k < i1) ? *soa(src, g, n, i + k) : 0.0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) if (i + k < i1) *soa(dst, g, n, i + k) = tmp[k];
+        }
+      };
+      copy_rows(a.z_next, a.z, a.Nz, zi0, zi1);
+      copy_rows(a.lam_next, a.lam, a.Nc, di0, di1);
+      copy_rows(a.lam_next, a.lam, a.Nc, ci0, ci1);
     }
     return;
   }
