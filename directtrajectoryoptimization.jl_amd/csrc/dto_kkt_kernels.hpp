@@ -902,12 +902,17 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
   const dto_solver_opts& o = a.opt;
   const int t_begin = blk * a.sb;
   double al = 0.0, ad = 0.0, mu_u = 0.0;
-  if (*soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0) {  // finished instance: its record stays frozen
+  // A finished instance takes no step.  In the fused pass its iterate still has to reach the other buffer: a tile whose lanes
+  // have ALL finished copies the rows and leaves; in a tile that mixes finished and running lanes the finished ones go through
+  // the pass like the others with the step masked out (z' = z, lam' = lam by a select -- their dz may be anything --, multipliers
+  // and slacks untouched, the record recomputed from the unchanged iterate: the values it already holds).  As a branch of their
+  // own (rounds 3 - 5) the few finished lanes of a tile made the wavefront run both paths one after the other: k_update_eval went
+  // from 30 to 52 ms between iterations 15 and 30 of the bench's batch (tools/update_eval_growth.py).
+  // (plugins with per-stage quasi-Newton blocks in their records keep the branch: a recomputed record would update those blocks)
+  const bool fin = *soa(a.scal, g, SC_COUNT, SC_STATUS) != 0.0;
+  constexpr bool MASKED = UPD && M::EVALUATE_HESSIAN != 0;
+  if (MASKED ? __all(fin) : fin) {
     if constexpr (UPD) {
-      // ... and its iterate moves to the other buffer unchanged
-      // (a tile that mixes finished and running lanes executes this path AND the one below.  k_update_eval grows from 30 to 52 ms
-      //  between iterations 15 and 30 of the bench's batch, while the first instances finish and nothing has been repacked yet;
-      //  the copy below with eight rows in flight did not change that -- the cause is still open)
       const int te = (blk + 1) * a.sb < a.T ? (blk + 1) * a.sb : a.T;
       const int zi0 = uload(a.zoff, t_begin), zi1 = uload(a.zoff, te), di0 = uload(a.cdoff, t_begin), di1 = uload(a.cdoff, te),
                 ci0 = uload(a.ccoff, t_begin), ci1 = uload(a.ccoff, te);
@@ -931,7 +936,7 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
     al = *soa(a.scal, g, SC_COUNT, SC_ALPHA);
     ad = *soa(a.scal, g, SC_COUNT, SC_ALPHA_DMAX);
     mu_u = *soa(a.scal, g, SC_COUNT, SC_MU);
-    if (blk == 0) *soa(a.scal, g, SC_COUNT, SC_ITER) += 1.0;
+    if (blk == 0 && !fin) *soa(a.scal, g, SC_COUNT, SC_ITER) += 1.0;
   }
   // the iterate as this pass sees it
   // (the updated value passes through an empty asm: the compiler then cannot fuse its multiply-add into the arithmetic that
@@ -939,15 +944,25 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
   // exactly the double k_update would have stored: the objective differed in the last bit without it)
   auto zrow = [&](int i) -> double {
     double v;
-    if constexpr (UPD) v = *soa(a.z, g, a.Nz, i) + al * *soa(a.dz, g, a.Nz, i);
-    else v = *soa(a.z, g, a.Nz, i);
+    if constexpr (UPD) {
+      const double v0 = *soa(a.z, g, a.Nz, i);
+      v = v0 + al * *soa(a.dz, g, a.Nz, i);
+      v = fin ? v0 : v;
+    } else {
+      v = *soa(a.z, g, a.Nz, i);
+    }
     asm("" : "+v"(v));
     return v;
   };
   auto lrow = [&](int i) -> double {
     double v;
-    if constexpr (UPD) v = *soa(a.lam, g, a.Nc, i) + al * *soa(a.dlam, g, a.Nc, i);
-    else v = *soa(a.lam, g, a.Nc, i);
+    if constexpr (UPD) {
+      const double v0 = *soa(a.lam, g, a.Nc, i);
+      v = v0 + al * *soa(a.dlam, g, a.Nc, i);
+      v = fin ? v0 : v;
+    } else {
+      v = *soa(a.lam, g, a.Nc, i);
+    }
     asm("" : "+v"(v));
     return v;
   };
@@ -979,8 +994,9 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
         const double pold = *soa(a.z, g, a.Nz, z0 + i);
         const double dp = *soa(a.dz, g, a.Nz, z0 + i);
         double pn = pold + al * dp;
+        pn = fin ? pold : pn;
         asm("" : "+v"(pn));
-        if (!o.newton_only) {
+        if (!o.newton_only && !fin) {
           const double lo = sbu.lo[i], hi = sbu.hi[i];
           if (lo != hi) {
             if (finite_lo(lo)) {
@@ -1091,7 +1107,7 @@ __device__ __forceinline__ void stage_eval_body(const dto_kkt_args& a) {
 #pragma unroll
       for (int j = 0; j < C::NC; ++j) {
         if constexpr (UPD) {
-          if (!o.newton_only && D::ineq(j)) {
+          if (!o.newton_only && D::ineq(j) && !fin) {
             constexpr double KSIG = 1e10;
             const int si = uload(a.ioff, t) + D::slack(j);
             const double sv = *soa(a.s, g, a.Ni, si);
