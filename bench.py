@@ -116,6 +116,37 @@ def full_solve_measurement(dev, T=101, B=1024):
                 iterations_max=int(np.max(iters)), sqp_iterations_per_sec=round(float(np.sum(iters)) / dt, 1))
 
 
+def full_solves_headline_workload(dev, T, B=65536, seed=1000):
+    """The headline workload solved to termination inside the driver's own run (VERDICT r5 item 2c / Missing 5: SURVEY section
+    8(d) defines "SQP iterations/sec" over FULL solves from the fixed guess to the reference `Options`, src/options.jl:7-13): the
+    first `B` instances of the bench's seeded stream of guesses, acrobot T = `T`, one dto_solve_batch call (repacking inside)."""
+    import time as _time
+    import dto_amd
+    from dto_amd import problems as P
+    p = P.build_acrobot(T=T, evaluate_hessian=True)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot")
+    nz = s.nlp.num_variables
+    z0 = make_guesses_device(s, p, B, seed, dev)
+    zo = torch.empty_like(z0)
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    t0 = _time.perf_counter()
+    status, iters = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, stream=st)
+    torch.cuda.synchronize()
+    dt = _time.perf_counter() - t0
+    conv = status == 1
+    out = dict(workload=f"acrobot swing-up T={T} (BASELINE.json configs[2]), the first {B} guesses of the bench's seeded stream, solved to the "
+                        f"reference Options (tol 1e-6, max_iter {s.options.max_iter})",
+               instances=B, seconds=round(dt, 3), converged=int(np.sum(conv)), converged_fraction=round(float(np.mean(conv)), 4),
+               acceptable=int(np.sum(status == 4)), iteration_limit=int(np.sum(status == 2)),
+               failed=int(np.sum((status == 3) | (status == 5))), cpu_time_limit=int(np.sum(status == 6)),
+               iterations_median=float(np.median(iters)), iterations_median_converged=float(np.median(iters[conv])) if conv.any() else None,
+               iterations_p99_converged=float(np.percentile(iters[conv], 99)) if conv.any() else None, iterations_max=int(np.max(iters)),
+               converged_solves_per_sec=round(float(np.sum(conv)) / dt, 1), sqp_iterations_per_sec=round(float(np.sum(iters)) / dt, 1))
+    s.close()
+    return out
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet, dense FP64 matrix (no local guide figure; SURVEY.md 8(d))
 
 
@@ -193,6 +224,29 @@ def _wide_counter_figures(B, T, ms):
         except Exception:
             continue
     return {}
+
+
+def _limited_by_from_counters(kernel, B):
+    """What the committed SQ-counter pass of this command says about `kernel` (read by key, never a literal: VERDICT r5 item 2b):
+    share of a wavefront's cycles with the vector ALU active / spent waiting, vector instructions per launch."""
+    for rnd in ("r06", "r05"):
+        fn = os.path.join("profiles", rnd, f"sq_counters_soa_sweeps_B{B}_steps20.json")
+        try:
+            with open(os.path.join(ROOT, fn)) as f:
+                d = json.load(f)
+            key = next(k for k in d if k.split(" ")[0] == kernel)
+            c = {k: v["mean"] for k, v in d[key].items()}
+            return dict(source=fn + " (rocprofv3 --pmc SQ_* passes of bench.py --loop-only --steps 20 --warmup 5, tools/prof_sq.sh)",
+                        wavefronts=int(c["SQ_WAVES"]), launches_profiled=int(d[key]["SQ_WAVE_CYCLES"]["launches"]),
+                        valu_active_frac_of_wave_cycles=round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+                        waiting_frac_of_wave_cycles=round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                        valu_instructions_per_launch=int(c["SQ_INSTS_VALU"]),
+                        vmem_instructions_per_launch=int(c["SQ_INSTS_VMEM_RD"] + c["SQ_INSTS_VMEM_WR"]),
+                        reading="not HBM: one wavefront per SIMD issuing FP64 vector instructions, and lock-step inertia-correction rounds "
+                                "(a tile pays for its slowest lane); DESIGN.md section 4.2")
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(a):
@@ -334,9 +388,11 @@ def main():
     # An allocation failure in dto_solver_begin (DTO_ERR_DEVICE) must not cost the headline number: retry with one residency of
     # the sequential sweep (131 072 instances) fewer, on every rank alike, and say so.
     while True:
-        z0 = make_guesses_device(s, p, B, 1000 + rank, dev)
-        ok = 1
+        ok, z0 = 1, None
         try:
+            # (inside the try: after a failed allocation HIP's last-error state used to outlive the failure and the next torch
+            #  launch tripped over it -- hip_fail now reads it, and a failure here is retried like one in begin: ADVICE r5)
+            z0 = make_guesses_device(s, p, B, 1000 + rank, dev)
             s.begin_batch(z0.data_ptr(), B, nz, stream=st)
         except RuntimeError:
             ok = 0
@@ -359,6 +415,10 @@ def main():
     torch.cuda.synchronize()
     it0 = s.scalar_batch("iter").copy()
     nf0 = s.scalar_batch("nfact").copy()
+    # every kernel launch of the TIMED iterations carries a HIP event pair on the stream it is launched on (include/dto.h:
+    # dto_solver_trace; read after the timed region): the `roofline` object below describes exactly the iterations `value` counts
+    if not a.loop_only:
+        s.trace(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -380,6 +440,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    s.trace(False)
     profile.append((done, dt, None))
     it1 = s.scalar_batch("iter")
     nf1 = s.scalar_batch("nfact")
@@ -415,70 +476,34 @@ def main():
                       + [dict(iterations=int(profile[-1][0]), seconds=round(profile[-1][1], 3), running=int(np.sum(status_end == 0)))],
                       note="rank 0's shard; status per instance after the timed iterations")
 
-    # the per-kernel replay below needs running instances: restart the batch and advance it a few iterations
-    if np.sum(status_end == 0) < B // 2:
-        s.begin_batch(z0.data_ptr(), B, nz, stream=st)
-        s.iterate_batch(5, stream=st)
-        torch.cuda.synchronize()
-
-    # ---- per-kernel durations (HIP events on the launch stream): the launch sequence of an iteration is
-    #      replayed kernel by kernel for a few more iterations; averages are over ALL launches of a kernel (for the
-    #      time-partitioned form that includes the rounds of k_kkt_fwd/k_kkt_sep that exit at once) -- what
-    #      `rocprofv3 --stats` reports.
+    # ---- per-kernel durations OF THE TIMED ITERATIONS (the launch trace recorded above)
     fp = s.footprint()
-    rounds = fp["factor_rounds"]
-    seq_sweep = s.partitions() == 1   # the sequential sweep: own two-wavefront-per-SIMD kernels, all rounds inside a launch, no k_kkt_sep
-    fwd_ops = ["kkt_fwd"] * rounds if seq_sweep else ["kkt_fwd", "kkt_sep"] * rounds
-    mid = ["conv"] + fwd_ops + ["kkt_bwd", "kkt_post", "linesearch", "ls_reduce"]
-    kname = dict(eval="k_stage_eval", conv="k_conv", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd",
-                 kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd",
-                 kkt_post="k_kkt_post", linesearch="k_linesearch", ls_reduce="k_ls_reduce", update="k_update",
-                 update_eval="k_update_eval")
-    if not seq_sweep:
-        kname["kkt_sep"] = "k_kkt_sep"
-    tot = {k: 0.0 for k in kname}
-    cnt = {k: 0 for k in kname}
-    # the loop above runs UPDATE of one iteration and EVAL of the next as one pass (k_update_eval) when the library could
-    # allocate its second iterate buffers; the replay does the same: the first iteration starts with k_stage_eval, the
-    # following (an even number: the pass swaps buffer pairs) with the fused pass, k_update closes the last one
-    fused = os.environ.get("DTO_FUSE_UPDATE", "1") != "0"
-    reps = 9
-    nf_a = float(np.sum(s.scalar_batch("nfact")))
-    it_a = float(np.sum(s.scalar_batch("iter")))
-    # (an event pair around every launch, ONE synchronisation at the end: synchronising after each kernel let the GPU idle
-    #  between them and inflated the figures -- k_update_eval 51 ms where the traced loop has 32, profiles/r05/headline_loop_per_launch_ms.json)
-    marks = []
-
-    def timed(op):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        s.launch_op(op, stream=st)
-        e1.record()
-        marks.append((op, e0, e1))
-
-    for r in range(reps):
-        first = "eval"
-        if fused and r > 0:
-            try:
-                timed("update_eval")
-                first = None
-            except RuntimeError:      # no memory for the second buffers: the two-kernel sequence
-                fused = False
-                timed("update")
-        for o in ([first] if first else []) + mid + ([] if (fused and r < reps - 1) else ["update"]):
-            timed(o)
-    torch.cuda.synchronize()
-    for op, e0, e1 in marks:
-        tot[op] += e0.elapsed_time(e1)
-        cnt[op] += 1
-    nf_b = float(np.sum(s.scalar_batch("nfact")))
-    it_b = float(np.sum(s.scalar_batch("iter")))
-    avg_ms = {k: tot[k] / max(cnt[k], 1) for k in kname}
-    per_iter_ms = {k: tot[k] / reps for k in kname}
+    seq_sweep = s.partitions() == 1
+    tr = s.read_trace()
+    kname = dict(eval="k_stage_eval", conv="k_conv (+ k_part_reduce)", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd",
+                 kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd", kkt_post="k_kkt_post", linesearch="k_linesearch",
+                 ls_reduce="k_ls_reduce (+ k_part_reduce)", update="k_update", update_eval="k_update_eval",
+                 kkt_bwd_early="k_kkt_bwd_early", kkt_bwd_rest="k_kkt_bwd_rest", kkt_bwd_gate="k_kkt_bwd_gate (one wavefront waiting, second stream)",
+                 factor_solve=("k_kkt_fwd_seq + k_kkt_bwd_seq + k_kkt_post" if seq_sweep else "k_kkt_fwd / k_kkt_sep rounds + k_kkt_bwd + k_kkt_post"),
+                 kkt_sep="k_kkt_sep", kkt_refine="k_kkt_refine + k_kkt_refine_join")
+    ops = sorted(set(tr["name"]))
+    dur = {o: tr["duration_ms"][np.array([n == o for n in tr["name"]])] for o in ops}
+    n_it = int(tr["iteration"].max()) + 1 if len(tr["op"]) else 0
+    tot = {o: float(np.sum(dur[o])) for o in ops}
+    avg_ms = {o: float(np.mean(dur[o])) for o in ops}
+    per_iter_ms = {o: tot[o] / max(n_it, 1) for o in ops}
+    # wall time of every timed iteration: from the start of its first launch to the start of the next iteration's (the last one:
+    # to the end of its last launch) -- they add up to the timed region minus the repack / synchronisation of a slice boundary
+    it_start = np.array([tr["start_ms"][tr["iteration"] == k].min() for k in range(n_it)]) if n_it else np.zeros(0)
+    it_end = np.append(it_start[1:], (tr["start_ms"] + tr["duration_ms"]).max()) if n_it else np.zeros(0)
+    it_ms = it_end - it_start
+    tail = it_ms[-min(8, n_it):] if n_it else np.zeros(1)
     nfact_per_iter = facts_done / max(iters_done, 1.0)
-    # factorisations per lane and k_kkt_fwd launch: < 1 for the time-partitioned sweep (one round per launch, launches of a
-    # finished tile exit at once), > 1 for the sequential sweep (every round of the inertia correction inside one launch)
-    working = (nf_b - nf_a) / max(B * reps * rounds, 1)
+    dom_op = max((o for o in ops if o != "kkt_bwd_gate"), key=lambda o: tot[o]) if ops else "kkt_fwd"
+    launches = max(len(dur.get(dom_op, [])), 1)
+    # factorisations / accepted factorisations per instance and launch of the dominant kernel, over the timed window (this rank)
+    working = facts_done / world / max(B * launches, 1) if dist is not None else facts_done / max(B * launches, 1)
+    accepted = (iters_done / world if dist is not None else iters_done) / max(B * launches, 1)
     # Algorithmic bytes per instance and launch.  The sweeps no longer read derivative values: they
     # re-evaluate them from the iterate.  What a sweep MUST move per stage is therefore: the iterate (p_t, x_{t+1}, lambda_t,
     # nu_t), the stage's right-hand side (record: r_p, d, c) and the carry that the backward sweep resumes from
@@ -488,46 +513,60 @@ def main():
     rec_d = fp["record_doubles"]
     carry_d = (T - 1) * (nx_ * (nx_ + 1) // 2 + nx_ + (nx_ * nx_ if parts > 1 else 0))
     sweep_read = 8 * (nz + (T - 1) * nx_ + nc + rec_d)
-    alg_bytes = dict(                                          # per instance and per launch
-        eval=8 * (2 * nz + 2 * nc) + 8 * rec_d + 8 * 10 * T,   # iterate (+ previous stage for E'lambda), record and partials out
-        kkt_fwd=working * (sweep_read + 8 * carry_d),          # per factorisation actually done by a lane
-        kkt_bwd=sweep_read + 8 * carry_d + 8 * (nz + nc),      # + the step written
+    fact_bytes = sweep_read + 8 * carry_d                       # one forward factorisation of one instance
+    bwd_bytes = sweep_read + 8 * carry_d + 8 * (nz + nc)        # one back substitution (+ the step written)
+    alg_bytes = dict(                                           # per instance and per launch
+        eval=8 * (2 * nz + 2 * nc) + 8 * rec_d + 8 * 10 * T,    # iterate (+ previous stage for E'lambda), record and partials out
+        kkt_fwd=working * fact_bytes,                           # per factorisation actually done by a lane
+        kkt_bwd=bwd_bytes, kkt_bwd_early=bwd_bytes, kkt_bwd_rest=bwd_bytes,   # (early + rest together visit every tile once)
+        factor_solve=working * fact_bytes + bwd_bytes,
         linesearch=8 * (2 * nz + (T - 1) * 2 * nx_) + 8 * 16 * T, update=8 * 3 * (nz + nc), conv=8 * 10 * T, ls_reduce=8 * 16 * T,
-        kkt_sep=8 * 64, kkt_post=8 * 4,
+        kkt_sep=8 * 64, kkt_post=8 * 4, kkt_bwd_gate=0, kkt_refine=2 * 8 * rec_d + 8 * (2 * nz + 2 * nc),
         update_eval=8 * 3 * (nz + nc) + 8 * rec_d + 8 * 10 * T)   # z, dz, lam, dlam in; z', lam', record, partials out
-    dom = max(per_iter_ms, key=per_iter_ms.get)
-    achieved = B * alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    achieved = B * alg_bytes.get(dom_op, 0.0) / (avg_ms[dom_op] * 1e-3) / 1e9 if ops else 0.0
+    achieved_accepted = B * accepted * fact_bytes / (avg_ms[dom_op] * 1e-3) / 1e9 if ops and dom_op == "kkt_fwd" else None
     # HBM bytes per launch: NOT measured in this run (PMC counters need a profiler pass) -- taken from the committed
     # rocprofv3 --pmc passes of this same command and batch size if there are any, with the file named; else null
     traffic, traffic_source = None, None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    pmc_name = dict(kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd").get(dom_op, kname.get(dom_op, dom_op))
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         fn = os.path.join("profiles", rnd, f"pmc_traffic_acrobot_T{T}_B{B}.json")
         try:
             with open(os.path.join(ROOT, fn)) as f:
-                traffic = json.load(f)["kernels"][kname[dom]]["hbm_bytes_per_launch_mean"]
+                traffic = json.load(f)["kernels"][pmc_name]["hbm_bytes_per_launch_mean"]
             traffic_source = fn + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --loop-only, tools/profile_headline.sh)"
             break
         except Exception:
             continue
     # `bound` follows the contract (the kernel is priced against the HBM roofline: it is a streaming sweep whose arithmetic is
-    # FP64 vector, not MFMA); what actually limits k_kkt_fwd_seq is recorded next to it (profiles/r05: SQ counters)
-    limited_by = ("instruction issue at one wavefront per SIMD (FP64 vector unit active 63.5 % of a wavefront's cycles, 16.6 % waiting) and "
-                  "lock-step inertia-correction rounds (a tile pays for its slowest lane: 2.9 round-equivalents per launch over iterations "
-                  "0 - 24 for 1.5 factorisations per instance); not HBM: profiles/r05/sq_counters_soa_sweeps_B524288_steps20.txt, "
-                  "DESIGN.md section 4.2") if kname[dom].startswith("k_kkt_fwd") else None
-    roofline = dict(kernel=kname[dom], bound="hbm", limited_by=limited_by, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+    # FP64 vector, not MFMA); what the SQ counters of the committed profiler pass say limits it is read from that file BY KEY
+    limited_by = _limited_by_from_counters(pmc_name, B)
+    roofline = dict(kernel=kname.get(dom_op, dom_op), bound="hbm", limited_by=limited_by, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
-                    avg_launch_ms=round(avg_ms[dom], 5), launches_per_iteration=cnt[dom] // reps,
-                    algorithmic_bytes_per_launch=int(B * alg_bytes[dom]),
-                    factorizations_per_launch=round(working, 4),
-                    working_fraction_of_launches=round(min(1.0, (it_b - it_a) / max(B * reps, 1)) if rounds == 1 else working, 4),
+                    avg_launch_ms=round(avg_ms.get(dom_op, 0.0), 5), launches_timed=int(launches),
+                    launches_per_iteration=round(launches / max(n_it, 1), 3),
+                    algorithmic_bytes_per_launch=int(B * alg_bytes.get(dom_op, 0.0)),
+                    factorizations_per_launch=round(working, 4), accepted_factorizations_per_launch=round(accepted, 4),
+                    achieved_accepted_work=None if achieved_accepted is None else round(achieved_accepted, 2),
+                    frac_accepted_work=None if achieved_accepted is None else round(achieved_accepted / HBM_PEAK_GBS, 5),
                     bound_note="priced against the HBM roofline as the bench contract prescribes (streaming sweep, FP64 vector arithmetic, no MFMA); "
-                               "see limited_by for what the counters say limits this kernel",
-                    replay="kernel-by-kernel replay: the launches of nine iterations back to back on one stream with a HIP event pair around "
-                           "each (one synchronisation at the end), no second-stream overlap -- the timed loop runs k_kkt_bwd_early beside "
-                           "k_kkt_fwd_seq and k_kkt_bwd_rest after it instead of k_kkt_bwd_seq, so the replayed kernels sum to more than ms_per_step",
-                    kernel_ms_per_iteration={kname[k]: round(v, 4) for k, v in per_iter_ms.items()},
-                    kernel_avg_launch_ms={kname[k]: round(v, 5) for k, v in avg_ms.items()})
+                               "see limited_by for what the counters say limits this kernel; frac counts every factorisation a lane did in the "
+                               "timed launches, frac_accepted_work only the one per running instance and launch that the step uses",
+                    source="HIP event pairs around every launch of the timed iterations, on the stream of the launch (dto_solver_trace); "
+                           "k_kkt_bwd_early runs on the library's second stream beside k_kkt_fwd_seq: the per-kernel figures add up to more than "
+                           "the iteration by what overlaps (overlapped_ms_per_iteration)",
+                    iterations_traced=n_it,
+                    iteration_ms=dict(mean=round(float(np.mean(it_ms)), 4) if n_it else None, first=round(float(it_ms[0]), 4) if n_it else None,
+                                      last=round(float(it_ms[-1]), 4) if n_it else None, min=round(float(np.min(it_ms)), 4) if n_it else None,
+                                      max=round(float(np.max(it_ms)), 4) if n_it else None),
+                    steady_state_ms_per_step=round(float(np.mean(tail)), 4),
+                    steady_state_note=f"mean of the last {len(tail)} timed iterations (the window mean mixes the cheap penalty-phase iterations "
+                                      "with the filter phase's: DESIGN.md section 7)",
+                    dominant_kernel_ms_first_last=[round(float(dur[dom_op][0]), 3), round(float(dur[dom_op][-1]), 3)] if ops else None,
+                    # (the gate kernel is one wavefront WAITING on the second stream until every forward block has started: not work)
+                    overlapped_ms_per_iteration=round(sum(v for k, v in per_iter_ms.items() if k != "kkt_bwd_gate") - (float(np.mean(it_ms)) if n_it else 0.0), 4),
+                    kernel_ms_per_iteration={kname.get(k, k): round(v, 4) for k, v in per_iter_ms.items()},
+                    kernel_avg_launch_ms={kname.get(k, k): round(v, 5) for k, v in avg_ms.items()})
 
     # ---- Jacobian assembly (the MOI callback, instance-major, reference COO order)
     Bj = min(B, 32768)                                         # 6.8 GB of output: enough to fill the GPU, leaves HBM to the solver state
@@ -572,6 +611,14 @@ def main():
         except Exception as e:  # side measurement, never part of `value`
             full = dict(error=str(e))
 
+    # the --steps form times K iterations; the time to solution of the same workload rides along as a side block
+    full_T = None
+    if rank == 0 and world == 1 and not a.no_full_solves and a.steps + a.warmup < 1000:
+        try:
+            full_T = full_solves_headline_workload(dev, T, B=min(65536, B))
+        except Exception as e:  # side measurement, never part of `value`
+            full_T = dict(error=str(e))
+
     dense = None
     if rank == 0 and world == 1 and not a.no_dense_blocks:
         try:
@@ -596,6 +643,7 @@ def main():
             factorizations_per_iteration=round(nfact_per_iter, 3), time_partitions=time_partitions,
             gathered_trajectories=n_gathered, gathered_status_sum=float(gsum), hbm_free_min_gb=hbm_free_min_gb, engine=engine_name,
             roofline=roofline, cpu_baseline=cpu, full_solves=full, dense_blocks=dense,
+            **({f"full_solves_T{T}": full_T} if full_T is not None else {}),
         )
         print(json.dumps(out), flush=True)
     if dist is not None:

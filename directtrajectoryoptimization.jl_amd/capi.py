@@ -10,7 +10,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
 c_int32_p = C.POINTER(C.c_int32)
 
-DTO_ABI_VERSION = 3
+DTO_ABI_VERSION = 4
 DTO_OK = 0
 STATUS_NAMES = {0: "DTO_OK", 1: "DTO_ERR_INVALID", 2: "DTO_ERR_PLUGIN", 3: "DTO_ERR_DEVICE",
                 4: "DTO_ERR_UNSUPPORTED", 5: "DTO_ERR_NOT_CONVERGED"}
@@ -60,11 +60,11 @@ class COptions(C.Structure):
                 ("acceptable_constr_viol_tol", C.c_double), ("acceptable_compl_inf_tol", C.c_double),
                 ("acceptable_obj_change_tol", C.c_double), ("diverging_iterates_tol", C.c_double), ("mu_target", C.c_double),
                 ("line_search", C.c_int), ("penalty_switch_theta", C.c_double),
-                ("hessian_approximation", C.c_int)]
+                ("hessian_approximation", C.c_int), ("kkt_refinement", C.c_int)]
 
 
 DTO_LS_FILTER, DTO_LS_PENALTY_FILTER = 0, 1
-DTO_HESSIAN_EXACT, DTO_HESSIAN_LBFGS = 0, 1
+DTO_HESSIAN_EXACT, DTO_HESSIAN_LBFGS, DTO_HESSIAN_SR1_BLOCKS = 0, 1, 2
 DTO_STATUS_CPU_TIME = 6
 
 
@@ -134,6 +134,9 @@ def lib() -> C.CDLL:
         "dto_solver_end": [vp, vp, C.c_int64, vp, C.c_int64, vp],
         "dto_solver_scalar": [vp, C.c_int, c_double_p],
         "dto_solver_peek": [vp, C.c_int, vp, C.c_int64, vp],
+        "dto_solver_hessian_mode": [vp, C.POINTER(C.c_int)],
+        "dto_solver_trace": [vp, C.c_int],
+        "dto_solver_trace_read": [vp, c_int32_p, c_int32_p, c_double_p, c_double_p, C.c_int64, c_int64_p],
         "dto_solver_launch_op": [vp, C.c_int, vp],
         "dto_solver_footprint": [vp, c_int64_p, c_int64_p, c_int64_p, C.POINTER(C.c_int)],
         "dto_solver_set_partitions": [vp, C.c_int],

@@ -31,6 +31,10 @@ int set_error(int code, const std::string& msg) {
   return code;
 }
 int hip_fail(hipError_t e, const char* what) {
+  // HIP keeps the last error until it is read: left in place, the NEXT launch check of this library or of the caller's framework
+  // (torch's C10 launch check) would report this failure again -- e.g. after a hipMalloc that a caller recovers from by
+  // retrying with a smaller batch
+  (void)hipGetLastError();
   return set_error(DTO_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 }  // namespace dto
@@ -197,6 +201,7 @@ Problem::~Problem() {
     if (p) (void)hipFree(p);
   if (wide_flags) (void)hipFree(wide_flags);
   free_solver();
+  delete trace;
   if (stream) (void)hipStreamDestroy(stream);
   if (dl) dlclose(dl);
 }

@@ -74,6 +74,9 @@ enum dto_kkt_op {
   DTO_KKT_QN_SMALL = 22,     // U'Z, U'v0, C = M - U'Z, q = C^-1 U'v0, correction of the directional derivative
   DTO_KKT_QN_SAVE = 23,      // after LS_REDUCE: grad_x L(x_k, lam_{k+1}) and alpha dz for the next secant pair
   DTO_KKT_QN_COLS_RHS = 24,  // column state (the columns of U as instances of their own): r_p -= column (slot mod QN_M2) of the main state's U
+  // iterative refinement of the step (dto_options.kkt_refinement; round 6): see "iterative refinement" below
+  DTO_KKT_REFINE = 25,       // stage records := residual b - K v of the step just computed (v saved), one more factorisation requested at the accepted (delta_w, gamma)
+  DTO_KKT_REFINE_APPLY = 26, // step := saved step + correction; slack steps, step-length limits and the merit derivative recomputed from it
   DTO_KKT_OP_COUNT
 };
 
@@ -197,6 +200,9 @@ struct dto_kkt_args {
   // instance-major mirrors for pack/unpack
   const double* aos_in; double* aos_out; int64_t ld_aos; int aos_which;  // 0: z, 1: lam, 2: dz, 3: dlam
   dto_solver_opts opt;
+  // iterative refinement (DTO_KKT_REFINE / _APPLY): [G][T][MAX_NX][64] what stage t - 1 contributes to the x_t rows of K v, and the
+  // step being refined (laid out like dz / dlam).  Behind `opt`: no offset of the fields the sweeps read moves.
+  double* refq; double* refvz; double* refvl;
 };
 
 namespace dto {
@@ -1640,7 +1646,10 @@ struct Spike {
 //     v_t = L^-T D^-1 L^-1 (y - O xn - C xL),
 // and the panels X = L^-1 O, Z = L^-1 C are never formed: the backward sweep needs neither their registers (72 doubles for
 // the acrobot) nor their substitutions.
-template <class M, int K, bool SPK, bool BWD = false, class IO>
+// ASSEMBLE_ONLY (k_kkt_refine, round 6): stop before the factorisation -- S, X = O_t, YYl, y then hold the stage's rows of K and
+// of the right-hand side exactly as the sweeps factorise them (with an empty carry: of K itself).  A template constant so that
+// the sweeps' instantiations are, token for token, what they were: their code generation is sensitive to the shape of this function.
+template <class M, int K, bool SPK, bool BWD = false, bool ASSEMBLE_ONLY = false, class IO>
 __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO& io, double mu, double dw, double gam,
                                              bool first, const Carry<M>& cy, Spike<M>& sp, double* S, double* y,
                                              double* X, double* YYl, double* Z, double* cx_direct, double* dinv,
@@ -1914,6 +1923,7 @@ __device__ __forceinline__ void stage_factor(const dto_solver_opts& o, const IO&
     for (int k = 0; k < NY; ++k) keep[NP + Q + k] = R(D::R_D + k);
   }
   DTO_KKT_TICK(1);
+  if constexpr (ASSEMBLE_ONLY) return;
   if constexpr (BWD) {
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
@@ -3889,6 +3899,238 @@ static __global__ __launch_bounds__(WAVE) void k_qn_save(dto_kkt_args a) {   // 
 }
 
 // ------------------------------------------------------------------------------------------------
+// iterative refinement of the KKT step (dto_options.kkt_refinement = number of passes; round 6).
+//
+// Measured background (tools/step_truth.py, profiles/r06/step_truth_*: the step of the acrobot T = 1000 bench state against the
+// solution of the oracle's K in extended precision): the sequential sweeps are within 7e-10 of it, the time-partitioned form
+// within 1e-8 .. 2.5e-8 and, at delta_w = 0, 5e-6 -- the systems themselves are well conditioned (float64 sparse LU: 1e-14; half
+// an ulp of noise in the data moves the solution by 1e-15).  The loss is the partition's own: a chunk whose head state is the
+// separator eliminates lambda_a against u_a alone, three of its four pivots are -delta_c = -1e-8, and the separator's diagonal
+// block R_LL and right-hand side r_L collect +1e8 and -1e8 terms that cancel to O(1) -- eight digits.
+//
+// One pass: r = b - K v from the SAME assembly code the sweeps factorise (stage_factor<..., ASSEMBLE_ONLY> with an empty carry
+// gives the stage's rows of K and b), a solve K e = r with the sweeps at the accepted (delta_w, gamma) -- the stage records hold
+// r for it, the host keeps a copy of the real ones and puts it back --, and v := v + e with everything the back substitution
+// derives from the step recomputed from the sum.  (First built as ONE solve with b + r: the cancellation hits the right-hand
+// side path as well as the matrix, i.e. its error is relative to |b + r| = |b| again: 9.9e-9 -> 1.2e-8 on the test state.  The
+// correction solve's error is relative to |r| = 1e-8 |b|.)
+//   k_kkt_refine       (tile, stage): v_t -> refv;  own rows  rec := -(y - S v - O x_{t+1});  q_{t+1} := O' v + YY x_{t+1} -> refq
+//   k_kkt_refine_join  (tile, stage): x rows    rec += q_t;  stage 0: the tile's lanes ask for one more factorisation
+//   k_kkt_refine_apply (tile, chunk): dz, dlam := refv + e; ds, step-length limits, merit derivative as stage_backward forms them
+// ------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_refine(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const double mu = sc[SC_MU << 6], dw = sc[SC_DELTA_W << 6], gam = sc[SC_GAMMA << 6];   // the accepted factorisation
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    constexpr int NP = D::NP, Q = D::Q, NY = D::NY, BD = D::BD;
+    const SoaIO<M, K> io(a, g, t);
+    Carry<M> cy;
+    Spike<M> sp;
+#pragma unroll
+    for (int i = 0; i < M::MAX_NX * (M::MAX_NX + 1) / 2; ++i) cy.P[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M::MAX_NX; ++i) cy.py[i] = 0.0;
+    double S[BD * (BD + 1) / 2], y[BD], X[BD * (NY > 0 ? NY : 1)], YYl[NY > 0 ? NY * (NY + 1) / 2 : 1], Z[1], cxd[1], dinv[BD];
+    bool ok = true;
+    int nneg = 0;
+    stage_factor<M, K, false, false, true>(a.opt, io, mu, dw, gam, false, cy, sp, S, y, X, YYl, Z, cxd, dinv, ok, nneg, nullptr);
+    double v[BD], xn[NY > 0 ? NY : 1];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      v[i] = *soa(a.dz, g, a.Nz, io.z0 + i);
+      *soa(a.refvz, g, a.Nz, io.z0 + i) = v[i];
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      v[NP + j] = *soa(a.dlam, g, a.Nc, uload(a.ccoff, t) + j);
+      *soa(a.refvl, g, a.Nc, uload(a.ccoff, t) + j) = v[NP + j];
+    }
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+      v[NP + Q + k] = *soa(a.dlam, g, a.Nc, uload(a.cdoff, t) + k);
+      *soa(a.refvl, g, a.Nc, uload(a.cdoff, t) + k) = v[NP + Q + k];
+      xn[k] = *soa(a.dz, g, a.Nz, uload(a.zoff, t + 1) + k);
+    }
+    double* recw = const_cast<double*>(io.recp);
+    StageBounds<NP> sb;
+    if (!DTO_NEWTON(a.opt)) io.bounds(sb);
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      double r = y[i];
+#pragma unroll
+      for (int k = 0; k < BD; ++k) r -= S[i >= k ? tri(i, k) : tri(k, i)] * v[k];
+#pragma unroll
+      for (int c = 0; c < NY; ++c) r -= X[i * NY + c] * xn[c];
+      // The correction solve assembles its right-hand side from the record like any other: y = -(entry + what the assembly adds
+      // for barrier terms and eliminated slacks).  The entry that makes y = r is therefore -r plus those terms (the same
+      // expressions, in the order the assembly subtracts them).  A fixed variable's row is the identity with y = 0 whatever the
+      // record says, and its step is 0.
+      if (i < NP) {
+        double e = -r;
+        bool fx = false;
+        if (!DTO_NEWTON(a.opt)) {
+          const double lo = sb.lo[i], hi = sb.hi[i];
+          fx = lo == hi;
+          if (!fx) {
+            if (finite_hi(hi)) e -= mu / (hi - sb.p[i]);
+            if (finite_lo(lo)) e += mu / (sb.p[i] - lo);
+          }
+        }
+        if (!fx) recw[pair_at(D::R_RP + i)] = e;
+      } else if (i < NP + Q) {
+        const int j = i - NP;
+        double e = -r;
+        if (!DTO_NEWTON(a.opt) && D::ineq(j)) {
+          const double sv = io.slack(j), zv = io.slack_mult(j);
+          e += (sv / zv) * (io.nu(j) - mu / sv);
+        }
+        recw[pair_at(D::R_C + j)] = e;
+      } else {
+        recw[pair_at(D::R_D + (i - NP - Q))] = -r;
+      }
+    }
+    if constexpr (NY > 0) {
+      double* q = a.refq + (((g * a.T + (t + 1)) * M::MAX_NX) << 6) + threadIdx.x;
+#pragma unroll
+      for (int c = 0; c < NY; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < BD; ++i) acc += X[i * NY + c] * v[i];
+#pragma unroll
+        for (int e = 0; e < NY; ++e) acc += YYl[c >= e ? tri(c, e) : tri(e, c)] * xn[e];
+        q[(int64_t)c << 6] = acc;
+      }
+    }
+  });
+}
+
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_refine_join(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.T;
+  const int t = blockIdx.x % a.T;
+  double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    using D = KindDims<M, K>;
+    using KD = typename D::KD;
+    if constexpr (KD::PREV >= 0) {
+      const SoaIO<M, K> io(a, g, t);
+      double* recw = const_cast<double*>(io.recp);
+      const double* q = a.refq + (((g * a.T + t) * M::MAX_NX) << 6) + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < D::NX; ++i) {
+        const bool fx = !DTO_NEWTON(a.opt) && uload(a.lo, io.z0 + i) == uload(a.hi, io.z0 + i);
+        // r_i -= q_i  <=>  entry += q_i
+        if (!fx) recw[pair_at(D::R_RP + i)] += q[(int64_t)i << 6];
+      }
+    }
+  });
+  if (t != 0) return;
+  sc[SC_NEED << 6] = 1.0;
+  sc[SC_ATTEMPT << 6] = (double)a.opt.max_refactor;   // this attempt is the one that gets used, whatever its inertia
+  sc[SC_TRY_DW << 6] = sc[SC_DELTA_W << 6];
+  sc[SC_TRY_GAM << 6] = sc[SC_GAMMA << 6];
+}
+
+// v := saved step + correction, and what the back substitution derives from a step (the tail of stage_backward, expression for
+// expression and in its order -- stages of a chunk from the last to the first, so that a zero correction reproduces its sums bit
+// for bit): slack steps, fraction-to-the-boundary limits, directional derivative of the barrier objective.  The stage records are
+// the REAL ones again when this runs (the host has put its copy back).  grid = G * P; k_kkt_post folds the chunk partials.
+template <class M>
+__global__ __launch_bounds__(WAVE) void k_kkt_refine_apply(dto_kkt_args a) {
+  const int64_t g = blockIdx.x / a.P;
+  const int p = blockIdx.x % a.P;
+  const dto_solver_opts& o = a.opt;
+  const double* sc = a.scal + ((g * SC_COUNT) << 6) + threadIdx.x;
+  if (sc[SC_STATUS << 6] != 0.0) return;
+  const double mu = sc[SC_MU << 6];
+  const double tau = fmax(o.tau_min, 1.0 - mu);
+  const int t0 = uload(a.cstart, p), t1 = uload(a.cstart, p + 1);
+  StepAcc acc{1.0, 1.0, 0.0, 0.0};
+  for (int t = t1 - 1; t >= t0; --t) {
+    dispatch_uniform<M>(uload(a.kind, t), [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      using D = KindDims<M, K>;
+      constexpr int NP = D::NP, Q = D::Q, NY = D::NY;
+      const SoaIO<M, K> io(a, g, t);
+      StageBounds<NP> sb;
+      if (!DTO_NEWTON(o)) io.bounds(sb);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const double dp = *soa(a.refvz, g, a.Nz, io.z0 + i) + *soa(a.dz, g, a.Nz, io.z0 + i);
+        io.put_dp(i, dp);
+        acc.gphid += io.rec(D::R_RP + i) * dp;
+        if (!DTO_NEWTON(o)) {
+          const double lo = sb.lo[i], hi = sb.hi[i];
+          if (lo != hi) {
+            const double pv = sb.p[i];
+            if (finite_lo(lo)) {
+              const double zl = sb.zl[i];
+              const double gap = pv - lo;
+              const double dzl = mu / gap - zl - (zl / gap) * dp;
+              if (dp < 0.0) acc.apmax = fmin(acc.apmax, -tau * gap / dp);
+              if (dzl < 0.0) acc.admax = fmin(acc.admax, -tau * zl / dzl);
+              acc.gphid -= mu / gap * dp;
+            }
+            if (finite_hi(hi)) {
+              const double zu = sb.zu[i];
+              const double gap = hi - pv;
+              const double dzu = mu / gap - zu + (zu / gap) * dp;
+              if (dp > 0.0) acc.apmax = fmin(acc.apmax, tau * gap / dp);
+              if (dzu < 0.0) acc.admax = fmin(acc.admax, -tau * zu / dzu);
+              acc.gphid += mu / gap * dp;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const int row = uload(a.ccoff, t) + j;
+        const double dnu = *soa(a.refvl, g, a.Nc, row) + *soa(a.dlam, g, a.Nc, row);
+        const double nu = io.nu(j);
+        const double r = io.rec(D::R_C + j);
+        io.put_dnu(j, dnu);
+        double dsv = 0.0;
+        if (!DTO_NEWTON(o) && D::ineq(j)) {
+          const double sv = io.slack(j);
+          const double zv = io.slack_mult(j);
+          dsv = -(sv / zv) * (nu - mu / sv + dnu);
+          const double dzs = mu / sv - zv - (zv / sv) * dsv;
+          io.put_ds(j, dsv);
+          if (dsv < 0.0) acc.apmax = fmin(acc.apmax, -tau * sv / dsv);
+          if (dzs < 0.0) acc.admax = fmin(acc.admax, -tau * zv / dzs);
+          acc.gphid -= mu / sv * dsv;
+        }
+        acc.gphid += nu * (r - o.delta_c * dnu + dsv);
+        acc.rlam += r * (nu + dnu);
+      }
+#pragma unroll
+      for (int k = 0; k < NY; ++k) {
+        const int row = uload(a.cdoff, t) + k;
+        const double dl = *soa(a.refvl, g, a.Nc, row) + *soa(a.dlam, g, a.Nc, row);
+        const double lam = io.lam(k);
+        const double r = io.rec(D::R_D + k);
+        io.put_dlam(k, dl);
+        acc.gphid += lam * (r - o.delta_c * dl);
+        acc.rlam += r * (lam + dl);
+      }
+    });
+  }
+  double* ca = a.cacc + (((g * a.P + p) * 4) << 6) + threadIdx.x;
+  st_join(&ca[0 << 6], acc.apmax);
+  st_join(&ca[1 << 6], acc.admax);
+  st_join(&ca[2 << 6], acc.gphid);
+  st_join(&ca[3 << 6], acc.rlam);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
 template <class M>
@@ -4027,6 +4269,16 @@ int launch_kkt(int op, const dto_kkt_args* args, void* stream_) {
       case DTO_KKT_QN_COLS_RHS:
         if (!a.qn_main) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_qn_cols_rhs<M>, dim3(gt), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_REFINE:
+        if (!a.refq || !a.refvz || !a.refvl) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_kkt_refine<M>, dim3(gt), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_kkt_refine_join<M>, dim3(gt), dim3(WAVE), 0, st, a);
+        break;
+      case DTO_KKT_REFINE_APPLY:
+        if (!a.refvz || !a.refvl) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_kkt_refine_apply<M>, dim3((unsigned)((int64_t)a.G * a.P)), dim3(WAVE), 0, st, a);
+        hipLaunchKernelGGL(k_kkt_post, dim3((unsigned)a.G), dim3(WAVE), 0, st, a);
         break;
       default: return -1;
     }

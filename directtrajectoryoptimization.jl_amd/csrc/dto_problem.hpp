@@ -17,6 +17,30 @@ int hip_fail(hipError_t e, const char* what);
 struct SolverState;  // dto_solver.cpp
 struct ImState;      // dto_solver.cpp: instance-major engine
 
+// dto_solver_trace: a HIP event pair around every kernel launch of the solver entry points, on the stream the kernel is launched
+// on (the caller's, or the low-priority one of the early back substitutions) -- so that a caller can report what each kernel
+// took INSIDE the region it timed instead of replaying the launches afterwards.  Events are pooled; nothing is synchronised
+// until the trace is read.
+struct LaunchTrace {
+  struct Rec { int op, iteration, e0, e1; };
+  bool on = false;
+  int iteration = 0;                 // iterations of dto_solver_iterate since the trace was switched on
+  std::vector<hipEvent_t> pool;      // events created so far (re-used by the next trace)
+  size_t used = 0;
+  std::vector<Rec> recs;
+  static constexpr size_t MAX_RECS = 1u << 18;
+  int take() {
+    if (used == pool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return -1;
+      pool.push_back(e);
+    }
+    return (int)used++;
+  }
+  void clear() { used = 0; recs.clear(); iteration = 0; }
+  ~LaunchTrace() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
 struct Problem {
   void* dl = nullptr;
   const dto_model_vtable* vt = nullptr;
@@ -34,6 +58,8 @@ struct Problem {
   hipStream_t stream = nullptr;
   SolverState* solver = nullptr;
   ImState* im = nullptr;
+  LaunchTrace* trace = nullptr;   // dto_solver_trace
+  int hessian_mode_last = -1;     // dto_solver_hessian_mode: what the last solve / begun batch used
   int engine_req = 0;      // dto_solver_set_engine: 0 automatic, 1 SoA tiles, 2 instance-major
   bool im_active = false;  // which engine holds the batch that was begun last
   // factor storage and inertia flags of the wide-stage KKT kernels

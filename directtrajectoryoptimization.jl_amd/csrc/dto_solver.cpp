@@ -60,6 +60,8 @@ struct SolverState {
   double* qn = nullptr;                          // limited-memory BFGS: history, columns and small matrices per tile (QnRows)
   SolverState* cols = nullptr;                   // ... and, for small batches, a second state whose instances are the columns of U
   size_t qn_len = 0;
+  // iterative refinement (dto_options.kkt_refinement): cross-stage terms, the step being refined, copy of the records (lazy)
+  double *refq = nullptr, *refvz = nullptr, *refvl = nullptr, *rec_bak = nullptr;
   double *z_alt = nullptr, *lam_alt = nullptr;   // second iterate / multiplier buffers of the fused UPDATE+EVAL pass (lazy)
   int fuse_state = 0;                            // 0 not decided, 1 buffers allocated, -1 not available (memory, switch)
   double *dz = nullptr, *dlam = nullptr, *ds = nullptr;
@@ -88,10 +90,11 @@ struct SolverState {
                     (void*)fac, (void*)part, (void*)lspart, (void*)scal, (void*)filt, (void*)csum, (void*)sfac, (void*)xsep,
                     (void*)cacc, (void*)cpart, (void*)d_cstart_all, (void*)wtile, (void*)sigx, (void*)sigc, (void*)d_inst_of_slot,
                     (void*)d_src_slot, (void*)repack_tmp, (void*)d_runs, (void*)z_alt, (void*)lam_alt, (void*)tile_fwd_tag, (void*)tile_bwd_tag, (void*)fwd_started,
-                    (void*)qn, (void*)csync})
+                    (void*)qn, (void*)csync, (void*)refq, (void*)refvz, (void*)refvl, (void*)rec_bak})
       if (p) (void)hipFree(p);
     d_ioff = nullptr; d_recoff = d_facoff = nullptr; d_lo = d_hi = nullptr; d_runs = nullptr; n_runs = 0;
     z = lam = zl = zu = s = zs = dz = dlam = ds = rec = fac = part = lspart = scal = filt = nullptr;
+    refq = refvz = refvl = rec_bak = nullptr;
     z_alt = lam_alt = nullptr; fuse_state = 0; qn = nullptr; qn_len = 0; tile_fwd_tag = tile_bwd_tag = fwd_started = nullptr; sweep_tag = 0;
     if (stream_lo) { (void)hipStreamDestroy(stream_lo); stream_lo = nullptr; }
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
@@ -922,6 +925,7 @@ static void fill_kkt_args(Problem* p, dto_kkt_args& a) {
   a.inst_of_slot = S.d_inst_of_slot;
   a.fwd_rounds = fwd_rounds_per_launch();
   a.qn = S.qn; a.qn_mode = 0; a.qn_col = 0;
+  a.refq = S.refq; a.refvz = S.refvz; a.refvl = S.refvl;
   a.prof = nullptr;
   if (const char* e = getenv("DTO_KKT_PROF")) a.prof = (long long*)(uintptr_t)strtoull(e, nullptr, 0);  // debug: device pointer
   a.P = S.P; a.cstart = S.d_cstart; a.csum = S.csum; a.sfac = S.sfac; a.xsep = S.xsep; a.cacc = S.cacc; a.cpart = S.cpart;
@@ -974,9 +978,46 @@ static bool fused_update_available(Problem* p) {
 }
 
 static int kkt_launch(Problem* p, int op, const dto_kkt_args& a, hipStream_t st) {
+  LaunchTrace* tr = (p->trace && p->trace->on && p->trace->recs.size() < LaunchTrace::MAX_RECS) ? p->trace : nullptr;
+  int e0 = -1, e1 = -1;
+  if (tr) {
+    e0 = tr->take(); e1 = tr->take();
+    if (e0 < 0 || e1 < 0) tr = nullptr;
+    else HIP_TRY(hipEventRecord(tr->pool[(size_t)e0], st));
+  }
   const int rc = p->vt->launch_kkt(op, &a, (void*)st);
   if (rc != 0) return hip_fail((hipError_t)rc, "KKT kernel launch");
+  if (tr) {
+    HIP_TRY(hipEventRecord(tr->pool[(size_t)e1], st));
+    tr->recs.push_back({op, tr->iteration, e0, e1});
+  }
   return DTO_OK;
+}
+
+// One pass of iterative refinement of the step in dz / dlam (csrc/dto_kkt_kernels.hpp: "iterative refinement"): the residual goes
+// into the stage records (a copy of the real ones is kept), `solve` runs the factor + solve of the caller's path once more at the
+// accepted (delta_w, gamma), the records come back, and the step becomes saved step + correction with its by-products recomputed.
+static int ensure_refine_buffers(Problem* p, dto_kkt_args& a) {
+  SolverState& S = *p->solver;
+  const size_t lanes = (size_t)S.G * 64;
+  int rc;
+  if (!S.refq && (rc = dev_alloc(&S.refq, lanes * (size_t)p->L.T * (size_t)S.info.nx))) return rc;
+  if (!S.refvz && (rc = dev_alloc(&S.refvz, lanes * (size_t)p->L.Nz))) return rc;
+  if (!S.refvl && (rc = dev_alloc(&S.refvl, lanes * (size_t)std::max<int64_t>(1, p->L.Nc)))) return rc;
+  if (!S.rec_bak && (rc = dev_alloc(&S.rec_bak, lanes * (size_t)S.rec_total))) return rc;
+  a.refq = S.refq; a.refvz = S.refvz; a.refvl = S.refvl;
+  return DTO_OK;
+}
+template <class F>
+static int refine_pass(Problem* p, dto_kkt_args& a, hipStream_t st, F&& solve) {
+  SolverState& S = *p->solver;
+  int rc;
+  const size_t rec_bytes = (size_t)a.G * 64 * (size_t)S.rec_total * sizeof(double);
+  HIP_TRY(hipMemcpyAsync(S.rec_bak, S.rec, rec_bytes, hipMemcpyDeviceToDevice, st));
+  if ((rc = kkt_launch(p, DTO_KKT_REFINE, a, st))) return rc;
+  if ((rc = solve())) return rc;
+  HIP_TRY(hipMemcpyAsync(S.rec, S.rec_bak, rec_bytes, hipMemcpyDeviceToDevice, st));
+  return kkt_launch(p, DTO_KKT_REFINE_APPLY, a, st);
 }
 
 static int pack(Problem* p, dto_kkt_args a, int which, const double* src, int64_t ld, hipStream_t st) {
@@ -2178,6 +2219,7 @@ int dto_options_default(dto_options* o) {
   o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
   o->line_search = DTO_LS_PENALTY_FILTER; o->penalty_switch_theta = 1.0;
   o->hessian_approximation = DTO_HESSIAN_EXACT;
+  o->kkt_refinement = 0;
   return DTO_OK;
 }
 
@@ -2303,6 +2345,7 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
     if ((rc = dto::ensure_im_state(p, b->B))) return rc;
     if ((rc = dto::im_begin(p, opt, b, false, 0.0))) return rc;
     p->im_active = true;
+    p->hessian_mode_last = DTO_HESSIAN_EXACT;   // the instance-major engine exists for exact-Hessian plugins only
     return DTO_OK;
   }
   rc = dto::ensure_state(p, b->B);
@@ -2317,8 +2360,13 @@ int dto_solver_begin(dto_problem* h, const dto_options* opt, const dto_batch* b)
   dto::default_opts(S.opt, u);
   if (S.info.quasi_newton) S.opt.pen_gn = 0;   // per-stage SR1 blocks: dropping them for the penalty phase would also restart them
   hipStream_t st = (hipStream_t)b->stream;
+  // A plugin generated without Hessians (evaluate_hessian = 0: `emit_model(...; evaluate_hessian = false)` on the Julia side) keeps
+  // per-stage SR1 blocks in its records and has no code for the compact L-BFGS border: a limited-memory request runs those blocks
+  // (what such a problem ran before ABI 3) instead of failing, and dto_solver_hessian_mode says so
+  if (S.opt.qn_lbfgs && S.info.quasi_newton) S.opt.qn_lbfgs = 0;
+  p->hessian_mode_last = S.info.quasi_newton ? DTO_HESSIAN_SR1_BLOCKS : (S.opt.qn_lbfgs ? DTO_HESSIAN_LBFGS : DTO_HESSIAN_EXACT);
   if (S.opt.qn_lbfgs) {
-    if (p->L.Ngen != 0 || S.info.quasi_newton)
+    if (p->L.Ngen != 0)
       return set_error(DTO_ERR_UNSUPPORTED, "hessian_approximation = limited-memory: lane-per-instance solver path without GeneralConstraint rows");
     const size_t need = (size_t)S.G * (size_t)dto::QnRows{p->L.Nz}.total() * 64;
     if (S.qn_len < need) {
@@ -2382,7 +2430,11 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
   const bool qn = S.opt.qn_lbfgs != 0;
   const bool overlap = !qn && dto::overlap_sweeps(p, st);
   static const bool gate = [] { const char* e = getenv("DTO_OVERLAP_GATE"); return !e || atoi(e) != 0; }();
+  // (limited-memory mode and per-stage quasi-Newton records rewrite the records themselves: no refinement there)
+  const int n_refine = (!qn && !S.info.quasi_newton && S.user.kkt_refinement > 0) ? std::min(S.user.kkt_refinement, 4) : 0;
+  if (n_refine > 0 && (rc = dto::ensure_refine_buffers(p, a))) return rc;
   for (int it = 0; it < n; ++it) {
+    if (p->trace && p->trace->on && it > 0) ++p->trace->iteration;
     if (it > 0 && it <= n_fused) {
       a.z_next = S.z_alt; a.lam_next = S.lam_alt;
       if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE_EVAL, a, st))) return rc;
@@ -2393,6 +2445,7 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
     }
     if (qn && (rc = dto::kkt_launch(p, DTO_KKT_QN_BEGIN, a, st))) return rc;   // secant pair of the last step, history, sigma
     if ((rc = dto::kkt_launch(p, DTO_KKT_CONV, a, st))) return rc;
+    auto factor_solve = [&]() -> int {
     if (overlap) {
       // forward sweeps on the caller's stream, early back substitutions on the low-priority one, the rest and the post pass
       // after both have finished
@@ -2418,6 +2471,12 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
     } else {
       if ((rc = dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st))) return rc;
     }
+    return DTO_OK;
+    };
+    if ((rc = factor_solve())) return rc;
+    // iterative refinement (dto_options.kkt_refinement passes; csrc/dto_kkt_kernels.hpp: "iterative refinement")
+    for (int r = 0; r < n_refine; ++r)
+      if ((rc = dto::refine_pass(p, a, st, factor_solve))) return rc;
     if (qn) {
       // limited-memory BFGS (csrc/dto_kkt_kernels.hpp): the step above is v0 = K0^-1 b; one solve per column of U = [sigma S, Y],
       // the 12 x 12 system per instance, and the corrected step as one more solve (its step-length limits come with it)
@@ -2461,6 +2520,48 @@ int dto_solver_iterate(dto_problem* h, int n, void* stream) {
     if (qn && (rc = dto::kkt_launch(p, DTO_KKT_QN_SAVE, a, st))) return rc;
     if (!(it + 1 < n && it + 1 <= n_fused))
       if ((rc = dto::kkt_launch(p, DTO_KKT_UPDATE, a, st))) return rc;
+  }
+  if (p->trace && p->trace->on) ++p->trace->iteration;   // the next call starts a new iteration
+  return DTO_OK;
+}
+
+int dto_solver_hessian_mode(dto_problem* h, int* mode) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !mode) return set_error(DTO_ERR_INVALID, "null argument");
+  *mode = p->hessian_mode_last;
+  return DTO_OK;
+}
+
+int dto_solver_trace(dto_problem* h, int on) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p) return set_error(DTO_ERR_INVALID, "null argument");
+  if (!p->trace) p->trace = new dto::LaunchTrace();
+  if (on) p->trace->clear();
+  p->trace->on = on != 0;
+  return DTO_OK;
+}
+
+int dto_solver_trace_read(dto_problem* h, int32_t* op, int32_t* iteration, double* start_ms, double* duration_ms, int64_t capacity,
+                          int64_t* count) {
+  Problem* p = reinterpret_cast<Problem*>(h);
+  if (!p || !count) return set_error(DTO_ERR_INVALID, "null argument");
+  *count = 0;
+  if (!p->trace) return DTO_OK;
+  dto::LaunchTrace& T = *p->trace;
+  *count = (int64_t)T.recs.size();
+  if (T.recs.empty() || capacity <= 0) return DTO_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  const hipEvent_t origin = T.pool[(size_t)T.recs[0].e0];
+  const int64_t n = std::min<int64_t>(capacity, (int64_t)T.recs.size());
+  for (int64_t i = 0; i < n; ++i) {
+    const dto::LaunchTrace::Rec& r = T.recs[(size_t)i];
+    float t0 = 0.f, dt = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t0, origin, T.pool[(size_t)r.e0]));
+    HIP_TRY(hipEventElapsedTime(&dt, T.pool[(size_t)r.e0], T.pool[(size_t)r.e1]));
+    if (op) op[i] = r.op;
+    if (iteration) iteration[i] = r.iteration;
+    if (start_ms) start_ms[i] = (double)t0;
+    if (duration_ms) duration_ms[i] = (double)dt;
   }
   return DTO_OK;
 }
@@ -2534,6 +2635,16 @@ int dto_solver_launch_op(dto_problem* h, int op, void* stream) {
     std::swap(S.z, S.z_alt); std::swap(S.lam, S.lam_alt);
     return DTO_OK;
   }
+  if (op == DTO_KKT_REFINE) {
+    // one whole pass, as dto_solver_iterate runs it after FACTOR_SOLVE (here with the plain, non-overlapped factor + solve)
+    SolverState& S = *p->solver;
+    if (S.info.quasi_newton || S.opt.qn_lbfgs) return set_error(DTO_ERR_UNSUPPORTED, "iterative refinement: exact-Hessian plugins, not in limited-memory mode");
+    int rc = dto::ensure_refine_buffers(p, a);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return dto::refine_pass(p, a, st, [&]() { return dto::kkt_launch(p, DTO_KKT_FACTOR_SOLVE, a, st); });
+  }
+  if (op == DTO_KKT_REFINE_APPLY) return set_error(DTO_ERR_INVALID, "DTO_KKT_REFINE_APPLY is part of DTO_KKT_REFINE");
   return dto::kkt_launch(p, op, a, (hipStream_t)stream);
 }
 
@@ -2814,10 +2925,16 @@ int dto_solver_repack(dto_problem* h, int* num_running, void* stream) {
 int dto_solve_batch(dto_problem* h, const dto_options* opt, const dto_batch* b, double* x_out, int64_t ldxo,
                     double* mu_out, int64_t ldmuo, int32_t* status, int32_t* iterations) {
   Problem* p = reinterpret_cast<Problem*>(h);
-  if (p && b && b->x && x_out && p->vt->launch_wide)
+  // (the tile and the bordered paths have no limited-memory mode: they run the exact second derivatives of the traced
+  //  expressions whatever dto_options.hessian_approximation asks for, and dto_solver_hessian_mode reports it -- ADVICE r5)
+  if (p && b && b->x && x_out && p->vt->launch_wide) {
+    p->hessian_mode_last = DTO_HESSIAN_EXACT;
     return dto::wide_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
-  if (p && b && b->x && x_out && p->L.Ngen > 0)
+  }
+  if (p && b && b->x && x_out && p->L.Ngen > 0) {
+    p->hessian_mode_last = DTO_HESSIAN_EXACT;
     return dto::general_solve_batch(p, opt, b, x_out, ldxo, mu_out, ldmuo, status, iterations);
+  }
   int rc = dto_solver_begin(h, opt, b);
   if (rc) return rc;
   return dto_solver_run(h, x_out, ldxo, mu_out, ldmuo, status, iterations, b->stream);
@@ -2843,7 +2960,9 @@ int dto_solver_begin_warm(dto_problem* h, const dto_options* opt, const dto_batc
   S.user = u;
   dto::default_opts(S.opt, u);
   if (S.info.quasi_newton) S.opt.pen_gn = 0;
+  if (S.opt.qn_lbfgs && S.info.quasi_newton) S.opt.qn_lbfgs = 0;   // as in dto_solver_begin: such a plugin runs its SR1 blocks
   if (S.opt.qn_lbfgs && !S.qn) return set_error(DTO_ERR_INVALID, "dto_solver_begin_warm: the previous solve did not run in limited-memory mode");
+  p->hessian_mode_last = S.info.quasi_newton ? DTO_HESSIAN_SR1_BLOCKS : (S.opt.qn_lbfgs ? DTO_HESSIAN_LBFGS : DTO_HESSIAN_EXACT);
   S.opt.warm = 1;
   S.opt.mu_warm = mu0;
   S.G_active = S.G;   // every instance runs again (the slot map of an earlier dto_solver_repack stays valid)

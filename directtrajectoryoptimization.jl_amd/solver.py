@@ -60,6 +60,10 @@ class Options:
     # "filter" is the filter line search from the first iteration (what Ipopt runs for the reference)
     line_search: str = "penalty-filter"
     penalty_switch_theta: float = 1.0
+    # not a reference field (dto_options.kkt_refinement, ABI 4): passes of iterative refinement per KKT step.  0 for the batches
+    # that fill the GPU (their sequential sweeps are within 1e-9 of an extended-precision solve); one pass brings the
+    # time-partitioned sweeps of small batches from 2.5e-8 (5e-6 at delta_w = 0) to 1e-10 for one more factor + solve per iteration
+    kkt_refinement: int = 0
 
 
 class Indices:
@@ -358,6 +362,7 @@ def _c_options(o: "Options", check_every: int = 10, lbfgs: bool = False) -> "cap
     c.line_search = capi.DTO_LS_PENALTY_FILTER if o.line_search == "penalty-filter" else capi.DTO_LS_FILTER
     c.penalty_switch_theta = float(o.penalty_switch_theta)
     c.hessian_approximation = capi.DTO_HESSIAN_LBFGS if lbfgs else capi.DTO_HESSIAN_EXACT
+    c.kkt_refinement = int(o.kkt_refinement)
     return c
 
 
@@ -452,6 +457,10 @@ class Solver:
         if self.hessian_mode == "lbfgs":
             traced = s_eh                        # (user-Jacobian dynamics cannot be differentiated: their plugin carries SR1 blocks)
             if not traced:
+                # an explicit request that cannot be honoured is an error like the other ones below; only "auto" falls back
+                if ha == "lbfgs":
+                    raise ValueError("Options(hessian_approximation='lbfgs'): dynamics with a user-provided Jacobian (src/dynamics.jl:59-101) "
+                                     "have no traced expression to build the limited-memory border from; use 'sr1' or 'auto'")
                 self.hessian_mode = "sr1"
             elif gen is not None or self._pad is not None or max(d.num_state for d in s_dyn) >= 17:
                 if ha == "lbfgs":
@@ -529,6 +538,8 @@ class Solver:
         return status, iters
 
     def begin_batch(self, x0_ptr, B, ldx, stream=0, params_ptr=0, ldp=0):
+        if self.solve_unsupported:
+            raise ValueError(self.solve_unsupported)
         b = self._solve_nlp._batch(x0_ptr, B, ldx, stream, params_ptr, ldp)
         co = _c_options(self.options, lbfgs=self.hessian_mode == "lbfgs")
         capi.check(self._solve_nlp._lib.dto_solver_begin(self._solve_nlp._h, C.byref(co), C.byref(b)))
@@ -537,6 +548,8 @@ class Solver:
     def begin_warm_batch(self, B, x0_ptr=0, ldx=0, stream=0, params_ptr=0, ldp=0, mu0=0.0):
         """dto_solver_begin_warm: re-solve from the device-resident state of the previous solve (receding-horizon MPC).
         x0_ptr = 0 keeps the final iterate; mu0 <= 0 keeps the barrier parameter."""
+        if self.solve_unsupported:
+            raise ValueError(self.solve_unsupported)
         b = self._solve_nlp._batch(x0_ptr, B, ldx or self._solve_nlp.num_variables, stream, params_ptr, ldp)
         co = _c_options(self.options, lbfgs=self.hessian_mode == "lbfgs")
         capi.check(self._solve_nlp._lib.dto_solver_begin_warm(self._solve_nlp._h, C.byref(co), C.byref(b), float(mu0)))
@@ -597,7 +610,7 @@ class Solver:
         return dict(status=st, iterations=it, **dict(zip(names, arrs)))
 
     KKT_OPS = dict(eval=3, conv=4, factor_solve=5, linesearch=6, ls_reduce=7, update=8, kkt_fwd=9, kkt_sep=10, kkt_bwd=11,
-                   kkt_post=12, update_eval=15)
+                   kkt_post=12, update_eval=15, kkt_refine=25)
 
     def set_partitions(self, partitions: int):
         """Chunks of the time-partitioned factorisation (0 = automatic, 1 = sequential)."""
@@ -642,6 +655,29 @@ class Solver:
         r, f, n, k = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         capi.check(self._solve_nlp._lib.dto_solver_footprint(self._solve_nlp._h, C.byref(r), C.byref(f), C.byref(n), C.byref(k)))
         return dict(record_doubles=r.value, factor_doubles=f.value, num_slacks=n.value, factor_rounds=k.value)
+
+    def trace(self, on: bool = True):
+        """Switch the launch trace of the solver entry points on (clearing it) or off (include/dto.h: dto_solver_trace)."""
+        capi.check(self._solve_nlp._lib.dto_solver_trace(self._solve_nlp._h, 1 if on else 0))
+
+    def read_trace(self):
+        """Launch by launch in issue order: (op name, iteration, start_ms, duration_ms) as numpy arrays (dto_solver_trace_read)."""
+        n = C.c_int64(0)
+        capi.check(self._solve_nlp._lib.dto_solver_trace_read(self._solve_nlp._h, None, None, None, None, 0, C.byref(n)))
+        cnt = int(n.value)
+        op, it = np.zeros(max(cnt, 1), np.int32), np.zeros(max(cnt, 1), np.int32)
+        t0, dt = np.zeros(max(cnt, 1)), np.zeros(max(cnt, 1))
+        capi.check(self._solve_nlp._lib.dto_solver_trace_read(self._solve_nlp._h, op.ctypes.data_as(capi.c_int32_p), it.ctypes.data_as(capi.c_int32_p),
+                                                       capi.dptr(t0), capi.dptr(dt), cnt, C.byref(n)))
+        names = {v: k for k, v in self.KKT_OPS.items()}
+        names.update({16: "kkt_bwd_early", 17: "kkt_bwd_rest", 18: "kkt_bwd_gate", 25: "kkt_refine"})
+        return dict(op=op[:cnt], name=[names.get(int(o), str(int(o))) for o in op[:cnt]], iteration=it[:cnt], start_ms=t0[:cnt], duration_ms=dt[:cnt])
+
+    def hessian_mode_last(self) -> str:
+        """What stood in for the Hessian of the Lagrangian in the solve / batch begun last (dto_solver_hessian_mode)."""
+        v = C.c_int(-1)
+        capi.check(self._solve_nlp._lib.dto_solver_hessian_mode(self._solve_nlp._h, C.byref(v)))
+        return {-1: "none", 0: "exact", 1: "lbfgs", 2: "sr1"}[v.value]
 
     def scalar_batch(self, name: str):
         out = np.zeros(self._B)

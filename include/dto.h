@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTO_ABI_VERSION 3
+#define DTO_ABI_VERSION 4
 
 enum dto_status {
   DTO_OK = 0,
@@ -194,11 +194,20 @@ typedef struct dto_options {
    * DTO_HESSIAN_LBFGS: Ipopt's hessian_approximation = limited-memory, i.e. what the reference runs when a problem is built
    * with evaluate_hessian = false (src/solver.jl:7, its default and its own acrobot / car examples): compact L-BFGS, history 6,
    * sigma = s'y / s's, updates skipped without curvature -- no second derivatives are evaluated.  Lane-per-instance solver
-   * path without GeneralConstraint rows (DTO_ERR_UNSUPPORTED otherwise). */
+   * path.  Where the mode does not exist the library says what it runs instead (dto_solver_hessian_mode): a model plugin built
+   * without Hessians (evaluate_hessian = 0 in its generator) keeps per-stage SR1 blocks; the tile (17 .. 64 states) and the
+   * bordered (multi-knot GeneralConstraint) paths use the exact second derivatives of the traced expressions. */
   int hessian_approximation;         /* DTO_HESSIAN_EXACT */
+  /* ABI 4: passes of iterative refinement per KKT step (0 = none).  One pass: the residual r = b - K v of the step just computed,
+   * evaluated stage by stage from the code the sweeps factorise, one more factor + solve for K e = r, v := v + e.  Measured on the
+   * acrobot T = 1000 bench state against an extended-precision solve of the oracle's K (profiles/r06/step_truth_*.json): the
+   * sequential sweeps (batches that fill the GPU) are within 1e-9 of it without any pass; the time-partitioned sweeps (small
+   * batches: chunks joined through a separator system) within 2.5e-8, 5e-6 at delta_w = 0, and within 1e-10 after one pass, which
+   * costs them one more factor + solve per iteration.  Lane-per-instance path, exact-Hessian plugins; ignored elsewhere. */
+  int kkt_refinement;                /* 0 */
 } dto_options;
 enum { DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 };
-enum { DTO_HESSIAN_EXACT = 0, DTO_HESSIAN_LBFGS = 1 };
+enum { DTO_HESSIAN_EXACT = 0, DTO_HESSIAN_LBFGS = 1, DTO_HESSIAN_SR1_BLOCKS = 2 /* reported only: dto_solver_hessian_mode */ };
 /* per-instance status reported by dto_solve[_batch] / dto_solver_run / dto_solver_stats */
 enum { DTO_STATUS_RUNNING = 0, DTO_STATUS_CONVERGED = 1, DTO_STATUS_MAX_ITER = 2, DTO_STATUS_NONFINITE = 3,
        DTO_STATUS_ACCEPTABLE = 4, DTO_STATUS_DIVERGING = 5, DTO_STATUS_CPU_TIME = 6 /* cut off by max_cpu_time */ };
@@ -311,6 +320,20 @@ int dto_solver_scalar(dto_problem* p, int slot, double* out);
  * inequality row, in stage order).  Used by the tests that re-derive the interior-point step in numpy. */
 int dto_solver_peek(dto_problem* p, int which, double* out, int64_t ld, void* stream);
 int dto_solver_end(dto_problem* p, double* x_out, int64_t ldxo, double* mu_out, int64_t ldmuo, void* stream);
+/* What stood in for the Hessian of the Lagrangian in the solve / batch begun last on this handle: DTO_HESSIAN_EXACT,
+ * DTO_HESSIAN_LBFGS or DTO_HESSIAN_SR1_BLOCKS -- a caller that asked for DTO_HESSIAN_LBFGS on a path without that mode reads
+ * here what it got (-1: nothing solved yet). */
+int dto_solver_hessian_mode(dto_problem* p, int* mode);
+/* Diagnostic: time every kernel launch of the solver entry points (dto_solver_iterate, dto_solver_launch_op, dto_solver_run ...)
+ * with a HIP event pair on the stream the kernel is launched on -- the caller's, or the library's low-priority stream for the
+ * early back substitutions.  on = 1 clears the records and starts, on = 0 stops.  dto_solver_trace_read synchronises the device
+ * and returns, launch by launch in issue order: the op (enum dto_kkt_op in csrc/dto_kkt_kernels.hpp; FACTOR_SOLVE = 5 covers the
+ * kernels behind it when they are not launched one by one), the iteration index since the trace was switched on, the start
+ * relative to the first traced launch and the duration in milliseconds.  HOST arrays of `capacity` entries (any may be NULL);
+ * *count = launches recorded (may exceed capacity).  bench.py uses it to report per-kernel times of the iterations it timed. */
+int dto_solver_trace(dto_problem* p, int on);
+int dto_solver_trace_read(dto_problem* p, int32_t* op, int32_t* iteration, double* start_ms, double* duration_ms, int64_t capacity,
+                          int64_t* count);
 
 /* single instance, HOST pointers: solve!(solver) (src/solver.jl:45-47) */
 int dto_solve(dto_problem* p, const dto_options* opt, const double* x0, double* x, double* mu, int32_t* status,

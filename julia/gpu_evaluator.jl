@@ -17,7 +17,7 @@
 # tests/c_abi/drive_solve.c exercises from plain C.
 
 const libdto = get(ENV, "DTO_AMD_LIB", joinpath(@__DIR__, "..", "directtrajectoryoptimization.jl_amd", "libdto_hip.so"))
-const DTO_ABI_VERSION = Cint(3)
+const DTO_ABI_VERSION = Cint(4)
 
 struct DtoSpec                      # include/dto.h: dto_problem_spec
     abi_version::Cint
@@ -54,6 +54,7 @@ struct DtoOptions                   # include/dto.h: dto_options (src/options.jl
     line_search::Cint               # DTO_LS_FILTER = 0, DTO_LS_PENALTY_FILTER = 1 (default)
     penalty_switch_theta::Float64
     hessian_approximation::Cint     # DTO_HESSIAN_EXACT = 0, DTO_HESSIAN_LBFGS = 1 (Ipopt's limited-memory mode)
+    kkt_refinement::Cint            # ABI 4: passes of iterative refinement per KKT step (0)
 end
 
 struct DtoBatch                     # include/dto.h: dto_batch (DEVICE pointers)
@@ -67,13 +68,22 @@ end
 
 dto_check(rc) = rc == 0 || error(unsafe_string(ccall((:dto_last_error, libdto), Cstring, ())))
 
+const DTO_LS_FILTER = Cint(0)          # Ipopt's filter line search from the first iteration: what the reference itself runs
+const DTO_LS_PENALTY_FILTER = Cint(1)  # l1-penalty line search far from the constraint manifold, then the filter (the library's default)
+
 # limited_memory: what the reference means by evaluate_hessian = false (src/solver.jl:7: Ipopt's hessian_approximation stays
-# "limited-memory") -- the callers below pass !ev.hessian_lagrangian
-DtoOptions(o::Options; limited_memory::Bool = false) = DtoOptions(o.tol, o.s_max, o.max_iter, o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol,
-                                    0.1, 1.0e-8, 1.0e-4, 10, o.max_cpu_time,
-                                    o.acceptable_tol, o.acceptable_iter, o.acceptable_dual_inf_tol,
-                                    o.acceptable_constr_viol_tol, o.acceptable_compl_inf_tol, o.acceptable_obj_change_tol,
-                                    o.diverging_iterates_tol, o.mu_target, Cint(1), 1.0, Cint(limited_memory ? 1 : 0))
+# "limited-memory") -- the callers below pass !ev.hessian_lagrangian.  (A plugin emitted with evaluate_hessian = false carries
+# no second derivatives at all; the library then runs its per-stage SR1 blocks and `hessian_mode(ev)` says so.)
+# line_search / penalty_switch_theta / kkt_refinement: the library's own knobs (include/dto.h) -- line_search = DTO_LS_FILTER
+# reproduces the reference's globalisation.
+DtoOptions(o::Options; limited_memory::Bool = false, line_search::Integer = DTO_LS_PENALTY_FILTER,
+           penalty_switch_theta::Real = 1.0, kkt_refinement::Integer = 0) =
+    DtoOptions(o.tol, o.s_max, o.max_iter, o.dual_inf_tol, o.constr_viol_tol, o.compl_inf_tol,
+               0.1, 1.0e-8, 1.0e-4, 10, o.max_cpu_time,
+               o.acceptable_tol, o.acceptable_iter, o.acceptable_dual_inf_tol,
+               o.acceptable_constr_viol_tol, o.acceptable_compl_inf_tol, o.acceptable_obj_change_tol,
+               o.diverging_iterates_tol, o.mu_target, Cint(line_search), Float64(penalty_switch_theta),
+               Cint(limited_memory ? 1 : 0), Cint(kkt_refinement))
 
 mutable struct GPUEvaluator <: MOI.AbstractNLPEvaluator
     handle::Ptr{Cvoid}
@@ -166,8 +176,10 @@ guess is what `initialize_states!` / `initialize_controls!` stored (src/solver.j
 (src/solver.jl:41-43) returns the solution.  Returns (status, iterations); status 1 = converged, 2 = iteration limit,
 4 = acceptable level, see include/dto.h.
 """
-function solve!(solver::Solver, ev::GPUEvaluator; options = Options())
-    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
+function solve!(solver::Solver, ev::GPUEvaluator; options = Options(), line_search = DTO_LS_PENALTY_FILTER,
+                penalty_switch_theta = 1.0, kkt_refinement = 0)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian, line_search = line_search,
+                     penalty_switch_theta = penalty_switch_theta, kkt_refinement = kkt_refinement)
     x0 = Float64[something(MOI.get(solver.data.optimizer, MOI.VariablePrimalStart(), v), 0.0) for v in solver.data.variables]
     x = similar(x0)
     μ = zeros(max(1, ev.num_constraint))
@@ -179,6 +191,18 @@ function solve!(solver::Solver, ev::GPUEvaluator; options = Options())
     trajectory!(solver.nlp.trajopt.states, solver.nlp.trajopt.actions, x,                # src/data.jl:258-267
                 solver.nlp.indices.states, solver.nlp.indices.actions)
     return Int(status[]), Int(iters[])
+end
+
+"""
+    hessian_mode(ev)
+
+What stood in for the Hessian of the Lagrangian in the last solve on `ev`: 0 exact second derivatives, 1 limited-memory BFGS,
+2 per-stage SR1 blocks (a plugin emitted without Hessians), -1 nothing solved yet (`dto_solver_hessian_mode`).
+"""
+function hessian_mode(ev::GPUEvaluator)
+    m = Ref{Cint}(-1)
+    dto_check(ccall((:dto_solver_hessian_mode, libdto), Cint, (Ptr{Cvoid}, Ref{Cint}), ev.handle, m))
+    return Int(m[])
 end
 
 # --- device buffers without a HIP binding in the host language
@@ -197,10 +221,12 @@ Solve the columns of `X0` (num_variables × B initial guesses) as B independent 
 `dto_solve_batch` call; `parameters` (num_parameters × B) gives every instance its own flattened `parameters` vector
 (src/solver.jl:10), e.g. the measured state of each MPC rollout.  Returns (X, status, iterations).
 """
-function solve_batch(ev::GPUEvaluator, X0::Matrix{Float64}; options = Options(), parameters = nothing)
+function solve_batch(ev::GPUEvaluator, X0::Matrix{Float64}; options = Options(), parameters = nothing,
+                     line_search = DTO_LS_PENALTY_FILTER, penalty_switch_theta = 1.0, kkt_refinement = 0)
     nz, B = size(X0)
     nz == ev.num_variables || error("X0 must have num_variables rows")
-    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian, line_search = line_search,
+                     penalty_switch_theta = penalty_switch_theta, kkt_refinement = kkt_refinement)
     dx0 = dto_device_array(X0)                                   # column-major nz × B == instance-major [B][nz]
     dx = dto_device_array(zeros(nz, B))
     dpar = parameters === nothing ? Ptr{Float64}(C_NULL) : dto_device_array(Matrix{Float64}(parameters))
@@ -225,8 +251,10 @@ Receding-horizon re-solve of the batch solved last on `ev` (same B): the multipl
 barrier parameter stay on the device (`dto_solver_begin_warm`), only the per-instance `parameters` (num_parameters × B)
 change.  Returns (X, status, iterations).
 """
-function resolve_warm!(ev::GPUEvaluator, B::Int, parameters::Matrix{Float64}; options = Options(), mu0 = 0.0)
-    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian)
+function resolve_warm!(ev::GPUEvaluator, B::Int, parameters::Matrix{Float64}; options = Options(), mu0 = 0.0,
+                       line_search = DTO_LS_PENALTY_FILTER, penalty_switch_theta = 1.0, kkt_refinement = 0)
+    opt = DtoOptions(options; limited_memory = !ev.hessian_lagrangian, line_search = line_search,
+                     penalty_switch_theta = penalty_switch_theta, kkt_refinement = kkt_refinement)
     nz = ev.num_variables
     dpar = dto_device_array(parameters)
     dx = dto_device_array(zeros(nz, B))

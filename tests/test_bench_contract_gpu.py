@@ -38,6 +38,25 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # value = iterations of all instances per second over the timed steps
     assert abs(d["value"] - 8192 * 4 / (d["ms_per_step"] * 4e-3)) <= 0.02 * d["value"]
+    # the roofline describes the TIMED iterations (launch trace, round 6): as many iterations traced as timed, the per-iteration
+    # wall times of the trace add up to the timed region (to the host-side overhead of a slice boundary), the dominant kernel's
+    # launches are the timed ones, and `limited_by` is either absent or read from a committed counter file by name
+    assert r["iterations_traced"] == 4 and r["launches_timed"] >= 4
+    assert 0.5 * d["ms_per_step"] <= r["iteration_ms"]["mean"] <= 1.05 * d["ms_per_step"], (r["iteration_ms"], d["ms_per_step"])
+    assert r["steady_state_ms_per_step"] > 0 and r["factorizations_per_launch"] > 0
+    assert sum(v for k, v in r["kernel_ms_per_iteration"].items() if "gate" not in k) >= 0.9 * r["iteration_ms"]["mean"]
+    assert r["limited_by"] is None or r["limited_by"]["source"].startswith("profiles/")
+
+
+def test_bench_steps_form_carries_full_solves_of_the_headline_workload():
+    """`--steps K` (the driver's form) times K iterations; the full solves SURVEY section 8(d) defines the metric over ride along as
+    `full_solves_T<horizon>` (here on a short horizon and a small batch)."""
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2048", "--horizon", "101", "--no-dense-blocks", "--no-cpu-baseline"])
+    f = d["full_solves_T101"]
+    for k in ("instances", "seconds", "converged", "converged_fraction", "iterations_median_converged", "iterations_p99_converged",
+              "converged_solves_per_sec", "iteration_limit"):
+        assert k in f, k
+    assert f["instances"] == 2048 and f["converged_fraction"] >= 0.95 and f["converged_solves_per_sec"] > 0
 
 
 def test_loop_only_line():

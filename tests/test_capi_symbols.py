@@ -46,7 +46,8 @@ def test_header_compiles_as_c99_and_structs_match_the_ctypes_mirror():
 #include "dto.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(dto_problem_spec), sizeof(dto_options), sizeof(dto_batch), sizeof(dto_kkt_system), sizeof(dto_sizes_t));
-  printf("%zu %zu %zu\n", offsetof(dto_problem_spec, evaluate_hessian), offsetof(dto_options, mu_target), offsetof(dto_kkt_system, delta_c));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(dto_problem_spec, evaluate_hessian), offsetof(dto_options, mu_target), offsetof(dto_kkt_system, delta_c),
+         offsetof(dto_options, hessian_approximation), offsetof(dto_options, kkt_refinement));
   return 0;
 }
 '''
@@ -59,7 +60,8 @@ int main(void) {
     sizes = [int(v) for v in out]
     assert sizes[:5] == [ctypes.sizeof(capi.ProblemSpec), ctypes.sizeof(capi.COptions), ctypes.sizeof(capi.Batch),
                          ctypes.sizeof(capi.KktSystem), ctypes.sizeof(capi.Sizes)]
-    assert sizes[5:] == [capi.ProblemSpec.evaluate_hessian.offset, capi.COptions.mu_target.offset, capi.KktSystem.delta_c.offset]
+    assert sizes[5:] == [capi.ProblemSpec.evaluate_hessian.offset, capi.COptions.mu_target.offset, capi.KktSystem.delta_c.offset,
+                         capi.COptions.hessian_approximation.offset, capi.COptions.kkt_refinement.offset]   # ABI 3 / ABI 4 fields
 
 
 def test_shard_range_on_the_c_abi():

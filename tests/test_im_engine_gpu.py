@@ -11,6 +11,8 @@ of inside one launch) and in the order in which the per-stage partial sums of a 
     (the first iterations), and KKT points at the end -- checked with the oracle's kkt_report like every other solve test.
 Tolerances are written at the asserts.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -78,7 +80,12 @@ def _run_iterations(s, Z, engine, n_iter, names):
         s.set_engine("auto")
 
 
-@pytest.mark.parametrize("model,T,B", [("pendulum", 50, 70), ("acrobot", 101, 130), ("cartpole", 200, 3), ("car", 51, 66)])
+# The engine is frozen (round 6: opt-in, 1.7x slower than the SoA tiles, no further development): the default suite keeps the
+# pendulum cases as smoke tests; DTO_IM_ALL=1 (at build time too: __graft_entry__.build) runs the four models of rounds 3 - 5.
+_ALL = os.environ.get("DTO_IM_ALL") == "1"
+
+
+@pytest.mark.parametrize("model,T,B", [("pendulum", 50, 70), ("acrobot", 101, 130), ("cartpole", 200, 3), ("car", 51, 66)] if _ALL else [("pendulum", 50, 70)])
 def test_first_iterations_match_the_soa_engine(model, T, B):
     """Same guesses, k iterations on each engine: iterates, multipliers, bound multipliers, slacks and the last step."""
     s, p = im_solver(model, T)
@@ -111,7 +118,7 @@ def test_first_iterations_match_the_soa_engine(model, T, B):
             assert np.max(np.abs(a[n] - b[n])) <= tol * scale, (k, n, np.max(np.abs(a[n] - b[n])), scale)
 
 
-@pytest.mark.parametrize("model,T,B", [("pendulum", 50, 64), ("acrobot", 101, 200), ("car", 51, 100), ("cartpole", 200, 2)])
+@pytest.mark.parametrize("model,T,B", [("pendulum", 50, 64), ("acrobot", 101, 200), ("car", 51, 100), ("cartpole", 200, 2)] if _ALL else [("pendulum", 50, 64)])
 def test_full_solves_are_kkt_points(model, T, B):
     """Solve to the reference tolerances on the instance-major engine; every converged instance is checked against the
     oracle's KKT conditions (tests/test_solve_gpu.py's checker); convergence and iteration counts are compared with the SoA

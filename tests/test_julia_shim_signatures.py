@@ -4,7 +4,10 @@ no julia in the image -- so its `struct`s and `ccall` tuples are parsed and comp
   * every Julia struct that mirrors a C struct has the same fields, in the same order, with types of the same width / class;
   * every `ccall((:name, libdto), Cint, (types...), args...)` names a function the header declares, with the same number of
     parameters, the same class (pointer / int / int64 / double) in every position, and as many arguments as types;
-  * the ABI version constants agree.
+  * the ABI version constants agree;
+  * the same for the fenced ```julia blocks of INTEGRATION.md -- the listing a maintainer reads (it showed
+    `DtoSpec(2, ...)` and a 19-field `DtoOptions` filled with 22 values while the library was at ABI 3): every struct it
+    declares, every positional `DtoOptions(...)` / `DtoSpec(...)` construction and every ccall.
 """
 import os
 import re
@@ -127,6 +130,40 @@ def _jl_ccalls(src):
     return calls
 
 
+def _md_julia_blocks():
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        md = f.read()
+    return "\n\n".join(re.findall(r"```julia\n(.*?)```", md, flags=re.S))
+
+
+def _positional_calls(src, name):
+    """argument lists of `name(...)` calls that are neither the struct declaration nor an outer-constructor definition"""
+    out = []
+    for m in re.finditer(r"(?<![\w.{])%s\(" % name, src):
+        line_start = src.rfind("\n", 0, m.start()) + 1
+        if src[line_start:m.start()].strip().startswith(("struct", "#")):
+            continue
+        i, depth = m.end() - 1, 0
+        j = i
+        while True:
+            if src[j] == "(":
+                depth += 1
+            elif src[j] == ")":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        args = _split_top(re.sub(r"#[^\n]*", "", src[i + 1:j]))      # (comments inside the call may hold commas)
+        tail = src[j + 1:j + 40].lstrip()
+        if tail.startswith("=") and not tail.startswith("=="):     # `DtoOptions(o::Options; ...) = ...`: a definition
+            continue
+        # keyword calls of an outer constructor (`DtoOptions(options; limited_memory = ...)`) are not positional constructions
+        if any("::" in a for a in args) or any(";" in a for a in args):
+            continue
+        out.append(args)
+    return out
+
+
 def _load():
     with open(os.path.join(ROOT, "include", "dto.h")) as f:
         header = _strip_c_comments(f.read())
@@ -169,3 +206,34 @@ def test_julia_ccalls_match_the_header_prototypes():
     for name, ret, types, values in _jl_ccalls(md.replace("libdto", "libdto")):
         if name in fn:
             assert [_jl_class(t) for t in types] == fn[name], (name, types, fn[name])
+
+
+def test_integration_md_listing_matches_the_header():
+    """INTEGRATION.md sections 3 - 4: the structs, the abi version literal, the positional constructions and the ccalls of its
+    ```julia blocks against include/dto.h."""
+    header, _ = _load()
+    md = _md_julia_blocks()
+    cs, js, fn = _c_structs(header), _jl_structs(md), _c_functions(header)
+    abi = int(re.search(r"#define\s+DTO_ABI_VERSION\s+(\d+)", header).group(1))
+    assert int(re.search(r"const DTO_ABI_VERSION = Cint\((\d+)\)", md).group(1)) == abi
+    for jname, cname in (("DtoSpec", "dto_problem_spec"), ("DtoOptions", "dto_options")):
+        assert jname in js, (jname, sorted(js))
+        assert [n for n, _ in js[jname]] == [n for n, _ in cs[cname]], (jname, js[jname], cs[cname])
+        assert [c for _, c in js[jname]] == [c for _, c in cs[cname]], (jname, js[jname], cs[cname])
+        calls = _positional_calls(md, jname)
+        assert calls, f"no positional {jname}(...) construction in INTEGRATION.md"
+        for args in calls:
+            assert len(args) == len(cs[cname]), (jname, len(args), len(cs[cname]), args)
+            if jname == "DtoSpec":       # the first field is the ABI version: the constant, never a stale literal
+                assert args[0] in ("DTO_ABI_VERSION", f"Cint({abi})", str(abi)), args[0]
+    calls = _jl_ccalls(md)
+    assert len(calls) >= 12
+    for name, ret, types, values in calls:
+        assert name in fn, f"INTEGRATION.md: {name} is not declared in include/dto.h"
+        assert [_jl_class(t) for t in types] == fn[name], (name, types, fn[name])
+        assert len(values) == len(types), (name, types, values)
+    # and the shipped shim constructs its structs positionally with the right counts too
+    _, jl = _load()
+    for jname, cname in (("DtoSpec", "dto_problem_spec"), ("DtoOptions", "dto_options"), ("DtoBatch", "dto_batch")):
+        for args in _positional_calls(jl, jname):
+            assert len(args) == len(cs[cname]), (jname, len(args), len(cs[cname]), args)

@@ -152,6 +152,38 @@ def test_kkt_step_random_heterogeneous_problem(seed):
     assert ok
 
 
+def primal_dual_system(onlp, n, x, l, zl, zu, sl, zs, mu, dw, gam, dc=1e-8):
+    """Dense primal-dual system of one interior-point iteration from the ORACLE's derivatives (the docstring of
+    test_interior_point_step_matches_dense_primal_dual_system spells it out); `n`: the product-side NLPData (bounds only)."""
+    nz, nc = n.num_variables, n.num_constraint
+    lo, hi = n.variable_bounds
+    clo, _ = n.constraint_bounds
+    ineq = np.where(np.isneginf(clo))[0]
+    H = np.zeros((nz, nz))
+    lam_h = l if gam != 0.0 else np.zeros(nc)      # Gauss-Newton fallback drops the constraint curvature
+    for (r, c), v in zip(onlp.hessian_lagrangian_structure(), onlp.eval_hessian_lagrangian(x, 1.0, lam_h)):
+        H[r - 1, c - 1] = v
+    J = np.zeros((nc, nz))
+    for (r, c), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(x)):
+        J[r - 1, c - 1] = v
+    g, cv = onlp.eval_objective_gradient(x), onlp.eval_constraint(x)
+    fixed = lo == hi
+    flo, fhi = np.isfinite(lo) & ~fixed, np.isfinite(hi) & ~fixed
+    sig = np.zeros(nz); rz = g + J.T @ l
+    sig[flo] += zl[flo] / (x[flo] - lo[flo]); rz[flo] -= mu / (x[flo] - lo[flo])
+    sig[fhi] += zu[fhi] / (hi[fhi] - x[fhi]); rz[fhi] += mu / (hi[fhi] - x[fhi])
+    D = np.full(nc, dc); rc = cv.copy()
+    if len(ineq):
+        sv, zv, nu = sl, zs, l[ineq]
+        D[ineq] += sv / zv
+        rc[ineq] = cv[ineq] + sv - (sv / zv) * (nu - mu / sv)
+    K = np.block([[H + np.diag(sig) + dw * np.eye(nz), J.T], [J, -np.diag(D)]])
+    rhs = -np.concatenate([rz, rc])
+    for i in np.where(fixed)[0]:
+        K[i, :] = 0.0; K[:, i] = 0.0; K[i, i] = 1.0; rhs[i] = 0.0
+    return K, rhs
+
+
 @pytest.mark.parametrize("model,T", [("cartpole", 6), ("car", 6), ("car", 40)])
 def test_interior_point_step_matches_dense_primal_dual_system(model, T):
     """The step of a REAL interior-point iteration (bounds, barrier, slack-eliminated inequality rows, variables fixed by
@@ -189,31 +221,13 @@ def test_interior_point_step_matches_dense_primal_dual_system(model, T):
     clo, _ = n.constraint_bounds
     ineq = np.where(np.isneginf(clo))[0]
     assert len(ineq) == sl.shape[1]
-    dc = 1e-8
+    fixed = lo == hi
+    flo, fhi = np.isfinite(lo) & ~fixed, np.isfinite(hi) & ~fixed
     for b in range(B):
         x, l = z[b], lam[b]
-        H = np.zeros((nz, nz))
-        lam_h = l if gam[b] != 0.0 else np.zeros(nc)      # Gauss-Newton fallback drops the constraint curvature
-        for (r, c), v in zip(onlp.hessian_lagrangian_structure(), onlp.eval_hessian_lagrangian(x, 1.0, lam_h)):
-            H[r - 1, c - 1] = v
-        J = np.zeros((nc, nz))
-        for (r, c), v in zip(onlp.jacobian_structure(), onlp.eval_constraint_jacobian(x)):
-            J[r - 1, c - 1] = v
-        g, cv = onlp.eval_objective_gradient(x), onlp.eval_constraint(x)
-        fixed = lo == hi
-        flo, fhi = np.isfinite(lo) & ~fixed, np.isfinite(hi) & ~fixed
-        sig = np.zeros(nz); rz = g + J.T @ l
-        sig[flo] += zl[b][flo] / (x[flo] - lo[flo]); rz[flo] -= mu[b] / (x[flo] - lo[flo])
-        sig[fhi] += zu[b][fhi] / (hi[fhi] - x[fhi]); rz[fhi] += mu[b] / (hi[fhi] - x[fhi])
-        D = np.full(nc, dc); rc = cv.copy()
+        K, rhs = primal_dual_system(onlp, n, x, l, zl[b], zu[b], sl[b], zs[b], mu[b], dw[b], gam[b])
         if len(ineq):
             sv, zv, nu = sl[b], zs[b], l[ineq]
-            D[ineq] += sv / zv
-            rc[ineq] = cv[ineq] + sv - (sv / zv) * (nu - mu[b] / sv)
-        K = np.block([[H + np.diag(sig) + dw[b] * np.eye(nz), J.T], [J, -np.diag(D)]])
-        rhs = -np.concatenate([rz, rc])
-        for i in np.where(fixed)[0]:
-            K[i, :] = 0.0; K[:, i] = 0.0; K[i, i] = 1.0; rhs[i] = 0.0
         sol = np.linalg.solve(K, rhs)
         scale = np.max(np.abs(sol))
         # forward error: 1e-8 of the step, relaxed in proportion to the conditioning of this particular system (a
