@@ -1932,13 +1932,34 @@ static __global__ __launch_bounds__(64) void k_wide_sum_rows(const double* rows,
 // model code runs wave-uniform into LDS, results leave in full-line coalesced stores.  The stage Jacobian is
 // the constant nonzero table (L2 resident) copied to the output plus the few state-dependent entries.
 // ---------------------------------------------------------------------------------------------------
+// The constant part of the stage Jacobian lives in one table per dynamics class.  k_wide_eval<CON> and k_wide_merit stage ONE
+// class's table in LDS -- that of the middle stage of the horizon: the class nearly every stage has -- and read the table of any
+// other class (time-varying dynamics; the embedding of stage constraints gives the first and the last stage classes of their
+// own, solver.py: pad_to_wide) from global memory.  (Rounds 1-5 staged Dyn<0>'s table and used it for EVERY stage.)
+template <class M>
+__device__ __forceinline__ int staged_dyn_class(const int* kind, int T) {
+  int dyn = 0;
+  M::dispatch_wk(M::wk_of_kind(kind[T > 1 ? (T - 1) / 2 : 0]), [&](auto wkc) {
+    using KD = typename M::template WKind<decltype(wkc)::value>;
+    dyn = KD::DYN >= 0 ? KD::DYN : 0;
+  });
+  return dyn;
+}
+template <class M, int C = 0>
+__device__ __forceinline__ const double* fe_const_of(int dyn) {
+  if constexpr (C + 1 < M::N_DYN) {
+    if (dyn != C) return fe_const_of<M, C + 1>(dyn);
+  }
+  return M::template Dyn<C>::fe_const();
+}
+
 constexpr int EV_WAVES = 4;
 
 template <class M>
 struct EvalLds {
   static constexpr int N = M::WIDE_N, NU = M::WIDE_NU;
   static constexpr int PT = 3 * N + NU + 3;                                   // x, u, y, lam
-  static constexpr int OUT = (M::MAX_KEY > N + NU + 8 ? M::MAX_KEY : N + NU + 8) + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8;
+  static constexpr int OUT = (M::MAX_KEY > N + NU + 8 ? M::MAX_KEY : N + NU + 8) + M::MAX_NH + M::MAX_SNH + M::MAX_NJV + 8 + 2 * M::MAX_CON;
   static constexpr int PER_WAVE = PT + OUT;
 };
 
@@ -1957,10 +1978,14 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
   double* hv = ov + (M::MAX_KEY > N + NU + 8 ? M::MAX_KEY : N + NU + 8);
   double* chv = hv + M::MAX_NH;
   double* jvv = chv + M::MAX_SNH;
+  double* cvv = jvv + M::MAX_NJV + 8;           // [MAX_CON] values / Jacobian / Hessian nonzeros of the knot's stage constraint
+  double* nuv = cvv + M::MAX_CON;               // [MAX_CON] its multipliers
   double* fe_s = sm + EV_WAVES * EL::PER_WAVE;  // [N][NC] constant Jacobian, OP == CON only
+  int staged = 0;
   if constexpr (OP == DTO_OP_CON) {
-    // every dynamics class of a wide model shares one table per class; stage it once per workgroup
-    const double* fe = M::template Dyn<0>::fe_const();
+    // the constant Jacobian table of the horizon's main dynamics class, staged once per workgroup (fe_const_of)
+    staged = staged_dyn_class<M>(a.kind, a.T);
+    const double* fe = fe_const_of<M>(staged);
     for (int i = threadIdx.x; i < N * NC; i += EV_WAVES * 64) fe_s[i] = fe[i];
     __syncthreads();
   }
@@ -2000,12 +2025,21 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
           if (l < DY::NNL) ov[DY::nl_row(l)] = hv[l];
           wave_lds_fence();   // lane nl_row(q) reads what lane q stored
           if (ln) {
+            // (one dynamics class: the LDS copy, through LDS addressing as in rounds 1-5; several: a generic pointer)
             const double* row = fe_s + l * NC;
+            if constexpr (M::N_DYN > 1) { if (KD::DYN != staged) row = DY::fe_const() + l * NC; }
             double acc = ov[l] + dot_rr<N>(row, xv) + dot_rr<N>(row + N + NU, yv);
 #pragma unroll
             for (int j = 0; j < NU; ++j) acc += row[N + j] * uv[j];
             a.out[b * a.ldout + a.cdoff[t] + l] = acc;
           }
+        }
+        // stage-constraint rows of this knot (src/constraints.jl:80-88): behind all dynamics rows (src/data.jl:68-69)
+        if constexpr (KD::CON >= 0) {
+          using CN = typename M::template Con<KD::CON>;
+          CN::eval(xv, uv, wp, cvv);
+          wave_lds_fence();
+          for (int j = l; j < CN::NC; j += 64) a.out[b * a.ldout + a.ccoff[t] + j] = cvv[j];
         }
       } else if constexpr (OP == DTO_OP_JAC) {
         if constexpr (HAS_DYN) {
@@ -2025,6 +2059,14 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           if (l < DY::NJV) o[DY::jv_k(l)] = jvv[l];
+        }
+        if constexpr (KD::CON >= 0) {   // src/constraints.jl:90-96: the knot's nonzeros in the class's CSC order
+          using CN = typename M::template Con<KD::CON>;
+          if constexpr (CN::NJ > 0) {
+            CN::jac(xv, uv, wp, cvv);
+            wave_lds_fence();
+            for (int k = l; k < CN::NJ; k += 64) a.out[b * a.ldout + a.jcoff[t] + k] = cvv[k];
+          }
         }
       } else if constexpr (OP == DTO_OP_HESS) {
         const double* mu = a.mu + b * a.ldmu;
@@ -2047,6 +2089,21 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
             for (int i = l; i < DY::NH; i += 64) {
               const int m = mrow[i];
               if (m >= 0) ov[m] += hv[i];
+            }
+            wave_lds_fence();
+          }
+        }
+        if constexpr (KD::CON >= 0) {   // src/constraints.jl:98-104: nu_t' c_t''
+          using CN = typename M::template Con<KD::CON>;
+          if constexpr (CN::NH > 0) {
+            for (int j = l; j < CN::NC; j += 64) nuv[j] = mu[a.ccoff[t] + j];
+            wave_lds_fence();
+            CN::hess(xv, uv, wp, nuv, cvv);
+            wave_lds_fence();
+            const int* mrow = a.hmap_con + kind * a.hmap_stride;
+            for (int i = l; i < CN::NH; i += 64) {
+              const int m = mrow[i];
+              if (m >= 0) ov[m] += cvv[i];
             }
             wave_lds_fence();
           }
@@ -2131,8 +2188,9 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
   const int w = wave_id(), l = lane_id();
   const int64_t b = blockIdx.x;
   if (a.active && !a.active[b]) return;
+  const int staged = staged_dyn_class<M>(a.kind, a.T);
   {
-    const double* fe = M::template Dyn<0>::fe_const();
+    const double* fe = fe_const_of<M>(staged);
     for (int i = threadIdx.x; i < N * NC; i += WG) fe_s[i] = fe[i];
   }
   __syncthreads();
@@ -2157,7 +2215,9 @@ __global__ __launch_bounds__(WG) void k_wide_merit(dto_wide_args a) {
       if constexpr (HAS_DYN) {
         yv[l] = z[a.zoff[t + 1] + l]; dy[l] = dz[a.zoff[t + 1] + l];
         wave_lds_fence();   // the row products below read every lane's entries
+        using DYc = typename M::template Dyn<KD::DYN>;
         const double* row = fe_s + l * NC;
+        if constexpr (M::N_DYN > 1) { if (KD::DYN != staged) row = DYc::fe_const() + l * NC; }
         // (the four 64-term products in one pass over the row, eight terms in flight: as four fully unrolled dot_rr calls this
         //  kernel spilled 360 registers)
         double l0a = 0.0, l0b = 0.0, lda_ = 0.0, ldb_ = 0.0;

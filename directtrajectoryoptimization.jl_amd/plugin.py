@@ -95,14 +95,17 @@ class Structure:
                   and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == nu0 for d in self.dyn)
                   and 1 <= nu0 <= WIDE_MAX_ACTION
                   and all(c.num_state == n0 for c in self.cost)
-                  and not self.con and self.general is None)
+                  and self.general is None)
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
                                  f"one uniform state dimension up to {WIDE_STATE}, one to {WIDE_MAX_ACTION} actions (the same number at "
-                                 f"every knot) and bound-only stage constraints")
+                                 f"every knot) and no GeneralConstraint")
             self.wide_n = n0
             self.wide_nu = nu0
-        self.wide_solver = self.wide and self.wide_n == WIDE_STATE
+        # (the tile KKT kernels have dynamics rows and variable bounds, no stage rows: problems with stage constraints are solved
+        #  through the embedding of solver.py: pad_to_wide, which turns the rows into auxiliary states -- their own plugin, the
+        #  one with the Constraint objects, carries the evaluator callbacks only)
+        self.wide_solver = self.wide and self.wide_n == WIDE_STATE and not self.con
         if self.evaluate_hessian:
             # all objects must agree on the flag
             for o in list(self.dyn) + list(self.cost) + list(self.con):
@@ -270,12 +273,12 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("#include <type_traits>")
     out.append('#include "dto_wide_kernels.hpp"')
     out.append("namespace {")
-    wkinds: List[Tuple[int, int]] = []
+    wkinds: List[Tuple[int, int, int]] = []
     wk_of_kind = []
     for (d, p, c, kc) in st.kinds:
-        if (d, c) not in wkinds:
-            wkinds.append((d, c))
-        wk_of_kind.append(wkinds.index((d, c)))
+        if (d, c, kc) not in wkinds:
+            wkinds.append((d, c, kc))
+        wk_of_kind.append(wkinds.index((d, c, kc)))
     dev_tables: List[str] = []
     host_tables: List[str] = []
     classes: List[str] = []
@@ -350,6 +353,28 @@ def generate_wide_source(st: Structure, name: str) -> str:
         dev_tables.append(_dev_int_array(f"cost{i}_sc0", [q - 1 for q in c.solver_sparsity[1]]))
         host_tables.append(_int_array(f"cost{i}_hr", c.sparsity[0] if st.evaluate_hessian else []))
         host_tables.append(_int_array(f"cost{i}_hc", c.sparsity[1] if st.evaluate_hessian else []))
+    # stage constraints (round 6): evaluator callbacks only (k_wide_eval) -- values, Jacobian nonzeros, Hessian of nu' c
+    max_con = 1
+    for i, c in enumerate(st.con):
+        va = {"x": "x", "u": "u", "w": "w", "lam": "lam"}
+        nh = c.num_hessian if st.evaluate_hessian else 0
+        max_con = max(max_con, c.num_constraint, c.num_jacobian, nh)
+        sig = "const double* x, const double* u, const double* w, double* out"
+        cl = [f"template <> struct Model::Con<{i}> {{"]
+        cl.append(f"  static constexpr int NX = {c.num_state}, NU = {c.num_action}, NW = {c.num_parameter}, "
+                  f"NC = {c.num_constraint}, NJ = {c.num_jacobian}, NH = {nh};")
+        cl.append(_fn("eval", sig, emit_body(c.evaluate_expr, "out", va)))
+        cl.append(_fn("jac", sig, emit_body(c.jacobian_expr, "out", va) if c.num_jacobian else "    (void)x;"))
+        if nh:
+            sigh = "const double* x, const double* u, const double* w, const double* lam, double* out"
+            cl.append(_fn("hess", sigh, emit_body(c.hessian_expr, "out", va)))
+        cl.append("};")
+        classes.append("\n".join(cl))
+        host_tables.append(_int_array(f"con{i}_jr", c.jacobian_sparsity[0]))
+        host_tables.append(_int_array(f"con{i}_jc", c.jacobian_sparsity[1]))
+        host_tables.append(_int_array(f"con{i}_hr", c.hessian_sparsity[0] if nh else []))
+        host_tables.append(_int_array(f"con{i}_hc", c.hessian_sparsity[1] if nh else []))
+        host_tables.append(_int_array(f"con{i}_iq", sorted(c.indices_inequality)))
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     dev_extra: List[str] = []
@@ -366,16 +391,19 @@ def generate_wide_source(st: Structure, name: str) -> str:
             raise ValueError(f"wide stages: {lds} bytes of stage data per instance exceed the 160 KB of LDS of one workgroup "
                              f"({nu} actions, {max_nh} dynamics-Hessian / {max_snh} cost-Hessian / {max_njv} variable Jacobian entries)")
     out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = {1 if st.evaluate_hessian else 0}, MAX_KEY = {max_key};")
+    out.append(f"  static constexpr int N_DYN = {len(st.dyn)};")
+    out.append(f"  static constexpr int N_CON = {len(st.con)}, MAX_CON = {max_con};   // stage-constraint classes; largest of their value / Jacobian / Hessian counts")
     out.append("  template <int K> struct WKind;")
     out.append("  template <int C> struct Dyn;")
     out.append("  template <int C> struct Cost;")
+    out.append("  template <int C> struct Con;")
     out.append("  static __device__ __forceinline__ int wk_of_kind(int k) { return k_wk_of_kind[k]; }")
     out.append("  template <class F> static __device__ __forceinline__ void dispatch_wk(int wk, F&& f) {")
     for i in range(len(wkinds)):
         out.append(f"    if (wk == {i}) {{ f(std::integral_constant<int, {i}>{{}}); return; }}")
     out.append("  }")
     out.append("};")
-    for i, (d, c) in enumerate(wkinds):
+    for i, (d, c, kc) in enumerate(wkinds):
         # states that the actions couple to through second derivatives: rows of A_xu (x-u entries of the cost and of lam' d'')
         # and of V_u (u-y entries of lam' d'').  The rank-one terms of the action elimination touch only these rows / columns of
         # the stage matrices (csrc/dto_wide_kernels.hpp, phase 5): for the acrobot embedding 1 + 1 of 64 + 64.  (Several actions:
@@ -401,7 +429,7 @@ def generate_wide_source(st: Structure, name: str) -> str:
         au_l, vu_l = sorted(au_s), sorted(vu_s)
         dev_extra.append(_dev_int_array(f"wk{i}_aus", au_l))
         dev_extra.append(_dev_int_array(f"wk{i}_vus", vu_l))
-        out.append(f"template <> struct Model::WKind<{i}> {{ static constexpr int DYN = {d}, COST = {c}, AU_N = {len(au_l)}, VU_N = {len(vu_l)};")
+        out.append(f"template <> struct Model::WKind<{i}> {{ static constexpr int DYN = {d}, COST = {c}, CON = {kc}, AU_N = {len(au_l)}, VU_N = {len(vu_l)};")
         out.append(_lookup("au_s", f"wk{i}_aus") + _lookup("vu_s", f"wk{i}_vus"))
         out.append("};")
     out[dev_extra_at:dev_extra_at] = dev_extra
@@ -415,14 +443,19 @@ def generate_wide_source(st: Structure, name: str) -> str:
     rows = [f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_hessian if st.evaluate_hessian else 0}, cost{i}_hr, cost{i}_hc}}"
             for i, c in enumerate(st.cost)]
     out.append("static const dto_cost_class k_cost[] = {\n" + ",\n".join(rows) + "\n};")
-    out.append("static const dto_con_class k_con[] = {\n  {0}\n};")
+    rows = []
+    for i, c in enumerate(st.con):
+        nh = c.num_hessian if st.evaluate_hessian else 0
+        rows.append(f"  {{{c.num_state}, {c.num_action}, {c.num_parameter}, {c.num_constraint}, {c.num_jacobian}, {nh}, "
+                    f"con{i}_jr, con{i}_jc, con{i}_hr, con{i}_hc, {len(c.indices_inequality)}, con{i}_iq}}")
+    out.append("static const dto_con_class k_con[] = {\n" + (",\n".join(rows) if rows else "  {0}") + "\n};")
     rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
     out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
     out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::wide::launch_wide_eval<Model>(op, a, s); }")
     if st.wide_solver:
         out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
-    out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, 0, {len(st.kinds)},')
+    out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
     out.append(f"  k_dyn, k_cost, k_con, k_kinds, nullptr, {1 if st.evaluate_hessian else 0},")
     out.append(f"  {max_key}, launch, nullptr, nullptr, "
                + ("launch_wide, dto::wide::wide_info<Model>" if st.wide_solver else "nullptr, nullptr") + ", nullptr, nullptr")

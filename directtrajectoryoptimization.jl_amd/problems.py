@@ -262,7 +262,8 @@ def padded_action_cost(x, u):
     return c
 
 
-def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1, parameters=None):
+def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1, parameters=None,
+                         stage_constraints=None):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
     blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
     terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
@@ -289,10 +290,26 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
         bT = Bound(n, 0, state_lower=lo, state_upper=hi)
     else:
         bT = Bound(n, 0, state_lower=xT, state_upper=xT)
+    cons = [Constraint() for _ in range(T)]
+    if stage_constraints is not None:
+        # stage_constraints = (a, b, r): the reference's two uses of `Constraint` on a model with more than 16 states (round 6) --
+        # the endpoints as EQUALITY ROWS instead of bounds (examples/acrobot/acrobot.jl:114-118: x - x1 at the first knot, the
+        # physical states - xT at the last) and an obstacle-style INEQUALITY ROW at every knot (examples/car/car.jl:53-60):
+        # r^2 - (q1 - a)^2 - (q2 - b)^2 <= 0 keeps the joint angles out of a disc the straight-line guess runs through
+        a_, b_, r_ = (float(v) for v in stage_constraints)
+        obs = lambda x: r_ ** 2.0 - (x[0] - a_) ** 2.0 - (x[1] - b_) ** 2.0
+        con1 = Constraint(lambda x, u, w: np.array(list(x - x1) + [obs(x)], dtype=object), n, m, indices_inequality=[n + 1],
+                          evaluate_hessian=evaluate_hessian)
+        cont = Constraint(lambda x, u, w: np.array([obs(x)], dtype=object), n, m, indices_inequality=[1], evaluate_hessian=evaluate_hessian)
+        conT = Constraint(lambda x, u, w: np.array(list(x[0:4] - xT[0:4]) + [obs(x)], dtype=object), n, 0, indices_inequality=[5],
+                          evaluate_hessian=evaluate_hessian)
+        cons = [con1] + [cont] * (T - 2) + [conT]
+        b1 = Bound(n, m, **ub)
+        bT = Bound(n, 0)
     return dict(
         dynamics=[dt] * (T - 1),
         objective=[ct] * (T - 1) + [cT],
-        constraints=[Constraint() for _ in range(T)],
+        constraints=cons,
         bounds=[b1] + [bt] * (T - 2) + [bT],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
         parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,

@@ -435,8 +435,8 @@ class Solver:
         if gen is None and s_eh:
             padded = pad_to_wide(s_dyn, s_obj, s_con, bounds, s_eh)
             if padded is not None:
-                s_dyn, s_obj, s_con, s_bounds, zmap, mumap = padded
-                self._pad = (zmap, mumap)
+                s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = padded
+                self._pad = (zmap, mumap, musign)
                 changed = True
         # 17 .. 63 states that the embedding cannot take: the problem gets evaluator callbacks (a tile-family plugin of its own
         # size) but no solver -- say so here, not as "plugin has no KKT kernels" at the first solve
@@ -444,7 +444,8 @@ class Solver:
         n_max = max(d.num_state for d in s_dyn)
         if _WMIN <= n_max < _WST and self._pad is None:
             why = ("a GeneralConstraint" if gen is not None else "the per-stage SR1 mode (no second derivatives to embed)" if not s_eh else
-                   "stage constraints, more than four actions, varying dimensions or user-Jacobian dynamics")
+                   "more than four actions, varying dimensions, user-Jacobian dynamics, or more stage-constraint rows in one stage than "
+                   "there are padding states (rows of the last knot count with the last stage's; parameters in them are not supported)")
             self.solve_unsupported = (f"problems with {_WMIN} .. {_WST - 1} states are solved through the 64-state embedding of the tile "
                                       f"kernels, which does not take {why}: the MOI callbacks of this Solver work, solve!/solve_batch do not")
         else:
@@ -507,7 +508,8 @@ class Solver:
         Z = np.asarray(Z)
         if self._pad is None:
             return Z
-        return Z[..., self._pad[1 if multipliers else 0]]
+        # (multipliers: a stage row that the embedding carries as an auxiliary dynamics row comes back with the opposite sign)
+        return Z[..., self._pad[1]] * self._pad[2] if multipliers else Z[..., self._pad[0]]
 
     def multipliers_to_reference(self, mu):
         """Multipliers of the batched entry points come back in the SOLVER's row order; when a stage-local GeneralConstraint
@@ -735,9 +737,23 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
     """Stage objects of a problem with 17 .. 63 states embedded in the 64 states the tile (MFMA) kernels are built for
     (csrc/dto_wide_kernels.hpp; the reference allows any dimensions, src/dynamics.jl:206-211): the padding states follow
     y_k - x_k = 0, cost nothing and are fixed at zero by equal bounds at every knot, so the kernels treat them as identity
-    rows.  Returns (dynamics, objective, constraints, bounds, zmap, mumap) -- zmap / mumap: positions of the padded problem's
-    variables / constraint rows that belong to the original problem, in the original order -- or None if the problem does not
-    fit the tile path either way (more than four actions, stage constraints, varying dimensions, user Jacobians)."""
+    rows.
+
+    Stage constraints (round 6; src/constraints.jl:21-64, e.g. the endpoint rows of examples/acrobot/acrobot.jl:114-118 or the
+    obstacle row of examples/car/car.jl:53-60 on a model with more than 16 states): the tile kernels have dynamics rows and
+    variable bounds, no stage rows -- so a row c_j(x_t, u_t) becomes an AUXILIARY STATE a_{t+1, j} of the embedding,
+        y_{n + j} - c_j(x, u, w) = 0      as one more dynamics row of stage t,
+        a_{t+1, j} = 0 (equal bounds: a fixed variable) for an equality row,   a_{t+1, j} <= 0 for an inequality row
+    (Ipopt's own slack formulation, the slack being a bounded state here: primal-dual barrier on the tile path).  The rows of
+    the LAST knot, c(x_T), ride on the last dynamics stage as functions of its next state, y_{n + q + j} - c_j(y).  The multiplier
+    of row j is minus the multiplier of its dynamics row (L = ... + lam (a - c) against ... + nu c).  Needs n + the largest number
+    of rows that meet in one stage <= 64; rows of the last knot must not use parameters (they are evaluated with the last
+    stage's).
+
+    Returns (dynamics, objective, constraints, bounds, zmap, mumap, musign) -- zmap / mumap: positions of the padded problem's
+    variables / constraint rows that belong to the original problem, in the original order [dynamics rows; stage rows]
+    (src/data.jl:64-75), musign: +1 / -1 per original row -- or None if the problem does not fit the tile path either way (more
+    than four actions, varying dimensions, user Jacobians, too many rows)."""
     from .plugin import WIDE_MAX_ACTION, WIDE_MIN_STATE, WIDE_STATE
     from .symbolic import expr as E
     T = len(objective)
@@ -749,34 +765,75 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
         return None
     if any(d.num_state != n or d.num_next_state != n or d.num_action != nu or d.user_jacobian for d in dynamics):
         return None
-    if any(c.num_constraint > 0 for c in constraints):
-        return None
     N = WIDE_STATE
+    Q = [c.num_constraint for c in constraints]
+    if any(Q):
+        if T < 2 or len(constraints) != T:
+            return None
+        for t, c in enumerate(constraints):
+            if c.num_constraint and (c.num_state != n or c.num_action != (nu if t < T - 1 else 0)):
+                return None
+        if Q[T - 1] and constraints[T - 1].num_parameter > 0:
+            return None
+    term = constraints[T - 1] if (any(Q) and Q[T - 1] > 0) else None
+    slots = [Q[t] + (Q[T - 1] if t == T - 2 else 0) for t in range(T - 1)] if any(Q) else [0]
+    QS = max(slots)
+    if n + QS > N:
+        return None
     x, y = E.variables("x", N), E.variables("y", N)
     cache = {}
 
-    def pad(o):
+    def pad_cost(o):
         if id(o) not in cache:
-            if isinstance(o, Dynamics):
-                cache[id(o)] = Dynamics(list(o.evaluate_expr) + [y[k] - x[k] for k in range(n, N)], N, N, nu,
-                                        num_parameter=o.num_parameter, evaluate_hessian=evaluate_hessian)
-            else:
-                cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, num_parameter=o.num_parameter,
-                                    evaluate_hessian=evaluate_hessian)
+            cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, num_parameter=o.num_parameter, evaluate_hessian=evaluate_hessian)
         return cache[id(o)]
 
-    dyn2 = [pad(d) for d in dynamics]
-    obj2 = [pad(c) for c in objective]
-    z0 = np.zeros(N - n)
-    bnd2 = [Bound(N, len(b.action_lower), state_lower=np.concatenate([b.state_lower, z0]), state_upper=np.concatenate([b.state_upper, z0]),
-                  action_lower=b.action_lower, action_upper=b.action_upper) for b in bounds]
-    zmap, mumap = [], []
+    def pad_dyn(d, c, ct):
+        key = (id(d), id(c) if (c is not None and c.num_constraint) else None, id(ct) if ct is not None else None)
+        if key not in cache:
+            rows = list(d.evaluate_expr)
+            k, nw = n, d.num_parameter
+            if key[1] is not None:
+                rows += [y[k + j] - e for j, e in enumerate(c.evaluate_expr)]
+                k += c.num_constraint
+                nw = max(nw, c.num_parameter)
+            if ct is not None:
+                at_y = E.substitute(list(ct.evaluate_expr), {x[i]: y[i] for i in range(n)})
+                rows += [y[k + j] - e for j, e in enumerate(at_y)]
+                k += ct.num_constraint
+            rows += [y[q] + 0.0 for q in range(k, n + QS)]             # aux slots no row of this stage feeds: a = 0
+            rows += [y[q] - x[q] for q in range(n + QS, N)]
+            cache[key] = Dynamics(rows, N, N, nu, num_parameter=nw, evaluate_hessian=evaluate_hessian)
+        return cache[key]
+
+    dyn2 = [pad_dyn(dynamics[t], constraints[t] if any(Q) else None, term if t == T - 2 else None) for t in range(T - 1)]
+    obj2 = [pad_cost(c) for c in objective]
+    inf = float("inf")
+    bnd2 = []
+    for t, b in enumerate(bounds):
+        alo, ahi = np.zeros(N - n), np.zeros(N - n)
+        if t >= 1 and any(Q):
+            feed = [(constraints[t - 1], 0)] + ([(term, Q[t - 1])] if (t - 1 == T - 2 and term is not None) else [])
+            for c, off in feed:
+                for j1 in c.indices_inequality:
+                    alo[off + j1 - 1] = -inf
+        bnd2.append(Bound(N, len(b.action_lower), state_lower=np.concatenate([b.state_lower, alo]), state_upper=np.concatenate([b.state_upper, ahi]),
+                          action_lower=b.action_lower, action_upper=b.action_upper))
+    zmap, mumap, musign = [], [], []
     for t in range(T):
         base = t * (N + nu)
         zmap += list(range(base, base + n)) + (list(range(base + N, base + N + nu)) if t < T - 1 else [])
         if t < T - 1:
             mumap += list(range(t * N, t * N + n))
-    return dyn2, obj2, [Constraint() for _ in range(T)], bnd2, np.asarray(zmap, dtype=np.int64), np.asarray(mumap, dtype=np.int64)
+            musign += [1.0] * n
+    for t in range(T):
+        if not (any(Q) and Q[t]):
+            continue
+        first = (t * N + n) if t < T - 1 else ((T - 2) * N + n + Q[T - 2])
+        mumap += list(range(first, first + Q[t]))
+        musign += [-1.0] * Q[t]
+    return (dyn2, obj2, [Constraint() for _ in range(T)], bnd2, np.asarray(zmap, dtype=np.int64), np.asarray(mumap, dtype=np.int64),
+            np.asarray(musign))
 
 
 def fold_general_constraint(dynamics, objective, constraints, general, evaluate_hessian):

@@ -178,3 +178,66 @@ def kkt_residual_blockwise(model: PaddedAcrobot, T: int, z, lam):
             c[t * n:(t + 1) * n] = model.residual(x, u, y)
             r[o:o + 2 * n + m] += model.jacobian(x, u, y).T @ lt
     return c, r
+
+
+class PaddedStageRows:
+    """ORACLE restatement of the stage constraints of problems.build_acrobot_padded(stage_constraints=(a, b, r)) (round 6: the
+    reference's two uses of `Constraint` on a model with more than 16 states) -- rows in the reference order, knot by knot behind
+    all dynamics rows (src/data.jl:68-69):
+        knot 1:      x - x1 (n equality rows, examples/acrobot/acrobot.jl:114-116),  obstacle row
+        knots 2..T-1: obstacle row   r^2 - (x_1 - a)^2 - (x_2 - b)^2 <= 0   (examples/car/car.jl:53-60)
+        knot T:      x[1:4] - xT[1:4] (4 equality rows),  obstacle row
+    Closed forms only: values, dense Jacobian, Hessian of nu' c."""
+
+    def __init__(self, n, m, T, x1, xT, a, b, r):
+        self.n, self.m, self.T = n, m, T
+        self.x1, self.xT, self.a, self.b, self.r = np.asarray(x1, float), np.asarray(xT, float), float(a), float(b), float(r)
+        self.rows_of = [n + 1] + [1] * (T - 2) + [5]
+        self.off = np.concatenate([[0], np.cumsum(self.rows_of)])
+        self.num = int(self.off[-1])
+        ineq = np.zeros(self.num, dtype=bool)
+        for t in range(T):
+            ineq[self.off[t + 1] - 1] = True
+        self.inequality = ineq
+
+    def _x(self, z, t):
+        o = t * (self.n + self.m)
+        return o, z[o:o + self.n]
+
+    def values(self, z):
+        c = np.zeros(self.num)
+        for t in range(self.T):
+            _, x = self._x(z, t)
+            k = self.off[t]
+            if t == 0:
+                c[k:k + self.n] = x - self.x1
+                k += self.n
+            if t == self.T - 1:
+                c[k:k + 4] = x[:4] - self.xT[:4]
+                k += 4
+            c[k] = self.r ** 2 - (x[0] - self.a) ** 2 - (x[1] - self.b) ** 2
+        return c
+
+    def jacobian(self, z):
+        J = np.zeros((self.num, len(z)))
+        for t in range(self.T):
+            o, x = self._x(z, t)
+            k = self.off[t]
+            if t == 0:
+                J[k:k + self.n, o:o + self.n] = np.eye(self.n)
+                k += self.n
+            if t == self.T - 1:
+                J[k:k + 4, o:o + 4] = np.eye(4)
+                k += 4
+            J[k, o] = -2.0 * (x[0] - self.a)
+            J[k, o + 1] = -2.0 * (x[1] - self.b)
+        return J
+
+    def hessian(self, z, nu):
+        H = np.zeros((len(z), len(z)))
+        for t in range(self.T):
+            o, _ = self._x(z, t)
+            v = nu[self.off[t + 1] - 1]
+            H[o, o] += -2.0 * v
+            H[o + 1, o + 1] += -2.0 * v
+        return H

@@ -85,14 +85,23 @@ def test_wide_plugin_source_and_structure_rules(padded):
     cost2 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 2, evaluate_hessian=True)
     st2 = Structure([d2], [cost2, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
     assert st2.wide_nu == 2 and "WIDE_NU = 2" in generate_source(st2, "m20u2")
-    # ... more than that, or stage constraints in the wide range, are still refused
+    # ... more than that is still refused
     bad = dto_amd.Dynamics(lambda y, x, u, w: y - x, 20, 20, 5, evaluate_hessian=True)
     cost5 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 20, 5, evaluate_hessian=True)
     with pytest.raises(ValueError):
         Structure([bad], [cost5, costT], [dto_amd.Constraint(), dto_amd.Constraint()], None, True)
-    con = dto_amd.Constraint(lambda x, u, w: [x[0] - 1.0], 20, 1, evaluate_hessian=True)
-    with pytest.raises(ValueError):
-        Structure([d20], [cost, costT], [con, dto_amd.Constraint()], None, True)
+    # stage constraints in the wide range (round 6): the plugin gets `Con` classes for the evaluator callbacks; the tile KKT kernels
+    # have no stage rows, so such a structure is never a solver plugin itself (solver.py: pad_to_wide carries the rows as
+    # auxiliary states of the embedding)
+    con = dto_amd.Constraint(lambda x, u, w: [x[0] - 1.0, x[1] * u[0]], 20, 1, indices_inequality=[2], evaluate_hessian=True)
+    stc = Structure([d20], [cost, costT], [con, dto_amd.Constraint()], None, True)
+    srcc = generate_source(stc, "m20c")
+    assert stc.wide and not stc.wide_solver and "struct Model::Con<0>" in srcc and "NC = 2, NJ = 3, NH = 2" in srcc and "CON = 0" in srcc
+    d64 = dto_amd.Dynamics(lambda y, x, u, w: y - x, 64, 64, 1, evaluate_hessian=True)
+    c64 = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 64, 1, evaluate_hessian=True)
+    c64T = dto_amd.Cost(lambda x, u, w: dto_amd.dot(x, x), 64, 0, evaluate_hessian=True)
+    con64 = dto_amd.Constraint(lambda x, u, w: [x[0] - 1.0], 64, 1, evaluate_hessian=True)
+    assert not Structure([d64], [c64, c64T], [con64, dto_amd.Constraint()], None, True).wide_solver
 
 
 def test_full_horizon_layout_totals():
@@ -116,7 +125,8 @@ def test_embedding_of_a_24_state_problem_in_the_64_state_kernels():
     p = P.build_acrobot_padded(T=T, n=n, terminal="physical")
     out = pad_to_wide(p["dynamics"], p["objective"], p["constraints"], p["bounds"], True)
     assert out is not None
-    dyn, obj, cons, bnds, zmap, mumap = out
+    dyn, obj, cons, bnds, zmap, mumap, musign = out
+    assert np.all(musign == 1.0)
     assert dyn[0] is dyn[1] and obj[0] is obj[1] and obj[-1] is not obj[0]           # object sharing preserved (stage classes)
     assert (dyn[0].num_state, dyn[0].num_next_state, dyn[0].num_action) == (64, 64, 1) and obj[-1].num_state == 64
     rng = np.random.default_rng(2)
@@ -143,7 +153,7 @@ def test_embedding_of_a_24_state_problem_in_the_64_state_kernels():
                        [dto_amd.Bound(20, 2), dto_amd.Bound(20, 2), dto_amd.Bound(20, 0)], True)
     assert out2 is not None and out2[0][0].num_action == 2
     assert np.array_equal(out2[4][20:22], [64, 65]) and out2[4][22] == 66 and len(out2[4]) == 2 * 22 + 20
-    # not eligible: more than four actions, stage constraints, or already 64 states
+    # not eligible: more than four actions, or already 64 states
     assert pad_to_wide(P.build_acrobot_padded(T=3)["dynamics"], *[P.build_acrobot_padded(T=3)[k] for k in ("objective", "constraints", "bounds")], True) is None
 
 
@@ -213,3 +223,63 @@ def test_parametric_model_matches_oracle_restatement():
     st = Structure(p["dynamics"], p["objective"], p["constraints"], None, True)
     src = generate_source(st, "acrobot_padded_par")
     assert st.wide and "NW = 2" in src
+
+
+def test_stage_constraints_ride_the_embedding_as_auxiliary_states():
+    """solver.py: pad_to_wide with `Constraint`s (round 6): row j of c_t becomes the dynamics row y_{n+j} - c_j(x, u) of stage t, the
+    rows of the last knot ride on the last stage as functions of its next state; the auxiliary states are fixed at 0 (equality) or
+    bounded above by 0 (inequality); mumap / musign pick the rows out in the reference order [dynamics; stage rows] with the sign
+    flipped for the stage rows.  Values against the ORACLE's closed forms (oracle/padded_model.py: PaddedStageRows)."""
+    from dto_amd.solver import pad_to_wide
+    from oracle.padded_model import PaddedAcrobot, PaddedStageRows
+    n, T, disc = 24, 5, (0.4, -2.56, 0.3)
+    p = P.build_acrobot_padded(T=T, n=n, target=0.4, terminal="physical", stage_constraints=disc)
+    out = pad_to_wide(p["dynamics"], p["objective"], p["constraints"], p["bounds"], True)
+    assert out is not None
+    dyn, obj, cons, bnds, zmap, mumap, musign = out
+    assert all(c.num_constraint == 0 for c in cons) and len(dyn) == T - 1
+    # three dynamics classes: the first stage (endpoint rows + obstacle row of knot 1), the interior ones, the last (its own
+    # obstacle row + the five rows of knot T)
+    assert dyn[1] is dyn[2] and dyn[0] is not dyn[1] and dyn[3] is not dyn[1]
+    rows = PaddedStageRows(n, 1, T, p["x1"], p["xT"], *disc)
+    om = PaddedAcrobot(n)
+    rng = np.random.default_rng(11)
+    X = rng.random((T, 64)); U = rng.random((T - 1, 1))
+    z = np.concatenate([np.concatenate([X[t, :n], U[t]]) if t < T - 1 else X[t, :n] for t in range(T)])
+    cs = rows.values(z)
+    QS = n + 1
+    for t in range(T - 1):
+        env = {("x", i): float(v) for i, v in enumerate(X[t])}
+        env.update({("y", i): float(v) for i, v in enumerate(X[t + 1])}); env[("u", 0)] = float(U[t, 0])
+        r = np.array(evaluate(dyn[t].evaluate_expr, env))
+        assert np.max(np.abs(r[:n] - om.residual(X[t, :n], U[t], X[t + 1, :n]))) < 1e-13
+        q = rows.rows_of[t]
+        assert np.max(np.abs(r[n:n + q] - (X[t + 1, n:n + q] - cs[rows.off[t]:rows.off[t + 1]]))) < 1e-14     # y_aux - c_t(x, u)
+        k = n + q
+        if t == T - 2:   # the rows of the LAST knot, evaluated at the next state
+            assert np.max(np.abs(r[k:k + 5] - (X[t + 1, k:k + 5] - cs[rows.off[T - 1]:]))) < 1e-14
+            k += 5
+        assert k == n + QS or np.max(np.abs(r[k:n + QS] - X[t + 1, k:n + QS])) == 0.0                        # unused slots: a = 0
+        assert np.max(np.abs(r[n + QS:] - (X[t + 1, n + QS:] - X[t, n + QS:]))) == 0.0                       # padding
+    # bounds of the auxiliary states: knot 1 none feeds (fixed 0); knot 2: n fixed + one <= 0; interior: one <= 0; last: 1 + 4 fixed + 1
+    assert np.all(bnds[0].state_lower[n:] == 0.0) and np.all(bnds[0].state_upper[n:] == 0.0)
+    assert np.all(bnds[1].state_lower[n:2 * n] == 0.0) and np.isneginf(bnds[1].state_lower[2 * n]) and np.all(bnds[1].state_upper[n:] == 0.0)
+    assert np.isneginf(bnds[2].state_lower[n]) and np.all(bnds[2].state_lower[n + 1:] == 0.0)
+    lo_T = bnds[T - 1].state_lower[n:]
+    assert np.isneginf(lo_T[0]) and np.all(lo_T[1:5] == 0.0) and np.isneginf(lo_T[5]) and np.all(lo_T[6:] == 0.0)
+    # multiplier map: dynamics rows first (+), then the stage rows knot by knot (-)
+    nd = (T - 1) * n
+    assert len(mumap) == nd + rows.num and np.all(musign[:nd] == 1.0) and np.all(musign[nd:] == -1.0)
+    assert np.array_equal(mumap[:n], np.arange(n)) and mumap[n] == 64
+    assert np.array_equal(mumap[nd:nd + n + 1], n + np.arange(n + 1))                       # knot 1: aux rows of stage 1
+    assert mumap[nd + n + 1] == 64 + n                                                       # knot 2: first aux row of stage 2
+    assert np.array_equal(mumap[-5:], (T - 2) * 64 + n + 1 + np.arange(5))                  # knot T: behind stage T-1's own row
+    # the problem's own plugin (callbacks) carries the Constraint classes; the embedding's is a plain tile-solver model
+    st = Structure(p["dynamics"], p["objective"], p["constraints"], None, True)
+    src = generate_source(st, "acrobot24c")
+    assert st.wide and not st.wide_solver and "struct Model::Con<2>" in src and "N_CON = 3" in src
+    st2 = Structure(dyn, obj, cons, None, True)
+    assert st2.wide_solver and len(st2.dyn) == 3
+    # too many rows for the padding states: not eligible (a 60-state model with its n endpoint rows)
+    p60 = P.build_acrobot_padded(T=4, n=60, terminal="physical", stage_constraints=disc)
+    assert pad_to_wide(p60["dynamics"], p60["objective"], p60["constraints"], p60["bounds"], True) is None

@@ -4,7 +4,7 @@ Rounds 4-5: the same source returned NaN steps (or ran into the iteration limit)
 preserving build changes -- cycle stamps in / out, -fno-strict-aliasing, an unrelated edit -- while the plain KKT step stayed
 correct.  Two root causes: a compiler fault (a register reload placed behind an unsaved exec narrowing:
 tools/check_exec_merge.py, worked around in every device build) and a source bug (k_wide_merit read, through LDS, what another
-lane of the wavefront had stored without a wavefront-scope fence).  This test pins both: six solver-mode solves -- each checked
+lane of the wavefront had stored without a wavefront-scope fence).  This test pins both: seven solver-mode solves -- each checked
 against the ORACLE (oracle/padded_model.py) inside the test functions of tests/test_wide_gpu.py it calls -- with the plugins
 built at -O3 (the product), -O3 -fno-strict-aliasing and -O1.  The variants are prebuilt by __graft_entry__.build()
 (`prebuild_variants`), so that the GPU box compiles nothing.
@@ -27,6 +27,9 @@ _FAMILIES = {
     "padded_par": "p = P.build_acrobot_padded(T=4, parameters=(1.3, 0.7)); S(p, 'acrobot_padded_par', parameters=p['parameters'])",
     "emb24u2": "p = P.build_acrobot_padded(T=4, n=24, m=2, target=0.4, terminal='physical', parameters=(1.2, 0.8)); "
                "S(p, 'acrobot24u2', parameters=p['parameters'])",
+    "emb24": "p = P.build_acrobot_padded(T=4, n=24, target=0.4, terminal='physical'); S(p, 'acrobot24')",
+    # round 6: stage constraints carried as auxiliary states of the embedding (three dynamics classes, barrier instantiation)
+    "emb24c": "p = P.build_acrobot_padded(T=5, n=24, target=0.4, terminal='physical', stage_constraints=(0.4, -2.56, 0.3)); S(p, 'acrobot24c')",
 }
 _PRELUDE = ("import sys; sys.path.insert(0, {root!r}); import dto_amd; from dto_amd import problems as P\n"
             "def S(p, name, **kw): return dto_amd.Solver(p['dynamics'], p['objective'], p['constraints'], p['bounds'], "
@@ -53,7 +56,7 @@ def prebuild_variants(verbose=False):
 
 
 @pytest.mark.parametrize("flagset", list(FLAGSETS))
-def test_six_solver_mode_solves_under_flag_set(flagset, monkeypatch):
+def test_seven_solver_mode_solves_under_flag_set(flagset, monkeypatch):
     import test_wide_gpu as W
     from dto_amd.plugin import COMPILED
     monkeypatch.setenv("DTO_PLUGIN_CXXFLAGS", FLAGSETS[flagset])
@@ -64,5 +67,6 @@ def test_six_solver_mode_solves_under_flag_set(flagset, monkeypatch):
     W.test_wide_solve_with_three_bounded_actions()                        # action block 3 x 3
     W.test_wide_parameters_shared_and_per_instance()                      # stage parameters
     W.test_24_state_two_action_parametric_problem_through_the_embedding()  # padding states fixed at every knot (the r5 NaN case)
+    W.test_24_state_problem_with_stage_constraints_solved_through_the_embedding()   # round 6: stage rows as auxiliary states
     assert len(COMPILED) == n0 or os.environ.get("DTO_ALLOW_TEST_COMPILES"), \
         f"plugins were compiled inside the test ({COMPILED[n0:]}): __graft_entry__.build() must prebuild the flag-set variants"
