@@ -64,6 +64,10 @@ class Options:
     # that fill the GPU (their sequential sweeps are within 1e-9 of an extended-precision solve); one pass brings the
     # time-partitioned sweeps of small batches from 2.5e-8 (5e-6 at delta_w = 0) to 1e-10 for one more factor + solve per iteration
     kkt_refinement: int = 0
+    # not a reference field: how GeneralConstraint rows that couple several knots are solved.  "auto": rows that are sums of
+    # one-knot terms ride accumulator states through the ordinary device loop (solver.py: accumulate_general_constraint) when the
+    # state stays within the lane-per-instance kernels' 16, everything else takes the bordered path; "border": always the border
+    general_rows: str = "auto"
 
 
 class Indices:
@@ -407,6 +411,7 @@ class Solver:
         # multipliers are mapped back to it ([dynamics; stage; general], src/data.jl:64-75).
         self._solve_nlp = self.nlp
         self._mu_to_reference = None
+        self.general_rows_path = None        # "accumulators" | "border" | "folded" | None: how GeneralConstraint rows are solved
         s_dyn, s_obj, s_con, s_eh, changed = list(dynamics), list(objective), list(constraints), bool(evaluate_hessian), False
         ha = self.options.hessian_approximation
         if ha not in ("auto", "exact", "sr1", "lbfgs"):
@@ -455,6 +460,15 @@ class Solver:
             if folded is not None:
                 s_con, self._mu_to_reference = folded
                 gen, changed = None, True
+        if self.options.general_rows not in ("auto", "border"):
+            raise ValueError("Options.general_rows must be 'auto' or 'border'")
+        if gen is not None and self._pad is None and s_eh and self.options.general_rows == "auto":
+            acc = accumulate_general_constraint(s_dyn, s_obj, s_con, s_bounds, gen, s_eh)
+            if acc is not None:
+                s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = acc
+                self._pad = (zmap, mumap, musign)
+                self.general_rows_path = "accumulators"
+                gen, changed = None, True
         if self.hessian_mode == "lbfgs":
             traced = s_eh                        # (user-Jacobian dynamics cannot be differentiated: their plugin carries SR1 blocks)
             if not traced:
@@ -463,13 +477,17 @@ class Solver:
                     raise ValueError("Options(hessian_approximation='lbfgs'): dynamics with a user-provided Jacobian (src/dynamics.jl:59-101) "
                                      "have no traced expression to build the limited-memory border from; use 'sr1' or 'auto'")
                 self.hessian_mode = "sr1"
-            elif gen is not None or self._pad is not None or max(d.num_state for d in s_dyn) >= 17:
+            elif gen is not None or (self._pad is not None and self.general_rows_path != "accumulators") or max(d.num_state for d in s_dyn) >= 17:
                 if ha == "lbfgs":
                     raise ValueError("Options(hessian_approximation='lbfgs'): the limited-memory mode runs on the lane-per-instance "
                                      "solver path (at most 16 states, no GeneralConstraint rows over several knots)")
                 self.hessian_mode = "exact-from-trace"
         if self.hessian_mode == "exact-from-trace" and ha == "auto":
             _notice_default_mode()
+        if gen is not None:
+            self.general_rows_path = "border"
+        elif self._mu_to_reference is not None:
+            self.general_rows_path = "folded"
         if changed:
             self._solve_nlp = NLPData(s_dyn, s_obj, s_con, s_bounds, evaluate_hessian=s_eh, general_constraint=gen,
                                       parameters=parameters, name=name if gen is None and self._mu_to_reference is None else name + "_folded")
@@ -883,6 +901,148 @@ def fold_general_constraint(dynamics, objective, constraints, general, evaluate_
         for kind, j in stage_rows[t]:
             mu_map.append(n_dyn + int(stage_base[t]) + j if kind == "s" else n_dyn + n_stage + j)
     return new_constraints, np.asarray(mu_map, dtype=np.int64)
+
+
+def accumulate_general_constraint(dynamics, objective, constraints, bounds, general, evaluate_hessian, max_state=16):
+    """GeneralConstraint rows that couple SEVERAL knots (src/general_constraint.jl:18-59) as ordinary stage structure, when every
+    row is a sum of terms of one knot each, g_r(z) = sum_t e_{r,t}(x_t, u_t) + const -- which is what coupling rows look like in
+    practice ("theta_15 + theta_35 <= total", "x_4[1] + x_8[1] = 0.9" are sums): one ACCUMULATOR STATE per coupling row,
+        s_1 = 0 (equal bounds),   s_{t+1} = s_t + e_{r,t}(x_t, u_t)  as one more dynamics row of stage t,
+        s_T + e_{r,T}(x_T) + const  (= | <=) 0   as one more stage-constraint row of the last knot;
+    rows that touch one knot only (the reference's own use, test/solve.jl:273) join that knot's stage constraint as
+    fold_general_constraint does.  The problem then has no general rows at all: it runs the lane-per-instance solver loop on the
+    device at full speed -- no border, no host-driven filter loop --, with variable bounds, stage inequalities and the
+    limited-memory mode beside the rows, none of which the bordered path (csrc/dto_solver.cpp: general_solve_batch) has.  The
+    multiplier of a coupling row is the multiplier of its last-knot row.
+
+    Returns (dynamics, objective, constraints, bounds, zmap, mumap, musign) in the convention of pad_to_wide, or None when a row is
+    not additively separable over the knots (a product of variables of two knots, ...), reads parameters, or the state would
+    exceed `max_state` (the lane-per-instance kernels)."""
+    from .symbolic import expr as E
+    from .symbolic import diff as D
+    T = len(objective)
+    ng = general.num_constraint
+    nxs = [c.num_state for c in objective]
+    nus = [c.num_action for c in objective]
+    if len(set(nxs)) != 1 or any(d.user_jacobian for d in dynamics) or T < 2:
+        return None
+    n = nxs[0]
+    zoff = np.concatenate([[0], np.cumsum([nxs[t] + nus[t] for t in range(T)])])
+    nz = int(zoff[-1])
+    if general.num_variables != nz or general.num_parameter != 0:
+        return None
+    stage_of = np.zeros(nz, dtype=int)
+    for t in range(T):
+        stage_of[zoff[t]:zoff[t + 1]] = t
+    z = E.variables("z", nz)
+    zero = E.const(0.0)
+    # per general row: the knots it touches and its expression
+    knots_of, used_of = [], []
+    for r, e in enumerate(general.evaluate_expr):
+        nodes = E.topo_order([e])
+        if any(nd.op == E.VAR and nd.name == "w" for nd in nodes):
+            return None
+        used = sorted({nd.index for nd in nodes if nd.op == E.VAR and nd.name == "z"})
+        used_of.append(used)
+        knots_of.append(sorted({int(stage_of[i]) for i in used}))
+    acc_rows = [r for r in range(ng) if len(knots_of[r]) > 1]           # coupling rows: one accumulator state each
+    na = len(acc_rows)
+    N = n + na
+    if N > max_state or na == 0:
+        return None
+    x = E.variables("x", N)
+    y = E.variables("y", N)
+
+    def localise(exprs, t, drop=()):
+        """expressions over z -> over the local x / u symbols of knot t; variables in `drop` are set to zero first"""
+        local = {z[zoff[t] + i]: x[i] for i in range(n)}
+        local.update({z[zoff[t] + n + j]: E.variables("u", nus[t])[j] for j in range(nus[t])})
+        if drop:
+            exprs = E.substitute(exprs, {z[i]: zero for i in drop})
+        return E.substitute(exprs, local)
+
+    terms = {r: [None] * T for r in acc_rows}     # terms[r][t]: e_{r,t} over the local symbols of knot t, or None
+    consts = {}
+    for r in acc_rows:
+        e, used = general.evaluate_expr[r], used_of[r]
+        # additively separable over the knots <=> no second derivative couples two knots
+        rr, cc, _ = D.sparse_hessian(e, [z[i] for i in used])
+        if any(stage_of[used[a]] != stage_of[used[b]] for a, b in zip(rr, cc)):
+            return None
+        e0 = E.substitute([e], {z[i]: zero for i in used})[0]
+        if not e0.is_const:
+            return None
+        consts[r] = e0
+        for t in knots_of[r]:
+            et = localise([e], t, drop=[i for i in used if stage_of[i] != t])[0] - e0
+            if not (et.is_const and float(et.value) == 0.0):
+                terms[r][t] = et
+    # extra stage rows per knot: single-knot general rows where they belong, the accumulator rows at the last knot
+    extra = [[] for _ in range(T)]                # (general row, local expression)
+    for r in range(ng):
+        if r in terms:
+            continue
+        t = knots_of[r][0] if knots_of[r] else T - 1
+        extra[t].append((r, localise([general.evaluate_expr[r]], t)[0]))
+    for k, r in enumerate(acc_rows):
+        row = x[n + k] + consts[r]
+        extra[T - 1].append((r, row + terms[r][T - 1] if terms[r][T - 1] is not None else row))
+    cache = {}
+
+    def wide_cost(o):
+        if id(o) not in cache:
+            cache[id(o)] = Cost(list(o.evaluate_expr), N, o.num_action, num_parameter=o.num_parameter, evaluate_hessian=evaluate_hessian)
+        return cache[id(o)]
+
+    def wide_con(o, t):
+        if not extra[t]:
+            if o.num_constraint == 0:
+                return o
+            if id(o) not in cache:
+                cache[id(o)] = Constraint(list(o.evaluate_expr), N, o.num_action, num_parameter=o.num_parameter,
+                                          indices_inequality=o.indices_inequality, evaluate_hessian=evaluate_hessian)
+            return cache[id(o)]
+        rows = list(o.evaluate_expr) + [e for _, e in extra[t]]
+        ineq = list(o.indices_inequality) + [o.num_constraint + k + 1 for k, (r, _) in enumerate(extra[t]) if (r + 1) in general.indices_inequality]
+        return Constraint(rows, N, nus[t], num_parameter=o.num_parameter if o.num_constraint else objective[t].num_parameter,
+                          indices_inequality=ineq, evaluate_hessian=evaluate_hessian)
+
+    def wide_dyn(d, t):
+        key = (id(d), tuple(id(terms[r][t]) if terms[r][t] is not None else 0 for r in acc_rows))
+        if key not in cache:
+            rows = list(d.evaluate_expr)
+            for k, r in enumerate(acc_rows):
+                acc = y[n + k] - x[n + k]
+                rows.append(acc - terms[r][t] if terms[r][t] is not None else acc)
+            cache[key] = Dynamics(rows, N, N, d.num_action, num_parameter=d.num_parameter, evaluate_hessian=evaluate_hessian)
+        return cache[key]
+
+    dyn2 = [wide_dyn(dynamics[t], t) for t in range(T - 1)]
+    obj2 = [wide_cost(c) for c in objective]
+    con2 = [wide_con(constraints[t], t) for t in range(T)]
+    inf = float("inf")
+    bnd2 = []
+    for t, b in enumerate(bounds):
+        alo = np.zeros(na) if t == 0 else np.full(na, -inf)
+        ahi = np.zeros(na) if t == 0 else np.full(na, inf)
+        bnd2.append(Bound(N, len(b.action_lower), state_lower=np.concatenate([b.state_lower, alo]), state_upper=np.concatenate([b.state_upper, ahi]),
+                          action_lower=b.action_lower, action_upper=b.action_upper))
+    zmap, mumap = [], []
+    for t in range(T):
+        base = t * N + sum(nus[:t])
+        zmap += list(range(base, base + n)) + list(range(base + N, base + N + nus[t]))
+        if t < T - 1:
+            mumap += list(range(t * N, t * N + n))
+    off = (T - 1) * N
+    gen_pos = {}
+    for t in range(T):
+        q = constraints[t].num_constraint
+        mumap += list(range(off, off + q))
+        for k, (r, _) in enumerate(extra[t]):
+            gen_pos[r] = off + q + k
+        off += con2[t].num_constraint
+    mumap += [gen_pos[r] for r in range(ng)]
+    return dyn2, obj2, con2, bnd2, np.asarray(zmap, dtype=np.int64), np.asarray(mumap, dtype=np.int64), np.ones(len(mumap))
 
 
 def solve(solver: Solver):

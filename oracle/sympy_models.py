@@ -424,3 +424,40 @@ def build(name, T, evaluate_hessian=True):
     else:
         raise KeyError(name)
     return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=cons, bounds=bnds, T=T, n=n, m=m)
+
+
+def build_coupled(name, T=None, total=None, inequality=True, u_max=None, evaluate_hessian=True):
+    """Problems with a GeneralConstraint row that couples two knots (src/general_constraint.jl:18-59), restated from their
+    descriptions for the tests of the bordered and the accumulator paths:
+      "pendulum_coupled"     pendulum swing-up (build("pendulum")) + theta_15 + theta_35 - total (<= 0 | = 0); optionally
+                             |u| <= u_max at every knot (examples/cartpole/cartpole.jl:81-89 style bounds beside the general row);
+      "ref_general_coupled"  test/solve.jl:227-296 (double integrator, T = 11, x1 fixed by bounds, rows z[end-1:end] - xT) + the row
+                             x_4[1] + x_8[1] - total (default 0.9; <= 0 with inequality=True)."""
+    if name == "pendulum_coupled":
+        T = 50 if T is None else T
+        p = build("pendulum", T, evaluate_hessian=evaluate_hessian)
+        n, m = 2, 1
+        nz = n * T + m * (T - 1)
+        i15, i35 = 14 * (n + m), 34 * (n + m)
+        tot = fl(1.0 if total is None else total)
+        p["general_constraint"] = GeneralConstraint(lambda z, w: [z[i15] + z[i35] - tot], nz, 0,
+                                                    indices_inequality=([1] if inequality else []), evaluate_hessian=evaluate_hessian)
+        if u_max is not None:
+            p["bounds"] = [Bound(n, m, action_lower=[-u_max], action_upper=[u_max])] * (T - 1) + [Bound(n, 0)]
+        return p
+    if name == "ref_general_coupled":
+        T, n, m = 11, 2, 1
+        x1, xT = [0.0, 0.0], [1.0, 0.0]
+        dt = Dynamics(double_integrator, n, n, m, evaluate_hessian=evaluate_hessian)
+        ct = Cost(lambda x, u, w: fl(0.1) * dot(x, x) + fl(0.1) * dot(u, u), n, m, evaluate_hessian=evaluate_hessian)
+        cT = Cost(lambda x, u, w: fl(0.1) * dot(x, x), n, 0, evaluate_hessian=evaluate_hessian)
+        nz = n * T + m * (T - 1)
+        i4, i8 = 3 * (n + m), 7 * (n + m)
+        tot = fl(0.9 if total is None else total)
+        ineq = total is not None and inequality
+        gc = GeneralConstraint(lambda z, w: [z[nz - 2] - fl(xT[0]), z[nz - 1] - fl(xT[1]), z[i4] + z[i8] - tot], nz, 0,
+                               indices_inequality=([3] if ineq else []), evaluate_hessian=evaluate_hessian)
+        bnds = [Bound(n, m, state_lower=x1, state_upper=x1)] + [Bound(n, m)] * (T - 2) + [Bound(n, 0)]
+        return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=[Constraint() for _ in range(T)], bounds=bnds,
+                    general_constraint=gc, T=T, n=n, m=m)
+    raise KeyError(name)

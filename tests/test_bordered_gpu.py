@@ -29,7 +29,7 @@ def test_bordered_kkt_step_matches_dense_solve_of_the_oracles_matrix():
     T, B = 8, 3
     p = P.build_acrobot_coupled(T=T)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                       general_constraint=p["general_constraint"], name="acrobot_coupled")
+                       general_constraint=p["general_constraint"], options=dto_amd.Options(general_rows="border"), name="acrobot_coupled")
     n = s.nlp
     nz, nc = n.num_variables, n.num_constraint
     onlp = _oracle_acrobot_coupled(T)
@@ -71,7 +71,7 @@ def test_reference_general_constraint_solve_with_a_row_coupling_two_knots():
     from dto_amd import problems as P
     p = P.build_ref_general_coupled()
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                       general_constraint=p["general_constraint"], name="ref_general_coupled")
+                       general_constraint=p["general_constraint"], options=dto_amd.Options(general_rows="border"), name="ref_general_coupled")
     rng = np.random.Generator(np.random.PCG64(5))
     dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
     dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
@@ -107,7 +107,7 @@ def test_device_border_agrees_with_the_host_border(monkeypatch):
     T, B = 8, 40
     p = P.build_acrobot_coupled(T=T)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                       general_constraint=p["general_constraint"], name="acrobot_coupled")
+                       general_constraint=p["general_constraint"], options=dto_amd.Options(general_rows="border"), name="acrobot_coupled")
     nz, nc = s.nlp.num_variables, s.nlp.num_constraint
     rng = np.random.default_rng(3)
     z = torch.tensor(0.5 * rng.standard_normal((B, nz)), device="cuda")
@@ -136,7 +136,7 @@ def test_inequality_row_coupling_two_knots(total, active):
     from dto_amd import problems as P
     p = P.build_ref_general_coupled(inequality=total)
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                       general_constraint=p["general_constraint"], name="ref_general_coupled_ineq")
+                       general_constraint=p["general_constraint"], options=dto_amd.Options(general_rows="border"), name="ref_general_coupled_ineq")
     rng = np.random.Generator(np.random.PCG64(5))
     dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
     dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
@@ -175,7 +175,7 @@ def test_inequality_coupling_row_on_the_nonlinear_pendulum():
     def solve(total):
         p = P.build_pendulum_coupled(T=50, total=total, inequality=True) if total is not None else P.build_pendulum(T=50, evaluate_hessian=True)
         s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
-                           general_constraint=p.get("general_constraint"), name="pendulum_coupled" if total is not None else "pendulum")
+                           general_constraint=p.get("general_constraint"), options=dto_amd.Options(general_rows="border"), name="pendulum_coupled" if total is not None else "pendulum")
         xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
         dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
         assert dto_amd.solve(s) == 1, (total, s.status, s.iterations)

@@ -232,7 +232,7 @@ def test_stage_constraints_ride_the_embedding_as_auxiliary_states():
     flipped for the stage rows.  Values against the ORACLE's closed forms (oracle/padded_model.py: PaddedStageRows)."""
     from dto_amd.solver import pad_to_wide
     from oracle.padded_model import PaddedAcrobot, PaddedStageRows
-    n, T, disc = 24, 5, (0.4, -2.56, 0.3)
+    n, T, disc = 24, 5, (0.4, -2.56, 0.1)
     p = P.build_acrobot_padded(T=T, n=n, target=0.4, terminal="physical", stage_constraints=disc)
     out = pad_to_wide(p["dynamics"], p["objective"], p["constraints"], p["bounds"], True)
     assert out is not None

@@ -29,7 +29,7 @@ _FAMILIES = {
                "S(p, 'acrobot24u2', parameters=p['parameters'])",
     "emb24": "p = P.build_acrobot_padded(T=4, n=24, target=0.4, terminal='physical'); S(p, 'acrobot24')",
     # round 6: stage constraints carried as auxiliary states of the embedding (three dynamics classes, barrier instantiation)
-    "emb24c": "p = P.build_acrobot_padded(T=5, n=24, target=0.4, terminal='physical', stage_constraints=(0.4, -2.56, 0.3)); S(p, 'acrobot24c')",
+    "emb24c": "p = P.build_acrobot_padded(T=5, n=24, target=0.4, terminal='physical', stage_constraints=(0.4, -2.56, 0.1)); S(p, 'acrobot24c')",
 }
 _PRELUDE = ("import sys; sys.path.insert(0, {root!r}); import dto_amd; from dto_amd import problems as P\n"
             "def S(p, name, **kw): return dto_amd.Solver(p['dynamics'], p['objective'], p['constraints'], p['bounds'], "

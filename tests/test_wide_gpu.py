@@ -278,7 +278,7 @@ def test_24_state_problem_callbacks_and_solve_through_the_64_state_embedding():
     assert Zp.shape == (1, (T - 1) * 65 + 64) and np.array_equal(s.unpad_batch(Zp)[0], s._z0)
 
 
-def _constrained_24_state_problem(T, target=0.4, disc=(0.4, -2.56, 0.3)):
+def _constrained_24_state_problem(T, target=0.4, disc=(0.4, -2.56, 0.1)):
     import dto_amd
     from dto_amd import problems as P
     n_ = 24
@@ -298,7 +298,7 @@ def test_24_state_problem_with_stage_constraints_callbacks_vs_oracle():
     s, p, n_ = _constrained_24_state_problem(T)
     n = s.nlp
     nz = n.num_variables
-    rows = PaddedStageRows(n_, 1, T, p["x1"], p["xT"], 0.4, -2.56, 0.3)
+    rows = PaddedStageRows(n_, 1, T, p["x1"], p["xT"], 0.4, -2.56, 0.1)
     nd = (T - 1) * n_
     assert n.num_constraint == nd + rows.num and rows.num == (n_ + 1) + (T - 2) + 5
     clo, chi = n.constraint_bounds
@@ -336,15 +336,24 @@ def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
     from dto_amd import problems as P
     from oracle.padded_model import PaddedAcrobot, PaddedStageRows, dense_derivatives
     T = 30
-    disc = (0.4, -2.56, 0.3)
+    disc = (0.4, -2.56, 0.1)
     s, p, n_ = _constrained_24_state_problem(T, disc=disc)
     n = s.nlp
     nz = n.num_variables
     nd = (T - 1) * n_
     assert s.solve_unsupported is None and s._pad is not None and s._solve_nlp.num_variables == (T - 1) * 65 + 64
     assert s._solve_nlp.num_constraint == (T - 1) * 64               # the embedding has dynamics rows only
+    # the same problem WITHOUT the disc (endpoints as bounds: the round-4 test's problem) swings straight through it -- knots 7 - 9
+    # of its solution lie inside; the constrained solve starts from that trajectory and has to leave the disc
     xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
-    dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+    p0 = P.build_acrobot_padded(T=T, n=n_, target=0.4, terminal="physical")
+    s0 = dto_amd.Solver(p0["dynamics"], p0["objective"], p0["constraints"], p0["bounds"], evaluate_hessian=True, name="acrobot24")
+    dto_amd.initialize_states(s0, xs); dto_amd.initialize_controls(s0, [0.1 * u for u in us])
+    assert dto_amd.solve(s0) == 1
+    x0_sol, u0_sol = dto_amd.get_trajectory(s0)
+    inside = [disc[2] ** 2 - (x[0] - disc[0]) ** 2 - (x[1] - disc[1]) ** 2 for x in x0_sol]
+    assert max(inside) > 5e-3 and sum(v > 0 for v in inside) >= 2, inside
+    dto_amd.initialize_states(s, x0_sol); dto_amd.initialize_controls(s, u0_sol)
     assert dto_amd.solve(s) == 1, (s.status, s.iterations)
     zs, ls = s._solution, s._duals
     assert zs.shape == (nz,) and ls.shape == (n.num_constraint,)
@@ -361,16 +370,8 @@ def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
     assert np.max(np.abs(nu[iq] * cs[iq])) <= 1e-3                   # complementarity to the barrier accuracy (compl_inf_tol, mu_target = 1e-4)
     x_sol, _ = dto_amd.get_trajectory(s)
     assert np.linalg.norm(x_sol[0] - p["x1"]) < 1e-3 and np.linalg.norm(x_sol[-1][:4] - p["xT"][:4]) < 1e-3   # test/solve.jl:136-137
-    # the same problem without the disc (endpoints as bounds: the round-4 test's problem) swings straight through it -- knots 7 - 9
-    # of its solution lie inside -- so the row matters: the constrained solution either touches the disc with a positive
-    # multiplier or has gone another way altogether, at a cost that is no lower
-    p0 = P.build_acrobot_padded(T=T, n=n_, target=0.4, terminal="physical")
-    s0 = dto_amd.Solver(p0["dynamics"], p0["objective"], p0["constraints"], p0["bounds"], evaluate_hessian=True, name="acrobot24")
-    dto_amd.initialize_states(s0, xs); dto_amd.initialize_controls(s0, [0.1 * u for u in us])
-    assert dto_amd.solve(s0) == 1
-    x0_sol, _ = dto_amd.get_trajectory(s0)
-    inside = [disc[2] ** 2 - (x[0] - disc[0]) ** 2 - (x[1] - disc[1]) ** 2 for x in x0_sol]
-    assert max(inside) > 1e-2, max(inside)
+    # the row matters: the constrained solution touches the disc with a positive multiplier (or has gone another way altogether),
+    # at a cost that is no lower
     binds = np.sum(nu[iq] > 1e-3) >= 1 and np.min(-cs[iq]) <= 1e-2
     elsewhere = max(np.max(np.abs(a - b)) for a, b in zip(x_sol, x0_sol)) > 1e-2
     assert binds or elsewhere, (np.max(nu[iq]), np.min(-cs[iq]))
