@@ -2143,6 +2143,25 @@ __global__ __launch_bounds__(EV_WAVES * 64) void k_wide_eval(dto_eval_args a) {
   }
 }
 
+// GeneralConstraint rows of a wide model (src/general_constraint.jl:73-83: values and Jacobian nonzeros behind the dynamics and
+// stage blocks): one thread per instance, as dto_eval_kernels.hpp does it for the lane family
+template <class M>
+__global__ void k_wide_general(dto_eval_args a, int jac) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if constexpr (M::HAS_GENERAL) {
+    constexpr int NO = M::General::NC > M::General::NJ ? M::General::NC : M::General::NJ;
+    double o[NO > 0 ? NO : 1];
+    if (jac) {
+      M::General::jac(a.z + b * a.ldz, a.w + b * a.ldw, o);
+      for (int i = 0; i < M::General::NJ; ++i) a.out[b * a.ldout + a.general_jac0 + i] = o[i];
+    } else {
+      M::General::eval(a.z + b * a.ldz, a.w + b * a.ldw, o);
+      for (int i = 0; i < M::General::NC; ++i) a.out[b * a.ldout + a.general_row0 + i] = o[i];
+    }
+  }
+}
+
 template <class M>
 int launch_wide_eval(int op, const dto_eval_args* a, void* stream) {
   using EL = EvalLds<M>;
@@ -2167,6 +2186,10 @@ int launch_wide_eval(int op, const dto_eval_args* a, void* stream) {
     }
     case DTO_OP_JAC: hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_JAC>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a); break;
     case DTO_OP_HESS: hipLaunchKernelGGL((k_wide_eval<M, DTO_OP_HESS>), dim3(grid), dim3(EV_WAVES * 64), lds, st, *a); break;
+    case DTO_OP_GENERAL_CON:
+    case DTO_OP_GENERAL_JAC:
+      hipLaunchKernelGGL(k_wide_general<M>, dim3((unsigned)((a->B + 63) / 64)), dim3(64), 0, st, *a, op == DTO_OP_GENERAL_JAC ? 1 : 0);
+      break;
     default: return (int)hipErrorInvalidValue;
   }
   return (int)hipGetLastError();

@@ -94,18 +94,17 @@ class Structure:
             ok = (WIDE_MIN_STATE <= n0 <= WIDE_STATE
                   and all(d.num_state == n0 and d.num_next_state == n0 and d.num_action == nu0 for d in self.dyn)
                   and 1 <= nu0 <= WIDE_MAX_ACTION
-                  and all(c.num_state == n0 for c in self.cost)
-                  and self.general is None)
+                  and all(c.num_state == n0 for c in self.cost))
             if not ok:
                 raise ValueError(f"stages with more than {WIDE_MIN_STATE - 1} states use the tile kernels, which are built for "
-                                 f"one uniform state dimension up to {WIDE_STATE}, one to {WIDE_MAX_ACTION} actions (the same number at "
-                                 f"every knot) and no GeneralConstraint")
+                                 f"one uniform state dimension up to {WIDE_STATE} and one to {WIDE_MAX_ACTION} actions (the same number at "
+                                 f"every knot)")
             self.wide_n = n0
             self.wide_nu = nu0
         # (the tile KKT kernels have dynamics rows and variable bounds, no stage rows: problems with stage constraints are solved
         #  through the embedding of solver.py: pad_to_wide, which turns the rows into auxiliary states -- their own plugin, the
         #  one with the Constraint objects, carries the evaluator callbacks only)
-        self.wide_solver = self.wide and self.wide_n == WIDE_STATE and not self.con
+        self.wide_solver = self.wide and self.wide_n == WIDE_STATE and not self.con and self.general is None
         if self.evaluate_hessian:
             # all objects must agree on the flag
             for o in list(self.dyn) + list(self.cost) + list(self.con):
@@ -375,6 +374,23 @@ def generate_wide_source(st: Structure, name: str) -> str:
         host_tables.append(_int_array(f"con{i}_hr", c.hessian_sparsity[0] if nh else []))
         host_tables.append(_int_array(f"con{i}_hc", c.hessian_sparsity[1] if nh else []))
         host_tables.append(_int_array(f"con{i}_iq", sorted(c.indices_inequality)))
+    # GeneralConstraint (round 6): evaluator callbacks only; the solver reaches such rows through solver.py's transformations
+    g = st.general
+    if g is not None:
+        va = {"z": "z", "w": "w", "lam": "lam"}
+        sigg = "const double* z, const double* w, double* out"
+        cl = ["struct Model::General {", f"  static constexpr int NC = {g.num_constraint}, NJ = {g.num_jacobian};"]
+        cl.append(_fn("eval", sigg, emit_body(g.evaluate_expr, "out", va)))
+        cl.append(_fn("jac", sigg, emit_body(g.jacobian_expr, "out", va) if g.num_jacobian else "    (void)z;"))
+        cl.append("};")
+        classes.append("\n".join(cl))
+        host_tables.append(_int_array("gen_jr", g.jacobian_sparsity[0]))
+        host_tables.append(_int_array("gen_jc", g.jacobian_sparsity[1]))
+        host_tables.append(_int_array("gen_hr", g.hessian_sparsity[0] if st.evaluate_hessian else []))
+        host_tables.append(_int_array("gen_hc", g.hessian_sparsity[1] if st.evaluate_hessian else []))
+        host_tables.append(_int_array("gen_iq", sorted(g.indices_inequality)))
+    else:
+        classes.append("struct Model::General { static constexpr int NC = 0, NJ = 0; };")
     out.extend(dev_tables)
     out.append(_dev_int_array("k_wk_of_kind", wk_of_kind))
     dev_extra: List[str] = []
@@ -392,6 +408,8 @@ def generate_wide_source(st: Structure, name: str) -> str:
                              f"({nu} actions, {max_nh} dynamics-Hessian / {max_snh} cost-Hessian / {max_njv} variable Jacobian entries)")
     out.append(f"  static constexpr int MAX_NH = {max_nh}, MAX_SNH = {max_snh}, MAX_NJV = {max_njv}, EVALUATE_HESSIAN = {1 if st.evaluate_hessian else 0}, MAX_KEY = {max_key};")
     out.append(f"  static constexpr int N_DYN = {len(st.dyn)};")
+    out.append(f"  static constexpr bool HAS_GENERAL = {'true' if st.general is not None else 'false'};")
+    out.append("  struct General;")
     out.append(f"  static constexpr int N_CON = {len(st.con)}, MAX_CON = {max_con};   // stage-constraint classes; largest of their value / Jacobian / Hessian counts")
     out.append("  template <int K> struct WKind;")
     out.append("  template <int C> struct Dyn;")
@@ -451,12 +469,16 @@ def generate_wide_source(st: Structure, name: str) -> str:
     out.append("static const dto_con_class k_con[] = {\n" + (",\n".join(rows) if rows else "  {0}") + "\n};")
     rows = [f"  {{{d}, {p}, {c}, {kc}}}" for (d, p, c, kc) in st.kinds]
     out.append("static const dto_kind k_kinds[] = {\n" + ",\n".join(rows) + "\n};")
+    if g is not None:
+        nhg = g.num_hessian if st.evaluate_hessian else 0
+        out.append(f"static const dto_general_class k_general = {{{g.num_variables}, {g.num_parameter}, {g.num_constraint}, "
+                   f"{g.num_jacobian}, {nhg}, gen_jr, gen_jc, gen_hr, gen_hc, {len(g.indices_inequality)}, gen_iq}};")
     out.append("static int launch(int op, const dto_eval_args* a, void* s) { return dto::wide::launch_wide_eval<Model>(op, a, s); }")
     if st.wide_solver:
         out.append("static int launch_wide(int op, const dto_wide_args* a, void* s) { return dto::wide::launch_wide<Model>(op, a, s); }")
     out.append("static const dto_model_vtable k_vtable = {")
     out.append(f'  DTO_PLUGIN_ABI, "{name}", {len(st.dyn)}, {len(st.cost)}, {len(st.con)}, {len(st.kinds)},')
-    out.append(f"  k_dyn, k_cost, k_con, k_kinds, nullptr, {1 if st.evaluate_hessian else 0},")
+    out.append(f"  k_dyn, k_cost, k_con, k_kinds, {'&k_general' if g is not None else 'nullptr'}, {1 if st.evaluate_hessian else 0},")
     out.append(f"  {max_key}, launch, nullptr, nullptr, "
                + ("launch_wide, dto::wide::wide_info<Model>" if st.wide_solver else "nullptr, nullptr") + ", nullptr, nullptr")
     out.append("};")

@@ -263,7 +263,7 @@ def padded_action_cost(x, u):
 
 
 def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, terminal="full", u_max=None, m=1, parameters=None,
-                         stage_constraints=None):
+                         stage_constraints=None, general_row=None):
     """cfg5 (BASELINE.json configs[4]): acrobot swing-up with the state padded to n = 64 so that the per-stage KKT
     blocks are dense 129 x 129; endpoints fixed by equal bounds (as examples/car/car.jl:44-49 does).
     terminal="physical" fixes only the four acrobot states at the last knot (the padding states stay free): with one action a
@@ -306,6 +306,17 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
         cons = [con1] + [cont] * (T - 2) + [conT]
         b1 = Bound(n, m, **ub)
         bT = Bound(n, 0)
+    gc = None
+    if general_row is not None:
+        # general_row = (ka, kb, total[, inequality]): one GeneralConstraint row coupling two knots (src/general_constraint.jl:18-59),
+        # q1 at knot ka + q1 at knot kb - total (= 0 | <= 0) -- round 6: coupling rows on a model with more than 16 states
+        from .model import GeneralConstraint
+        ka, kb, tot = int(general_row[0]), int(general_row[1]), float(general_row[2])
+        iq = bool(general_row[3]) if len(general_row) > 3 else False
+        nz = n * T + m * (T - 1)
+        ia, ib = (ka - 1) * (n + m), (kb - 1) * (n + m)
+        gc = GeneralConstraint(lambda z, w: np.array([z[ia] + z[ib] - tot], dtype=object), nz, 0, indices_inequality=([1] if iq else []),
+                               evaluate_hessian=evaluate_hessian)
     return dict(
         dynamics=[dt] * (T - 1),
         objective=[ct] * (T - 1) + [cT],
@@ -313,6 +324,7 @@ def build_acrobot_padded(T=2000, n=64, evaluate_hessian=True, target=PI, termina
         bounds=[b1] + [bt] * (T - 2) + [bT],
         x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=evaluate_hessian,
         parameters=[np.array(parameters, dtype=float) for _ in range(T)] if par else None,
+        general_constraint=gc,
         guess=lambda rng: (linear_interpolation(x1, xT, T), [rng.standard_normal(m) for _ in range(T - 1)]),
     )
 

@@ -433,42 +433,52 @@ class Solver:
                 s_dyn, s_obj, s_con = up
                 s_eh, changed = True, True
         gen = general_constraint if (general_constraint is not None and general_constraint.num_constraint > 0) else None
-        # 17 .. 63 states: embedded in the 64 states of the tile kernels (padding states fixed at zero); solve() /
-        # get_trajectory() map between the two layouts, the batched entry points take the solver's (pad_batch / unpad_batch)
+        from .plugin import WIDE_MIN_STATE as _WMIN, WIDE_STATE as _WST
+        if self.options.general_rows not in ("auto", "border"):
+            raise ValueError("Options.general_rows must be 'auto' or 'border'")
+        n_max = max(d.num_state for d in s_dyn)
         self._pad = None
         s_bounds = bounds
+        # ---- 1. GeneralConstraint rows become stage structure where they can (both transformations feed the steps below):
+        #      rows of one knot each join that knot's stage constraint; coupling rows that are sums of one-knot terms ride
+        #      accumulator states (Options.general_rows = "border" keeps those on the bordered path)
+        if gen is not None:
+            folded = fold_general_constraint(s_dyn, s_obj, s_con, gen, s_eh)
+            if folded is not None:
+                s_con, self._mu_to_reference = folded
+                gen, changed = None, True
+        if gen is not None and s_eh and self.options.general_rows == "auto":
+            acc = accumulate_general_constraint(s_dyn, s_obj, s_con, s_bounds, gen, s_eh, max_state=16 if n_max < _WMIN else _WST - 1)
+            if acc is not None:
+                s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = acc
+                self._pad = (zmap, mumap, musign)
+                self.general_rows_path = "accumulators"
+                gen, changed = None, True
+        # ---- 2. 17 .. 63 states: embedded in the 64 states of the tile kernels (padding states fixed at zero, stage constraints as
+        #      auxiliary states); solve() / get_trajectory() map between the layouts, the batched entry points take the solver's
+        #      (pad_batch / unpad_batch).  After step 1 the maps compose.
+        n_max = max(d.num_state for d in s_dyn)
+        wide_embedded = False
         if gen is None and s_eh:
-            padded = pad_to_wide(s_dyn, s_obj, s_con, bounds, s_eh)
+            padded = pad_to_wide(s_dyn, s_obj, s_con, s_bounds, s_eh)
             if padded is not None:
                 s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = padded
+                if self._pad is not None:
+                    za, ma, sa = self._pad
+                    zmap, mumap, musign = zmap[za], mumap[ma], musign[ma] * sa
                 self._pad = (zmap, mumap, musign)
-                changed = True
+                changed = wide_embedded = True
         # 17 .. 63 states that the embedding cannot take: the problem gets evaluator callbacks (a tile-family plugin of its own
         # size) but no solver -- say so here, not as "plugin has no KKT kernels" at the first solve
-        from .plugin import WIDE_MIN_STATE as _WMIN, WIDE_STATE as _WST
-        n_max = max(d.num_state for d in s_dyn)
-        if _WMIN <= n_max < _WST and self._pad is None:
-            why = ("a GeneralConstraint" if gen is not None else "the per-stage SR1 mode (no second derivatives to embed)" if not s_eh else
+        if _WMIN <= n_max < _WST and not wide_embedded:
+            why = ("GeneralConstraint rows that are not sums of one-knot terms" if gen is not None else
+                   "the per-stage SR1 mode (no second derivatives to embed)" if not s_eh else
                    "more than four actions, varying dimensions, user-Jacobian dynamics, or more stage-constraint rows in one stage than "
                    "there are padding states (rows of the last knot count with the last stage's; parameters in them are not supported)")
             self.solve_unsupported = (f"problems with {_WMIN} .. {_WST - 1} states are solved through the 64-state embedding of the tile "
                                       f"kernels, which does not take {why}: the MOI callbacks of this Solver work, solve!/solve_batch do not")
         else:
             self.solve_unsupported = None
-        if gen is not None:
-            folded = fold_general_constraint(s_dyn, s_obj, s_con, gen, s_eh)
-            if folded is not None:
-                s_con, self._mu_to_reference = folded
-                gen, changed = None, True
-        if self.options.general_rows not in ("auto", "border"):
-            raise ValueError("Options.general_rows must be 'auto' or 'border'")
-        if gen is not None and self._pad is None and s_eh and self.options.general_rows == "auto":
-            acc = accumulate_general_constraint(s_dyn, s_obj, s_con, s_bounds, gen, s_eh)
-            if acc is not None:
-                s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = acc
-                self._pad = (zmap, mumap, musign)
-                self.general_rows_path = "accumulators"
-                gen, changed = None, True
         if self.hessian_mode == "lbfgs":
             traced = s_eh                        # (user-Jacobian dynamics cannot be differentiated: their plugin carries SR1 blocks)
             if not traced:
@@ -477,7 +487,7 @@ class Solver:
                     raise ValueError("Options(hessian_approximation='lbfgs'): dynamics with a user-provided Jacobian (src/dynamics.jl:59-101) "
                                      "have no traced expression to build the limited-memory border from; use 'sr1' or 'auto'")
                 self.hessian_mode = "sr1"
-            elif gen is not None or (self._pad is not None and self.general_rows_path != "accumulators") or max(d.num_state for d in s_dyn) >= 17:
+            elif gen is not None or wide_embedded or max(d.num_state for d in s_dyn) >= 17:
                 if ha == "lbfgs":
                     raise ValueError("Options(hessian_approximation='lbfgs'): the limited-memory mode runs on the lane-per-instance "
                                      "solver path (at most 16 states, no GeneralConstraint rows over several knots)")
@@ -1057,11 +1067,7 @@ def solve(solver: Solver):
     capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver.pad_batch(solver._z0))), capi.dptr(x), capi.dptr(mu),
                                 C.byref(status), C.byref(iters)))
     solver._solution = solver.unpad_batch(x)
-    solver._duals = solver.unpad_batch(mu[:n.num_constraint], multipliers=True)
-    if solver._mu_to_reference is not None:
-        ref = np.zeros(solver.nlp.num_constraint)
-        ref[solver._mu_to_reference] = mu[:n.num_constraint]
-        solver._duals = ref
+    solver._duals = solver.multipliers_to_reference(solver.unpad_batch(mu[:n.num_constraint], multipliers=True))
     solver.status, solver.iterations = int(status.value), int(iters.value)
     if solver.options.print_level >= 5:
         # the reference prints Ipopt's iteration log at this level (src/options.jl:23); here: one summary line
