@@ -423,7 +423,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    done, profile = 0, []
+    done, profile, first_slice = 0, [], None
     while done < a.steps:
         k = min(25, a.steps - done)
         s.iterate_batch(k, stream=st)
@@ -432,6 +432,10 @@ def main():
             running = s.repack_batch(stream=st)      # finished instances leave the tiles (part of the solve, hence timed)
             torch.cuda.synchronize()
             profile.append((done, time.perf_counter() - t0, running))
+            if first_slice is None:
+                # counters at the end of the first slice (every instance was running, the tiles are as loaded): the window the
+                # `roofline` object of a full-solve run describes (one read of two scalar rows, ~20 ms once in the timed region)
+                first_slice = (done, float(np.sum(s.scalar_batch("iter") - it0)), float(np.sum(s.scalar_batch("nfact") - nf0)))
     # one more evaluation classifies the last iterate (converged / iteration limit); it is part of the solve
     if a.steps + a.warmup >= s.options.max_iter:
         s.launch_op("eval", stream=st)
@@ -480,6 +484,14 @@ def main():
     fp = s.footprint()
     seq_sweep = s.partitions() == 1
     tr = s.read_trace()
+    # a full-solve run repacks between slices and may change the form of its sweeps: its `roofline` is taken over the first slice
+    # (the iterations in which every instance runs); a --steps run has one slice: all of it
+    roof_iters, roof_its_done, roof_facts_done = a.steps, iters_done / world, facts_done / world
+    if first_slice is not None:
+        roof_iters, roof_its_done, roof_facts_done = int(first_slice[0]), first_slice[1], first_slice[2]
+        keep = tr["iteration"] < roof_iters
+        tr = dict(op=tr["op"][keep], name=[n_ for n_, k_ in zip(tr["name"], keep) if k_], iteration=tr["iteration"][keep],
+                  start_ms=tr["start_ms"][keep], duration_ms=tr["duration_ms"][keep])
     kname = dict(eval="k_stage_eval", conv="k_conv (+ k_part_reduce)", kkt_fwd="k_kkt_fwd_seq" if seq_sweep else "k_kkt_fwd",
                  kkt_bwd="k_kkt_bwd_seq" if seq_sweep else "k_kkt_bwd", kkt_post="k_kkt_post", linesearch="k_linesearch",
                  ls_reduce="k_ls_reduce (+ k_part_reduce)", update="k_update", update_eval="k_update_eval",
@@ -502,8 +514,8 @@ def main():
     dom_op = max((o for o in ops if o != "kkt_bwd_gate"), key=lambda o: tot[o]) if ops else "kkt_fwd"
     launches = max(len(dur.get(dom_op, [])), 1)
     # factorisations / accepted factorisations per instance and launch of the dominant kernel, over the timed window (this rank)
-    working = facts_done / world / max(B * launches, 1) if dist is not None else facts_done / max(B * launches, 1)
-    accepted = (iters_done / world if dist is not None else iters_done) / max(B * launches, 1)
+    working = roof_facts_done / max(B * launches, 1)
+    accepted = roof_its_done / max(B * launches, 1)
     # Algorithmic bytes per instance and launch.  The sweeps no longer read derivative values: they
     # re-evaluate them from the iterate.  What a sweep MUST move per stage is therefore: the iterate (p_t, x_{t+1}, lambda_t,
     # nu_t), the stage's right-hand side (record: r_p, d, c) and the carry that the backward sweep resumes from
@@ -556,6 +568,8 @@ def main():
                            "k_kkt_bwd_early runs on the library's second stream beside k_kkt_fwd_seq: the per-kernel figures add up to more than "
                            "the iteration by what overlaps (overlapped_ms_per_iteration)",
                     iterations_traced=n_it,
+                    window=(f"the {n_it} timed iterations" if first_slice is None else
+                            f"the first {n_it} of the {a.steps} timed iterations (before the first repack: every instance running)"),
                     iteration_ms=dict(mean=round(float(np.mean(it_ms)), 4) if n_it else None, first=round(float(it_ms[0]), 4) if n_it else None,
                                       last=round(float(it_ms[-1]), 4) if n_it else None, min=round(float(np.min(it_ms)), 4) if n_it else None,
                                       max=round(float(np.max(it_ms)), 4) if n_it else None),
