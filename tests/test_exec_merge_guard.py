@@ -100,3 +100,18 @@ def test_product_plugin_isa_has_no_unsaved_exec_narrowing(family):
     assert sum(1 for ln in isa.split("\n") if C.NARROW.match(ln)) == 0
     if family == "lane":
         os.remove(path)
+
+
+def test_standalone_reproducer_of_the_dropped_exec_restore():
+    """tools/micro/endcf_unsaved_narrowing.hip (65 lines, no project headers): with the compiler's defaults the innermost region's
+    exec restore is dropped (one unsaved narrowing in the ISA -- the precondition of the fault), with the product's flag it is
+    kept.  What an upstream report would carry next to tests/golden/exec_merge_fault_excerpt.s."""
+    C = _scanner()
+    src = os.path.join(ROOT, "tools", "micro", "endcf_unsaved_narrowing.hip")
+    with open(src) as f:
+        assert len(f.read().split("\n")) <= 150
+    default = C.compile_to_isa(src, [])
+    fixed = C.compile_to_isa(src, ["-mllvm", "-amdgpu-remove-redundant-endcf=0"])
+    n_default = sum(1 for ln in default.split("\n") if C.NARROW.match(ln))
+    n_fixed = sum(1 for ln in fixed.split("\n") if C.NARROW.match(ln))
+    assert n_default >= 1 and n_fixed == 0, (n_default, n_fixed)
