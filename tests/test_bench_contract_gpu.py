@@ -59,6 +59,17 @@ def test_bench_steps_form_carries_full_solves_of_the_headline_workload():
     assert f["instances"] == 2048 and f["converged_fraction"] >= 0.95 and f["converged_solves_per_sec"] > 0
 
 
+def test_roofline_of_a_run_with_several_slices_is_taken_over_the_first():
+    """More than 25 timed iterations (the default run times 1000): the batch is repacked between slices and instances leave, so the
+    `roofline` object describes the first slice -- every instance running -- and says so."""
+    d = _run(["--gpus", "1", "--steps", "30", "--warmup", "0", "--batch", "8192", "--horizon", "200", "--no-full-solves",
+              "--no-dense-blocks", "--no-cpu-baseline"])
+    r = d["roofline"]
+    assert r["iterations_traced"] == 25 and "first 25 of the 30" in r["window"]
+    assert 0.0 < r["frac"] < 1.0 and r["factorizations_per_launch"] >= 0.9
+    assert len(d["solve"]["profile"]) >= 2
+
+
 def test_loop_only_line():
     d = _run(["--loop-only", "--steps", "3", "--warmup", "1", "--batch", "8192", "--horizon", "200"])
     assert d["steps"] == 3 and d["instances_per_gpu"] == 8192 and d["value"] > 0 and d["engine"] == "soa"
