@@ -380,22 +380,24 @@ def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
           f"largest obstacle multiplier {np.max(nu[iq]):.3e}, closest approach {np.min(-cs[iq]):.3e}")
 
 
-def test_24_state_problem_with_a_coupling_general_row():
-    """A GeneralConstraint row that couples two knots (src/general_constraint.jl:18-59) on the 24-state model: q1 at knot 10 + q1 at
-    knot 20 = 0.2 (the solution without the row has -0.18 there).  Callbacks: the general block behind the dynamics rows
+@pytest.mark.parametrize("ka,kb,path", [(10, 20, "accumulators"), (15, 15, "folded")])
+def test_24_state_problem_with_a_general_row(ka, kb, path):
+    """A GeneralConstraint row (src/general_constraint.jl:18-59) on the 24-state model: q1 at knot ka + q1 at knot kb = 0.2 (the
+    solution without the row has -0.18 / -0.84 there).  ka != kb couples two knots; ka = kb is the reference's own kind of row
+    (test/solve.jl:273: one knot), folded into that knot's stage constraint, which then rides an auxiliary state.  Callbacks: the general block behind the dynamics rows
     (src/data.jl:72-75) from the tile-family plugin.  Solve: the row rides an accumulator state (solver.py:
     accumulate_general_constraint -> 25 states), whose last-knot row rides an auxiliary state of the 64-state embedding
     (pad_to_wide) -- two transformations, maps composed.  KKT conditions with the oracle's derivatives + the row's closed form."""
     import dto_amd
     from dto_amd import problems as P
     from oracle.padded_model import PaddedAcrobot, dense_derivatives
-    n_, T, ka, kb, tot = 24, 30, 10, 20, 0.2
+    n_, T, tot = 24, 30, 0.2
     p = P.build_acrobot_padded(T=T, n=n_, target=0.4, terminal="physical", general_row=(ka, kb, tot))
     s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True,
                        general_constraint=p["general_constraint"], name="acrobot24g")
     n = s.nlp
     nz, nd = n.num_variables, (T - 1) * n_
-    assert n.num_constraint == nd + 1 and s.general_rows_path == "accumulators" and s.solve_unsupported is None
+    assert n.num_constraint == nd + 1 and s.general_rows_path == path and s.solve_unsupported is None
     assert s._solve_nlp.num_variables == (T - 1) * 65 + 64
     ia, ib = (ka - 1) * (n_ + 1), (kb - 1) * (n_ + 1)
     # callbacks at a random point
@@ -406,7 +408,7 @@ def test_24_state_problem_with_a_coupling_general_row():
     assert abs(cv[-1] - (z[ia] + z[ib] - tot)) <= 1e-14
     jr, jc = np.array(n.jacobian_structure()).T - 1
     gen = jr == nd
-    assert sorted(jc[gen].tolist()) == [ia, ib] and np.all(Jv[gen] == 1.0)
+    assert sorted(jc[gen].tolist()) == sorted({ia, ib}) and np.all(Jv[gen] == (1.0 if ka != kb else 2.0))
     # solve
     xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
     dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
@@ -415,14 +417,14 @@ def test_24_state_problem_with_a_coupling_general_row():
     assert zs.shape == (nz,) and ls.shape == (nd + 1,)
     om = PaddedAcrobot(n_)
     f, g, c, J, _ = dense_derivatives(om, T, zs, ls[:nd], 1.0)
-    a = np.zeros(nz); a[ia] = a[ib] = 1.0
+    a = np.zeros(nz); a[ia] += 1.0; a[ib] += 1.0
     vlo, vhi = n.variable_bounds
     fixed = vlo == vhi
     assert np.max(np.abs(c)) <= 1e-6 and abs(zs[ia] + zs[ib] - tot) <= 1e-6 and np.max(np.abs(zs[fixed] - vlo[fixed])) < 1e-12
     r = g + J.T @ ls[:nd] + a * ls[nd]
     assert np.max(np.abs(r[~fixed])) <= 1e-5 * max(1.0, np.max(np.abs(ls))), np.max(np.abs(r[~fixed]))
-    assert abs(ls[nd]) > 1e-3                                       # the row is active: without it the sum is -0.18
-    print(f"[coupling row on the tile path] {s.iterations} iterations, multiplier {ls[nd]:.4f}")
+    assert abs(ls[nd]) > 1e-3                                       # the row is active: without it the sum is -0.18 / -0.84
+    print(f"[general row on the tile path, {path}] {s.iterations} iterations, multiplier {ls[nd]:.4f}")
 
 
 def test_wide_solve_with_action_bounds():
