@@ -455,19 +455,22 @@ def build_ref_general_coupled(inequality=None):
                 bounds=bounds, general_constraint=gc, x1=x1, xT=xT, T=T, n=n, m=m, evaluate_hessian=True, coupling=(i4, i8, tot))
 
 
-def build_pendulum_coupled(T=50, total=1.0, inequality=True, u_max=None):
+def build_pendulum_coupled(T=50, total=1.0, inequality=True, u_max=None, nonlinear=False, evaluate_hessian=True):
     """The pendulum swing-up (examples/pendulum/pendulum.jl, nonlinear dynamics) with one GeneralConstraint row that couples
     knots 15 and 35: theta_15 + theta_35 - total (<= 0 with inequality=True, = 0 otherwise).  Without the row the sum is 1.449.
-    u_max: action bounds |u| <= u_max at every knot beside the general row (examples/cartpole/cartpole.jl:81-89 style)."""
+    u_max: action bounds |u| <= u_max at every knot beside the general row (examples/cartpole/cartpole.jl:81-89 style).
+    nonlinear: the row is sin(theta_15) + theta_35^2 - total instead (a sum of NONLINEAR one-knot terms)."""
     from .model import GeneralConstraint
-    p = build_pendulum(T=T, evaluate_hessian=True)
+    p = build_pendulum(T=T, evaluate_hessian=evaluate_hessian)
     n, m = 2, 1
     if u_max is not None:
         p["bounds"] = [Bound(n, m, action_lower=-u_max * np.ones(m), action_upper=u_max * np.ones(m))] * (T - 1) + [Bound(n, 0)]
     nz = n * T + m * (T - 1)
     i15, i35 = 14 * (n + m), 34 * (n + m)
-    p["general_constraint"] = GeneralConstraint(lambda z, w: np.array([z[i15] + z[i35] - total], dtype=object), nz, 0,
-                                                indices_inequality=([1] if inequality else []), evaluate_hessian=True)
+    row = (lambda z, w: np.array([np.sin(z[i15]) + z[i35] ** 2.0 - total], dtype=object)) if nonlinear else \
+          (lambda z, w: np.array([z[i15] + z[i35] - total], dtype=object))
+    p["general_constraint"] = GeneralConstraint(row, nz, 0, indices_inequality=([1] if inequality else []),
+                                                evaluate_hessian=evaluate_hessian and not nonlinear)   # src/general_constraint.jl:87 is broken
     p["coupling"] = (i15, i35, total)
     return p
 

@@ -426,10 +426,11 @@ def build(name, T, evaluate_hessian=True):
     return dict(dynamics=[dt] * (T - 1), objective=[ct] * (T - 1) + [cT], constraints=cons, bounds=bnds, T=T, n=n, m=m)
 
 
-def build_coupled(name, T=None, total=None, inequality=True, u_max=None, evaluate_hessian=True):
+def build_coupled(name, T=None, total=None, inequality=True, u_max=None, evaluate_hessian=True, nonlinear=False):
     """Problems with a GeneralConstraint row that couples two knots (src/general_constraint.jl:18-59), restated from their
     descriptions for the tests of the bordered and the accumulator paths:
-      "pendulum_coupled"     pendulum swing-up (build("pendulum")) + theta_15 + theta_35 - total (<= 0 | = 0); optionally
+      "pendulum_coupled"     pendulum swing-up (build("pendulum")) + theta_15 + theta_35 - total (<= 0 | = 0), or with nonlinear=True
+                             sin(theta_15) + theta_35^2 - total; optionally
                              |u| <= u_max at every knot (examples/cartpole/cartpole.jl:81-89 style bounds beside the general row);
       "ref_general_coupled"  test/solve.jl:227-296 (double integrator, T = 11, x1 fixed by bounds, rows z[end-1:end] - xT) + the row
                              x_4[1] + x_8[1] - total (default 0.9; <= 0 with inequality=True)."""
@@ -440,8 +441,9 @@ def build_coupled(name, T=None, total=None, inequality=True, u_max=None, evaluat
         nz = n * T + m * (T - 1)
         i15, i35 = 14 * (n + m), 34 * (n + m)
         tot = fl(1.0 if total is None else total)
-        p["general_constraint"] = GeneralConstraint(lambda z, w: [z[i15] + z[i35] - tot], nz, 0,
-                                                    indices_inequality=([1] if inequality else []), evaluate_hessian=evaluate_hessian)
+        row = (lambda z, w: [sp.sin(z[i15]) + z[i35] ** 2 - tot]) if nonlinear else (lambda z, w: [z[i15] + z[i35] - tot])
+        p["general_constraint"] = GeneralConstraint(row, nz, 0, indices_inequality=([1] if inequality else []),
+                                                    evaluate_hessian=evaluate_hessian)
         if u_max is not None:
             p["bounds"] = [Bound(n, m, action_lower=[-u_max], action_upper=[u_max])] * (T - 1) + [Bound(n, 0)]
         return p

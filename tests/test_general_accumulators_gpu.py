@@ -112,6 +112,31 @@ def test_default_mode_on_a_problem_with_coupling_rows():
     assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"] and rep["compl"] <= 1e-3, rep
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_nonlinear_coupling_row(exact):
+    """sin(theta_15) + theta_35^2 = 2.5: a coupling row of NONLINEAR one-knot terms.  The reference takes such a row only in its
+    default mode (its second-derivative call for general rows is broken: src/general_constraint.jl:87), the bordered path here
+    only linear rows; on the accumulator path the terms are part of the dynamics rows, second derivatives included."""
+    import dto_amd
+    from dto_amd import problems as P
+    from test_solve_gpu import kkt_report
+    p = P.build_pendulum_coupled(T=50, total=2.5, inequality=False, nonlinear=True, evaluate_hessian=exact)
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=exact,
+                       general_constraint=p["general_constraint"], name="pendulum_coupled_nl")
+    assert s.general_rows_path == "accumulators" and s.hessian_mode == ("exact" if exact else "lbfgs")
+    xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
+    dto_amd.initialize_states(s, xs); dto_amd.initialize_controls(s, [0.1 * u for u in us])
+    st = dto_amd.solve(s)
+    assert st == 1, (st, s.iterations)
+    z, lam = s._solution, s._duals
+    rep = kkt_report(_oracle("pendulum_coupled", total=2.5, inequality=False, nonlinear=True), z, lam)
+    assert rep["violation"] <= 1e-6 and rep["stationarity"] <= 1e-5 and rep["sign_ok"], rep
+    i15, i35 = p["coupling"][0], p["coupling"][1]
+    assert abs(np.sin(z[i15]) + z[i35] ** 2 - 2.5) <= 1e-6 and abs(lam[-1]) > 1e-3
+    print(f"[accumulators] nonlinear coupling row, {'exact' if exact else 'limited-memory'}: {s.iterations} iterations, "
+          f"theta_15 = {z[i15]:.3f}, theta_35 = {z[i35]:.3f}, multiplier {lam[-1]:.3f}")
+
+
 def test_batch_of_512_instances_with_coupling_rows_on_the_device_loop():
     """The acrobot with two coupling rows (problems.build_acrobot_coupled), T = 101, 512 seeded guesses in one dto_solve_batch:
     two accumulator states, the ordinary device loop (repacking, in-kernel filter); every instance that converges satisfies the
