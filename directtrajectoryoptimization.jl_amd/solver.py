@@ -459,8 +459,30 @@ class Solver:
         #      (pad_batch / unpad_batch).  After step 1 the maps compose.
         n_max = max(d.num_state for d in s_dyn)
         wide_embedded = False
+        self._pins = None
         if gen is None and s_eh:
             padded = pad_to_wide(s_dyn, s_obj, s_con, s_bounds, s_eh)
+            if padded is None and _WMIN <= n_max < _WST and any(c.num_constraint for c in s_con):
+                # more rows in one stage than padding states: rows that pin ONE variable (the reference's endpoint rows) become
+                # variable bounds, only the rest needs auxiliary states; their multipliers are recovered after the solve
+                pb = pins_to_bounds(s_con, s_bounds, s_eh)
+                if pb is not None:
+                    padded = pad_to_wide(s_dyn, s_obj, pb[0], pb[1], s_eh)
+                    if padded is not None:
+                        _, _, _, _, zm, mm, ms = padded
+                        nd_ = sum(d.num_next_state for d in s_dyn)
+                        n_rows_pad = sum(d.num_next_state for d in padded[0])
+                        full_m, full_s = np.zeros(nd_ + len(pb[2]) + len(pb[3]), dtype=np.int64), np.ones(nd_ + len(pb[2]) + len(pb[3]))
+                        full_m[:nd_], full_s[:nd_] = mm[:nd_], ms[:nd_]
+                        for k, pos in enumerate(pb[3]):
+                            full_m[nd_ + pos], full_s[nd_ + pos] = mm[nd_ + k], ms[nd_ + k]
+                        nvar_t = [o.num_state + o.num_action for o in s_obj]
+                        voff = np.concatenate([[0], np.cumsum(nvar_t)])
+                        self._pins = []
+                        for k, (pos, t, col, a) in enumerate(pb[2]):
+                            full_m[nd_ + pos] = n_rows_pad + k          # (unpad_batch appends the recovered multipliers)
+                            self._pins.append((int(zm[voff[t] + col]), float(a)))
+                        padded = padded[:5] + (full_m, full_s)
             if padded is not None:
                 s_dyn, s_obj, s_con, s_bounds, zmap, mumap, musign = padded
                 if self._pad is not None:
@@ -474,7 +496,8 @@ class Solver:
             why = ("GeneralConstraint rows that are not sums of one-knot terms" if gen is not None else
                    "the per-stage SR1 mode (no second derivatives to embed)" if not s_eh else
                    "more than four actions, varying dimensions, user-Jacobian dynamics, or more stage-constraint rows in one stage than "
-                   "there are padding states (rows of the last knot count with the last stage's; parameters in them are not supported)")
+                   "there are padding states (rows affine in one variable are restated as bounds and do not count; rows of the last knot count "
+                   "with the last stage's; parameters in them are not supported)")
             self.solve_unsupported = (f"problems with {_WMIN} .. {_WST - 1} states are solved through the 64-state embedding of the tile "
                                       f"kernels, which does not take {why}: the MOI callbacks of this Solver work, solve!/solve_batch do not")
         else:
@@ -532,12 +555,46 @@ class Solver:
         out[..., self._pad[0]] = Z
         return out
 
-    def unpad_batch(self, Z, multipliers=False):
+    def unpad_batch(self, Z, multipliers=False, solution=None):
+        """The solver's layout -> the problem's.  multipliers=True: Z holds constraint multipliers (solver row order); when stage
+        rows were restated as variable bounds (pins_to_bounds) their multipliers are recovered from stationarity, which needs the
+        solver-layout `solution` the multipliers belong to."""
         Z = np.asarray(Z)
         if self._pad is None:
             return Z
-        # (multipliers: a stage row that the embedding carries as an auxiliary dynamics row comes back with the opposite sign)
-        return Z[..., self._pad[1]] * self._pad[2] if multipliers else Z[..., self._pad[0]]
+        if not multipliers:
+            return Z[..., self._pad[0]]
+        if self._pins:
+            if solution is None:
+                raise ValueError("unpad_batch(multipliers=True): this problem's endpoint rows were restated as variable bounds; pass "
+                                 "solution= (the solver-layout iterates the multipliers belong to) to recover their multipliers")
+            Z = np.concatenate([Z, self._pin_multipliers(np.asarray(solution), Z)], axis=-1)
+        # (a stage row that the embedding carries as an auxiliary dynamics row comes back with the opposite sign)
+        return Z[..., self._pad[1]] * self._pad[2]
+
+    def _pin_multipliers(self, Zs, Mu):
+        """Multipliers of the stage rows pins_to_bounds turned into bounds: lam = -(grad f + J^T mu)_v / a, evaluated with the batched
+        callbacks of the solver-layout problem (the rows that are left, auxiliary rows included, carry their multipliers in Mu)."""
+        import torch
+        n = self._solve_nlp
+        Zs2, Mu2 = np.atleast_2d(Zs), np.atleast_2d(Mu)
+        B = Zs2.shape[0]
+        if getattr(self, "_pin_entries", None) is None:
+            rows, cols = (np.array(v, dtype=np.int64) - 1 for v in zip(*n.jacobian_structure()))
+            self._pin_entries = [(np.flatnonzero(cols == p), rows[cols == p]) for p, _ in self._pins]
+        z = torch.tensor(Zs2, device="cuda", dtype=torch.float64).contiguous()
+        g = torch.empty_like(z)
+        J = torch.empty((B, max(1, len(n.jacobian_structure()))), device="cuda", dtype=torch.float64)
+        n.eval_objective_gradient_batch(z.data_ptr(), B, z.shape[1], g.data_ptr(), g.shape[1])
+        n.eval_constraint_jacobian_batch(z.data_ptr(), B, z.shape[1], J.data_ptr(), J.shape[1])
+        torch.cuda.synchronize()
+        out = np.zeros((B, len(self._pins)))
+        for k, ((p, a), (ent, rws)) in enumerate(zip(self._pins, self._pin_entries)):
+            gk = g[:, p].cpu().numpy()
+            if len(ent):
+                gk = gk + np.sum(J[:, torch.as_tensor(ent, device="cuda")].cpu().numpy() * Mu2[:, rws], axis=1)
+            out[:, k] = -gk / a
+        return out.reshape(np.asarray(Mu).shape[:-1] + (len(self._pins),))
 
     def multipliers_to_reference(self, mu):
         """Multipliers of the batched entry points come back in the SOLVER's row order; when a stage-local GeneralConstraint
@@ -864,6 +921,83 @@ def pad_to_wide(dynamics, objective, constraints, bounds, evaluate_hessian):
             np.asarray(musign))
 
 
+def pins_to_bounds(constraints, bounds, evaluate_hessian):
+    """Stage-constraint rows that are affine in ONE state or action -- the endpoint rows `x - x1`, `x - xT` of the reference's
+    examples (examples/acrobot/acrobot.jl:114-118), a box written as rows -- restated as variable bounds (src/bounds.jl:1-24):
+        a v + b  = 0   ->   v fixed at -b / a  (states only: a fixed action has no interior for the barrier),
+        a v + b <= 0   ->   v <= -b / a  (a > 0)   or   v >= -b / a  (a < 0)  where that side has no bound yet.
+    Used by the 64-state embedding when a problem has more stage rows than padding states (pad_to_wide: every remaining row
+    needs an auxiliary state).  The multiplier of a restated row follows from stationarity in its variable,
+    lam = -(grad f + J^T mu)_v / a  over the rows that are left (Solver._pin_multipliers).
+
+    Returns (constraints, bounds, pins, keep) -- pins: [(position among the original stage rows, knot, position of the variable in
+    the knot's [x; u], a)], keep: positions among the original stage rows of the rows that are left, in order -- or None when no row
+    qualifies."""
+    from .symbolic import diff as D, expr as E
+    T = len(constraints)
+    inf = float("inf")
+    new_con, new_bnd, pins, keep = [], [], [], []
+    base = 0
+    for t, (c, b) in enumerate(zip(constraints, bounds)):
+        q = c.num_constraint
+        if q == 0:
+            new_con.append(c); new_bnd.append(b); continue
+        nx, nu = c.num_state, c.num_action
+        slo, shi = np.array(b.state_lower, dtype=float), np.array(b.state_upper, dtype=float)
+        alo, ahi = np.array(b.action_lower, dtype=float), np.array(b.action_upper, dtype=float)
+        if len(slo) != nx or len(alo) != nu:
+            new_con.append(c); new_bnd.append(b); keep += list(range(base, base + q)); base += q; continue
+        jr, jc = c.jacobian_sparsity
+        per_row = {}
+        for k, (r1, c1) in enumerate(zip(jr, jc)):
+            per_row.setdefault(r1 - 1, []).append((c1 - 1, c.jacobian_expr[k]))
+        taken, left = set(), []
+        for j in range(q):
+            ent = per_row.get(j, [])
+            e = c.evaluate_expr[j]
+            ok = len(ent) == 1 and ent[0][1].op == E.CONST and ent[0][1].value != 0.0 and ent[0][0] not in taken \
+                and not any(n.op == E.VAR and n.name == "w" for n in E.topo_order([e]))
+            if ok:
+                col, a = ent[0][0], float(ent[0][1].value)
+                v = E.var("x", col) if col < nx else E.var("u", col - nx)
+                at0 = E.substitute([e], {v: E.const(0.0)})[0]
+                ok = at0.op == E.CONST
+            if ok:
+                val = -float(at0.value) / a
+                lo, hi, i = (slo, shi, col) if col < nx else (alo, ahi, col - nx)
+                if (j + 1) in c.indices_inequality:
+                    if a > 0 and hi[i] == inf:
+                        hi[i] = val
+                    elif a < 0 and lo[i] == -inf:
+                        lo[i] = val
+                    else:
+                        ok = False
+                elif col < nx and lo[i] <= val <= hi[i]:
+                    lo[i] = hi[i] = val
+                else:
+                    ok = False
+            if ok:
+                taken.add(col)
+                pins.append((base + j, t, col, a))
+            else:
+                left.append(j)
+        if len(left) == q:
+            new_con.append(c); new_bnd.append(b)
+        else:
+            if left:
+                ineq = [k + 1 for k, j in enumerate(left) if (j + 1) in c.indices_inequality]
+                new_con.append(Constraint([c.evaluate_expr[j] for j in left], nx, nu, num_parameter=c.num_parameter, indices_inequality=ineq,
+                                          evaluate_hessian=evaluate_hessian))
+            else:
+                new_con.append(Constraint())
+            new_bnd.append(Bound(nx, nu, state_lower=slo, state_upper=shi, action_lower=alo, action_upper=ahi))
+        keep += [base + j for j in left]
+        base += q
+    if not pins:
+        return None
+    return new_con, new_bnd, pins, keep
+
+
 def fold_general_constraint(dynamics, objective, constraints, general, evaluate_hessian):
     """Stage constraints equivalent to `constraints` + `general` when every general row depends on one knot only.
 
@@ -1067,7 +1201,7 @@ def solve(solver: Solver):
     capi.check(n._lib.dto_solve(n._h, C.byref(co), capi.dptr(np.ascontiguousarray(solver.pad_batch(solver._z0))), capi.dptr(x), capi.dptr(mu),
                                 C.byref(status), C.byref(iters)))
     solver._solution = solver.unpad_batch(x)
-    solver._duals = solver.multipliers_to_reference(solver.unpad_batch(mu[:n.num_constraint], multipliers=True))
+    solver._duals = solver.multipliers_to_reference(solver.unpad_batch(mu[:n.num_constraint], multipliers=True, solution=x))
     solver.status, solver.iterations = int(status.value), int(iters.value)
     if solver.options.print_level >= 5:
         # the reference prints Ipopt's iteration log at this level (src/options.jl:23); here: one summary line

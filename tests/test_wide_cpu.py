@@ -283,3 +283,33 @@ def test_stage_constraints_ride_the_embedding_as_auxiliary_states():
     # too many rows for the padding states: not eligible (a 60-state model with its n endpoint rows)
     p60 = P.build_acrobot_padded(T=4, n=60, terminal="physical", stage_constraints=disc)
     assert pad_to_wide(p60["dynamics"], p60["objective"], p60["constraints"], p60["bounds"], True) is None
+
+
+def test_pins_to_bounds_restates_single_variable_rows():
+    """solver.py: pins_to_bounds -- rows affine in one variable become bounds (equalities on states only, inequalities where that
+    side is free), everything else stays a row; positions and coefficients of the restated rows are reported for the multipliers."""
+    import numpy as np
+    from dto_amd import Bound, Constraint
+    from dto_amd.solver import pins_to_bounds
+    n, m = 3, 1
+    c1 = Constraint(lambda x, u, w: np.array([x[0] - 0.5, 2.0 * x[1] + 1.0, x[0] * x[2] - 1.0, u[0] - 0.3, -x[2] + 0.25, x[0] + 1.0], dtype=object), n, m,
+                    indices_inequality=[2, 4, 5], evaluate_hessian=True)
+    c2 = Constraint()
+    c3 = Constraint(lambda x, u, w: np.array([x[1] - 2.0, x[1] + x[2]], dtype=object), n, 0, evaluate_hessian=True)
+    b = [Bound(n, m), Bound(n, m, state_lower=np.array([-1.0, -1.0, -1.0])), Bound(n, 0)]
+    out = pins_to_bounds([c1, c2, c3], b, True)
+    assert out is not None
+    con, bnd, pins, keep = out
+    # knot 1: row 0 (x0 = 0.5) pinned; row 1 (2 x1 + 1 <= 0 -> x1 <= -0.5); row 2 nonlinear: stays; row 3 (u0 - 0.3 <= 0 -> u0 <= 0.3);
+    # row 4 (-x2 + 0.25 <= 0 -> x2 >= 0.25); row 5 is a second row in x0: stays
+    assert [(p[0], p[1], p[2]) for p in pins] == [(0, 0, 0), (1, 0, 1), (3, 0, 3), (4, 0, 2), (6, 2, 1)]
+    assert [p[3] for p in pins] == [1.0, 2.0, 1.0, -1.0, 1.0]
+    assert keep == [2, 5, 7]
+    assert con[0].num_constraint == 2 and con[0].indices_inequality == [] and con[1].num_constraint == 0 and con[2].num_constraint == 1
+    assert np.array_equal(bnd[0].state_lower, [0.5, -np.inf, 0.25]) and np.array_equal(bnd[0].state_upper, [0.5, -0.5, np.inf])
+    assert np.array_equal(bnd[0].action_upper, [0.3]) and np.array_equal(bnd[0].action_lower, [-np.inf])
+    assert np.array_equal(bnd[2].state_lower, [-np.inf, 2.0, -np.inf]) and np.array_equal(bnd[2].state_upper, [np.inf, 2.0, np.inf])
+    assert bnd[1] is b[1]
+    # nothing to restate: None; an equality on an action stays a row (a fixed action has no interior for the barrier)
+    c4 = Constraint(lambda x, u, w: np.array([u[0] - 0.3, x[0] * x[1]], dtype=object), n, m, evaluate_hessian=True)
+    assert pins_to_bounds([c4, c2, c2], b, True) is None

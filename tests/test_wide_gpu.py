@@ -278,12 +278,11 @@ def test_24_state_problem_callbacks_and_solve_through_the_64_state_embedding():
     assert Zp.shape == (1, (T - 1) * 65 + 64) and np.array_equal(s.unpad_batch(Zp)[0], s._z0)
 
 
-def _constrained_24_state_problem(T, target=0.4, disc=(0.4, -2.56, 0.1)):
+def _constrained_24_state_problem(T, target=0.4, disc=(0.4, -2.56, 0.1), n_=24):
     import dto_amd
     from dto_amd import problems as P
-    n_ = 24
     p = P.build_acrobot_padded(T=T, n=n_, target=target, terminal="physical", stage_constraints=disc)
-    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot24c")
+    s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name=f"acrobot{n_}c")
     return s, p, n_
 
 
@@ -325,7 +324,19 @@ def test_24_state_problem_with_stage_constraints_callbacks_vs_oracle():
     assert np.max(np.abs(Hd - H)) <= 1e-8 * max(1.0, np.max(np.abs(H)))
 
 
+def test_40_state_problem_with_more_endpoint_rows_than_padding_states():
+    """41 rows meet at the first knot of the 40-state model, more than its 24 padding states: the 40 endpoint rows x - x1 (and the
+    four of the last knot), each affine in one state, are restated as variable bounds (solver.py: pins_to_bounds) and only the
+    obstacle rows ride auxiliary states; the multipliers of the restated rows come back from stationarity and are checked against
+    the oracle like all the others."""
+    _stage_constraints_solved_through_the_embedding(40)
+
+
 def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
+    _stage_constraints_solved_through_the_embedding(24)
+
+
+def _stage_constraints_solved_through_the_embedding(n_states):
     """The same problem solved: the tile kernels have dynamics rows and variable bounds, so every stage row rides as an auxiliary
     state of the 64-state embedding (solver.py: pad_to_wide -- y_{n+j} - c_j(x, u) = 0 as one more dynamics row, the auxiliary
     state fixed at 0 for an equality row, <= 0 for an inequality row; rows of the last knot on the last stage as functions of its
@@ -336,18 +347,19 @@ def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
     from dto_amd import problems as P
     from oracle.padded_model import PaddedAcrobot, PaddedStageRows, dense_derivatives
     T = 30
-    disc = (0.4, -2.56, 0.1)
-    s, p, n_ = _constrained_24_state_problem(T, disc=disc)
+    disc = {24: (0.4, -2.56, 0.1), 40: (0.43, -2.21, 0.08)}[n_states]      # on the path of the solution without the disc
+    s, p, n_ = _constrained_24_state_problem(T, disc=disc, n_=n_states)
     n = s.nlp
     nz = n.num_variables
     nd = (T - 1) * n_
     assert s.solve_unsupported is None and s._pad is not None and s._solve_nlp.num_variables == (T - 1) * 65 + 64
+    assert (s._pins is None) if n_ == 24 else (len(s._pins) == n_ + 4)
     assert s._solve_nlp.num_constraint == (T - 1) * 64               # the embedding has dynamics rows only
     # the same problem WITHOUT the disc (endpoints as bounds: the round-4 test's problem) swings straight through it -- knots 7 - 9
     # of its solution lie inside; the constrained solve starts from that trajectory and has to leave the disc
     xs, us = p["guess"](np.random.Generator(np.random.PCG64(0)))
     p0 = P.build_acrobot_padded(T=T, n=n_, target=0.4, terminal="physical")
-    s0 = dto_amd.Solver(p0["dynamics"], p0["objective"], p0["constraints"], p0["bounds"], evaluate_hessian=True, name="acrobot24")
+    s0 = dto_amd.Solver(p0["dynamics"], p0["objective"], p0["constraints"], p0["bounds"], evaluate_hessian=True, name=f"acrobot{n_}")
     dto_amd.initialize_states(s0, xs); dto_amd.initialize_controls(s0, [0.1 * u for u in us])
     assert dto_amd.solve(s0) == 1
     x0_sol, u0_sol = dto_amd.get_trajectory(s0)
@@ -378,6 +390,20 @@ def test_24_state_problem_with_stage_constraints_solved_through_the_embedding():
     assert n.eval_objective(zs) >= s0.nlp.eval_objective(s0._solution) - 1e-6
     print(f"[stage rows on the tile path] {s.iterations} iterations, objective {n.eval_objective(zs):.4f} (without the disc {s0.nlp.eval_objective(s0._solution):.4f}), "
           f"largest obstacle multiplier {np.max(nu[iq]):.3e}, closest approach {np.min(-cs[iq]):.3e}")
+    if s._pins:
+        # the batched entry point hands back solver-layout arrays: the multipliers of the restated rows need the solution beside them
+        import torch
+        B, nzs, ncs = 3, s._solve_nlp.num_variables, s._solve_nlp.num_constraint
+        z0 = torch.tensor(np.tile(s.pad_batch(s._z0), (B, 1)), device="cuda")
+        zo, mo = torch.empty_like(z0), torch.empty((B, ncs), device="cuda", dtype=torch.float64)
+        st, _ = s.solve_batch(z0.data_ptr(), B, nzs, zo.data_ptr(), nzs, mo.data_ptr(), ncs)
+        torch.cuda.synchronize()
+        assert np.all(st == 1)
+        with pytest.raises(ValueError):
+            s.unpad_batch(mo.cpu().numpy(), multipliers=True)
+        lb = s.multipliers_to_reference(s.unpad_batch(mo.cpu().numpy(), multipliers=True, solution=zo.cpu().numpy()))
+        assert lb.shape == (B, n.num_constraint)
+        assert np.max(np.abs(lb - ls[None, :])) <= 1e-6 * max(1.0, np.max(np.abs(ls))), np.max(np.abs(lb - ls[None, :]))
 
 
 @pytest.mark.parametrize("ka,kb,path", [(10, 20, "accumulators"), (15, 15, "folded")])
