@@ -1509,8 +1509,11 @@ __device__ __forceinline__ void conv_body(const dto_solver_opts& o, double* sc, 
     // entered at kappa_w^- delta_last directly; 0 is probed again once delta_w has decayed to the floor or after two
     // consecutive full steps (fast local convergence needs the unmodified matrix).  C port, acrobot: T=101 -18 %
     // factorisations, -7 % iterations; T=301 -31 % / -10 %; pendulum unchanged; every instance still converges.
-    else if (dlast > 1.1 * o.delta_w_init && sc[SC_FULL_STREAK << SH] < 2.0)
-      sc[SC_TRY_DW << SH] = fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+    // (round 6: the decaying delta_w is floored at delta_w^min = 1e-20 as in Ipopt's IpPDPerturbationHandler, not at delta_w_init:
+    //  with a floor of 1e-4 the acrobot T = 1000 instances that enter a valley whose reduced Hessian has an eigenvalue of 2e-7 are
+    //  frozen along it -- 227 of 256 seeds converged on the C port, 256 of 256 with Ipopt's floor)
+    else if (dlast > 1.1 * o.delta_w_min && sc[SC_FULL_STREAK << SH] < 2.0)
+      sc[SC_TRY_DW << SH] = fmax(o.delta_w_min, o.kappa_w_minus * dlast);
     else sc[SC_TRY_DW << SH] = 0.0;
     // penalty phase: Gauss-Newton model (constraint curvature dropped), delta_w >= delta_w_init.  Far from the manifold the exact
     // Hessian is so indefinite that the ladder ends at delta_w ~ 10 .. 100 anyway -- its curvature is swamped while every probe
@@ -2129,7 +2132,7 @@ __device__ __forceinline__ void retry_update_t(const dto_solver_opts& o, int Nc,
     // constraint curvature lam'd'' + nu'c'' (proportional to the multipliers, which a large
     // delta_w I only inflates further) is dropped instead -- Gauss-Newton convexification.
     const bool skip_ladder = (sc[SC_GAMMA << SH] == 0.0) && (((int)sc[SC_ITER << SH]) % 4 != 0);
-    if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_init, o.kappa_w_minus * dlast);
+    if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o.delta_w_init : fmax(o.delta_w_min, o.kappa_w_minus * dlast);
     else if (!skip_ladder) dw *= (dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
     if (skip_ladder || dw > o.delta_w_exact_cap) {
       gam = 0.0;

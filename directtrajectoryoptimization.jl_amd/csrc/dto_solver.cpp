@@ -167,6 +167,8 @@ static void default_opts(dto_solver_opts& o, const dto_options& u) {
   o.mu_init = u.mu_init; o.kappa_eps = 10.0; o.kappa_mu = 0.2; o.theta_mu = 1.5; o.tau_min = 0.99;
   o.bound_push = 1e-2; o.bound_frac = 1e-2;
   o.delta_c = u.delta_c; o.delta_w_init = u.delta_w_init; o.delta_w_min = 1e-20; o.delta_w_max = 1e20;
+  // (measurement knob: DTO_DW_FLOOR=1e-4 restores the floor of rounds 2 - 5 for the decaying delta_w)
+  if (const char* e = getenv("DTO_DW_FLOOR")) { const double v = atof(e); if (v > 0.0) o.delta_w_min = v; }
   o.kappa_w_minus = 1.0 / 3.0; o.kappa_w_plus = 8.0; o.kappa_w_plus_first = 100.0;
   // largest delta_w tried on the exact Hessian before the constraint curvature is dropped (Gauss-Newton fallback).  Round 1
   // used 1: measured on the C port over 128-256 seeds per config, 100 halves the iterations of
@@ -447,7 +449,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
       if (s.status != 0) continue;
       s.attempt = 0;
       if (s.ls_fail) s.dw = std::min(o.delta_w_exact_cap, std::max(10.0 * s.dlast, o.delta_w_init));
-      else if (s.dlast > 1.1 * o.delta_w_init && s.full_streak < 2) s.dw = std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
+      else if (s.dlast > 1.1 * o.delta_w_min && s.full_streak < 2) s.dw = std::max(o.delta_w_min, o.kappa_w_minus * s.dlast);
       else s.dw = 0.0;
       s.gam = 1.0;  // the exact Hessian of the Lagrangian first
       h_dw[(size_t)i] = s.dw;
@@ -543,7 +545,7 @@ static int wide_solve_batch(Problem* p, const dto_options* opt, const dto_batch*
           // (Gauss-Newton) instead of inflating delta_w further -- large delta_w only inflates the multipliers it fights
           if (s.gam != 0.0) {
             const bool skip_ladder = (s.gamma_acc == 0.0) && (s.iter % 4 != 0);
-            if (s.dw == 0.0 && !skip_ladder) s.dw = (s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast);
+            if (s.dw == 0.0 && !skip_ladder) s.dw = (s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_min, o.kappa_w_minus * s.dlast);
             else if (!skip_ladder) s.dw *= (s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus;
             if (skip_ladder || s.dw > o.delta_w_exact_cap) { s.gam = 0.0; s.dw = o.delta_w_init; }
           } else {
@@ -1964,7 +1966,7 @@ static int general_solve_batch(Problem* p, const dto_options* opt, const dto_bat
         Inst& s = I[(size_t)i];
         if (s.status != 0 || okv[(size_t)i] || attempt >= o.max_refactor) continue;
         double& dw = dwv[(size_t)i];
-        dw = (dw == 0.0) ? ((s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_init, o.kappa_w_minus * s.dlast))
+        dw = (dw == 0.0) ? ((s.dlast == 0.0) ? o.delta_w_init : std::max(o.delta_w_min, o.kappa_w_minus * s.dlast))
                          : dw * ((s.dlast == 0.0) ? o.kappa_w_plus_first : o.kappa_w_plus);
         again = true;
       }

@@ -47,7 +47,7 @@ typedef struct {
   int acceptable_iter;
   double diverging_iterates_tol, mu_target;
   double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac;
-  double delta_c, delta_w_init, delta_w_max, delta_w_exact_cap, kappa_w_minus, kappa_w_plus, kappa_w_plus_first, piv_tol;
+  double delta_c, delta_w_init, delta_w_min, delta_w_max, delta_w_exact_cap, kappa_w_minus, kappa_w_plus, kappa_w_plus_first, piv_tol;
   int max_refactor, watchdog_trigger, watchdog_trials, max_soc;
   int ls_penalty;        /* 1: l1-penalty line search while the iterate is far from the constraint manifold, then the filter */
   int pen_gn;            /* 1: Gauss-Newton Hessian model during the penalty phase (factor_solve) */
@@ -102,7 +102,7 @@ void port_default_options(port_options* o) {
   o->acceptable_tol = 1e-6; o->acceptable_iter = 15; o->acceptable_dual_inf_tol = 1e10; o->acceptable_constr_viol_tol = 1e-2;
   o->acceptable_compl_inf_tol = 1e-2; o->acceptable_obj_change_tol = 1e-5; o->diverging_iterates_tol = 1e8; o->mu_target = 1e-4;
   o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99; o->bound_push = 1e-2; o->bound_frac = 1e-2;
-  o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_max = 1e20; o->delta_w_exact_cap = 100.0;
+  o->delta_c = 1e-8; o->delta_w_init = 1e-4; o->delta_w_min = 1e-20; o->delta_w_max = 1e20; o->delta_w_exact_cap = 100.0;
   o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_first = 100.0; o->piv_tol = 1e-9;
   o->max_refactor = 9; o->watchdog_trigger = 2; o->watchdog_trials = 4; o->max_soc = 0;
   if (getenv("DTO_WATCHDOG")) sscanf(getenv("DTO_WATCHDOG"), "%d,%d", &o->watchdog_trigger, &o->watchdog_trials);
@@ -793,13 +793,20 @@ static void qn_factor_solve(port_solver* S) {
 }
 
 /* inertia correction: k_conv's choice of the first delta_w + k_kkt_sep's ladder */
+/* floor of the decaying delta_w: Ipopt's delta_w^min = 1e-20 (IpPDPerturbationHandler), rounds 2 - 5 used delta_w_init = 1e-4 --
+ * DTO_DW_FLOOR=1e-4 restores that (tools/port_stats.py: acrobot T = 1000, 256 seeds: 227 converge with 1e-4, 256 with 1e-20) */
+static double dw_floor(const port_options* o) {
+  static double v = -1;
+  if (v < 0) v = getenv("DTO_DW_FLOOR") ? atof(getenv("DTO_DW_FLOOR")) : o->delta_w_min;
+  return v;
+}
 static void factor_solve(port_solver* S) {
   if (S->qn_mode == 2) { qn_factor_solve(S); return; }
   const port_options* o = &S->o;
   const double dlast = S->delta_last;
   double dw = 0.0, gam = 1.0;
   if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * dlast, o->delta_w_init));
-  else if (dlast > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * dlast);
+  else if (dlast > 1.1 * dw_floor(o) && S->full_streak < 2) dw = fmax(dw_floor(o), o->kappa_w_minus * dlast);
   {
     static double lm = -1, lup, ldn, lthr;
     if (lm < 0) { lm = getenv("DTO_LM") ? atof(getenv("DTO_LM")) : 0.0; lup = getenv("DTO_LM_UP") ? atof(getenv("DTO_LM_UP")) : 4.0;
@@ -829,7 +836,7 @@ static void factor_solve(port_solver* S) {
     if (gam != 0.0) {
       const int skip_ladder = (S->gamma == 0.0) && (S->iter % 4 != 0);
       const double dw_failed = dw;
-      if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o->delta_w_init : fmax(o->delta_w_init, o->kappa_w_minus * dlast);
+      if (dw == 0.0 && !skip_ladder) dw = (dlast == 0.0) ? o->delta_w_init : fmax(dw_floor(o), o->kappa_w_minus * dlast);
       else if (!skip_ladder) dw *= (dlast == 0.0) ? o->kappa_w_plus_first : o->kappa_w_plus;
       {   /* experiment: jump the ladder to the level the most negative primal pivot of the failed sweep asks for */
         static double kj = -1; if (kj < 0) kj = getenv("DTO_PIV_JUMP") ? atof(getenv("DTO_PIV_JUMP")) : 0.0;

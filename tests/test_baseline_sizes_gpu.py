@@ -201,8 +201,9 @@ def test_cfg3_acrobot_T1000_full_solves_are_kkt_points_of_the_oracle():
     torch.cuda.synchronize()
     Zs, Ls = zo.cpu().numpy(), lo.cpu().numpy()
     conv = np.flatnonzero(status == 1)
-    # 83-85 % of the bench's instances converge within max_iter; the rest must be at the iteration limit
-    assert len(conv) >= 0.7 * B, (np.bincount(status), np.median(iters))
+    # round 6 (delta_w floored at Ipopt's 1e-20 instead of delta_w_init): 99.9 % of the bench's instances converge within max_iter
+    # (88 - 91 % in rounds 4 - 5); an instance that does not must be at the iteration limit
+    assert len(conv) >= 0.95 * B, (np.bincount(status), np.median(iters))
     assert np.all((status == 1) | (status == 2)), np.bincount(status)
     op = S.build("acrobot", T, evaluate_hessian=False)
     onlp = O.NLPData(op["dynamics"], op["objective"], op["constraints"], op["bounds"], evaluate_hessian=False)

@@ -98,7 +98,7 @@ def test_cfg3_T1000_overlapped_multi_round_sequential_sweeps_step_and_solve_vs_o
     finally:
         s.set_partitions(0)
     assert np.all((status == 1) | (status == 2)), np.bincount(status)
-    assert np.mean(status == 1) >= 0.75, np.bincount(status)
+    assert np.mean(status == 1) >= 0.99, np.bincount(status)          # 70 359 of 70 400 (round 5: 91 %)
     sel = np.arange(0, B, B // 64)[:64]
     Zs, Ls = zo[torch.tensor(sel, device="cuda")].cpu().numpy(), lo[torch.tensor(sel, device="cuda")].cpu().numpy()
     s.release_state()
@@ -116,5 +116,5 @@ def test_cfg3_T1000_overlapped_multi_round_sequential_sweeps_step_and_solve_vs_o
         assert viol <= 1e-6 and stat <= 1e-5, (b, stat, viol, iters[b])
         assert np.linalg.norm(z[np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3      # test/solve.jl:136
         assert np.linalg.norm(z[np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3     # test/solve.jl:137
-    assert n_conv >= 40, n_conv
+    assert n_conv >= 60, n_conv
     print(f"[bench path] {int(np.sum(status == 1))}/{B} converged, median iterations {np.median(iters):.0f}; {n_conv}/64 sampled instances KKT-checked")
