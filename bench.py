@@ -338,8 +338,13 @@ def main():
         launcher_selftest(rank, world, cpu)
         return
     dist = None
-    if world > 1:
+    # DTO_BENCH_FORCE_DIST=1: initialise RCCL and run every collective of the N > 1 path with ONE rank too (what a 1-GPU box can show
+    # of the multi-GPU path on hardware: process-group set-up, the sizing all-reduces, the chunked all-gather of the trajectories)
+    force_dist = os.environ.get("DTO_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k_, v_)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -614,7 +619,7 @@ def main():
     gsum = torch.zeros((), device=dev, dtype=torch.float64)
     def _sink(g0, rows):
         gsum.add_(rows[:, -1].sum())
-    n_gathered = int(gather_trajectories(zout, status, dist, sink=_sink))
+    n_gathered = int(gather_trajectories(zout, status, dist, sink=_sink, force_collective=force_dist))
     del zout, status
     torch.cuda.empty_cache()
 
@@ -649,7 +654,8 @@ def main():
             config=dict(workload=f"acrobot swing-up, implicit midpoint h=0.05, T={T}, exact Hessians, "
                                  f"{B} independent instances per GPU (BASELINE.json configs[2])",
                         horizon=T, instances_per_gpu=B, instances_total=B * world, num_variables=nz, num_constraint=nc,
-                        jacobian_nnz=nj, hessian_key=nh, parallelism=f"instance sharding x{world}, all-gather of trajectories"),
+                        jacobian_nnz=nj, hessian_key=nh, parallelism=f"instance sharding x{world}, all-gather of trajectories",
+                        collective_backend=("nccl (RCCL)" if dist is not None else None)),
             jacobian_nnz_per_sec=float(jt[0]), jacobian=jac,
             iteration_throughput=dict(value=float(thr0[0]), unit="SQP iterations/s",
                                       note=f"first {first_k} timed iterations, every instance still running"),

@@ -22,7 +22,7 @@ def shard_range(num_instances: int, rank: int, world: int) -> Tuple[int, int]:
     return first.value, first.value + count.value
 
 
-def gather_trajectories(z_local, status_local, dist, sink=None, max_bytes=8 << 30):
+def gather_trajectories(z_local, status_local, dist, sink=None, max_bytes=8 << 30, force_collective=False):
     """All-gather [B_local, Nz] trajectories (+ status as an extra column) from every rank.
 
     Shards may have different sizes (B not divisible by the world size): they are padded to the largest
@@ -37,7 +37,9 @@ def gather_trajectories(z_local, status_local, dist, sink=None, max_bytes=8 << 3
       * no sink: the chunks are assembled into the full result -- on the device if it fits `max_bytes`, else in host memory.
     """
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    # (force_collective: run the collectives with a single rank too -- bench.py under DTO_BENCH_FORCE_DIST=1, the N > 1 path on a
+    #  one-GPU box)
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         full = torch.cat([z_local, status_local.to(z_local.dtype).reshape(-1, 1)], dim=1)
         if sink is not None:
             sink(0, full)

@@ -83,3 +83,21 @@ def test_cpu_baseline_object():
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
     assert c["host"]["affinity_cpus"] >= c["cores"]
+
+
+def test_collective_path_with_one_rank_over_rccl():
+    """The N > 1 path of bench.py on the one GPU a test box has: started the way the driver starts several ranks
+    (`python -m torch.distributed.run --nproc-per-node 1`), DTO_BENCH_FORCE_DIST=1 makes the single rank initialise RCCL and run
+    every collective -- the sizing all-reduces, the barriers around the timed region, the max-over-ranks of the time and the
+    chunked all-gather of the trajectories (131 072 x 9 004 doubles = 9.4 GB: two chunks under the 8 GiB bound)."""
+    env = dict(os.environ, DTO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "131072",
+           "--no-full-solves", "--no-dense-blocks", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl (RCCL)"
+    assert d["gathered_trajectories"] == 131072 and d["value"] > 0
