@@ -1077,6 +1077,17 @@ static __global__ void k_gather_rows(double* dst, const double* src, int64_t n, 
   dst[((tile * n + i) << 6) + lane] = src[((((int64_t)(ss >> 6)) * n + i) << 6) + (ss & 63)];
 }
 
+// the same for rows [row0, row0 + n) of an array with `total` rows per tile (the limited-memory history block): dst is compact
+static __global__ void k_gather_rows_of(double* dst, const double* src, int64_t n, int64_t total, int64_t row0, const int* src_slot,
+                                        unsigned nrb) {
+  const int64_t tile = blockIdx.x / nrb;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)(blockIdx.x % nrb) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int ss = src_slot[tile * 64 + lane];
+  dst[((tile * n + i) << 6) + lane] = src[((((int64_t)(ss >> 6)) * total + row0 + i) << 6) + (ss & 63)];
+}
+
 // Move the instances that are still running to the leading tiles (stable), the finished ones behind them, so that the
 // per-iteration kernels only cover tiles with work: without it a batch keeps paying for all its tiles until the last lane
 // of each has terminated.  Only the persistent per-instance state moves (iterates, multipliers, filter, scalars,
@@ -1085,9 +1096,10 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   SolverState& S = *p->solver;
   const Layout& L = p->L;
   const int lanes = S.G * 64;
-  // (quasi-Newton state stays with its slot: the per-stage SR1 blocks live in the records, the limited-memory history in `qn` --
-  //  neither moves, so such batches are not repacked; finished lanes are skipped by every kernel all the same)
-  if (S.info.quasi_newton || S.opt.qn_lbfgs) { if (n_running_out) *n_running_out = -1; return DTO_OK; }
+  // (the per-stage SR1 blocks of a plugin without second derivatives live in the records, which do not move: such batches are not
+  //  repacked; finished lanes are skipped by every kernel all the same.  The limited-memory history block `qn` moves with its
+  //  instance since round 6 -- rounds 5's batches in that mode paid for every tile until its last lane ended)
+  if (S.info.quasi_newton) { if (n_running_out) *n_running_out = -1; return DTO_OK; }
   if (S.inst_of_slot.empty()) {
     S.inst_of_slot.resize(lanes); S.slot_of_inst.resize(lanes);
     for (int i = 0; i < lanes; ++i) S.inst_of_slot[i] = S.slot_of_inst[i] = i;
@@ -1136,6 +1148,20 @@ static int repack(Problem* p, hipStream_t st, int* n_running_out) {
   if ((rc = move(S.filt, 2 * S.info.filter_cap))) return rc;
   if ((rc = move(S.scal, S.info.nscal))) return rc;
   if (S.use_wtile && (rc = move(S.wtile, L.Nw))) return rc;
+  if (S.opt.qn_lbfgs && S.qn) {
+    // history block [G][total][64]: in pieces of at most `widest` rows through the same staging buffer
+    const int64_t total = dto::QnRows{L.Nz}.total();
+    for (int64_t row0 = 0; row0 < total; row0 += widest) {
+      const int64_t n = std::min<int64_t>(widest, total - row0);
+      const unsigned nrb = (unsigned)((n + 3) / 4);
+      if ((uint64_t)nrb * (uint64_t)S.G > 0x7fffffffull) return set_error(DTO_ERR_INVALID, "batch too large to repack");
+      hipLaunchKernelGGL(k_gather_rows_of, dim3(nrb * (unsigned)S.G), dim3(256), 0, st, S.repack_tmp, (const double*)S.qn, n, total, row0,
+                         (const int*)S.d_src_slot, nrb);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy2DAsync(S.qn + ((size_t)row0 << 6), (size_t)total * 64 * sizeof(double), S.repack_tmp, (size_t)n * 64 * sizeof(double),
+                               (size_t)n * 64 * sizeof(double), (size_t)S.G, hipMemcpyDeviceToDevice, st));
+    }
+  }
   std::vector<int> inst_new(lanes);
   for (int sl = 0; sl < lanes; ++sl) inst_new[sl] = S.inst_of_slot[src[sl]];
   S.inst_of_slot.swap(inst_new);

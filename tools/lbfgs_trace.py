@@ -9,7 +9,7 @@ from dto_amd import problems as P
 from bench import make_guesses
 
 OPN = {19: "qn_begin", 20: "qn_rhs", 21: "qn_col", 22: "qn_small", 23: "qn_save", 24: "qn_cols_rhs"}
-for T, B in ((101, 1), (101, 64), (101, 1024)):
+for T, B in ((101, 1), (101, 64), (101, 1024), (101, 4096)):
     for mode in ("lbfgs", "exact"):
         p = P.build_acrobot(T=T, evaluate_hessian=True)
         s = dto_amd.Solver(p["dynamics"], p["objective"], p["constraints"], p["bounds"], evaluate_hessian=True, name="acrobot",
