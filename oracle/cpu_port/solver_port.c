@@ -189,6 +189,11 @@ void port_set_double(port_solver* S, const char* name, double v) {
   else if (!strcmp(name, "tol")) S->o.tol = v;
   else if (!strcmp(name, "delta_w_exact_cap")) S->o.delta_w_exact_cap = v;
   else if (!strcmp(name, "ls_switch")) S->o.ls_switch = v;
+  else if (!strcmp(name, "kappa_w_minus")) S->o.kappa_w_minus = v;
+  else if (!strcmp(name, "kappa_w_plus")) S->o.kappa_w_plus = v;
+  else if (!strcmp(name, "kappa_w_plus_first")) S->o.kappa_w_plus_first = v;
+  else if (!strcmp(name, "delta_w_init")) S->o.delta_w_init = v;
+  else if (!strcmp(name, "delta_w_min")) S->o.delta_w_min = v;
 }
 
 /* slack index of row j of stage t (-1: equality row) */
