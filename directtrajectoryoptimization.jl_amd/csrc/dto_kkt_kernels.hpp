@@ -1503,7 +1503,11 @@ __device__ __forceinline__ void conv_body(const dto_solver_opts& o, double* sc, 
     // after a failed line search start from a larger regularisation -- but never beyond the exact-Hessian cap: without
     // the cap an instance whose trials keep being rejected by the filter multiplies delta_w by 10 every iteration
     // (1e163 was observed), its steps vanish and it can never leave that state
-    if (sc[SC_LS_FAIL << SH] != 0.0) sc[SC_TRY_DW << SH] = fmin(o.delta_w_exact_cap, fmax(10.0 * dlast, o.delta_w_init));
+    // (limited-memory mode: delta_last is never recorded there (gam = 0), so the escalation starts from the delta_w the rejected
+    //  direction was computed with -- with delta_w_init again and again a null step repeated itself for the rest of the
+    //  iterations: same point, same direction; 24 of 4 096 acrobot T = 101 instances, round 6)
+    if (sc[SC_LS_FAIL << SH] != 0.0)
+      sc[SC_TRY_DW << SH] = fmin(o.delta_w_exact_cap, fmax(10.0 * fmax(dlast, o.qn_lbfgs ? sc[SC_DELTA_W << SH] : 0.0), o.delta_w_init));
     // Ipopt's Algorithm IC probes delta_w = 0 in every iteration.  While the last iteration needed a regularisation well
     // above the floor that probe almost always fails and costs a whole factorisation, so it is skipped and the ladder is
     // entered at kappa_w^- delta_last directly; 0 is probed again once delta_w has decayed to the floor or after two

@@ -730,7 +730,10 @@ static void qn_factor_solve(port_solver* S) {
   const double sig = S->qn_sigma;
   /* first delta_w: the rules of conv_body (the ladder state delta_last stays 0 in this mode: gam = 0 never records it) */
   double dw = 0.0;
-  if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * S->delta_last, o->delta_w_init));
+  /* (round 6: after a failed line search the escalation starts from the delta_w the rejected direction was computed with -- with
+   *  delta_last = 0 for ever the rule gave delta_w_init again and again: same point, same direction, same null step, for the rest of
+   *  the iterations -- 3 of 512 acrobot T = 101 seeds here, 24 of 4 096 on the GPU) */
+  if (S->ls_fail) dw = fmin(o->delta_w_exact_cap, fmax(10.0 * fmax(S->delta_last, S->delta_w), o->delta_w_init));
   else if (S->delta_last > 1.1 * o->delta_w_init && S->full_streak < 2) dw = fmax(o->delta_w_init, o->kappa_w_minus * S->delta_last);
   if (S->ls_mode == 1 && o->pen_gn) dw = fmax(dw, o->delta_w_init);
   double* U = (double*)malloc((size_t)(m2 > 0 ? m2 : 1) * Nz * sizeof(double));

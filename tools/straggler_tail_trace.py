@@ -37,7 +37,8 @@ Emin, Emax = E.min(axis=0), E.max(axis=0)
 out = dict(instances=B, still_running_at_1000=int(len(run)), tail_iterations=TAIL,
            min_error_over_tail=dict(le_1e_6=int(np.sum(Emin <= 1e-6)), le_2e_6=int(np.sum(Emin <= 2e-6)), le_1e_5=int(np.sum(Emin <= 1e-5)), le_1e_4=int(np.sum(Emin <= 1e-4))),
            max_error_over_tail=dict(le_1e_5=int(np.sum(Emax <= 1e-5)), le_1e_4=int(np.sum(Emax <= 1e-4)), le_1e_3=int(np.sum(Emax <= 1e-3))),
-           smallest_step_fraction=float(np.mean(A <= 0.0078125)), full_step_fraction=float(np.mean(A >= 1.0)),
+           smallest_step_fraction=float(np.mean(A <= 0.0078125)), null_step_fraction=float(np.mean(A == 0.0)),
+           no_step_in_the_whole_tail=int(np.sum(np.all(A == 0.0, axis=0))), full_step_fraction=float(np.mean(A >= 1.0)),
            objective_drop_over_tail=dict(median=float(np.median(F[0] - F[-1])), p10=float(np.quantile(F[0] - F[-1], 0.1)), p90=float(np.quantile(F[0] - F[-1], 0.9))),
            examples=[])
 order = np.argsort(Emin)
