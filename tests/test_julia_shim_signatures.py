@@ -11,6 +11,7 @@ no julia in the image -- so its `struct`s and `ccall` tuples are parsed and comp
 """
 import os
 import re
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -237,3 +238,107 @@ def test_integration_md_listing_matches_the_header():
     for jname, cname in (("DtoSpec", "dto_problem_spec"), ("DtoOptions", "dto_options"), ("DtoBatch", "dto_batch")):
         for args in _positional_calls(jl, jname):
             assert len(args) == len(cs[cname]), (jname, len(args), len(cs[cname]), args)
+
+
+# ---- block structure of the Julia files (no Julia in this image: the files have never been parsed; this is the part of a
+#      parser that catches a lost `end`, an unbalanced bracket or an unterminated string) ---------------------------------------
+_OPENERS = {"function", "if", "for", "while", "begin", "let", "struct", "module", "try", "do", "quote", "macro", "baremodule"}
+
+
+def _julia_tokens(src):
+    """(token, bracket depth, line) with comments, strings, chars and triple-quoted strings removed."""
+    out, i, n, depth, line = [], 0, len(src), 0, 1
+    stack = []
+    while i < n:
+        c = src[i]
+        if c == "\n":
+            line += 1; i += 1
+        elif src.startswith("#=", i):
+            j = src.index("=#", i + 2); line += src.count("\n", i, j); i = j + 2
+        elif c == "#":
+            while i < n and src[i] != "\n":
+                i += 1
+        elif src.startswith('"""', i):
+            j = src.index('"""', i + 3); line += src.count("\n", i, j); i = j + 3
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                if src[j] == "\\":
+                    j += 1
+                if src[j] == "$" and src[j + 1] == "(":          # interpolation: skip to the matching parenthesis
+                    d, j = 1, j + 2
+                    while d:
+                        d += (src[j] == "(") - (src[j] == ")"); j += 1
+                    continue
+                assert src[j] != "\n", f"unterminated string at line {line}"
+                j += 1
+            i = j + 1
+        elif c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            i += 3 if src[i + 2] == "'" else 4
+        elif c in "([{":
+            stack.append((c, line)); depth += 1; out.append((c, depth, line)); i += 1
+        elif c in ")]}":
+            assert stack, f"closing {c} without an opener at line {line}"
+            o, l0 = stack.pop()
+            assert "([{".index(o) == ")]}".index(c), f"{o} opened at line {l0} closed by {c} at line {line}"
+            out.append((c, depth, line)); depth -= 1; i += 1
+        elif c.isalpha() or c == "_" or c == "@":
+            j = i + 1
+            while j < n and (src[j].isalnum() or src[j] in "_!"):
+                j += 1
+            prev = src[i - 1] if i else " "
+            out.append((src[i:j] if prev not in ".:" or src[i - 2:i] == "::" else "." + src[i:j], depth, line)); i = j
+        else:
+            i += 1
+    assert not stack, f"unclosed {stack[-1][0]} opened at line {stack[-1][1]}"
+    return out
+
+
+@pytest.mark.parametrize("path", ["julia/gpu_evaluator.jl", "julia/emit_plugin.jl", "tools/julia_parity_check.jl"])
+def test_julia_files_have_balanced_blocks_brackets_and_strings(path):
+    src = open(os.path.join(ROOT, path)).read()
+    toks = _julia_tokens(src)
+    blocks = []
+    prev = None
+    for t, depth, line in toks:
+        inside = depth > 0                       # `for` / `if` of a comprehension or generator, `end` of an index: no block
+        if t in _OPENERS and not inside:
+            if t == "struct" and prev == "mutable":
+                pass
+            blocks.append((t, line))
+        elif t == "type" and prev in ("abstract", "primitive") and not inside:
+            blocks.append((t, line))
+        elif t == "end" and not inside:
+            assert blocks, f"{path}:{line}: `end` without an open block"
+            blocks.pop()
+        prev = t
+    assert not blocks, f"{path}: block(s) never closed: {blocks[-3:]}"
+    # every top-level definition the binding relies on is there
+    if path.endswith("gpu_evaluator.jl"):
+        names = {toks[k + 1][0] for k in range(len(toks) - 1) if toks[k][0] == "function"}
+        for need in ("solve!", "solve_batch", "resolve_warm!"):
+            assert any(n == need or n.endswith("." + need) for n in names) or need in src, need
+
+
+def _check_blocks(src, path="<memory>"):
+    toks = _julia_tokens(src)
+    blocks, prev = [], None
+    for t, depth, line in toks:
+        if depth == 0 and (t in _OPENERS or (t == "type" and prev in ("abstract", "primitive"))):
+            blocks.append((t, line))
+        elif t == "end" and depth == 0:
+            assert blocks, f"{path}:{line}: `end` without an open block"
+            blocks.pop()
+        prev = t
+    assert not blocks, f"{path}: block(s) never closed: {blocks[-3:]}"
+
+
+def test_the_block_checker_notices_damage():
+    """The structural check above is only worth something if it fails on a damaged file: a lost `end`, an extra one, a lost
+    bracket and an unterminated string in copies of the shim."""
+    src = open(os.path.join(ROOT, "julia/gpu_evaluator.jl")).read()
+    _check_blocks(src)
+    k = src.rindex("\nend")
+    for bad in (src[:k] + src[k + 4:], src + "\nend\n", src.replace("ccall((", "ccall(", 1), src + '\nx = "abc\n'):
+        with pytest.raises((AssertionError, ValueError, IndexError)):
+            _check_blocks(bad)
