@@ -11,6 +11,7 @@ the solution norm).  Inertia: the test points use a delta_w for which H + delta_
 eigenvalue from a sparse Lanczos run), so K is quasi-definite and its inertia is exactly (N_z, N_c) -- the GPU's
 negative-pivot count must agree (`inertia_ok`).
 """
+import os
 import numpy as np
 import pytest
 
@@ -223,3 +224,32 @@ def test_cfg3_acrobot_T1000_full_solves_are_kkt_points_of_the_oracle():
         assert np.linalg.norm(z[np.array(idx.states[0]) - 1] - p["x1"]) < 1e-3      # test/solve.jl:136
         assert np.linalg.norm(z[np.array(idx.states[-1]) - 1] - p["xT"]) < 1e-3     # test/solve.jl:137
     print(f"[T=1000] {len(conv)}/{B} converged, median iterations {np.median(iters[conv]):.0f}, worst residuals {worst}")
+
+
+def test_ladder_floor_decides_the_valley_instances_of_cfg3():
+    """Round 6: the decaying delta_w is floored at Ipopt's delta_w^min = 1e-20; with the floor of rounds 2 - 5
+    (delta_w_init = 1e-4, restored by DTO_DW_FLOOR=1e-4, read at every dto_solver_begin) one bench instance in eleven is frozen in a
+    valley whose reduced Hessian has an eigenvalue of 2e-7 and ends at the iteration limit.  2 048 instances of the bench's stream,
+    both ways."""
+    import torch
+    from bench import make_guesses_device
+    T, B = 1000, 2048
+    s, p = product_solver("acrobot", T)
+    nz = s.nlp.num_variables
+    z0 = make_guesses_device(s, p, B, 1000, "cuda")
+    zo = torch.empty_like(z0)
+    got = {}
+    for name, floor in (("ipopt", None), ("delta_w_init", "1e-4")):
+        if floor is None:
+            os.environ.pop("DTO_DW_FLOOR", None)
+        else:
+            os.environ["DTO_DW_FLOOR"] = floor
+        try:
+            st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DTO_DW_FLOOR", None)
+        got[name] = (float(np.mean(st == 1)), float(np.median(it)), int(np.sum(st == 2)))
+    print(f"[ladder floor] converged / median iterations / at the limit: Ipopt's floor {got['ipopt']}, delta_w_init {got['delta_w_init']}")
+    assert got["ipopt"][0] >= 0.995 and got["ipopt"][1] <= 60, got
+    assert got["delta_w_init"][0] <= 0.95, got

@@ -188,3 +188,29 @@ def test_history_moves_with_its_instance_when_a_batch_is_repacked():
     assert np.array_equal(it_c[done], it_a[done].astype(np.int32)), np.flatnonzero(done & (it_c != it_a))
     sel = torch.tensor(np.flatnonzero(done), device="cuda")
     assert torch.equal(zc[sel], za[sel])
+
+
+def test_no_instance_repeats_a_null_step_for_ever():
+    """Round 6: 24 of these 4 096 acrobot T = 101 instances (guesses with the actions scaled by 0.01) used to end at max_iter with
+    alpha = 0 in every one of their last iterations -- after a null step the regularisation was meant to grow tenfold, but the
+    ladder's delta_last is never written in this mode and the rule returned delta_w_init again: same point, same direction.  The
+    escalation now starts from the delta_w of the rejected direction (k_conv): all but a handful converge, and none is stuck."""
+    import torch
+    import dto_amd
+    s, p = _solver("acrobot", 101)
+    nz = s._solve_nlp.num_variables
+    B = 4096
+    Z = np.zeros((B, nz))
+    for b in range(B):
+        xs, us = p["guess"](np.random.Generator(np.random.PCG64(b)))
+        dto_amd.initialize_states(s, xs)
+        dto_amd.initialize_controls(s, [0.01 * u for u in us])
+        Z[b] = s._z0
+    z0 = torch.tensor(Z, device="cuda")
+    zo = torch.empty_like(z0)
+    st, it = s.solve_batch(z0.data_ptr(), B, nz, zo.data_ptr(), nz)
+    torch.cuda.synchronize()
+    assert int(np.sum(st == 1)) >= 4090, (np.bincount(st), np.median(it))
+    alpha = s.stats_batch()["alpha"]
+    assert not np.any((st != 1) & (alpha == 0.0)), np.flatnonzero((st != 1) & (alpha == 0.0))
+    print(f"[lbfgs] 4 096 x acrobot T=101: {int(np.sum(st == 1))} converged, median {np.median(it):.0f} iterations")
