@@ -579,12 +579,22 @@ class Solver:
         n = self._solve_nlp
         Zs2, Mu2 = np.atleast_2d(Zs), np.atleast_2d(Mu)
         B = Zs2.shape[0]
+        nj = int(n.num_jacobian)
         if getattr(self, "_pin_entries", None) is None:
-            rows, cols = (np.array(v, dtype=np.int64) - 1 for v in zip(*n.jacobian_structure()))
-            self._pin_entries = [(np.flatnonzero(cols == p), rows[cols == p]) for p, _ in self._pins]
+            # (the raw index arrays of the C ABI: no Python list of (T - 1) x 64 x 129 pairs at long horizons)
+            rows, cols = np.zeros(max(1, nj), dtype=np.int64), np.zeros(max(1, nj), dtype=np.int64)
+            capi.check(n._lib.dto_jacobian_structure(n._h, rows.ctypes.data_as(capi.c_int64_p), cols.ctypes.data_as(capi.c_int64_p)))
+            rows, cols = rows[:nj] - 1, cols[:nj] - 1
+            order = np.argsort(cols, kind="stable")
+            sc = cols[order]
+            self._pin_entries = []
+            for p, _ in self._pins:
+                lo, hi = np.searchsorted(sc, p, "left"), np.searchsorted(sc, p, "right")
+                ent = np.sort(order[lo:hi])
+                self._pin_entries.append((ent, rows[ent]))
         z = torch.tensor(Zs2, device="cuda", dtype=torch.float64).contiguous()
         g = torch.empty_like(z)
-        J = torch.empty((B, max(1, len(n.jacobian_structure()))), device="cuda", dtype=torch.float64)
+        J = torch.empty((B, max(1, nj)), device="cuda", dtype=torch.float64)
         n.eval_objective_gradient_batch(z.data_ptr(), B, z.shape[1], g.data_ptr(), g.shape[1])
         n.eval_constraint_jacobian_batch(z.data_ptr(), B, z.shape[1], J.data_ptr(), J.shape[1])
         torch.cuda.synchronize()
