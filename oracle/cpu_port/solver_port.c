@@ -804,9 +804,9 @@ static void qn_factor_solve(port_solver* S) {
 /* floor of the decaying delta_w: Ipopt's delta_w^min = 1e-20 (IpPDPerturbationHandler), rounds 2 - 5 used delta_w_init = 1e-4 --
  * DTO_DW_FLOOR=1e-4 restores that (tools/port_stats.py: acrobot T = 1000, 256 seeds: 227 converge with 1e-4, 256 with 1e-20) */
 static double dw_floor(const port_options* o) {
-  static double v = -1;
-  if (v < 0) v = getenv("DTO_DW_FLOOR") ? atof(getenv("DTO_DW_FLOOR")) : o->delta_w_min;
-  return v;
+  static double env = -2;
+  if (env < -1) env = getenv("DTO_DW_FLOOR") ? atof(getenv("DTO_DW_FLOOR")) : -1.0;
+  return env > 0 ? env : o->delta_w_min;
 }
 static void factor_solve(port_solver* S) {
   if (S->qn_mode == 2) { qn_factor_solve(S); return; }
